@@ -1,0 +1,125 @@
+/*
+ * sgdfr.h -- C ABI of libsgdfr_hip.so: the MI355X (gfx950) StyleGAN2 generator hot path.
+ *
+ * Every entry point takes raw device pointers + sizes + a hipStream_t (passed as void*),
+ * launches asynchronously on that stream, never synchronises, never allocates, and returns
+ * 0 on success or a non-zero code with a message available from sgdfr_last_error().
+ * Tensors are fp32, contiguous, NCHW unless a stride argument says otherwise.
+ * Outputs are caller-allocated (the reference's natives allocate internally; the host mirror
+ * in stylegan_directions_face_reenactment_amd/ does the torch.empty for them).
+ *
+ * Reference interface each symbol replaces (paths relative to the reference repo,
+ * libs/gan/StyleGAN2/ unless noted):
+ *
+ *   sgdfr_fused_bias_act_f32   op/fused_bias_act.cpp:14-24  fused.fused_bias_act(input,bias,refer,act,grad,alpha,scale)
+ *                              (kernel op/fused_bias_act_kernel.cu:18-49)
+ *   sgdfr_upfirdn2d_f32        op/upfirdn2d.cpp:15-26       upfirdn2d.upfirdn2d(input,kernel,up_x,up_y,down_x,down_y,pad_x0..pad_y1)
+ *                              (kernel op/upfirdn2d_kernel.cu:52-137; unlike :172-223 unsupported combos are an ERROR, never a silent no-op)
+ *   sgdfr_linear_f32           model.py:148-157 EqualLinear.forward (F.linear + fused_leaky_relu),
+ *                              libs/models/direction_matrix.py:41-48 (nn.Linear)
+ *   sgdfr_pixelnorm_f32        model.py:11-16   PixelNorm.forward
+ *   sgdfr_latent_prepare_f32   model.py:494-508 truncation + W->W+ broadcast, libs/utilities/generic.py:116-135 shift add
+ *   sgdfr_modconv_prepack_f32  model.py:215,218-220,236 (scale*weight) -- layout change + sum-of-squares for demodulation
+ *   sgdfr_style_demod_f32      model.py:235-240 modulation(style) and rsqrt(sum w^2 + 1e-8)
+ *   sgdfr_modconv2d_fwd_f32    model.py:232-273 ModulatedConv2d.forward (+ :282-287 NoiseInjection, op/fused_act.py:81-86
+ *                              FusedLeakyReLU folded into the epilogue); the reference has NO native kernel for this --
+ *                              its boundary is the Python method
+ *   sgdfr_blur_bias_act_f32    model.py:257 Blur after the transposed conv (upfirdn2d pad (1,1)) + noise + bias + lrelu
+ *   sgdfr_torgb_fwd_f32        model.py:350-359 ToRGB.forward (1x1 modconv, bias, Upsample(skip) :38-46, add)
+ */
+#ifndef SGDFR_H
+#define SGDFR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGDFR_ABI_VERSION 1
+
+/* modes of sgdfr_modconv2d_fwd_f32 */
+#define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
+#define SGDFR_MODE_UP3 1    /* 3x3 transposed stride 2 -> phase planes of size (H+1)x(W+1) (model.py:246-256) */
+
+/* activation codes of sgdfr_linear_f32 */
+#define SGDFR_ACT_NONE 0
+#define SGDFR_ACT_LRELU 1 /* lrelu(v, slope) * gain */
+
+int sgdfr_abi_version(void);
+const char* sgdfr_last_error(void);
+
+/* y[i] = act(x[i] + bias[(i / step_b) % size_b]) * scale ; act==3 (lrelu) only, grad in {0,1,2}:
+ *   grad 0: y = (v>0 ? v : alpha*v) * scale, v = x + b
+ *   grad 1: y = (ref>0 ? x : alpha*x) * scale           (bias ignored by callers: pass NULL)
+ *   grad 2: y = 0
+ * bias / ref may be NULL ("empty tensor" in the reference). */
+int sgdfr_fused_bias_act_f32(const float* x, const float* bias, const float* ref, float* y, int64_t n,
+                             int step_b, int size_b, int act, int grad, float alpha, float scale,
+                             void* stream);
+
+/* x [major, in_h, in_w, minor] -> y [major, out_h, out_w, minor],
+ * out = ((in*up + pad0 + pad1 - k) / down) + 1 per axis; kernel k [kh, kw] is applied flipped
+ * (true convolution).  Negative pads crop. */
+int sgdfr_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int in_h, int in_w, int minor,
+                        int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                        int pad_y0, int pad_y1, void* stream);
+
+/* y[m, n] = act( (sum_k x[m*ldx + k] * w[n*K + k]) * wscale + bias[n] * bscale ), m<M, n<N.
+ * bias may be NULL.  act: SGDFR_ACT_*. */
+int sgdfr_linear_f32(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,
+                     int M, int N, int K, float wscale, float bscale, int act, float slope, float gain,
+                     void* stream);
+
+/* y[b,:] = x[b,:] * rsqrt(mean(x[b,:]^2) + eps) */
+int sgdfr_pixelnorm_f32(const float* x, float* y, int B, int D, float eps, void* stream);
+
+/* out[b,l,:] = t + psi * (v - t),   v = w[b,(l),:] + (l < shift_layers ? shift[b,(l),:] : 0)
+ *   w:     [B, L, D] if w_is_plus else [B, D] (broadcast over l)
+ *   shift: NULL, or [B, shift_layers, D] if shift_is_plus else [B, D] (added to the first shift_layers rows)
+ *   trunc: NULL (no truncation, psi ignored) or [D]
+ * Order matches generic.py:116-135 then model.py:494-500: shift first, truncation after. */
+int sgdfr_latent_prepare_f32(const float* w, int w_is_plus, const float* shift, int shift_is_plus,
+                             int shift_layers, const float* trunc, float psi, float* out, int B, int L, int D,
+                             void* stream);
+
+/* weight [Cout, Cin, k, k] -> wp [Cin, k*k, Cout] = weight * 1/sqrt(Cin*k*k)  and
+ *                              q  [Cout, Cin]     = sum_taps wp^2                (q may be NULL) */
+int sgdfr_modconv_prepack_f32(const float* weight, float* wp, float* q, int Cout, int Cin, int k, void* stream);
+
+/* s[b,i] = (sum_j style[b*ld_style + j] * mod_w[i*D + j]) / sqrt(D) + mod_b[i]
+ * d[b,o] = rsqrt( sum_i s[b,i]^2 * q[o*Cin + i] + 1e-8 )        (skipped when d == NULL) */
+int sgdfr_style_demod_f32(const float* style, int64_t ld_style, const float* mod_w, const float* mod_b,
+                          const float* q, float* s, float* d, int B, int D, int Cin, int Cout, void* stream);
+
+/* Shared-weight modulated 3x3 convolution on fp32 MFMA.
+ *   x      [B, Cin, H, W]  (x_bstride = Cin*H*W, or 0 to broadcast one [Cin,H,W] constant over the batch)
+ *   wp     [Cin, 9, Cout]  from sgdfr_modconv_prepack_f32
+ *   s      [B, Cin], d [B, Cout] (d may be NULL = no demodulation)
+ * mode PLAIN3: y [B, Cout, H, W] = act( d * conv3x3(x*s) + noise_w[0]*noise + bias[o] ), act = lrelu(slope)*gain
+ *              when `act` != 0; noise [H*W] with noise_bstride 0 (shared) or H*W (per sample); noise/noise_w/bias
+ *              may be NULL.
+ * mode UP3:    y [B, Cout, 4, H+1, W+1] = d * conv_transpose2d(x*s, stride 2) split by output parity:
+ *              plane ph = 2*(oy&1) + (ox&1) holds T[oy, ox] at [oy>>1, ox>>1]; entries of the odd planes that fall
+ *              outside the (2H+1)x(2W+1) result are written as exact zeros.  noise/bias/act are NOT applied
+ *              (sgdfr_blur_bias_act_f32 does that after the FIR). */
+int sgdfr_modconv2d_fwd_f32(const float* x, int64_t x_bstride, const float* wp, const float* s, const float* d,
+                            const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
+                            float* y, int B, int Cin, int Cout, int H, int W, int mode, int act, float slope,
+                            float gain, void* stream);
+
+/* t [B*C, 4, H+1, W+1] (phase planes from MODE_UP3) -> y [B, C, 2H, 2W]:
+ *   y = act( upfirdn2d(T, fir[4,4], pad=(1,1)) + noise_w[0]*noise[oy,ox] + bias[c] )   (model.py:257,287, fused_act.py:81) */
+int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const float* noise, int64_t noise_bstride,
+                            const float* noise_w, const float* bias, float* y, int B, int C, int H, int W, int act,
+                            float slope, float gain, void* stream);
+
+/* y[b,j,p] = sum_i w_rgb[j*Cin+i]/sqrt(Cin) * s[b,i] * x[b,i,p] + bias[j]
+ *          + (skip ? upfirdn2d(skip[b,j] (H/2 x W/2), fir[4,4], up=2, pad=(2,1))[p] : 0),  j<3 */
+int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, const float* bias, const float* skip,
+                        const float* fir, float* y, int B, int Cin, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGDFR_H */

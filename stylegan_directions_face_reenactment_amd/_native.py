@@ -1,0 +1,100 @@
+"""ctypes binding of csrc/libsgdfr_hip.so (C ABI declared in include/sgdfr.h).
+
+The library handle lives at module level (never on an nn.Module) so modules stay
+deepcopy-able and picklable (the reference deep-copies G in libs/optimization.py:28 and
+torch.save()s A in libs/utilities/utils_train.py:594-603).
+
+There is NO fallback: if the shared library is missing the first native call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libsgdfr_hip.so')
+ABI_VERSION = 1
+
+_c_f32p = ctypes.c_void_p
+_i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+# name -> argtypes ; every function returns int (0 = ok)
+SIGNATURES = {
+    'sgdfr_fused_bias_act_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _i, _i, _i, _i, _f, _f, ctypes.c_void_p],
+    'sgdfr_upfirdn2d_f32': [_c_f32p, _c_f32p, _c_f32p] + [_i] * 14 + [ctypes.c_void_p],
+    'sgdfr_linear_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i64, _i, _i, _i, _f, _f, _i, _f, _f,
+                         ctypes.c_void_p],
+    'sgdfr_pixelnorm_f32': [_c_f32p, _c_f32p, _i, _i, _f, ctypes.c_void_p],
+    'sgdfr_latent_prepare_f32': [_c_f32p, _i, _c_f32p, _i, _i, _c_f32p, _f, _c_f32p, _i, _i, _i, ctypes.c_void_p],
+    'sgdfr_modconv_prepack_f32': [_c_f32p, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],
+    'sgdfr_style_demod_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i,
+                              ctypes.c_void_p],
+    'sgdfr_modconv2d_fwd_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
+                                _i, _i, _i, _i, _i, _i, _i, _f, _f, ctypes.c_void_p],
+    'sgdfr_blur_bias_act_f32': [_c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i, _i, _f,
+                                _f, ctypes.c_void_p],
+    'sgdfr_torgb_fwd_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i,
+                            ctypes.c_void_p],
+}
+
+MODE_PLAIN3, MODE_UP3 = 0, 1
+ACT_NONE, ACT_LRELU = 0, 1
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes library; raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'native library %s is missing: run `python -m stylegan_directions_face_reenactment_amd.build_native` '
+            '(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for this path.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.sgdfr_abi_version.restype = ctypes.c_int
+    lib.sgdfr_last_error.restype = ctypes.c_char_p
+    if lib.sgdfr_abi_version() != ABI_VERSION:
+        raise RuntimeError('libsgdfr_hip.so ABI %d != expected %d: rebuild' % (lib.sgdfr_abi_version(), ABI_VERSION))
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (name, rc, lib.sgdfr_last_error().decode()))
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def require_device(*tensors):
+    """The reference's natives raise RuntimeError for non-CUDA tensors (CHECK_CUDA in
+    op/fused_bias_act.cpp, op/upfirdn2d.cpp); same contract here -- and no silent CPU path."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('expected a GPU (HIP) tensor, got device %s: this package has no CPU path' % t.device)
+        if t.dtype != torch.float32:
+            raise RuntimeError('expected float32, got %s' % t.dtype)
+
+
+def f32c(t):
+    """contiguous float32 view/copy (the reference natives force .contiguous() too)."""
+    return t if t.is_contiguous() else t.contiguous()

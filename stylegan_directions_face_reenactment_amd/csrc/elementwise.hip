@@ -1,0 +1,169 @@
+// Error plumbing + the HBM-bound pointwise pieces of the generator path:
+//   fused bias + leaky-ReLU (+ its first-order grad form), PixelNorm, latent preparation.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace sgdfr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return 2;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- fused_bias_act
+// 4 elements per thread when the bias period allows a float4 (step_b % 4 == 0 or no bias):
+// 16 B/lane coalesced, grid capped and grid-strided.
+template <bool VEC>
+__global__ __launch_bounds__(256) void fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                            const float* __restrict__ ref, float* __restrict__ y,
+                                                            int64_t n, int step_b, int size_b, int grad, float alpha,
+                                                            float scale) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (VEC) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            float4 v = reinterpret_cast<const float4*>(x)[i];
+            float b = bias ? bias[((i << 2) / step_b) % size_b] : 0.f;
+            float4 r = ref ? reinterpret_cast<const float4*>(ref)[i] : v;
+            float4 o;
+            if (grad == 0) {
+                v.x += b; v.y += b; v.z += b; v.w += b;
+                o.x = (v.x > 0.f ? v.x : v.x * alpha) * scale;
+                o.y = (v.y > 0.f ? v.y : v.y * alpha) * scale;
+                o.z = (v.z > 0.f ? v.z : v.z * alpha) * scale;
+                o.w = (v.w > 0.f ? v.w : v.w * alpha) * scale;
+            } else if (grad == 1) {
+                o.x = (r.x > 0.f ? v.x : v.x * alpha) * scale;
+                o.y = (r.y > 0.f ? v.y : v.y * alpha) * scale;
+                o.z = (r.z > 0.f ? v.z : v.z * alpha) * scale;
+                o.w = (r.w > 0.f ? v.w : v.w * alpha) * scale;
+            } else {
+                o = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            reinterpret_cast<float4*>(y)[i] = o;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            float v = x[i];
+            float b = bias ? bias[(i / step_b) % size_b] : 0.f;
+            float r = ref ? ref[i] : 0.f;
+            float o;
+            if (grad == 0) {
+                v += b;
+                o = (v > 0.f ? v : v * alpha) * scale;
+            } else if (grad == 1) {
+                o = (r > 0.f ? v : v * alpha) * scale;
+            } else {
+                o = 0.f;
+            }
+            y[i] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- pixelnorm
+// one wave per row: wave-shuffle reduction over D
+__global__ __launch_bounds__(256) void pixelnorm_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int D,
+                                                       float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float* xr = x + (int64_t)row * D;
+    float acc = 0.f;
+    for (int j = lane; j < D; j += 64) acc += xr[j] * xr[j];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    const float r = rsqrtf(acc / (float)D + eps);
+    for (int j = lane; j < D; j += 64) y[(int64_t)row * D + j] = xr[j] * r;
+}
+
+// ---------------------------------------------------------------- latent prepare
+__global__ __launch_bounds__(256) void latent_prepare_kernel(const float* __restrict__ w, int w_is_plus,
+                                                            const float* __restrict__ shift, int shift_is_plus,
+                                                            int shift_layers, const float* __restrict__ trunc, float psi,
+                                                            float* __restrict__ out, int B, int L, int D) {
+    const int64_t n = (int64_t)B * L * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % D);
+        const int l = (int)((i / D) % L);
+        const int b = (int)(i / ((int64_t)D * L));
+        float v = w_is_plus ? w[i] : w[(int64_t)b * D + j];
+        if (shift && l < shift_layers)
+            v += shift_is_plus ? shift[((int64_t)b * shift_layers + l) * D + j] : shift[(int64_t)b * D + j];
+        if (trunc) {
+            const float t = trunc[j];
+            v = t + psi * (v - t);
+        }
+        out[i] = v;
+    }
+}
+
+}  // namespace sgdfr
+
+using namespace sgdfr;
+
+extern "C" int sgdfr_abi_version(void) { return SGDFR_ABI_VERSION; }
+extern "C" const char* sgdfr_last_error(void) { return g_err; }
+
+static int grid_for(int64_t work_items, int cap = 256 * 8) {
+    int64_t g = (work_items + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+extern "C" int sgdfr_fused_bias_act_f32(const float* x, const float* bias, const float* ref, float* y, int64_t n,
+                                        int step_b, int size_b, int act, int grad, float alpha, float scale,
+                                        void* stream) {
+    SGDFR_REQUIRE(act == 3, "fused_bias_act: only act=3 (leaky relu) is implemented, got %d", act);
+    SGDFR_REQUIRE(grad >= 0 && grad <= 2, "fused_bias_act: grad must be 0,1,2, got %d", grad);
+    SGDFR_REQUIRE(n >= 0, "fused_bias_act: negative n");
+    if (n == 0) return 0;
+    SGDFR_REQUIRE(x && y, "fused_bias_act: null x/y");
+    SGDFR_REQUIRE(!bias || (step_b > 0 && size_b > 0), "fused_bias_act: bad bias geometry %d %d", step_b, size_b);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                           (ref ? reinterpret_cast<uintptr_t>(ref) : 0)) & 15) == 0;
+    const bool vec = aligned && (n % 4 == 0) && (!bias || step_b % 4 == 0);
+    if (vec)
+        hipLaunchKernelGGL(fused_bias_act_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), x, bias,
+                           ref, y, n, step_b, size_b, grad, alpha, scale);
+    else
+        hipLaunchKernelGGL(fused_bias_act_kernel<false>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, bias,
+                           ref, y, n, step_b, size_b, grad, alpha, scale);
+    return check_launch("fused_bias_act");
+}
+
+extern "C" int sgdfr_pixelnorm_f32(const float* x, float* y, int B, int D, float eps, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && D > 0, "pixelnorm: bad shape %d %d", B, D);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(x && y, "pixelnorm: null pointer");
+    hipLaunchKernelGGL(pixelnorm_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(stream), x, y, B, D, eps);
+    return check_launch("pixelnorm");
+}
+
+extern "C" int sgdfr_latent_prepare_f32(const float* w, int w_is_plus, const float* shift, int shift_is_plus,
+                                        int shift_layers, const float* trunc, float psi, float* out, int B, int L,
+                                        int D, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && L > 0 && D > 0, "latent_prepare: bad shape %d %d %d", B, L, D);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(w && out, "latent_prepare: null pointer");
+    SGDFR_REQUIRE(!shift || (shift_layers >= 0 && shift_layers <= L), "latent_prepare: shift_layers %d > L %d",
+                  shift_layers, L);
+    hipLaunchKernelGGL(latent_prepare_kernel, dim3(grid_for((int64_t)B * L * D)), dim3(256), 0, as_stream(stream), w,
+                       w_is_plus, shift, shift_is_plus, shift_layers, trunc, psi, out, B, L, D);
+    return check_launch("latent_prepare");
+}

@@ -1,0 +1,581 @@
+// Shared-weight modulated convolution for StyleGAN2 on gfx950 fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Algebra (reference formulation libs/gan/StyleGAN2/model.py:232-273):
+//     y[b,o] = d[b,o] * conv( x[b,i] * s[b,i], Wc[o,i,ky,kx] )        Wc = W / sqrt(Cin*9)
+// The reference materialises per-sample weights [B,Cout,Cin,3,3] and runs a grouped conv; here
+// the batch folds into the GEMM pixel dimension and ONE weight tensor is shared by every image:
+//     D[cout, pixel] += A[cout, k] * B[k, pixel],   k = (cin, ky, kx)
+// A (weights) and B (style-scaled inputs) are staged through LDS; the MFMA 32x32x2 k-pair is two
+// adjacent input channels at the same tap.  C/D layout puts pixels on lanes, so output rows are
+// written as 128-byte contiguous segments of NCHW.
+//
+// Input staging is im2col-free: all images live in one zero-padded "flat" space
+//     q = (img*(H+1) + row+1) * (W+1) + col+1
+// where one zero column / zero row is SHARED between neighbouring rows / images.  Every 3x3 (or,
+// for the stride-2 transposed conv, 2x2) neighbourhood of an output pixel is then a constant
+// offset in q, and the LDS tile of a block is simply a contiguous q-range [q0, q0+xlen) -- no
+// halo logic, any image size, several small images per tile.
+//
+// MODE_UP3 computes conv_transpose2d(stride 2) as its four output-parity phases in one pass:
+// super-pixel (a,b) of the (H+1)x(W+1) grid owns T[2a+py, 2b+px]; weight tap (ky,kx) feeds phase
+// (ky&1, kx&1) from input (a - (ky==2), b - (kx==2)), i.e. 9 MFMA groups per channel pair -- the
+// same 9 MACs per input pixel the transposed conv costs, with no zero-stuffed work.
+#include "common.h"
+
+namespace sgdfr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ModconvParams {
+    const float* x;
+    int64_t x_bstride;
+    const float* wp;
+    const float* s;
+    const float* d;
+    const float* noise;
+    int64_t noise_bstride;
+    const float* noise_w;
+    const float* bias;
+    float* y;
+    int B, Cin, Cout, H, W;
+    int P, R;             // padded pitch W+1, padded rows per image H+1
+    int n_pix_tiles, n_cout_tiles;
+    int xs;               // LDS floats per staged channel (multiple of 4, >= xlen)
+    int xlen;             // q-range length staged per channel
+    int64_t total_pix;    // PLAIN: B*H*W dense pixels ; UP: B*R*P super-pixels
+    int act;
+    float slope, gain;
+};
+
+constexpr int CK = 4;  // input channels per LDS stage (2 MFMA k-pairs)
+
+
+// Global -> registers for one K stage (CK input channels): inputs + styles of the block's q-range
+// and the [CK*9, NT] weight slab.  Issued BEFORE the MFMAs of the previous stage so HBM/L2 latency
+// hides under them; written to LDS after the next barrier (register-staged pipeline).
+// Branch-free per lane: zero-fill positions load a safe address and are masked at store time.
+template <int NT, int EX, int WV>
+__device__ __forceinline__ void load_stage(const ModconvParams& p, int c0, int tid, int n0, int HW, int nex,
+                                           const int64_t (&xoff)[EX], const int (&soff)[EX], float (&xr)[EX][CK],
+                                           float4 (&sr)[EX], float4 (&wr)[WV]) {
+    constexpr int WF4 = CK * 9 * NT / 4;
+#pragma unroll
+    for (int e = 0; e < EX; ++e) {
+        if (e < nex) {  // block-uniform
+            const float* xp = p.x + xoff[e] + (int64_t)c0 * HW;
+            sr[e] = *reinterpret_cast<const float4*>(p.s + soff[e] + c0);
+#pragma unroll
+            for (int c = 0; c < CK; ++c) xr[e][c] = xp[(int64_t)c * HW];
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < WV; ++v) {
+        const int f = tid + v * 256;
+        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < WF4) {
+            const int row = f / (NT / 4), col = (f - row * (NT / 4)) * 4;
+            if (n0 + col < p.Cout)
+                w4 = *reinterpret_cast<const float4*>(p.wp + ((int64_t)c0 * 9 + row) * p.Cout + n0 + col);
+        }
+        wr[v] = w4;
+    }
+}
+
+template <int NT, int EX, int WV>
+__device__ __forceinline__ void store_stage(const ModconvParams& p, int tid, int nex, unsigned okmask, float* lx,
+                                            float* lw, const float (&xr)[EX][CK], const float4 (&sr)[EX],
+                                            const float4 (&wr)[WV]) {
+    constexpr int WF4 = CK * 9 * NT / 4;
+#pragma unroll
+    for (int e = 0; e < EX; ++e) {
+        if (e < nex) {
+            const int j = tid + e * 256;
+            const bool ok = (okmask >> e) & 1u;
+            if (j < p.xlen) {
+                lx[0 * p.xs + j] = ok ? xr[e][0] * sr[e].x : 0.f;
+                lx[1 * p.xs + j] = ok ? xr[e][1] * sr[e].y : 0.f;
+                lx[2 * p.xs + j] = ok ? xr[e][2] * sr[e].z : 0.f;
+                lx[3 * p.xs + j] = ok ? xr[e][3] * sr[e].w : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < WV; ++v) {
+        const int f = tid + v * 256;
+        if (f < WF4) reinterpret_cast<float4*>(lw)[f] = wr[v];
+    }
+}
+
+template <int MODE, int WM, int WN, int MI, int NI, int EX>
+__global__ __launch_bounds__(256) void modconv_mfma_kernel(ModconvParams p) {
+    constexpr int NT = WM * MI * 32;
+    constexpr int PT = WN * NI * 32;
+    constexpr int PH = (MODE == SGDFR_MODE_UP3) ? 4 : 1;
+    constexpr int WROWS = CK * 9;
+    constexpr int WF4 = WROWS * NT / 4;            // float4 per weight stage
+    constexpr int WV = (WF4 + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves per block");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* lx = smem;
+    float* lw = smem + CK * p.xs;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int HW = p.H * p.W;
+    const int RP = p.R * p.P;
+
+    // XCD-aware (bijective) remap: the blocks resident on one XCD walk neighbouring pixel tiles of
+    // one cout tile, so its weight slice and the overlapping input rows stay in that XCD's L2.
+    int lid;
+    {
+        const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int ct = lid / p.n_pix_tiles, pt = lid - ct * p.n_pix_tiles;
+    const int n0 = ct * NT;
+    const int64_t p0 = (int64_t)pt * PT;
+
+    // ---- tile origin in the padded flat space
+    int64_t q0;
+    if (MODE == SGDFR_MODE_PLAIN3) {
+        const int64_t img = p0 / HW;
+        const int rem = (int)(p0 - img * HW);
+        const int a = rem / p.W, b = rem - a * p.W;
+        q0 = (img * p.R + a + 1) * p.P + b + 1 - p.P - 1;
+    } else {
+        q0 = p0;
+    }
+
+    // ---- per-lane B-fragment offsets (pixel -> position inside the staged q-range)
+    int boff[NI];
+    int64_t pixv[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        int64_t pix = p0 + (wn * NI + ni) * 32 + l31;
+        pixv[ni] = pix;
+        if (pix >= p.total_pix) pix = p.total_pix - 1;
+        int64_t qb;
+        if (MODE == SGDFR_MODE_PLAIN3) {
+            const int64_t img = pix / HW;
+            const int rem = (int)(pix - img * HW);
+            const int a = rem / p.W, b = rem - a * p.W;
+            qb = (img * p.R + a + 1) * p.P + b + 1;
+        } else {
+            qb = pix;
+        }
+        boff[ni] = (int)(qb - q0) + hi * p.xs;
+    }
+
+    // ---- staging descriptors (fixed for the whole K loop): element offsets into x / s; positions that
+    // are padding (or beyond the batch) point at offset 0 and are zeroed through okmask
+    int64_t xoff[EX];
+    int soff[EX];
+    unsigned okmask = 0;
+    const int nex = (p.xlen + 255) >> 8;
+#pragma unroll
+    for (int e = 0; e < EX; ++e) {
+        const int j = tid + e * 256;
+        const int64_t q = q0 + j;
+        const int64_t pir = q / p.P;
+        const int pc = (int)(q - pir * p.P);
+        const int64_t img = pir / p.R;
+        const int pr = (int)(pir - img * p.R);
+        const bool ok = (j < p.xlen) && pc >= 1 && pr >= 1 && img < p.B;
+        xoff[e] = ok ? img * p.x_bstride + (int64_t)(pr - 1) * p.W + (pc - 1) : 0;
+        soff[e] = ok ? (int)img * p.Cin : 0;
+        okmask |= ok ? (1u << e) : 0u;
+    }
+
+    f32x16 acc[PH][MI][NI];
+#pragma unroll
+    for (int ph = 0; ph < PH; ++ph)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ph][mi][ni][r] = 0.f;
+
+    float xr[EX][CK];
+    float4 sr[EX];
+    float4 wr[WV];
+
+    // tap offsets inside the q-range (uniform)
+    int tapoff[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int ky = k / 3, kx = k - ky * 3;
+        if (MODE == SGDFR_MODE_PLAIN3)
+            tapoff[k] = (ky - 1) * p.P + (kx - 1);
+        else
+            tapoff[k] = (ky == 2 ? 0 : p.P) + (kx == 2 ? 0 : 1);
+    }
+    const int aoff = wm * MI * 32 + l31;
+
+    const int nstage = p.Cin / CK;
+    load_stage<NT, EX, WV>(p, 0, tid, n0, HW, nex, xoff, soff, xr, sr, wr);
+    for (int st = 0; st < nstage; ++st) {
+        __syncthreads();  // previous stage's fragment reads are done
+        store_stage<NT, EX, WV>(p, tid, nex, okmask, lx, lw, xr, sr, wr);
+        __syncthreads();
+        if (st + 1 < nstage)  // in flight under the MFMAs below
+            load_stage<NT, EX, WV>(p, (st + 1) * CK, tid, n0, HW, nex, xoff, soff, xr, sr, wr);
+#pragma unroll
+        for (int cp = 0; cp < CK / 2; ++cp) {
+            const float* lxc = lx + (cp * 2) * p.xs;
+            const float* lwc = lw + ((cp * 2 + hi) * 9) * NT + aoff;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int ph = (MODE == SGDFR_MODE_UP3) ? (2 * ((k / 3) & 1) + ((k % 3) & 1)) : 0;
+                float a[MI], b[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) a[mi] = lwc[k * NT + mi * 32];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) b[ni] = lxc[boff[ni] + tapoff[k]];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[ph][mi][ni], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue.  C/D layout of 32x32: column (pixel) = lane&31, row (cout) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (MODE == SGDFR_MODE_PLAIN3) {
+        const float nw = (p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int64_t pix = pixv[ni];
+            if (pix >= p.total_pix) continue;
+            const int64_t img = pix / HW;
+            const int rem = (int)(pix - img * HW);
+            const float nz = p.noise ? nw * p.noise[img * p.noise_bstride + rem] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = n0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (co < p.Cout) {
+                        float v = acc[0][mi][ni][r];
+                        if (p.d) v *= p.d[img * p.Cout + co];
+                        v += nz;
+                        if (p.bias) v += p.bias[co];
+                        if (p.act) v = lrelu_gain(v, p.slope, p.gain);
+                        p.y[(img * p.Cout + co) * HW + rem] = v;
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int64_t pix = pixv[ni];
+            if (pix >= p.total_pix) continue;
+            const int64_t img = pix / RP;
+            const int rem = (int)(pix - img * RP);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = n0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (co < p.Cout) {
+                        const float dv = p.d ? p.d[img * p.Cout + co] : 1.f;
+                        float* dst = p.y + ((img * p.Cout + co) * 4) * RP + rem;
+#pragma unroll
+                        for (int ph = 0; ph < PH; ++ph) dst[(int64_t)ph * RP] = acc[ph][mi][ni][r] * dv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------- odd-shape path
+// Channel counts that are not multiples of 4 never occur in the generator (512..16 channels) but the
+// ModulatedConv2d API accepts them: one thread per output element, same packed weights, same output
+// layouts as the MFMA kernel.
+__global__ __launch_bounds__(256) void modconv_direct_kernel(ModconvParams p, int mode) {
+    const int HW = p.H * p.W, RP = p.R * p.P;
+    const int64_t per_img = (mode == SGDFR_MODE_PLAIN3) ? (int64_t)p.Cout * HW : (int64_t)p.Cout * 4 * RP;
+    const int64_t total = per_img * p.B;
+    const float nw = (p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t img = idx / per_img;
+        const int64_t r = idx - img * per_img;
+        const float* xb = p.x + img * p.x_bstride;
+        const float* sb = p.s + img * p.Cin;
+        float acc = 0.f;
+        if (mode == SGDFR_MODE_PLAIN3) {
+            const int co = (int)(r / HW), rem = (int)(r - (int64_t)co * HW);
+            const int a = rem / p.W, b = rem - a * p.W;
+            for (int i = 0; i < p.Cin; ++i) {
+                float part = 0.f;
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = a + ky - 1;
+                    if (yy < 0 || yy >= p.H) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = b + kx - 1;
+                        if (xx < 0 || xx >= p.W) continue;
+                        part = fmaf(xb[(int64_t)i * HW + yy * p.W + xx], p.wp[((int64_t)i * 9 + ky * 3 + kx) * p.Cout + co], part);
+                    }
+                }
+                acc = fmaf(part, sb[i], acc);
+            }
+            float v = acc * (p.d ? p.d[img * p.Cout + co] : 1.f);
+            if (p.noise) v = fmaf(nw, p.noise[img * p.noise_bstride + rem], v);
+            if (p.bias) v += p.bias[co];
+            if (p.act) v = lrelu_gain(v, p.slope, p.gain);
+            p.y[idx] = v;
+        } else {
+            const int co = (int)(r / (4 * RP));
+            const int r2 = (int)(r - (int64_t)co * 4 * RP);
+            const int ph = r2 / RP, r3 = r2 - ph * RP;
+            const int a = r3 / p.P, b = r3 - a * p.P;
+            const int oy = 2 * a + (ph >> 1), ox = 2 * b + (ph & 1);
+            if (oy <= 2 * p.H && ox <= 2 * p.W) {
+                for (int i = 0; i < p.Cin; ++i) {
+                    float part = 0.f;
+                    for (int ky = (oy & 1); ky < 3; ky += 2) {
+                        const int yy = (oy - ky) >> 1;
+                        if (oy - ky < 0 || yy >= p.H) continue;
+                        for (int kx = (ox & 1); kx < 3; kx += 2) {
+                            const int xx = (ox - kx) >> 1;
+                            if (ox - kx < 0 || xx >= p.W) continue;
+                            part = fmaf(xb[(int64_t)i * HW + yy * p.W + xx], p.wp[((int64_t)i * 9 + ky * 3 + kx) * p.Cout + co], part);
+                        }
+                    }
+                    acc = fmaf(part, sb[i], acc);
+                }
+                acc *= (p.d ? p.d[img * p.Cout + co] : 1.f);
+            }
+            p.y[idx] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- prepack
+// w [Cout,Cin,KK] -> wp [Cin,KK,Cout] * scale ; q [Cout,Cin] = sum_t (w*scale)^2
+__global__ __launch_bounds__(256) void prepack_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                                     float* __restrict__ q, int Cout, int Cin, int KK, float scale) {
+    const int64_t n = (int64_t)Cout * Cin;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(idx % Cout);  // o fastest: coalesced wp writes
+        const int i = (int)(idx / Cout);
+        const float* src = w + ((int64_t)o * Cin + i) * KK;
+        float ss = 0.f;
+        for (int t = 0; t < KK; ++t) {
+            const float v = src[t] * scale;
+            wp[((int64_t)i * KK + t) * Cout + o] = v;
+            ss = fmaf(v, v, ss);
+        }
+        if (q) q[(int64_t)o * Cin + i] = ss;
+    }
+}
+
+// ---------------------------------------------------------------- ToRGB
+// 1x1 modulated conv to 3 channels without demodulation + bias + FIR-upsampled skip.
+// HBM-bound: x is read exactly once (16 B/lane when V=4).  A block owns QB pixel groups of one
+// image; its 256/QB channel groups split Cin and are summed through LDS.
+template <int V>
+__global__ __launch_bounds__(256) void torgb_kernel(const float* __restrict__ x, const float* __restrict__ w_rgb,
+                                                   const float* __restrict__ s, const float* __restrict__ bias,
+                                                   const float* __restrict__ skip, const float* __restrict__ fir,
+                                                   float* __restrict__ y, int B, int Cin, int H, int W, int QB,
+                                                   int qb_shift, float scale) {
+    __shared__ float red[256 * 3 * V];
+    __shared__ float kf[16];
+    const int tid = threadIdx.x;
+    if (tid < 16) kf[tid] = fir ? fir[15 - tid] : 0.f;  // flipped taps
+    const int HW = H * W;
+    const int np = (HW + V - 1) / V;
+    const int qi = tid & (QB - 1), cg = tid >> qb_shift, CG = 256 >> qb_shift;
+    const int grp = blockIdx.x * QB + qi;
+    const int b = blockIdx.y;
+    const bool active = grp < np;
+    float acc[3][V];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[j][v] = 0.f;
+    if (active) {
+        const float* xb = x + (int64_t)b * Cin * HW + (int64_t)grp * V;
+        const float* sb = s + (int64_t)b * Cin;
+#pragma unroll 4
+        for (int i = cg; i < Cin; i += CG) {
+            const float sv = sb[i] * scale;
+            const float c0 = w_rgb[i] * sv, c1 = w_rgb[Cin + i] * sv, c2 = w_rgb[2 * Cin + i] * sv;
+            float xv[V];
+            if (V == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(xb + (int64_t)i * HW);
+                xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            } else {
+                xv[0] = xb[(int64_t)i * HW];
+            }
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                acc[0][v] = fmaf(c0, xv[v], acc[0][v]);
+                acc[1][v] = fmaf(c1, xv[v], acc[1][v]);
+                acc[2][v] = fmaf(c2, xv[v], acc[2][v]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int v = 0; v < V; ++v) red[(j * V + v) * 256 + tid] = acc[j][v];
+    __syncthreads();
+    if (cg == 0 && active) {
+        const int Hs = H >> 1, Ws = W >> 1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float out[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                float t = 0.f;
+                for (int g = 0; g < CG; ++g) t += red[(j * V + v) * 256 + g * QB + qi];
+                t += bias ? bias[j] : 0.f;
+                if (skip) {
+                    const int pix = grp * V + v;
+                    const int oy = pix / W, ox = pix - oy * W;
+                    const float* sp = skip + ((int64_t)b * 3 + j) * Hs * Ws;
+                    // upfirdn2d(up=2, pad=(2,1)): sample (m,n) of skip sits at padded position (2m+2, 2n+2)
+#pragma unroll
+                    for (int ky = 0; ky < 4; ++ky) {
+                        const int uy = oy + ky - 2;
+                        if (uy < 0 || (uy & 1) || (uy >> 1) >= Hs) continue;
+#pragma unroll
+                        for (int kx = 0; kx < 4; ++kx) {
+                            const int ux = ox + kx - 2;
+                            if (ux < 0 || (ux & 1) || (ux >> 1) >= Ws) continue;
+                            t = fmaf(sp[(uy >> 1) * Ws + (ux >> 1)], kf[ky * 4 + kx], t);
+                        }
+                    }
+                }
+                out[v] = t;
+            }
+            float* dst = y + ((int64_t)b * 3 + j) * HW + (int64_t)grp * V;
+            if (V == 4) {
+                *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+            } else {
+                dst[0] = out[0];
+            }
+        }
+    }
+}
+
+template <int MODE, int WM, int WN, int MI, int NI, int EX>
+static int launch_modconv(ModconvParams& p, hipStream_t stream) {
+    constexpr int NT = WM * MI * 32, PT = WN * NI * 32;
+    p.n_cout_tiles = (p.Cout + NT - 1) / NT;
+    p.n_pix_tiles = (int)((p.total_pix + PT - 1) / PT);
+    // q-range a tile of PT consecutive outputs can touch (see file header)
+    int xlen;
+    if (MODE == SGDFR_MODE_PLAIN3) {
+        // tiles start at multiples of PT: count the row / image boundaries a tile can straddle
+        const int HW = p.H * p.W;
+        const int rows_crossed = (p.W % PT == 0) ? 0 : ((PT % p.W == 0) ? PT / p.W - 1 : (PT - 1) / p.W + 1);
+        const int imgs_crossed = (HW % PT == 0) ? 0 : ((PT % HW == 0) ? PT / HW - 1 : (PT - 1) / HW + 1);
+        xlen = (PT - 1) + rows_crossed + imgs_crossed * p.P + 2 * p.P + 3;
+    } else {
+        xlen = PT + p.P + 2;
+    }
+    SGDFR_REQUIRE(xlen <= EX * 256, "modconv: staged range %d exceeds %d (W=%d too wide for this tile)", xlen, EX * 256,
+                  p.W);
+    p.xlen = xlen;
+    p.xs = (xlen + 3) & ~3;
+    const size_t lds = (size_t)(CK * p.xs + CK * 9 * NT) * sizeof(float);
+    const int64_t nblk = (int64_t)p.n_cout_tiles * p.n_pix_tiles;
+    SGDFR_REQUIRE(nblk < (1ll << 31), "modconv: grid too large");
+    hipLaunchKernelGGL((modconv_mfma_kernel<MODE, WM, WN, MI, NI, EX>), dim3((unsigned)nblk), dim3(256), lds, stream, p);
+    return check_launch("modconv2d_fwd");
+}
+
+}  // namespace sgdfr
+
+using namespace sgdfr;
+
+extern "C" int sgdfr_modconv_prepack_f32(const float* weight, float* wp, float* q, int Cout, int Cin, int k,
+                                         void* stream) {
+    SGDFR_REQUIRE(Cout > 0 && Cin > 0 && k > 0, "prepack: bad shape %d %d %d", Cout, Cin, k);
+    SGDFR_REQUIRE(weight && wp, "prepack: null pointer");
+    const int64_t n = (int64_t)Cout * Cin;
+    int64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(prepack_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), weight, wp, q, Cout, Cin, k * k,
+                       1.0f / sqrtf((float)Cin * k * k));
+    return check_launch("modconv_prepack");
+}
+
+extern "C" int sgdfr_modconv2d_fwd_f32(const float* x, int64_t x_bstride, const float* wp, const float* s,
+                                       const float* d, const float* noise, int64_t noise_bstride, const float* noise_w,
+                                       const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int mode,
+                                       int act, float slope, float gain, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "modconv: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B,
+                  Cin, Cout, H, W);
+    SGDFR_REQUIRE(mode == SGDFR_MODE_PLAIN3 || mode == SGDFR_MODE_UP3, "modconv: unknown mode %d", mode);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(x && wp && s && y, "modconv: null pointer");
+    SGDFR_REQUIRE(!noise || noise_w, "modconv: noise without noise_w");
+    SGDFR_REQUIRE(x_bstride == 0 || x_bstride >= (int64_t)Cin * H * W, "modconv: x_bstride too small");
+    ModconvParams p{};
+    p.x = x; p.x_bstride = x_bstride; p.wp = wp; p.s = s; p.d = d;
+    p.noise = noise; p.noise_bstride = noise_bstride; p.noise_w = noise_w; p.bias = bias; p.y = y;
+    p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.P = W + 1; p.R = H + 1;
+    const bool mfma_ok = (Cin % 4 == 0) && (Cout % 4 == 0) &&
+                         (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(wp)) & 15) == 0);
+    p.act = act; p.slope = slope; p.gain = gain;
+    hipStream_t st = as_stream(stream);
+    if (!mfma_ok) {
+        const int64_t total = (mode == SGDFR_MODE_PLAIN3) ? (int64_t)B * Cout * H * W
+                                                          : (int64_t)B * Cout * 4 * (H + 1) * (W + 1);
+        int64_t g = (total + 255) / 256;
+        if (g > 256 * 16) g = 256 * 16;
+        hipLaunchKernelGGL(modconv_direct_kernel, dim3((int)g), dim3(256), 0, st, p, mode);
+        return check_launch("modconv2d_fwd(direct)");
+    }
+    if (mode == SGDFR_MODE_PLAIN3) {
+        p.total_pix = (int64_t)B * H * W;
+        const int64_t big_blocks = ((p.total_pix + 127) / 128) * ((Cout + 127) / 128);
+        if (Cout % 128 == 0 && big_blocks >= 512) return launch_modconv<SGDFR_MODE_PLAIN3, 2, 2, 2, 2, 3>(p, st);
+        if (Cout % 64 == 0 && p.total_pix >= 128 * 512)
+            return launch_modconv<SGDFR_MODE_PLAIN3, 2, 2, 1, 2, 3>(p, st);                       // NT 64, PT 128
+        if (Cout > 32) return launch_modconv<SGDFR_MODE_PLAIN3, 2, 2, 1, 1, 3>(p, st);            // NT 64, PT 64
+        return launch_modconv<SGDFR_MODE_PLAIN3, 1, 4, 1, 1, 3>(p, st);                           // NT 32, PT 128
+    } else {
+        p.total_pix = (int64_t)B * (H + 1) * (W + 1);
+        const int64_t big_blocks = ((p.total_pix + 63) / 64) * ((Cout + 127) / 128);
+        if (Cout % 128 == 0 && big_blocks >= 512) return launch_modconv<SGDFR_MODE_UP3, 4, 1, 1, 2, 2>(p, st);  // NT 128, PT 64
+        if (Cout > 32) return launch_modconv<SGDFR_MODE_UP3, 2, 2, 1, 1, 2>(p, st);               // NT 64, PT 64
+        return launch_modconv<SGDFR_MODE_UP3, 1, 4, 1, 1, 2>(p, st);                              // NT 32, PT 128
+    }
+}
+
+extern "C" int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, const float* bias,
+                                   const float* skip, const float* fir, float* y, int B, int Cin, int H, int W,
+                                   void* stream) {
+    SGDFR_REQUIRE(B >= 0 && Cin > 0 && H > 0 && W > 0, "torgb: bad shape %d %d %d %d", B, Cin, H, W);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(x && w_rgb && s && y, "torgb: null pointer");
+    SGDFR_REQUIRE(!skip || (fir && H % 2 == 0 && W % 2 == 0), "torgb: skip needs fir taps and even H, W");
+    const int HW = H * W;
+    const bool vec = (HW % 4 == 0) && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
+    const int V = vec ? 4 : 1;
+    const int np = (HW + V - 1) / V;
+    int QB = 4, sh = 2;
+    while (QB < 64 && QB < np) { QB <<= 1; ++sh; }
+    dim3 grid((np + QB - 1) / QB, B);
+    const float scale = 1.0f / sqrtf((float)Cin);
+    if (vec)
+        hipLaunchKernelGGL(torgb_kernel<4>, grid, dim3(256), 0, as_stream(stream), x, w_rgb, s, bias, skip, fir, y, B,
+                           Cin, H, W, QB, sh, scale);
+    else
+        hipLaunchKernelGGL(torgb_kernel<1>, grid, dim3(256), 0, as_stream(stream), x, w_rgb, s, bias, skip, fir, y, B,
+                           Cin, H, W, QB, sh, scale);
+    return check_launch("torgb_fwd");
+}

@@ -1,0 +1,171 @@
+// upfirdn2d (zero-stuff up, pad/crop, 2-D FIR with the flipped kernel, decimate) and the
+// blur + noise + bias + leaky-ReLU pass that finishes an upsampling modulated conv.
+// Both are HBM-bound: every output is written once, inputs are read once from HBM and the
+// FIR overlap is served by L1/L2 (generic op) or by registers across the 2x2 output quad (blur).
+#include "common.h"
+
+namespace sgdfr {
+
+constexpr int kMaxTaps = 16;  // per axis
+
+struct UpfirdnParams {
+    const float* x;
+    const float* k;
+    float* y;
+    int major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, out_h, out_w;
+};
+
+// Generic path: one thread per output element (minor fastest, then x: coalesced stores), polyphase
+// tap stepping so only the kh/up * kw/up taps that hit real samples are visited.
+// The FIR taps live in LDS (broadcast reads).
+__global__ __launch_bounds__(256) void upfirdn2d_kernel(UpfirdnParams p) {
+    __shared__ float sk[kMaxTaps * kMaxTaps];
+    for (int i = threadIdx.x; i < p.kh * p.kw; i += blockDim.x) sk[i] = p.k[i];
+    __syncthreads();
+    const int64_t total = (int64_t)p.major * p.out_h * p.out_w * p.minor;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int mi = (int)(idx % p.minor);
+        int64_t r = idx / p.minor;
+        const int ox = (int)(r % p.out_w);
+        r /= p.out_w;
+        const int oy = (int)(r % p.out_h);
+        const int mj = (int)(r / p.out_h);
+        // position of tap (ky,kx) in up-sampled coordinates: uy = oy*down_y + ky - pad_y0, must be a multiple of up_y
+        const int by = oy * p.down_y - p.pad_y0, bx = ox * p.down_x - p.pad_x0;
+        int ky0 = (-by) % p.up_y;
+        if (ky0 < 0) ky0 += p.up_y;
+        int kx0 = (-bx) % p.up_x;
+        if (kx0 < 0) kx0 += p.up_x;
+        const float* xp = p.x + (int64_t)mj * p.in_h * p.in_w * p.minor + mi;
+        float acc = 0.f;
+        for (int ky = ky0; ky < p.kh; ky += p.up_y) {
+            const int uy = by + ky;
+            if (uy < 0) continue;
+            const int iy = uy / p.up_y;
+            if (iy >= p.in_h) break;
+            for (int kx = kx0; kx < p.kw; kx += p.up_x) {
+                const int ux = bx + kx;
+                if (ux < 0) continue;
+                const int ix = ux / p.up_x;
+                if (ix >= p.in_w) break;
+                acc = fmaf(xp[((int64_t)iy * p.in_w + ix) * p.minor], sk[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)], acc);
+            }
+        }
+        p.y[idx] = acc;
+    }
+}
+
+// Blur after the stride-2 transposed conv, reading the parity planes written by MODE_UP3.
+//   t: [planes, 4, H+1, W+1], plane ph = 2*(row&1)+(col&1) holds T[row,col] at [row>>1, col>>1]
+//   y: [planes, 2H, 2W];  y[oy,ox] = sum_{ky,kx} Tpad[oy+ky, ox+kx] * K[3-ky][3-kx],  Tpad[i,j] = T[i-1,j-1]
+// One thread per 2x2 output quad: a 5x5 window of T (25 coalesced dword loads) feeds 4 outputs
+// (two float2 stores).  Epilogue: + noise_w*noise + bias[c], leaky-ReLU * gain.
+__global__ __launch_bounds__(256) void blur_bias_act_kernel(const float* __restrict__ t, const float* __restrict__ fir,
+                                                           const float* __restrict__ noise, int64_t noise_bstride,
+                                                           const float* __restrict__ noise_w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                           int C, int H, int W, int act, float slope, float gain) {
+    __shared__ float kf[16];
+    if (threadIdx.x < 16) kf[threadIdx.x] = fir[15 - threadIdx.x];  // flipped: kf[ky*4+kx] = K[3-ky][3-kx]
+    __syncthreads();
+    const int GW = W + 1, GH = H + 1;
+    const int64_t plane_t = (int64_t)4 * GH * GW;
+    const int64_t quads = (int64_t)B * C * H * W;
+    const float nw = (noise && noise_w) ? noise_w[0] : 0.f;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < quads;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx % W);
+        int64_t r = idx / W;
+        const int m = (int)(r % H);
+        const int64_t pl = r / H;  // b*C + c
+        const float* tp = t + pl * plane_t;
+        float win[5][5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int tr = 2 * m - 1 + u;  // -1 .. 2H+1 ; rows 2H+1 are stored zeros of the odd planes
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                const int tc = 2 * n - 1 + v;
+                float val = 0.f;
+                if (tr >= 0 && tc >= 0)
+                    val = tp[((int64_t)(2 * (tr & 1) + (tc & 1)) * GH + (tr >> 1)) * GW + (tc >> 1)];
+                win[u][v] = val;
+            }
+        }
+        const int c = (int)(pl % C);
+        const int b = (int)(pl / C);
+        const float bv = bias ? bias[c] : 0.f;
+        float o[2][2];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                float acc = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) acc = fmaf(win[rr + ky][cc + kx], kf[ky * 4 + kx], acc);
+                o[rr][cc] = acc;
+            }
+        const int OW = 2 * W;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int oy = 2 * m + rr;
+            float2 out;
+            float v0 = o[rr][0] + bv, v1 = o[rr][1] + bv;
+            if (noise) {
+                const float* np = noise + (int64_t)b * noise_bstride + (int64_t)oy * OW + 2 * n;
+                v0 = fmaf(nw, np[0], v0);
+                v1 = fmaf(nw, np[1], v1);
+            }
+            if (act) {
+                v0 = lrelu_gain(v0, slope, gain);
+                v1 = lrelu_gain(v1, slope, gain);
+            }
+            out.x = v0;
+            out.y = v1;
+            *reinterpret_cast<float2*>(y + (pl * 2 * H + oy) * OW + 2 * n) = out;
+        }
+    }
+}
+
+}  // namespace sgdfr
+
+using namespace sgdfr;
+
+extern "C" int sgdfr_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int in_h, int in_w, int minor,
+                                   int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                                   int pad_y0, int pad_y1, void* stream) {
+    SGDFR_REQUIRE(major >= 0 && in_h > 0 && in_w > 0 && minor > 0, "upfirdn2d: bad input shape [%d,%d,%d,%d]", major,
+                  in_h, in_w, minor);
+    SGDFR_REQUIRE(kh > 0 && kw > 0 && kh <= kMaxTaps && kw <= kMaxTaps, "upfirdn2d: kernel %dx%d unsupported (max %d)",
+                  kh, kw, kMaxTaps);
+    SGDFR_REQUIRE(up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0, "upfirdn2d: up/down factors must be positive");
+    const int out_h = (in_h * up_y + pad_y0 + pad_y1 - kh + down_y) / down_y;
+    const int out_w = (in_w * up_x + pad_x0 + pad_x1 - kw + down_x) / down_x;
+    SGDFR_REQUIRE(out_h > 0 && out_w > 0, "upfirdn2d: empty output %dx%d", out_h, out_w);
+    if (major == 0) return 0;
+    SGDFR_REQUIRE(x && k && y, "upfirdn2d: null pointer");
+    UpfirdnParams p{x, k, y, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, out_h, out_w};
+    const int64_t total = (int64_t)major * out_h * out_w * minor;
+    int64_t g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    hipLaunchKernelGGL(upfirdn2d_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), p);
+    return check_launch("upfirdn2d");
+}
+
+extern "C" int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const float* noise, int64_t noise_bstride,
+                                       const float* noise_w, const float* bias, float* y, int B, int C, int H, int W,
+                                       int act, float slope, float gain, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0, "blur_bias_act: bad shape %d %d %d %d", B, C, H, W);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(t && fir && y, "blur_bias_act: null pointer");
+    SGDFR_REQUIRE(!noise || noise_w, "blur_bias_act: noise without noise_w");
+    const int64_t quads = (int64_t)B * C * H * W;
+    int64_t g = (quads + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    hipLaunchKernelGGL(blur_bias_act_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), t, fir, noise,
+                       noise_bstride, noise_w, bias, y, B, C, H, W, act, slope, gain);
+    return check_launch("blur_bias_act");
+}

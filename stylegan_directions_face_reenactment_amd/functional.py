@@ -1,0 +1,228 @@
+"""Functional host layer over the C ABI (include/sgdfr.h): allocation, shape checks, stream.
+
+Each function is one (or a fixed short sequence of) native launch(es) on torch's current HIP stream;
+nothing here computes with torch ops.  Reference lines each function stands for are cited inline
+(paths relative to the reference's libs/gan/StyleGAN2/).
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import _native as N
+
+SQRT2 = 2 ** 0.5
+
+
+# ------------------------------------------------------------------ autograd guard
+
+class _BackwardNotBuilt(Function):
+    """Marks a forward-only result: usable outside no_grad(), fails loudly if differentiated."""
+
+    @staticmethod
+    def forward(ctx, out, what, *deps):
+        ctx.what = what
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise NotImplementedError(
+            '%s: the HIP backward of this op (SURVEY.md §8 a17) is not built yet; there is no PyTorch '
+            'fallback on purpose. Run the generator under torch.no_grad().' % ctx.what)
+
+
+def forward_only(out, what, *deps):
+    if torch.is_grad_enabled():
+        live = [t for t in deps if isinstance(t, torch.Tensor) and t.requires_grad]
+        if live:
+            return _BackwardNotBuilt.apply(out, what, *live)
+    return out
+
+
+# ------------------------------------------------------------------ small dense ops
+
+def pixel_norm(x, eps=1e-8):
+    """model.py:11-16."""
+    N.require_device(x)
+    x2 = N.f32c(x).reshape(x.shape[0], -1) if x.ndim != 2 else N.f32c(x)
+    y = torch.empty_like(x2)
+    N.call('sgdfr_pixelnorm_f32', N.ptr(x2), N.ptr(y), x2.shape[0], x2.shape[1], float(eps), N.stream())
+    return forward_only(y.view(x.shape), 'pixel_norm', x)
+
+
+def linear(x, weight, bias=None, wscale=1.0, bscale=1.0, lrelu=False, slope=0.2, gain=SQRT2):
+    """act((x @ weight.T) * wscale + bias * bscale): EqualLinear (model.py:148-157) and nn.Linear
+    (libs/models/direction_matrix.py:44).  x [..., K] (last dim contiguous), weight [N, K]."""
+    N.require_device(x, weight, bias)
+    K = weight.shape[1]
+    if x.shape[-1] != K:
+        raise RuntimeError('linear: input has %d features, weight expects %d' % (x.shape[-1], K))
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < K):
+        x2 = x2.contiguous()
+    ldx = x2.stride(0) if x2.shape[0] > 1 else K
+    w = N.f32c(weight)
+    b = N.f32c(bias) if bias is not None else None
+    M, Nn = x2.shape[0], w.shape[0]
+    y = torch.empty(M, Nn, device=x.device, dtype=torch.float32)
+    N.call('sgdfr_linear_f32', N.ptr(x2), ldx, N.ptr(w), N.ptr(b), N.ptr(y), Nn, M, Nn, K, float(wscale),
+           float(bscale), N.ACT_LRELU if lrelu else N.ACT_NONE, float(slope), float(gain), N.stream())
+    return y.view(*x.shape[:-1], Nn)
+
+
+def latent_prepare(w, n_latent, shift=None, shift_layers=0, trunc=None, psi=1.0):
+    """W / W+ -> [B, n_latent, D] with optional direction shift and truncation in one pass
+    (libs/utilities/generic.py:116-135 followed by model.py:494-508)."""
+    N.require_device(w, shift, trunc)
+    w = N.f32c(w)
+    B, D = w.shape[0], w.shape[-1]
+    w_plus = w.ndim == 3
+    if w_plus and w.shape[1] != n_latent:
+        raise RuntimeError('W+ code has %d rows, generator needs %d' % (w.shape[1], n_latent))
+    shift_plus = 0
+    if shift is not None:
+        shift = N.f32c(shift)
+        shift_plus = int(shift.ndim == 3)
+        if shift_plus:
+            shift_layers = shift.shape[1]
+        if shift.shape[0] != B or shift.shape[-1] != D:
+            raise RuntimeError('shift shape %s does not match latent %s' % (tuple(shift.shape), tuple(w.shape)))
+    if trunc is not None:
+        trunc = N.f32c(trunc).reshape(-1)
+        if trunc.numel() != D:
+            raise RuntimeError('truncation latent must have %d elements' % D)
+    out = torch.empty(B, n_latent, D, device=w.device, dtype=torch.float32)
+    N.call('sgdfr_latent_prepare_f32', N.ptr(w), int(w_plus), N.ptr(shift), shift_plus, int(shift_layers),
+           N.ptr(trunc), float(psi), N.ptr(out), B, n_latent, D, N.stream())
+    return out
+
+
+# ------------------------------------------------------------------ modulated conv
+
+def prepack(weight):
+    """weight [1, Cout, Cin, k, k] (model.py:218-220) -> (wp [Cin, k*k, Cout] scaled, q [Cout, Cin])."""
+    N.require_device(weight)
+    w = N.f32c(weight)
+    _, cout, cin, k, _ = w.shape
+    wp = torch.empty(cin, k * k, cout, device=w.device, dtype=torch.float32)
+    q = torch.empty(cout, cin, device=w.device, dtype=torch.float32)
+    N.call('sgdfr_modconv_prepack_f32', N.ptr(w), N.ptr(wp), N.ptr(q), cout, cin, k, N.stream())
+    return wp, q
+
+
+def style_demod(style, mod_weight, mod_bias, q=None, cout=0):
+    """s = modulation(style) (model.py:235) and, when q is given, d = rsqrt(sum (scale W s)^2 + 1e-8)
+    (model.py:238-239) in the shared-weight form sum_i s^2 q[o,i]."""
+    N.require_device(style, mod_weight, mod_bias, q)
+    B, D = style.shape
+    if style.stride(1) != 1:
+        style = style.contiguous()
+    ld = style.stride(0) if B > 1 else D
+    cin = mod_weight.shape[0]
+    s = torch.empty(B, cin, device=style.device, dtype=torch.float32)
+    d = torch.empty(B, cout, device=style.device, dtype=torch.float32) if q is not None else None
+    N.call('sgdfr_style_demod_f32', N.ptr(style), ld, N.ptr(N.f32c(mod_weight)), N.ptr(N.f32c(mod_bias)),
+           N.ptr(q), N.ptr(s), N.ptr(d), B, D, cin, cout, N.stream())
+    return s, d
+
+
+def _noise_args(noise, B, H, W):
+    """(tensor, batch stride) for a [1,1,H,W] shared or [B,1,H,W] per-sample noise map."""
+    if noise is None:
+        return None, 0
+    N.require_device(noise)
+    noise = N.f32c(noise)
+    if noise.numel() == H * W:
+        return noise, 0
+    if noise.numel() == B * H * W:
+        return noise, H * W
+    raise RuntimeError('noise of shape %s does not broadcast to [%d,1,%d,%d]' % (tuple(noise.shape), B, H, W))
+
+
+def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_weight=None, bias=None,
+               activate=False, slope=0.2, gain=SQRT2, batch=None):
+    """Shared-weight modulated 3x3 conv (model.py:232-273) with the StyledConv tail fused in
+    (noise model.py:287, bias + leaky-ReLU op/fused_act.py:81-86).
+
+    x [B,Cin,H,W], or a [1,Cin,H,W] constant broadcast over `batch` images (ConstantInput,
+    model.py:296-300, without materialising the repeat).  upsample=True runs the stride-2 transposed
+    conv into parity planes and finishes with the 4x4 FIR pass (model.py:246-257)."""
+    N.require_device(x, wp, s, d, bias, noise_weight, fir)
+    x = N.f32c(x)
+    B = s.shape[0] if batch is None else batch
+    _, cin, H, W = x.shape
+    xb = 0 if (x.shape[0] == 1 and B != 1) else cin * H * W
+    if x.shape[0] not in (1, B):
+        raise RuntimeError('input batch %d does not match styles %d' % (x.shape[0], B))
+    st = N.stream()
+    if not upsample:
+        nz, nzb = _noise_args(noise, B, H, W)
+        y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+        N.call('sgdfr_modconv2d_fwd_f32', N.ptr(x), xb, N.ptr(wp), N.ptr(s), N.ptr(d), N.ptr(nz), nzb,
+               N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(y), B, cin, cout, H, W,
+               N.MODE_PLAIN3, int(activate), float(slope), float(gain), st)
+        return y
+    if fir is None:
+        raise RuntimeError('upsample modconv needs the blur FIR taps')
+    planes = torch.empty(B, cout, 4, H + 1, W + 1, device=x.device, dtype=torch.float32)
+    N.call('sgdfr_modconv2d_fwd_f32', N.ptr(x), xb, N.ptr(wp), N.ptr(s), N.ptr(d), None, 0, None, None,
+           N.ptr(planes), B, cin, cout, H, W, N.MODE_UP3, 0, 0.0, 1.0, st)
+    nz, nzb = _noise_args(noise, B, 2 * H, 2 * W)
+    y = torch.empty(B, cout, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+    N.call('sgdfr_blur_bias_act_f32', N.ptr(planes), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
+           N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(y), B, cout, H, W, int(activate),
+           float(slope), float(gain), st)
+    return y
+
+
+def torgb(x, w_rgb, s, bias=None, skip=None, fir=None):
+    """ToRGB (model.py:350-359): 1x1 modconv without demodulation + bias + FIR-upsampled skip."""
+    N.require_device(x, w_rgb, s, bias, skip, fir)
+    x = N.f32c(x)
+    B, cin, H, W = x.shape
+    if skip is not None and tuple(skip.shape) != (B, 3, H // 2, W // 2):
+        raise RuntimeError('skip shape %s does not match output [%d,3,%d,%d]/2' % (tuple(skip.shape), B, H, W))
+    y = torch.empty(B, 3, H, W, device=x.device, dtype=torch.float32)
+    N.call('sgdfr_torgb_fwd_f32', N.ptr(x), N.ptr(N.f32c(w_rgb)), N.ptr(s), N.ptr(N.f32c(bias)) if bias is not None else None,
+           N.ptr(N.f32c(skip)) if skip is not None else None, N.ptr(N.f32c(fir)) if fir is not None else None,
+           N.ptr(y), B, cin, H, W, N.stream())
+    return y
+
+
+def conv_flops(cin, cout, h, w, upsample=False):
+    """Algorithmic FLOPs of one 3x3 modconv on an h x w INPUT (the transposed conv is
+    counted at input resolution, 9 MACs per input pixel per (cin, cout))."""
+    return 2.0 * 9 * cin * cout * h * w
+
+
+# ------------------------------------------------------------------ differentiable affine map
+
+class _Affine(Function):
+    """y = x @ W.T + b with all three gradients computed by the same HIP linear kernel
+    (dX = g @ W, dW = g.T @ x, db = 1.T @ g).  Used by DirectionMatrix, the only trainable block of the
+    reference's trainer (libs/trainer.py:144,175)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g2 = g.reshape(-1, weight.shape[0])
+        x2 = x.reshape(-1, weight.shape[1])
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = linear(g2, weight.t().contiguous()).view_as(x)
+        if ctx.needs_input_grad[1]:
+            gw = linear(g2.t().contiguous(), x2.t().contiguous())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            ones = torch.ones(1, g2.shape[0], device=g.device, dtype=torch.float32)
+            gb = linear(ones, g2.t().contiguous()).view(-1)
+        return gx, gw, gb
+
+
+def affine(x, weight, bias=None):
+    return _Affine.apply(x, weight, bias)

@@ -1,0 +1,324 @@
+"""StyleGAN2 generator on MI355X: drop-in for the reference's ``libs/gan/StyleGAN2/model.py`` generator half.
+
+Kept from the reference (it is the compatibility contract): class names, constructor
+signatures, ``forward`` keyword arguments and return tuple, attribute names (``style``, ``input.input``,
+``conv1``, ``to_rgb1``, ``convs``, ``to_rgbs``, ``noises.noise_i``, ``n_latent``, ``num_layers``,
+``log_size``, ``size``, ``style_dim``, ``channels``) and the exact ``state_dict`` key set / shapes
+(model.py:362-447), so ``load_state_dict(ckpt['g_ema'])``, ``copy.deepcopy`` and
+``convs[i].parameters()`` behave as before.
+
+Different by design: no per-sample weight tensor is ever built.  Each modulated conv is one
+shared-weight fp32-MFMA launch with style scaling folded into input staging and demodulation, noise,
+bias and leaky-ReLU folded into its epilogue (csrc/modconv.hip); weights are re-packed once per weight
+version and cached outside the state_dict.  All arithmetic runs in the HIP library -- modules raise on
+CPU tensors instead of falling back.
+
+The discriminator-side classes of the reference file (model.py:542-709: ConvLayer, ResBlock,
+Discriminator, Encoder, ...) are never instantiated by the reenactment scripts and are out of scope.
+"""
+import math
+import random
+
+import torch
+from torch import nn
+
+from . import functional as F_
+from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d  # noqa: F401  (re-exported like model.py:8)
+
+
+def make_kernel(k):
+    """Normalised 2-D FIR from 1-D taps (model.py:19-27)."""
+    k = torch.as_tensor(k, dtype=torch.float32)
+    if k.ndim == 1:
+        k = torch.outer(k, k)
+    return k / k.sum()
+
+
+class PixelNorm(nn.Module):
+    def forward(self, input):
+        return F_.pixel_norm(input)
+
+
+class Upsample(nn.Module):
+    """2x FIR upsampling of the RGB skip (model.py:30-48).  Inside ToRGB the same taps are applied by
+    the fused kernel; this standalone module goes through ``upfirdn2d``."""
+
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer('kernel', make_kernel(kernel) * (factor ** 2))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2 + factor - 1, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=self.factor, down=1, pad=self.pad)
+
+
+class Blur(nn.Module):
+    """FIR blur (model.py:72-88)."""
+
+    def __init__(self, kernel, pad, upsample_factor=1):
+        super().__init__()
+        kernel = make_kernel(kernel)
+        if upsample_factor > 1:
+            kernel = kernel * (upsample_factor ** 2)
+        self.register_buffer('kernel', kernel)
+        self.pad = pad
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, pad=self.pad)
+
+
+class EqualLinear(nn.Module):
+    """Equalised-lr linear layer (model.py:129-162); also imported by the e4e encoder
+    (libs/gan/encoder4editing/models/encoders/psp_encoders.py:9)."""
+
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init)) if bias else None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+    def forward(self, input):
+        out = F_.linear(input, self.weight, self.bias, wscale=self.scale, bscale=self.lr_mul,
+                        lrelu=bool(self.activation))
+        return F_.forward_only(out, 'EqualLinear', input, self.weight, self.bias)
+
+    def __repr__(self):
+        return '{}({}, {})'.format(self.__class__.__name__, self.weight.shape[1], self.weight.shape[0])
+
+
+class ModulatedConv2d(nn.Module):
+    """Modulated / demodulated convolution (model.py:177-273) in shared-weight form.
+
+    3x3 (plain or 2x upsampling) runs on the MFMA kernel; 1x1 without demodulation is the ToRGB
+    kernel.  ``downsample`` exists only on the discriminator side of the reference and is refused."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
+                 downsample=False, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        if downsample:
+            raise NotImplementedError('downsample modulated conv is not on the generator path')
+        if kernel_size not in (1, 3):
+            raise NotImplementedError('kernel_size %d: the generator only uses 3x3 and 1x1' % kernel_size)
+        self.eps = 1e-8
+        self.kernel_size = kernel_size
+        self.in_channel = in_channel
+        self.out_channel = out_channel
+        self.upsample = upsample
+        self.downsample = downsample
+        if upsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
+            if kernel_size != 3 or tuple(self.blur.kernel.shape) != (4, 4) or self.blur.pad != (1, 1):
+                raise NotImplementedError('upsampling modconv is built for 3x3 weights and a 4-tap blur')
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+        self.demodulate = demodulate
+        self._pack = None          # (key, wp, q): re-packed weights, not part of the state_dict
+
+    def __repr__(self):
+        return '{}({}, {}, {}, upsample={}, downsample={})'.format(
+            self.__class__.__name__, self.in_channel, self.out_channel, self.kernel_size, self.upsample,
+            self.downsample)
+
+    def packed(self):
+        """[Cin, k*k, Cout] scaled weights and Q[o,i] = sum_taps (scale W)^2, rebuilt when the parameter's
+        storage or version changes (optimizer step, load_state_dict, .cuda())."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if self._pack is None or self._pack[0] != key:
+            with torch.no_grad():
+                wp, q = F_.prepack(w.detach())
+            self._pack = (key, wp, q)
+        return self._pack[1], self._pack[2]
+
+    def _styles(self, style):
+        wp, q = self.packed()
+        mod = self.modulation
+        s, d = F_.style_demod(style, mod.weight, mod.bias, q if self.demodulate else None, self.out_channel)
+        return wp, s, d
+
+    def fused(self, input, style, noise=None, noise_weight=None, bias=None, activate=False, batch=None):
+        """conv (+ noise + bias + leaky-ReLU) in one pass; what StyledConv.forward calls."""
+        wp, s, d = self._styles(style)
+        if self.kernel_size == 1:
+            if self.demodulate:
+                raise NotImplementedError('1x1 modulated conv with demodulation is not on the generator path')
+            return F_.torgb(input, self.weight.view(self.out_channel, self.in_channel), s, bias=bias) \
+                if self.out_channel == 3 else self._one_by_one(input, s, bias)
+        return F_.modconv3x3(input, wp, s, d, self.out_channel, upsample=self.upsample,
+                             fir=self.blur.kernel if self.upsample else None, noise=noise,
+                             noise_weight=noise_weight, bias=bias, activate=activate, batch=batch)
+
+    def _one_by_one(self, input, s, bias):
+        raise NotImplementedError('1x1 modulated conv is only built for 3 output channels (ToRGB)')
+
+    def forward(self, input, style):
+        out = self.fused(input, style)
+        return F_.forward_only(out, 'ModulatedConv2d', input, style, self.weight, self.modulation.weight,
+                               self.modulation.bias)
+
+
+class NoiseInjection(nn.Module):
+    """image + weight * noise (model.py:276-287).  Inside StyledConv this is part of the conv epilogue;
+    the standalone module is kept for API parity."""
+
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+    def forward(self, image, noise=None):
+        if noise is None:
+            batch, _, height, width = image.shape
+            noise = image.new_empty(batch, 1, height, width).normal_()
+        return image + self.weight * noise
+
+
+class ConstantInput(nn.Module):
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(torch.randn(1, channel, size, size))
+
+    def forward(self, input):
+        return self.input.repeat(input.shape[0], 1, 1, 1)
+
+
+class StyledConv(nn.Module):
+    """modconv -> noise -> bias + leaky-ReLU (model.py:303-337), as ONE fused launch
+    (two for the upsampling variant: MFMA transposed conv, then FIR + epilogue)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False, blur_kernel=[1, 3, 3, 1],
+                 demodulate=True):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample,
+                                    blur_kernel=blur_kernel, demodulate=demodulate)
+        self.noise = NoiseInjection()
+        self.activate = FusedLeakyReLU(out_channel)
+
+    def forward(self, input, style, noise=None, batch=None):
+        if noise is None:   # fresh per-sample noise, model.py:283-285
+            B = style.shape[0]
+            r = input.shape[-1] * (2 if self.conv.upsample else 1)
+            noise = torch.empty(B, 1, r, r, device=style.device, dtype=torch.float32).normal_()
+        out = self.conv.fused(input, style, noise=noise, noise_weight=self.noise.weight, bias=self.activate.bias,
+                              activate=True, batch=batch)
+        return F_.forward_only(out, 'StyledConv', input, style, *self.parameters())
+
+
+class ToRGB(nn.Module):
+    """model.py:340-359: 1x1 modconv (no demod) + bias + FIR-upsampled skip, one HBM-bound launch."""
+
+    def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        if upsample:
+            self.upsample = Upsample(blur_kernel)
+        self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+
+    def forward(self, input, style, skip=None):
+        conv = self.conv
+        s, _ = F_.style_demod(style, conv.modulation.weight, conv.modulation.bias)
+        fir = None
+        if skip is not None:
+            up = getattr(self, 'upsample', None)
+            if up is None or tuple(up.kernel.shape) != (4, 4) or up.pad != (2, 1):
+                raise NotImplementedError('ToRGB skip path is built for the 4-tap 2x Upsample')
+            fir = up.kernel
+        out = F_.torgb(input, conv.weight.view(3, conv.in_channel), s, bias=self.bias.view(3), skip=skip, fir=fir)
+        return F_.forward_only(out, 'ToRGB', input, style, skip, *self.parameters())
+
+
+class Generator(nn.Module):
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01):
+        super().__init__()
+        self.size = size
+        self.style_dim = style_dim
+        self.style = nn.Sequential(
+            PixelNorm(), *[EqualLinear(style_dim, style_dim, lr_mul=lr_mlp, activation='fused_lrelu')
+                           for _ in range(n_mlp)])
+        self.channels = {
+            4: 512, 8: 512, 16: 512, 32: 512,
+            64: 256 * channel_multiplier, 128: 128 * channel_multiplier, 256: 64 * channel_multiplier,
+            512: 32 * channel_multiplier, 1024: 16 * channel_multiplier,
+        }
+        self.input = ConstantInput(self.channels[4])
+        self.conv1 = StyledConv(self.channels[4], self.channels[4], 3, style_dim, blur_kernel=blur_kernel)
+        self.to_rgb1 = ToRGB(self.channels[4], style_dim, upsample=False)
+        self.log_size = int(math.log(size, 2))
+        self.num_layers = (self.log_size - 2) * 2 + 1
+        self.convs = nn.ModuleList()
+        self.upsamples = nn.ModuleList()
+        self.to_rgbs = nn.ModuleList()
+        self.noises = nn.Module()
+        for layer_idx in range(self.num_layers):
+            res = (layer_idx + 5) // 2
+            self.noises.register_buffer('noise_{}'.format(layer_idx), torch.randn(1, 1, 2 ** res, 2 ** res))
+        in_channel = self.channels[4]
+        for i in range(3, self.log_size + 1):
+            out_channel = self.channels[2 ** i]
+            self.convs.append(StyledConv(in_channel, out_channel, 3, style_dim, upsample=True,
+                                         blur_kernel=blur_kernel))
+            self.convs.append(StyledConv(out_channel, out_channel, 3, style_dim, blur_kernel=blur_kernel))
+            self.to_rgbs.append(ToRGB(out_channel, style_dim))
+            in_channel = out_channel
+        self.n_latent = self.log_size * 2 - 2
+
+    # ---- latent-side helpers (model.py:449-469)
+    def make_noise(self):
+        device = self.input.input.device
+        noises = [torch.randn(1, 1, 4, 4, device=device)]
+        for i in range(3, self.log_size + 1):
+            for _ in range(2):
+                noises.append(torch.randn(1, 1, 2 ** i, 2 ** i, device=device))
+        return noises
+
+    def mean_latent(self, n_latent):
+        latent_in = torch.randn(n_latent, self.style_dim, device=self.input.input.device)
+        return self.style(latent_in).mean(0, keepdim=True)
+
+    def get_latent(self, input):
+        return self.style(input)
+
+    # ---- the path itself (model.py:471-539)
+    def forward(self, styles, return_latents=False, return_features=False, inject_index=None, truncation=1,
+                truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=False):
+        if not input_is_latent:
+            styles = [self.style(s) for s in styles]
+        if noise is None:
+            noise = [None] * self.num_layers if randomize_noise else \
+                [getattr(self.noises, 'noise_{}'.format(i)) for i in range(self.num_layers)]
+        trunc = truncation_latent if truncation < 1 else None
+        if truncation < 1 and truncation_latent is None:
+            raise RuntimeError('truncation < 1 needs truncation_latent')
+        if len(styles) < 2:
+            # truncation (also of a full W+ code, as in the reference) + W -> W+ broadcast in one launch
+            latent = F_.latent_prepare(styles[0], self.n_latent, trunc=trunc, psi=truncation)
+        else:   # style mixing (model.py:510-517); unused by the reenactment scripts
+            if inject_index is None:
+                inject_index = random.randint(1, self.n_latent - 1)
+            a = F_.latent_prepare(styles[0], inject_index, trunc=trunc, psi=truncation)
+            b = F_.latent_prepare(styles[1], self.n_latent - inject_index, trunc=trunc, psi=truncation)
+            latent = torch.cat([a, b], 1)
+        batch = latent.shape[0]
+
+        # ConstantInput is broadcast inside the kernel (batch stride 0) instead of repeated
+        out = self.conv1(self.input.input, latent[:, 0], noise=noise[0], batch=batch)
+        skip = self.to_rgb1(out, latent[:, 1])
+        i = 1
+        for conv1, conv2, noise1, noise2, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2],
+                                                        noise[2::2], self.to_rgbs):
+            out = conv1(out, latent[:, i], noise=noise1)
+            out = conv2(out, latent[:, i + 1], noise=noise2)
+            skip = to_rgb(out, latent[:, i + 2], skip)
+            i += 2
+        image = skip
+        if torch.is_grad_enabled():
+            image = F_.forward_only(image, 'Generator.forward', *styles, *self.parameters())
+            latent = F_.forward_only(latent, 'Generator.forward', *styles)
+        return (image, latent) if return_latents else (image, None)

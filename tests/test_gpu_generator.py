@@ -1,0 +1,159 @@
+"""GPU parity of the whole generator path against (i) golden vectors captured from the real reference
+(tests/golden/kat3..5) and (ii) the CPU oracle on full tensors.  Bar from BASELINE.json: max-abs <= 1e-3 on
+fp32 images whose magnitude reaches ~10 with the synthetic weights; asserted tighter (2e-4) here."""
+import numpy as np
+import pytest
+import torch
+
+from util import O, S, SEED, golden, hip_generator, image_digest, maxabs, synthetic_state, t
+
+pytestmark = pytest.mark.gpu
+
+IMG_TOL = 2e-4      # |image| <= ~10, 14 layers of K<=4608 fp32 accumulations; north_star allows 1e-3
+
+
+def _check_digest(img, g, prefix, tol=IMG_TOL):
+    d = image_digest(img)
+    assert np.abs(d['sub'] - g[prefix + '.sub']).max() <= tol
+    # a row/col sum adds 256 values: allow sqrt(256)*tol-ish drift
+    assert np.abs(d['rowsum'] - g[prefix + '.rowsum']).max() <= 40 * tol
+    assert np.abs(d['colsum'] - g[prefix + '.colsum']).max() <= 40 * tol
+
+
+@pytest.mark.parametrize('size', [32, 64])
+def test_small_generators_all_layers(size):
+    """KAT-3: every StyledConv / ToRGB output of Generator(32) and Generator(64) vs the reference's probes."""
+    g = golden('kat3_small_generators.npz')
+    G = hip_generator(size, 1)
+    feats = {}
+    from stylegan_directions_face_reenactment_amd.model import StyledConv, ToRGB
+    hooks = [m.register_forward_hook(lambda mod, i, o, nm=nm: feats.__setitem__(nm, o.detach()))
+             for nm, m in G.named_modules() if isinstance(m, (StyledConv, ToRGB))]
+    w = t(g['g%d.w' % size]).cuda()
+    with torch.no_grad():
+        img, lat = G([w], input_is_latent=True)
+    for h in hooks:
+        h.remove()
+    assert lat is None
+    assert maxabs(img, t(g['g%d.image' % size])) <= IMG_TOL
+    assert len(feats) == G.num_layers + G.log_size - 1
+    for nm, f in feats.items():
+        idx = torch.from_numpy(g['g%d.%s.probe_idx' % (size, nm)])
+        got = f.reshape(-1).cpu()[idx]
+        assert maxabs(got, t(g['g%d.%s.probe' % (size, nm)])) <= 1e-4, nm
+        stats = g['g%d.%s.stats' % (size, nm)]
+        assert abs(float(f.double().mean()) - stats[0]) <= 1e-5
+        assert abs(float(f.double().abs().mean()) - stats[1]) <= 1e-5
+
+
+@pytest.mark.parametrize('cm', [1, 2])
+def test_generator256_golden_and_oracle(cm):
+    """KAT-4 (+KAT-7): z path and W+ path with psi=0.7 and an explicit truncation latent, and the
+    synthesis-only (psi=1) W+ path of bench config 2; channel_multiplier 1 (voxceleb) and 2 (ffhq)."""
+    g = golden('kat4_generator256.npz')
+    G = hip_generator(256, cm)
+    assert sum(p.numel() for p in G.parameters()) == int(g['n_params_cm%d' % cm])
+    z = S.synthetic_z(SEED, 2, key='kat4.z').cuda()
+    ztr = S.synthetic_z(SEED, 64, key='kat4.ztrunc').cuda()
+    w = S.synthetic_latents(SEED, 2, key='kat4.w').cuda()
+    with torch.no_grad():
+        trunc = G.style(ztr).mean(0, keepdim=True)                 # mean_latent with an injected z batch
+        assert maxabs(trunc, t(g['cm%d.trunc' % cm])) <= 1e-5
+        img_z, lat_z = G([z], return_latents=True, truncation=0.7, truncation_latent=trunc)
+        assert lat_z.shape == (2, 14, 512)
+        assert maxabs(lat_z, t(g['cm%d.lat_z' % cm])) <= 1e-5
+        _check_digest(img_z, g, 'cm%d.z' % cm)
+        img_w, _ = G([w], truncation=0.7, truncation_latent=trunc, input_is_latent=True)
+        _check_digest(img_w, g, 'cm%d.w' % cm)
+        img_p, _ = G([w], input_is_latent=True)
+        _check_digest(img_p, g, 'cm%d.p' % cm)
+    if cm == 1:
+        assert maxabs(img_p[0], t(g['cm1.p.full0'])) <= IMG_TOL     # one full image from the real reference
+        ref, _ = O.generator_forward(synthetic_state(256, 1), [w.cpu()], input_is_latent=True)
+        assert maxabs(img_p, ref) <= IMG_TOL                        # full tensors vs the oracle
+
+
+def test_generate_image_with_direction_shift():
+    """KAT-5: generate_image + DirectionMatrix shift, z path and W+ path, W-space shift over 8 layers."""
+    from stylegan_directions_face_reenactment_amd.direction_matrix import DirectionMatrix
+    from stylegan_directions_face_reenactment_amd.generic import generate_image
+    g4, g = golden('kat4_generator256.npz'), golden('kat5_generate_image.npz')
+    G = hip_generator(256, 1)
+    A = DirectionMatrix(512, input_dim=15, out_dim=512, w_plus=True, num_layers=8, verbose=False)
+    A.load_state_dict(S.synthetic_direction_state(SEED))
+    A = A.cuda()
+    trunc = t(g4['cm1.trunc']).cuda()
+    z = S.synthetic_z(SEED, 2, key='kat4.z').cuda()
+    w = S.synthetic_latents(SEED, 2, key='kat4.w').cuda()
+    sv = t(g['sv']).cuda()
+    with torch.no_grad():
+        for path, code, is_lat in (('z', z, False), ('w', w, True)):
+            img, lat = generate_image(G, code, 0.7, trunc, shift_code=A(sv), input_is_latent=is_lat,
+                                      return_latents=True)
+            assert maxabs(lat, t(g['%s.latent' % path])) <= 2e-5
+            _check_digest(img, g, path)
+        img = generate_image(G, w, 0.7, trunc, w_plus=False, num_layers_shift=8, shift_code=t(g['shift_w']).cuda(),
+                             input_is_latent=True)
+        _check_digest(img, g, 'wshift')
+        assert not isinstance(img, tuple)
+
+
+def test_batch_independence_at_bench_size():
+    """Size-independent property at the bench configuration (B=64, 256x256, cm=1): every image depends only on
+    its own latent row, so image i of a 64-batch equals image i computed alone / in a 2-batch."""
+    G = hip_generator(256, 1)
+    w = S.synthetic_latents(11, 64, key='prop.w').cuda()
+    with torch.no_grad():
+        big, _ = G([w], input_is_latent=True)
+        assert big.shape == (64, 3, 256, 256) and torch.isfinite(big).all()
+        for sl in (slice(0, 2), slice(31, 33), slice(63, 64)):
+            small, _ = G([w[sl].contiguous()], input_is_latent=True)
+            assert maxabs(big[sl], small) <= 1e-5
+        ref, _ = O.generator_forward(synthetic_state(256, 1), [w[62:64].cpu()], input_is_latent=True)
+        assert maxabs(big[62:64], ref) <= IMG_TOL
+
+
+def test_noise_modes_and_truncation_quirks():
+    G = hip_generator(64, 1)
+    w = S.synthetic_latents(12, 4, n_latent=G.n_latent, key='nz.w').cuda()
+    P = synthetic_state(64, 1)
+    with torch.no_grad():
+        a, _ = G([w], input_is_latent=True)
+        b, _ = G([w], input_is_latent=True)
+        assert maxabs(a, b) == 0.0                                   # fixed noise buffers by default (model.py:488-492)
+        c, _ = G([w], input_is_latent=True, randomize_noise=True)
+        assert c.shape == a.shape and torch.isfinite(c).all() and maxabs(a, c) > 1e-3
+        ns = G.make_noise()
+        assert [tuple(n.shape) for n in ns] == [tuple(getattr(G.noises, 'noise_%d' % i).shape) for i in range(G.num_layers)]
+        d, _ = G([w], input_is_latent=True, noise=ns)
+        ref, _ = O.generator_forward(P, [w.cpu()], input_is_latent=True, noise=[n.cpu() for n in ns])
+        assert maxabs(d, ref) <= 2e-4
+        # truncation is applied to a full W+ code too (model.py:494-500), by broadcasting trunc [1,512]
+        tr = S.counter_tensor(12, 'nz.t', (1, 512)).cuda()
+        e, lat = G([w], input_is_latent=True, truncation=0.5, truncation_latent=tr, return_latents=True)
+        assert maxabs(lat, tr + 0.5 * (w - tr)) <= 1e-6
+        ref, _ = O.generator_forward(P, [w.cpu()], input_is_latent=True, truncation=0.5, truncation_latent=tr.cpu())
+        assert maxabs(e, ref) <= 2e-4
+        # a batch of one and an empty-noise list element
+        f, _ = G([w[:1].contiguous()], input_is_latent=True)
+        assert maxabs(f, a[:1]) <= 1e-5
+
+
+def test_module_protocol_on_gpu():
+    """deepcopy / state_dict round trip / weight-version repack, as optimize_g and load_models use them."""
+    import copy
+    G = hip_generator(32, 1)
+    w = S.synthetic_latents(13, 2, n_latent=G.n_latent, key='mp.w').cuda()
+    with torch.no_grad():
+        a, _ = G([w], input_is_latent=True)
+        G2 = copy.deepcopy(G)
+        b, _ = G2([w], input_is_latent=True)
+        assert maxabs(a, b) == 0.0
+        G2.convs[0].conv.weight.mul_(1.5)                         # in-place update must invalidate the packed copy
+        c, _ = G2([w], input_is_latent=True)
+        P = {k: v.cpu() for k, v in G2.state_dict().items()}
+        ref, _ = O.generator_forward(P, [w.cpu()], input_is_latent=True)
+        assert maxabs(c, ref) <= 2e-4
+    with pytest.raises(NotImplementedError):
+        img, _ = G([w.clone().requires_grad_(True)], input_is_latent=True)
+        img.sum().backward()
