@@ -13,6 +13,20 @@ from . import _native as N
 
 SQRT2 = 2 ** 0.5
 
+# bench.py sets this to a list to time the MFMA conv launches: entries are
+# (start_event, end_event, algorithmic_flops, description) recorded on the launch stream
+CONV_TIMING = None
+
+
+def _timed_conv(desc, flops, launch):
+    if CONV_TIMING is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    CONV_TIMING.append((e0, e1, flops, desc))
+
 
 # ------------------------------------------------------------------ autograd guard
 
@@ -158,15 +172,17 @@ def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_we
     if not upsample:
         nz, nzb = _noise_args(noise, B, H, W)
         y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
-        N.call('sgdfr_modconv2d_fwd_f32', N.ptr(x), xb, N.ptr(wp), N.ptr(s), N.ptr(d), N.ptr(nz), nzb,
-               N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(y), B, cin, cout, H, W,
-               N.MODE_PLAIN3, int(activate), float(slope), float(gain), st)
+        _timed_conv('plain3 %d->%d @%dx%d' % (cin, cout, H, W), B * conv_flops(cin, cout, H, W), lambda: N.call(
+            'sgdfr_modconv2d_fwd_f32', N.ptr(x), xb, N.ptr(wp), N.ptr(s), N.ptr(d), N.ptr(nz), nzb,
+            N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(y), B, cin, cout, H, W,
+            N.MODE_PLAIN3, int(activate), float(slope), float(gain), st))
         return y
     if fir is None:
         raise RuntimeError('upsample modconv needs the blur FIR taps')
     planes = torch.empty(B, cout, 4, H + 1, W + 1, device=x.device, dtype=torch.float32)
-    N.call('sgdfr_modconv2d_fwd_f32', N.ptr(x), xb, N.ptr(wp), N.ptr(s), N.ptr(d), None, 0, None, None,
-           N.ptr(planes), B, cin, cout, H, W, N.MODE_UP3, 0, 0.0, 1.0, st)
+    _timed_conv('up3 %d->%d @%dx%d' % (cin, cout, H, W), B * conv_flops(cin, cout, H, W), lambda: N.call(
+        'sgdfr_modconv2d_fwd_f32', N.ptr(x), xb, N.ptr(wp), N.ptr(s), N.ptr(d), None, 0, None, None,
+        N.ptr(planes), B, cin, cout, H, W, N.MODE_UP3, 0, 0.0, 1.0, st))
     nz, nzb = _noise_args(noise, B, 2 * H, 2 * W)
     y = torch.empty(B, cout, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
     N.call('sgdfr_blur_bias_act_f32', N.ptr(planes), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
