@@ -48,7 +48,9 @@ def generator_state_template(size, cm):
 def cpu_baseline(size, cm, budget_s=20.0):
     """Times the oracle (checker side) on the host CPU: B=2 forwards of the same synthesis workload."""
     from oracle import sg2_oracle as O      # allowed here: the cpu_baseline leg only
-    threads = os.cpu_count() or 1
+    # 16 threads is this workload's sweet spot on the GPU box's 2x64-core EPYC 9575F (measured: 8 thr 5.4,
+    # 16 thr 5.65, 32 thr 4.1, 64 thr 2.5, 256 thr 0.03 frames/s): oneDNN's small grouped convs do not scale further
+    threads = min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     P = S.synthetic_state_dict(O.template_state(size, 512, 8, cm), seed=SEED)
     B = 2

@@ -1,0 +1,152 @@
+"""CPU: host logic of the package -- module/state_dict contract, synthetic generator determinism, the C-ABI
+library loads and exports every declared symbol, and the product path refuses CPU tensors (no fallback)."""
+import copy
+import ctypes
+import os
+import pickle
+import re
+
+import pytest
+import torch
+
+from util import O, ROOT, S, SEED, synthetic_state
+
+
+def test_counter_rng_is_pinned_and_normal():
+    v = S.counter_normal(1, 'abc', 200000)
+    assert abs(v.mean()) < 0.01 and abs(v.std() - 1.0) < 0.01 and abs(v).max() < 3.5
+    # fixed values: any change of the generator silently invalidates every golden fixture
+    w = S.counter_tensor(SEED, 'conv1.conv.weight', (4,))
+    assert [round(float(x), 6) for x in w] == [round(float(x), 6) for x in S.counter_tensor(SEED, 'conv1.conv.weight', (4,))]
+    a = S.counter_normal(SEED, 'kat1.x', 3)
+    b = S.counter_normal(SEED, 'kat1.x', 5)
+    assert (a == b[:3]).all()                      # counter-based: prefix stable
+    assert (S.counter_normal(SEED, 'kat1.y', 3) != a).all()
+
+
+def test_synthetic_state_matches_golden_inputs():
+    import numpy as np
+    from util import golden
+    g = golden('kat1_ops.npz')
+    assert np.array_equal(S.counter_tensor(SEED, 'kat1.x', (2, 3, 9, 9)).numpy(), g['x'])   # same generator as make_golden
+
+
+def test_generator_state_dict_contract():
+    from stylegan_directions_face_reenactment_amd.model import Generator, EqualLinear
+    for cm, nparams in ((1, 24767458), (2, 30034338)):
+        G = Generator(256, 512, 8, channel_multiplier=cm)
+        sd = G.state_dict()
+        shapes = O.generator_state_shapes(256, 512, 8, cm)
+        assert list(sd.keys()) == list(shapes.keys())
+        assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in sd)
+        assert sum(p.numel() for p in G.parameters()) == nparams
+    G = Generator(256, 512, 8, channel_multiplier=1)
+    assert (G.n_latent, G.num_layers, G.log_size, G.size, G.style_dim) == (14, 13, 8, 256, 512)
+    assert len(G.convs) == 12 and len(G.to_rgbs) == 6 and G.channels[256] == 64
+    assert tuple(G.input.input.shape) == (1, 512, 4, 4)
+    assert [tuple(getattr(G.noises, 'noise_%d' % i).shape)[-1] for i in range(13)] == \
+        [4, 8, 8, 16, 16, 32, 32, 64, 64, 128, 128, 256, 256]
+    # strict load of a synthetic state, non-strict load of a checkpoint without buffers (run_inference.py:66-67)
+    G.load_state_dict(synthetic_state(256, 1), strict=True)
+    partial = {k: v for k, v in synthetic_state(256, 1).items() if 'noises.' not in k and '.kernel' not in k}
+    missing = G.load_state_dict(partial, strict=False)
+    assert all(('noises.' in k) or k.endswith('.kernel') for k in missing.missing_keys)
+    # deepcopy / pickle (libs/optimization.py:28 deep-copies G) and optimizer parameter groups (:32-35)
+    G2 = copy.deepcopy(G)
+    assert torch.equal(G2.conv1.conv.weight, G.conv1.conv.weight)
+    pickle.loads(pickle.dumps(G.convs[0]))
+    assert len([p for i in range(4, 12) for p in G.convs[i].parameters()]) == 8 * 5
+    assert isinstance(G.style[1], EqualLinear) and G.style[1].lr_mul == 0.01
+    assert torch.allclose(G.convs[0].conv.blur.kernel.sum(), torch.tensor(4.0))
+    assert G.convs[0].conv.blur.pad == (1, 1) and G.to_rgbs[0].upsample.pad == (2, 1)
+
+
+def test_direction_matrix_contract():
+    from stylegan_directions_face_reenactment_amd.direction_matrix import DirectionMatrix
+    A = DirectionMatrix(512, input_dim=15, out_dim=512, w_plus=True, num_layers=8, verbose=False)
+    assert tuple(A.linear.weight.shape) == (4096, 15) and A.input_dim == 15
+    assert list(A.state_dict().keys()) == ['linear.weight', 'linear.bias']
+    assert 0.02 < float(A.linear.weight.std()) < 0.04
+    E = DirectionMatrix(512, input_dim=15, out_dim=512, w_plus=True, num_layers=8, initialization='eye', verbose=False)
+    assert int((E.linear.weight != 0).sum()) == 8 * 15
+    assert torch.equal(E.linear.weight[512 * 3:512 * 3 + 15, :15], torch.eye(15))
+    W = DirectionMatrix(512, verbose=False)                  # np.product-free default dims
+    assert (W.input_dim, W.out_dim) == (512, 512)
+    pickle.loads(pickle.dumps(A))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from stylegan_directions_face_reenactment_amd import _native
+    header = open(os.path.join(ROOT, 'include', 'sgdfr.h')).read()
+    declared = set(re.findall(r'\b(sgdfr_[a-z0-9_]+)\s*\(', header))
+    assert declared >= set(_native.SIGNATURES) | {'sgdfr_abi_version', 'sgdfr_last_error'}
+    lib = _native.load()                       # raises if the .so was not built
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.sgdfr_abi_version() == _native.ABI_VERSION
+    # argument validation happens before any launch, so error paths are testable without a GPU
+    rc = lib.sgdfr_upfirdn2d_f32(None, None, None, 1, 4, 4, 1, 99, 4, 1, 1, 1, 1, 0, 0, 0, 0, None)
+    assert rc != 0 and b'kernel' in lib.sgdfr_last_error()
+    rc = lib.sgdfr_fused_bias_act_f32(None, None, None, None, 0, 1, 1, 1, 0, 0.2, 1.0, None)
+    assert rc != 0 and b'act=3' in lib.sgdfr_last_error()
+    rc = lib.sgdfr_modconv2d_fwd_f32(None, 0, None, None, None, None, 0, None, None, None, 1, 8, 8, 4, 4, 7, 0, 0.2,
+                                     1.0, None)
+    assert rc != 0 and b'mode' in lib.sgdfr_last_error()
+
+
+def test_product_path_has_no_cpu_fallback():
+    from stylegan_directions_face_reenactment_amd.model import Generator
+    from stylegan_directions_face_reenactment_amd.op import fused_leaky_relu, upfirdn2d
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    G = Generator(32, 512, 8, channel_multiplier=1)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        G([torch.randn(1, 512)])
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        fused_leaky_relu(torch.randn(2, 3), torch.zeros(3))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        upfirdn2d(torch.randn(1, 1, 4, 4), torch.ones(4, 4))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        F_.linear(torch.randn(2, 4), torch.randn(3, 4))
+    # and nothing in the shipped package imports the oracle
+    pkg = os.path.join(ROOT, 'stylegan_directions_face_reenactment_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.replace('no oracle import', ''), os.path.join(dirpath, f)
+
+
+def test_compat_aliases():
+    import sys
+    from stylegan_directions_face_reenactment_amd import compat
+    saved = {k: sys.modules.get(k) for k in compat.ALIASES}
+    try:
+        compat.install()
+        from libs.gan.StyleGAN2.model import Generator, EqualLinear          # noqa: F401
+        from libs.models.direction_matrix import DirectionMatrix             # noqa: F401
+        from libs.gan.StyleGAN2.op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d   # noqa: F401
+        import stylegan_directions_face_reenactment_amd.model as M
+        assert Generator is M.Generator
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_shard_range_and_flops_table():
+    from stylegan_directions_face_reenactment_amd import distributed as D, functional as F_
+    for total, world in ((512, 8), (128, 8), (10, 4), (3, 8)):
+        spans = [D.shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+    # 29.75 GFLOP/img of 3x3 conv at cm=1
+    ch = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256, 128: 128, 256: 64}
+    fl = F_.conv_flops(512, 512, 4, 4)
+    cin = 512
+    for r in (8, 16, 32, 64, 128, 256):
+        fl += F_.conv_flops(cin, ch[r], r // 2, r // 2, upsample=True) + F_.conv_flops(ch[r], ch[r], r, r)
+        cin = ch[r]
+    assert abs(fl / 1e9 - 29.746) < 0.01

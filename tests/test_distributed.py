@@ -1,0 +1,74 @@
+"""CPU, world_size 2 over gloo: the multi-process path of bench.py (flat one-shot state broadcast from rank 0,
+contiguous latent sharding, max-over-ranks timing, gradient averaging for A)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from stylegan_directions_face_reenactment_amd import distributed as D, synthetic as S
+    from stylegan_directions_face_reenactment_amd.model import Generator
+    from stylegan_directions_face_reenactment_amd.direction_matrix import DirectionMatrix
+    r, lr, w = D.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)                      # different random init per rank
+    G = Generator(32, 512, 8, channel_multiplier=1)
+    A = DirectionMatrix(512, 15, 512, w_plus=True, num_layers=8, verbose=False)
+    trunc = torch.full((1, 512), float(rank))
+    if rank == 0:
+        G.load_state_dict(S.synthetic_state_dict(G.state_dict(), seed=5))
+    nbytes = D.broadcast_state(G, A, [trunc], src=0)
+    ref = S.synthetic_state_dict(G.state_dict(), seed=5)
+    ok = all(torch.equal(G.state_dict()[k], ref[k]) for k in ref if not k.endswith('.kernel'))
+    ok = ok and float(trunc.sum()) == 0.0
+    # A must now be rank 0's
+    gathered = [torch.zeros_like(A.linear.weight) for _ in range(world)]
+    dist.all_gather(gathered, A.linear.weight.detach())
+    ok = ok and torch.equal(gathered[0], gathered[1])
+    # sharding of a global latent batch
+    lo, hi = D.shard_range(10, rank, world)
+    total = torch.tensor([hi - lo])
+    dist.all_reduce(total)
+    ok = ok and int(total) == 10
+    # gradient averaging
+    A.linear.weight.grad = torch.full_like(A.linear.weight, float(rank + 1))
+    A.linear.bias.grad = torch.full_like(A.linear.bias, float(10 * (rank + 1)))
+    D.allreduce_grads(A)
+    ok = ok and float(A.linear.weight.grad[0, 0]) == 1.5 and float(A.linear.bias.grad[0]) == 15.0
+    m = D.max_over_ranks(float(rank), torch.device('cpu'))
+    ok = ok and m == float(world - 1)
+    D.barrier()
+    q.put((rank, bool(ok), nbytes))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_broadcast_and_shard_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res), res
+    assert all(p.exitcode == 0 for p in procs)
+    assert res[0][2] > 4 * 20e6     # ~23.6 M floats of Generator(32) state in one flat buffer
