@@ -21,6 +21,7 @@
  *   sgdfr_latent_prepare_f32   model.py:494-508 truncation + W->W+ broadcast, libs/utilities/generic.py:116-135 shift add
  *   sgdfr_modconv_prepack_f32  model.py:215,218-220,236 (scale*weight) -- layout change + sum-of-squares for demodulation
  *   sgdfr_style_demod_f32      model.py:235-240 modulation(style) and rsqrt(sum w^2 + 1e-8)
+ *   sgdfr_styles_batched_f32   the same for all 20 modulated convs of Generator.forward (model.py:520-531) at once
  *   sgdfr_modconv2d_fwd_f32    model.py:232-273 ModulatedConv2d.forward (+ :282-287 NoiseInjection, op/fused_act.py:81-86
  *                              FusedLeakyReLU folded into the epilogue); the reference has NO native kernel for this --
  *                              its boundary is the Python method
@@ -91,6 +92,21 @@ int sgdfr_modconv_prepack_f32(const float* weight, float* wp, float* q, int Cout
  * d[b,o] = rsqrt( sum_i s[b,i]^2 * q[o*Cin + i] + 1e-8 )        (skipped when d == NULL) */
 int sgdfr_style_demod_f32(const float* style, int64_t ld_style, const float* mod_w, const float* mod_b,
                           const float* q, float* s, float* d, int B, int D, int Cin, int Cout, void* stream);
+
+/* All style modulations and demodulation coefficients of one generator forward in two launches
+ * (sgdfr_style_demod_f32 for every layer at once).  `layers` is a HOST array; layer i reads
+ * latent[:, latent_index, :] of latent [B, L, D] and writes s [B,cin] and, when d != NULL, d [B,cout]. */
+#define SGDFR_MAX_STYLE_LAYERS 40
+typedef struct sgdfr_style_layer {
+    const float* mod_w; /* [cin, D] */
+    const float* mod_b; /* [cin]    */
+    const float* q;     /* [cout, cin] or NULL */
+    float* s;           /* [B, cin]  */
+    float* d;           /* [B, cout] or NULL */
+    int cin, cout, latent_index;
+} sgdfr_style_layer;
+int sgdfr_styles_batched_f32(const float* latent, int B, int L, int D, const sgdfr_style_layer* layers, int n_layers,
+                             void* stream);
 
 /* Shared-weight modulated 3x3 convolution on fp32 MFMA.
  *   x      [B, Cin, H, W]  (x_bstride = Cin*H*W, or 0 to broadcast one [Cin,H,W] constant over the batch)

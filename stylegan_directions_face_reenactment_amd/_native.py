@@ -37,6 +37,18 @@ SIGNATURES = {
                             ctypes.c_void_p],
 }
 
+
+
+class StyleLayer(ctypes.Structure):
+    """struct sgdfr_style_layer (include/sgdfr.h)."""
+    _fields_ = [('mod_w', ctypes.c_void_p), ('mod_b', ctypes.c_void_p), ('q', ctypes.c_void_p),
+                ('s', ctypes.c_void_p), ('d', ctypes.c_void_p), ('cin', ctypes.c_int), ('cout', ctypes.c_int),
+                ('latent_index', ctypes.c_int)]
+
+
+SIGNATURES['sgdfr_styles_batched_f32'] = [_c_f32p, _i, _i, _i, ctypes.POINTER(StyleLayer), _i, ctypes.c_void_p]
+MAX_STYLE_LAYERS = 40
+
 MODE_PLAIN3, MODE_UP3 = 0, 1
 ACT_NONE, ACT_LRELU = 0, 1
 

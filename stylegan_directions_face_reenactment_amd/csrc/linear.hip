@@ -6,31 +6,30 @@
 
 namespace sgdfr {
 
-constexpr int LBM = 32, LBN = 64, LBK = 32;
+constexpr int LBK = 32;
 
-// EPI 0: y = act(acc*wscale + bias*bscale);  EPI 1: y = rsqrt(acc + eps)  (wscale carries eps)
+// One BM x BN output tile of  y = epi(x[M,K] @ w[N,K]^T)  by a 256-thread block (16 x 16 threads, each
+// (BM/16) x (BN/16) outputs).  Tiles of x and w are staged k-major in LDS (lanes along k for the global
+// reads: 128-byte rows; padded rows make the transposed LDS writes conflict-free).
+// EPI 0: y = act(acc*wscale + bias*bscale);  EPI 1: y = rsqrt(acc + wscale)  (wscale carries eps)
 // SQX: use x^2 instead of x (demodulation: sum_i s^2 q)
-template <bool SQX, int EPI>
-__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int64_t ldx,
-                                                    const float* __restrict__ w, const float* __restrict__ bias,
-                                                    float* __restrict__ y, int64_t ldy, int M, int N, int K,
-                                                    float wscale, float bscale, int act, float slope, float gain) {
-    __shared__ float xs[LBK][LBM + 1];
-    __shared__ float ws[LBK][LBN + 1];
+template <bool SQX, int EPI, int BM, int BN>
+__device__ __forceinline__ void linear_tile(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                            const float* __restrict__ bias, float* __restrict__ y, int64_t ldy, int M,
+                                            int N, int K, int m0, int n0, float wscale, float bscale, int act,
+                                            float slope, float gain, float (*xs)[BM + 1], float (*ws)[BN + 1]) {
+    constexpr int TM = BM / 16, TN = BN / 16;
     const int tid = threadIdx.x;
-    const int tx = tid & 15;   // N direction: 4 columns each (tx + 16*j)
-    const int ty = tid >> 4;   // M direction: 2 rows each (ty + 16*i)
-    const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
-    float acc[2][4] = {};
+    const int tx = tid & 15, ty = tid >> 4;
+    float acc[TM][TN] = {};
     for (int k0 = 0; k0 < K; k0 += LBK) {
-        // x tile: LBM x LBK, lanes along k (contiguous in memory)
-        for (int e = tid; e < LBM * LBK; e += 256) {
+        for (int e = tid; e < BM * LBK; e += 256) {
             const int kk = e & (LBK - 1), mm = e >> 5;
             float v = 0.f;
             if (m0 + mm < M && k0 + kk < K) v = x[(int64_t)(m0 + mm) * ldx + k0 + kk];
             xs[kk][mm] = SQX ? v * v : v;
         }
-        for (int e = tid; e < LBN * LBK; e += 256) {
+        for (int e = tid; e < BN * LBK; e += 256) {
             const int kk = e & (LBK - 1), nn = e >> 5;
             float v = 0.f;
             if (n0 + nn < N && k0 + kk < K) v = w[(int64_t)(n0 + nn) * K + k0 + kk];
@@ -39,24 +38,24 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < LBK; ++kk) {
-            float a[2], b[4];
+            float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = xs[kk][ty + 16 * i];
+            for (int i = 0; i < TM; ++i) a[i] = xs[kk][ty + 16 * i];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = ws[kk][tx + 16 * j];
+            for (int j = 0; j < TN; ++j) b[j] = ws[kk][tx + 16 * j];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
         const int m = m0 + ty + 16 * i;
         if (m >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < TN; ++j) {
             const int n = n0 + tx + 16 * j;
             if (n >= N) continue;
             float v;
@@ -71,6 +70,19 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
     }
 }
 
+constexpr int LBM = 32, LBN = 32;
+
+template <bool SQX, int EPI>
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int64_t ldx,
+                                                    const float* __restrict__ w, const float* __restrict__ bias,
+                                                    float* __restrict__ y, int64_t ldy, int M, int N, int K,
+                                                    float wscale, float bscale, int act, float slope, float gain) {
+    __shared__ float xs[LBK][LBM + 1];
+    __shared__ float ws[LBK][LBN + 1];
+    linear_tile<SQX, EPI, LBM, LBN>(x, ldx, w, bias, y, ldy, M, N, K, blockIdx.y * LBM, blockIdx.x * LBN, wscale,
+                                    bscale, act, slope, gain, xs, ws);
+}
+
 template <bool SQX, int EPI>
 static int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int M,
                          int N, int K, float wscale, float bscale, int act, float slope, float gain, void* stream) {
@@ -78,6 +90,37 @@ static int launch_linear(const float* x, int64_t ldx, const float* w, const floa
     hipLaunchKernelGGL((linear_kernel<SQX, EPI>), grid, dim3(256), 0, as_stream(stream), x, ldx, w, bias, y, ldy, M, N,
                        K, wscale, bscale, act, slope, gain);
     return check_launch("linear");
+}
+
+// All per-layer style modulations (STAGE 0) or all demodulation coefficients (STAGE 1) of one generator
+// forward in ONE launch: 20 (resp. 13) small GEMMs are independent, so their tiles simply share a grid.
+struct StyleBatch {
+    sgdfr_style_layer layer[SGDFR_MAX_STYLE_LAYERS];
+    int tile_start[SGDFR_MAX_STYLE_LAYERS + 1];   // prefix sums of tiles per layer
+    int n_layers;
+    const float* latent;
+    int B, L, D;
+    float wscale;   // 1/sqrt(D), computed on the host like the single-layer entry point
+};
+
+template <int STAGE>
+__global__ __launch_bounds__(256) void styles_batched_kernel(StyleBatch sb) {
+    __shared__ float xs[LBK][LBM + 1];
+    __shared__ float ws[LBK][LBN + 1];
+    int li = 0;
+    while (li + 1 < sb.n_layers && (int)blockIdx.x >= sb.tile_start[li + 1]) ++li;
+    const sgdfr_style_layer& ly = sb.layer[li];
+    const int t = blockIdx.x - sb.tile_start[li];
+    const int N = STAGE == 0 ? ly.cin : ly.cout;
+    const int ntn = (N + LBN - 1) / LBN;
+    const int m0 = (t / ntn) * LBM, n0 = (t % ntn) * LBN;
+    if (STAGE == 0)
+        linear_tile<false, 0, LBM, LBN>(sb.latent + (int64_t)ly.latent_index * sb.D, (int64_t)sb.L * sb.D, ly.mod_w,
+                                        ly.mod_b, ly.s, ly.cin, sb.B, ly.cin, sb.D, m0, n0, sb.wscale, 1.f,
+                                        SGDFR_ACT_NONE, 0.f, 1.f, xs, ws);
+    else
+        linear_tile<true, 1, LBM, LBN>(ly.s, ly.cin, ly.q, nullptr, ly.d, ly.cout, sb.B, ly.cout, ly.cin, m0, n0, 1e-8f,
+                                       0.f, 0, 0.f, 1.f, xs, ws);
 }
 
 }  // namespace sgdfr
@@ -107,4 +150,47 @@ extern "C" int sgdfr_style_demod_f32(const float* style, int64_t ld_style, const
     if (rc || !d) return rc;
     SGDFR_REQUIRE(q && Cout > 0, "style_demod: d requested without q/Cout");
     return launch_linear<true, 1>(s, Cin, q, nullptr, d, Cout, B, Cout, Cin, 1e-8f, 0.f, 0, 0.f, 1.f, stream);
+}
+
+extern "C" int sgdfr_styles_batched_f32(const float* latent, int B, int L, int D, const sgdfr_style_layer* layers,
+                                        int n_layers, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && L > 0 && D > 0, "styles_batched: bad shape B=%d L=%d D=%d", B, L, D);
+    SGDFR_REQUIRE(n_layers > 0 && n_layers <= SGDFR_MAX_STYLE_LAYERS, "styles_batched: n_layers %d not in 1..%d",
+                  n_layers, SGDFR_MAX_STYLE_LAYERS);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(latent && layers, "styles_batched: null pointer");
+    StyleBatch sb{};
+    sb.n_layers = n_layers; sb.latent = latent; sb.B = B; sb.L = L; sb.D = D;
+    sb.wscale = 1.0f / sqrtf((float)D);
+    const int mt = (B + LBM - 1) / LBM;
+    int tiles = 0, dl = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const sgdfr_style_layer& ly = layers[i];
+        SGDFR_REQUIRE(ly.mod_w && ly.mod_b && ly.s && ly.cin > 0, "styles_batched: layer %d incomplete", i);
+        SGDFR_REQUIRE(ly.latent_index >= 0 && ly.latent_index < L, "styles_batched: layer %d latent index %d out of range",
+                      i, ly.latent_index);
+        SGDFR_REQUIRE(!ly.d || (ly.q && ly.cout > 0), "styles_batched: layer %d wants d without q", i);
+        sb.layer[i] = ly;
+        sb.tile_start[i] = tiles;
+        tiles += mt * ((ly.cin + LBN - 1) / LBN);
+    }
+    sb.tile_start[n_layers] = tiles;
+    hipLaunchKernelGGL(styles_batched_kernel<0>, dim3(tiles), dim3(256), 0, as_stream(stream), sb);
+    if (int rc = check_launch("styles_batched(modulation)")) return rc;
+    // demodulation coefficients: only layers that asked for d
+    StyleBatch sd{};
+    sd.latent = latent; sd.B = B; sd.L = L; sd.D = D;
+    tiles = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        if (!layers[i].d) continue;
+        sd.layer[dl] = layers[i];
+        sd.tile_start[dl] = tiles;
+        tiles += mt * ((layers[i].cout + LBN - 1) / LBN);
+        ++dl;
+    }
+    if (dl == 0) return 0;
+    sd.tile_start[dl] = tiles;
+    sd.n_layers = dl;
+    hipLaunchKernelGGL(styles_batched_kernel<1>, dim3(tiles), dim3(256), 0, as_stream(stream), sd);
+    return check_launch("styles_batched(demod)");
 }

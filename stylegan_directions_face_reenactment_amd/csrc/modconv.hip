@@ -106,8 +106,8 @@ __device__ __forceinline__ void store_stage(const ModconvParams& p, int tid, int
     }
 }
 
-template <int MODE, int WM, int WN, int MI, int NI, int EX>
-__global__ __launch_bounds__(256) void modconv_mfma_kernel(ModconvParams p) {
+template <int MODE, int WM, int WN, int MI, int NI, int EX, int OCC>
+__global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p) {
     constexpr int NT = WM * MI * 32;
     constexpr int PT = WN * NI * 32;
     constexpr int PH = (MODE == SGDFR_MODE_UP3) ? 4 : 1;
@@ -116,9 +116,9 @@ __global__ __launch_bounds__(256) void modconv_mfma_kernel(ModconvParams p) {
     constexpr int WV = (WF4 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per block");
 
+    // two LDS stages: [x: CK*xs][w: CK*9*NT] each
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* lx = smem;
-    float* lw = smem + CK * p.xs;
+    const int stage_floats = CK * p.xs + CK * 9 * NT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -136,13 +136,13 @@ __global__ __launch_bounds__(256) void modconv_mfma_kernel(ModconvParams p) {
     }
     const int ct = lid / p.n_pix_tiles, pt = lid - ct * p.n_pix_tiles;
     const int n0 = ct * NT;
-    const int64_t p0 = (int64_t)pt * PT;
+    const int p0 = pt * PT;      // host guarantees every pixel / q index fits int32
 
     // ---- tile origin in the padded flat space
-    int64_t q0;
+    int q0;
     if (MODE == SGDFR_MODE_PLAIN3) {
-        const int64_t img = p0 / HW;
-        const int rem = (int)(p0 - img * HW);
+        const int img = p0 / HW;
+        const int rem = p0 - img * HW;
         const int a = rem / p.W, b = rem - a * p.W;
         q0 = (img * p.R + a + 1) * p.P + b + 1 - p.P - 1;
     } else {
@@ -151,22 +151,23 @@ __global__ __launch_bounds__(256) void modconv_mfma_kernel(ModconvParams p) {
 
     // ---- per-lane B-fragment offsets (pixel -> position inside the staged q-range)
     int boff[NI];
-    int64_t pixv[NI];
+    int pixv[NI];
+    const int total_pix = (int)p.total_pix;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-        int64_t pix = p0 + (wn * NI + ni) * 32 + l31;
+        int pix = p0 + (wn * NI + ni) * 32 + l31;
         pixv[ni] = pix;
-        if (pix >= p.total_pix) pix = p.total_pix - 1;
-        int64_t qb;
+        if (pix >= total_pix) pix = total_pix - 1;
+        int qb;
         if (MODE == SGDFR_MODE_PLAIN3) {
-            const int64_t img = pix / HW;
-            const int rem = (int)(pix - img * HW);
+            const int img = pix / HW;
+            const int rem = pix - img * HW;
             const int a = rem / p.W, b = rem - a * p.W;
             qb = (img * p.R + a + 1) * p.P + b + 1;
         } else {
             qb = pix;
         }
-        boff[ni] = (int)(qb - q0) + hi * p.xs;
+        boff[ni] = (qb - q0) + hi * p.xs;
     }
 
     // ---- staging descriptors (fixed for the whole K loop): element offsets into x / s; positions that
@@ -178,14 +179,14 @@ __global__ __launch_bounds__(256) void modconv_mfma_kernel(ModconvParams p) {
 #pragma unroll
     for (int e = 0; e < EX; ++e) {
         const int j = tid + e * 256;
-        const int64_t q = q0 + j;
-        const int64_t pir = q / p.P;
-        const int pc = (int)(q - pir * p.P);
-        const int64_t img = pir / p.R;
-        const int pr = (int)(pir - img * p.R);
+        const int q = q0 + j;
+        const int pir = q / p.P;
+        const int pc = q - pir * p.P;
+        const int img = pir / p.R;
+        const int pr = pir - img * p.R;
         const bool ok = (j < p.xlen) && pc >= 1 && pr >= 1 && img < p.B;
-        xoff[e] = ok ? img * p.x_bstride + (int64_t)(pr - 1) * p.W + (pc - 1) : 0;
-        soff[e] = ok ? (int)img * p.Cin : 0;
+        xoff[e] = ok ? (int64_t)img * p.x_bstride + (pr - 1) * p.W + (pc - 1) : 0;
+        soff[e] = ok ? img * p.Cin : 0;
         okmask |= ok ? (1u << e) : 0u;
     }
 
@@ -215,14 +216,22 @@ __global__ __launch_bounds__(256) void modconv_mfma_kernel(ModconvParams p) {
     }
     const int aoff = wm * MI * 32 + l31;
 
+    // Software pipeline, ONE barrier per K stage: while the MFMAs consume LDS stage `cur`, the registers that
+    // were filled during the previous iteration are written to stage `cur^1` and the global loads of the stage
+    // after that are issued (their latency hides under this iteration's MFMAs).
     const int nstage = p.Cin / CK;
     load_stage<NT, EX, WV>(p, 0, tid, n0, HW, nex, xoff, soff, xr, sr, wr);
+    store_stage<NT, EX, WV>(p, tid, nex, okmask, smem, smem + CK * p.xs, xr, sr, wr);
+    if (nstage > 1) load_stage<NT, EX, WV>(p, CK, tid, n0, HW, nex, xoff, soff, xr, sr, wr);
+    __syncthreads();
     for (int st = 0; st < nstage; ++st) {
-        __syncthreads();  // previous stage's fragment reads are done
-        store_stage<NT, EX, WV>(p, tid, nex, okmask, lx, lw, xr, sr, wr);
-        __syncthreads();
-        if (st + 1 < nstage)  // in flight under the MFMAs below
-            load_stage<NT, EX, WV>(p, (st + 1) * CK, tid, n0, HW, nex, xoff, soff, xr, sr, wr);
+        float* lx = smem + (st & 1) * stage_floats;
+        float* lw = lx + CK * p.xs;
+        if (st + 1 < nstage) {
+            float* nx = smem + ((st + 1) & 1) * stage_floats;
+            store_stage<NT, EX, WV>(p, tid, nex, okmask, nx, nx + CK * p.xs, xr, sr, wr);
+            if (st + 2 < nstage) load_stage<NT, EX, WV>(p, (st + 2) * CK, tid, n0, HW, nex, xoff, soff, xr, sr, wr);
+        }
 #pragma unroll
         for (int cp = 0; cp < CK / 2; ++cp) {
             const float* lxc = lx + (cp * 2) * p.xs;
@@ -242,6 +251,7 @@ __global__ __launch_bounds__(256) void modconv_mfma_kernel(ModconvParams p) {
                         acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[ph][mi][ni], 0, 0, 0);
             }
         }
+        __syncthreads();  // stage st fully consumed, stage st+1 fully written
     }
 
     // ---- epilogue.  C/D layout of 32x32: column (pixel) = lane&31, row (cout) = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -249,10 +259,10 @@ __global__ __launch_bounds__(256) void modconv_mfma_kernel(ModconvParams p) {
         const float nw = (p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const int64_t pix = pixv[ni];
-            if (pix >= p.total_pix) continue;
+            const int pix = pixv[ni];
+            if (pix >= total_pix) continue;
             const int64_t img = pix / HW;
-            const int rem = (int)(pix - img * HW);
+            const int rem = pix - (int)img * HW;
             const float nz = p.noise ? nw * p.noise[img * p.noise_bstride + rem] : 0.f;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
@@ -273,10 +283,10 @@ __global__ __launch_bounds__(256) void modconv_mfma_kernel(ModconvParams p) {
     } else {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const int64_t pix = pixv[ni];
-            if (pix >= p.total_pix) continue;
+            const int pix = pixv[ni];
+            if (pix >= total_pix) continue;
             const int64_t img = pix / RP;
-            const int rem = (int)(pix - img * RP);
+            const int rem = pix - (int)img * RP;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -469,7 +479,7 @@ __global__ __launch_bounds__(256) void torgb_kernel(const float* __restrict__ x,
     }
 }
 
-template <int MODE, int WM, int WN, int MI, int NI, int EX>
+template <int MODE, int WM, int WN, int MI, int NI, int EX, int OCC>
 static int launch_modconv(ModconvParams& p, hipStream_t stream) {
     constexpr int NT = WM * MI * 32, PT = WN * NI * 32;
     p.n_cout_tiles = (p.Cout + NT - 1) / NT;
@@ -489,10 +499,11 @@ static int launch_modconv(ModconvParams& p, hipStream_t stream) {
                   p.W);
     p.xlen = xlen;
     p.xs = (xlen + 3) & ~3;
-    const size_t lds = (size_t)(CK * p.xs + CK * 9 * NT) * sizeof(float);
+    const size_t lds = 2 * (size_t)(CK * p.xs + CK * 9 * NT) * sizeof(float);   // double-buffered stages
+    SGDFR_REQUIRE(p.total_pix + 4ll * p.P + 8 < (1ll << 31), "modconv: batch too large for 32-bit pixel indices");
     const int64_t nblk = (int64_t)p.n_cout_tiles * p.n_pix_tiles;
     SGDFR_REQUIRE(nblk < (1ll << 31), "modconv: grid too large");
-    hipLaunchKernelGGL((modconv_mfma_kernel<MODE, WM, WN, MI, NI, EX>), dim3((unsigned)nblk), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((modconv_mfma_kernel<MODE, WM, WN, MI, NI, EX, OCC>), dim3((unsigned)nblk), dim3(256), lds, stream, p);
     return check_launch("modconv2d_fwd");
 }
 
@@ -542,17 +553,17 @@ extern "C" int sgdfr_modconv2d_fwd_f32(const float* x, int64_t x_bstride, const 
     if (mode == SGDFR_MODE_PLAIN3) {
         p.total_pix = (int64_t)B * H * W;
         const int64_t big_blocks = ((p.total_pix + 127) / 128) * ((Cout + 127) / 128);
-        if (Cout % 128 == 0 && big_blocks >= 512) return launch_modconv<SGDFR_MODE_PLAIN3, 2, 2, 2, 2, 3>(p, st);
+        if (Cout % 128 == 0 && big_blocks >= 512) return launch_modconv<SGDFR_MODE_PLAIN3, 2, 2, 2, 2, 3, 3>(p, st);
         if (Cout % 64 == 0 && p.total_pix >= 128 * 512)
-            return launch_modconv<SGDFR_MODE_PLAIN3, 2, 2, 1, 2, 3>(p, st);                       // NT 64, PT 128
-        if (Cout > 32) return launch_modconv<SGDFR_MODE_PLAIN3, 2, 2, 1, 1, 3>(p, st);            // NT 64, PT 64
-        return launch_modconv<SGDFR_MODE_PLAIN3, 1, 4, 1, 1, 3>(p, st);                           // NT 32, PT 128
+            return launch_modconv<SGDFR_MODE_PLAIN3, 2, 2, 1, 2, 3, 3>(p, st);                       // NT 64, PT 128
+        if (Cout > 32) return launch_modconv<SGDFR_MODE_PLAIN3, 2, 2, 1, 1, 3, 3>(p, st);            // NT 64, PT 64
+        return launch_modconv<SGDFR_MODE_PLAIN3, 1, 4, 1, 1, 3, 3>(p, st);                           // NT 32, PT 128
     } else {
         p.total_pix = (int64_t)B * (H + 1) * (W + 1);
         const int64_t big_blocks = ((p.total_pix + 63) / 64) * ((Cout + 127) / 128);
-        if (Cout % 128 == 0 && big_blocks >= 512) return launch_modconv<SGDFR_MODE_UP3, 4, 1, 1, 2, 2>(p, st);  // NT 128, PT 64
-        if (Cout > 32) return launch_modconv<SGDFR_MODE_UP3, 2, 2, 1, 1, 2>(p, st);               // NT 64, PT 64
-        return launch_modconv<SGDFR_MODE_UP3, 1, 4, 1, 1, 2>(p, st);                              // NT 32, PT 128
+        if (Cout % 128 == 0 && big_blocks >= 512) return launch_modconv<SGDFR_MODE_UP3, 4, 1, 1, 2, 2, 2>(p, st);  // NT 128, PT 64
+        if (Cout > 32) return launch_modconv<SGDFR_MODE_UP3, 2, 2, 1, 1, 2, 3>(p, st);               // NT 64, PT 64
+        return launch_modconv<SGDFR_MODE_UP3, 1, 4, 1, 1, 2, 3>(p, st);                              // NT 32, PT 128
     }
 }
 

@@ -140,6 +140,40 @@ def style_demod(style, mod_weight, mod_bias, q=None, cout=0):
     return s, d
 
 
+def styles_batched(latent, specs):
+    """All modulations / demodulation coefficients of one forward in two launches.
+    latent [B, L, D] contiguous; specs: list of (latent_index, mod_weight, mod_bias, q or None, cout).
+    Returns [(s [B,cin], d [B,cout] or None), ...] as views into two flat buffers."""
+    N.require_device(latent)
+    latent = N.f32c(latent)
+    B, L, D = latent.shape
+    if len(specs) > N.MAX_STYLE_LAYERS:
+        raise RuntimeError('too many modulated layers (%d)' % len(specs))
+    n_s = sum(mw.shape[0] for _, mw, _, _, _ in specs)
+    n_d = sum(cout for _, _, _, q, cout in specs if q is not None)
+    s_all = torch.empty(B * n_s, device=latent.device, dtype=torch.float32)
+    d_all = torch.empty(max(B * n_d, 1), device=latent.device, dtype=torch.float32)
+    arr = (N.StyleLayer * len(specs))()
+    out, so, do = [], 0, 0
+    for i, (li, mw, mb, q, cout) in enumerate(specs):
+        N.require_device(mw, mb, q)
+        cin = mw.shape[0]
+        s = s_all[so:so + B * cin].view(B, cin)
+        so += B * cin
+        d = None
+        if q is not None:
+            d = d_all[do:do + B * cout].view(B, cout)
+            do += B * cout
+        e = arr[i]
+        e.mod_w, e.mod_b = N.f32c(mw).data_ptr(), N.f32c(mb).data_ptr()
+        e.q = q.data_ptr() if q is not None else None
+        e.s, e.d = s.data_ptr(), (d.data_ptr() if d is not None else None)
+        e.cin, e.cout, e.latent_index = cin, cout, li
+        out.append((s, d))
+    N.call('sgdfr_styles_batched_f32', N.ptr(latent), B, L, D, arr, len(specs), N.stream())
+    return out
+
+
 def _noise_args(noise, B, H, W):
     """(tensor, batch stride) for a [1,1,H,W] shared or [B,1,H,W] per-sample noise map."""
     if noise is None:

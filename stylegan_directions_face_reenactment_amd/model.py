@@ -144,9 +144,19 @@ class ModulatedConv2d(nn.Module):
         s, d = F_.style_demod(style, mod.weight, mod.bias, q if self.demodulate else None, self.out_channel)
         return wp, s, d
 
-    def fused(self, input, style, noise=None, noise_weight=None, bias=None, activate=False, batch=None):
-        """conv (+ noise + bias + leaky-ReLU) in one pass; what StyledConv.forward calls."""
-        wp, s, d = self._styles(style)
+    def style_spec(self, latent_index):
+        """(latent row, modulation weight, bias, Q or None, Cout) for functional.styles_batched."""
+        _, q = self.packed() if self.kernel_size == 3 else (None, None)
+        return (latent_index, self.modulation.weight, self.modulation.bias, q if self.demodulate else None,
+                self.out_channel)
+
+    def fused(self, input, style, noise=None, noise_weight=None, bias=None, activate=False, batch=None, sd=None):
+        """conv (+ noise + bias + leaky-ReLU) in one pass; what StyledConv.forward calls.
+        `sd` = precomputed (s, d) from the generator's batched style launch."""
+        if sd is None:
+            wp, s, d = self._styles(style)
+        else:
+            wp, (s, d) = self.packed()[0], sd
         if self.kernel_size == 1:
             if self.demodulate:
                 raise NotImplementedError('1x1 modulated conv with demodulation is not on the generator path')
@@ -201,13 +211,13 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, noise=None, batch=None):
+    def forward(self, input, style, noise=None, batch=None, sd=None):
         if noise is None:   # fresh per-sample noise, model.py:283-285
-            B = style.shape[0]
+            B = style.shape[0] if sd is None else sd[0].shape[0]
             r = input.shape[-1] * (2 if self.conv.upsample else 1)
-            noise = torch.empty(B, 1, r, r, device=style.device, dtype=torch.float32).normal_()
+            noise = torch.empty(B, 1, r, r, device=input.device, dtype=torch.float32).normal_()
         out = self.conv.fused(input, style, noise=noise, noise_weight=self.noise.weight, bias=self.activate.bias,
-                              activate=True, batch=batch)
+                              activate=True, batch=batch, sd=sd)
         return F_.forward_only(out, 'StyledConv', input, style, *self.parameters())
 
 
@@ -221,9 +231,9 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
-    def forward(self, input, style, skip=None):
+    def forward(self, input, style, skip=None, sd=None):
         conv = self.conv
-        s, _ = F_.style_demod(style, conv.modulation.weight, conv.modulation.bias)
+        s = sd[0] if sd is not None else F_.style_demod(style, conv.modulation.weight, conv.modulation.bias)[0]
         fir = None
         if skip is not None:
             up = getattr(self, 'upsample', None)
@@ -307,16 +317,22 @@ class Generator(nn.Module):
             latent = torch.cat([a, b], 1)
         batch = latent.shape[0]
 
-        # ConstantInput is broadcast inside the kernel (batch stride 0) instead of repeated
-        out = self.conv1(self.input.input, latent[:, 0], noise=noise[0], batch=batch)
-        skip = self.to_rgb1(out, latent[:, 1])
+        # every layer's modulation s = A_l(w_l) and demodulation d_l in two launches (instead of 33)
+        order = [(self.conv1.conv, 0), (self.to_rgb1.conv, 1)]
         i = 1
+        for conv1, conv2, to_rgb in zip(self.convs[::2], self.convs[1::2], self.to_rgbs):
+            order += [(conv1.conv, i), (conv2.conv, i + 1), (to_rgb.conv, i + 2)]
+            i += 2
+        sd = iter(F_.styles_batched(latent, [m.style_spec(li) for m, li in order]))
+
+        # ConstantInput is broadcast inside the kernel (batch stride 0) instead of repeated
+        out = self.conv1(self.input.input, None, noise=noise[0], batch=batch, sd=next(sd))
+        skip = self.to_rgb1(out, None, sd=next(sd))
         for conv1, conv2, noise1, noise2, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2],
                                                         noise[2::2], self.to_rgbs):
-            out = conv1(out, latent[:, i], noise=noise1)
-            out = conv2(out, latent[:, i + 1], noise=noise2)
-            skip = to_rgb(out, latent[:, i + 2], skip)
-            i += 2
+            out = conv1(out, None, noise=noise1, sd=next(sd))
+            out = conv2(out, None, noise=noise2, sd=next(sd))
+            skip = to_rgb(out, None, skip, sd=next(sd))
         image = skip
         if torch.is_grad_enabled():
             image = F_.forward_only(image, 'Generator.forward', *styles, *self.parameters())
