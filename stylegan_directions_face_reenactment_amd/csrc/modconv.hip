@@ -554,8 +554,10 @@ extern "C" int sgdfr_modconv2d_fwd_f32(const float* x, int64_t x_bstride, const 
         p.total_pix = (int64_t)B * H * W;
         const int64_t big_blocks = ((p.total_pix + 127) / 128) * ((Cout + 127) / 128);
         if (Cout % 128 == 0 && big_blocks >= 512) return launch_modconv<SGDFR_MODE_PLAIN3, 2, 2, 2, 2, 3, 3>(p, st);
+        if (Cout % 64 == 0 && p.total_pix >= 256 * 1024)
+            return launch_modconv<SGDFR_MODE_PLAIN3, 1, 4, 2, 2, 4, 3>(p, st);                    // NT 64, PT 256
         if (Cout % 64 == 0 && p.total_pix >= 128 * 512)
-            return launch_modconv<SGDFR_MODE_PLAIN3, 2, 2, 1, 2, 3, 3>(p, st);                       // NT 64, PT 128
+            return launch_modconv<SGDFR_MODE_PLAIN3, 2, 2, 1, 2, 3, 3>(p, st);                    // NT 64, PT 128
         if (Cout > 32) return launch_modconv<SGDFR_MODE_PLAIN3, 2, 2, 1, 1, 3, 3>(p, st);            // NT 64, PT 64
         return launch_modconv<SGDFR_MODE_PLAIN3, 1, 4, 1, 1, 3, 3>(p, st);                           // NT 32, PT 128
     } else {

@@ -59,73 +59,87 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UpfirdnParams p) {
 // Blur after the stride-2 transposed conv, reading the parity planes written by MODE_UP3.
 //   t: [planes, 4, H+1, W+1], plane ph = 2*(row&1)+(col&1) holds T[row,col] at [row>>1, col>>1]
 //   y: [planes, 2H, 2W];  y[oy,ox] = sum_{ky,kx} Tpad[oy+ky, ox+kx] * K[3-ky][3-kx],  Tpad[i,j] = T[i-1,j-1]
-// One thread per 2x2 output quad: a 5x5 window of T (25 coalesced dword loads) feeds 4 outputs
-// (two float2 stores).  Epilogue: + noise_w*noise + bias[c], leaky-ReLU * gain.
+// One thread owns a vertical strip of QV 2x2 output quads and slides a 5-row x 5-col register window of
+// T down the strip: 2 new T rows (10 coalesced dword loads) per quad after the first 5 rows, two float2
+// stores per quad.  Lanes run along x so neighbouring windows share cache lines.
+// Epilogue: + noise_w*noise + bias[c], leaky-ReLU * gain.
+constexpr int BLUR_QV = 4;
+
 __global__ __launch_bounds__(256) void blur_bias_act_kernel(const float* __restrict__ t, const float* __restrict__ fir,
                                                            const float* __restrict__ noise, int64_t noise_bstride,
                                                            const float* __restrict__ noise_w,
                                                            const float* __restrict__ bias, float* __restrict__ y, int B,
                                                            int C, int H, int W, int act, float slope, float gain) {
-    __shared__ float kf[16];
-    if (threadIdx.x < 16) kf[threadIdx.x] = fir[15 - threadIdx.x];  // flipped: kf[ky*4+kx] = K[3-ky][3-kx]
-    __syncthreads();
+    float kf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kf[i] = fir[15 - i];  // flipped: kf[ky*4+kx] = K[3-ky][3-kx] (uniform -> SGPRs)
     const int GW = W + 1, GH = H + 1;
     const int64_t plane_t = (int64_t)4 * GH * GW;
-    const int64_t quads = (int64_t)B * C * H * W;
+    const int HS = (H + BLUR_QV - 1) / BLUR_QV;  // strips per column
+    const int64_t strips = (int64_t)B * C * HS * W;
     const float nw = (noise && noise_w) ? noise_w[0] : 0.f;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < quads;
+    const int OW = 2 * W;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < strips;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int n = (int)(idx % W);
         int64_t r = idx / W;
-        const int m = (int)(r % H);
-        const int64_t pl = r / H;  // b*C + c
+        const int ms = (int)(r % HS) * BLUR_QV;
+        const int64_t pl = r / HS;  // b*C + c
         const float* tp = t + pl * plane_t;
-        float win[5][5];
-#pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int tr = 2 * m - 1 + u;  // -1 .. 2H+1 ; rows 2H+1 are stored zeros of the odd planes
-#pragma unroll
-            for (int v = 0; v < 5; ++v) {
-                const int tc = 2 * n - 1 + v;
-                float val = 0.f;
-                if (tr >= 0 && tc >= 0)
-                    val = tp[((int64_t)(2 * (tr & 1) + (tc & 1)) * GH + (tr >> 1)) * GW + (tc >> 1)];
-                win[u][v] = val;
-            }
-        }
         const int c = (int)(pl % C);
         const int b = (int)(pl / C);
         const float bv = bias ? bias[c] : 0.f;
-        float o[2][2];
+        // column descriptors of the 5-wide window: T col 2n-1+v -> plane parity (v+1)&1, plane col (2n-1+v)>>1
+        int coff[5];
+        bool cok[5];
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
+        for (int v = 0; v < 5; ++v) {
+            const int tc = 2 * n - 1 + v;
+            cok[v] = tc >= 0;
+            coff[v] = (tc & 1) * GH * GW + (tc >> 1);
+        }
+        float win[5][5];
+        auto load_row = [&](int tr, float (&dst)[5]) {  // T row tr in [-1, 2H+1]; rows 2H+1 are stored zeros
+            const bool rok = tr >= 0;
+            const int roff = (tr & 1) * 2 * GH * GW + (tr >> 1) * GW;
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                float acc = 0.f;
+            for (int v = 0; v < 5; ++v) dst[v] = (rok && cok[v]) ? tp[roff + coff[v]] : 0.f;
+        };
+#pragma unroll
+        for (int u = 0; u < 3; ++u) load_row(2 * ms - 1 + u, win[u]);
+#pragma unroll
+        for (int qv = 0; qv < BLUR_QV; ++qv) {
+            const int m = ms + qv;
+            if (m >= H) break;
+            load_row(2 * m + 2, win[3]);
+            load_row(2 * m + 3, win[4]);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                float o0 = 0.f, o1 = 0.f;
 #pragma unroll
                 for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 4; ++kx) acc = fmaf(win[rr + ky][cc + kx], kf[ky * 4 + kx], acc);
-                o[rr][cc] = acc;
+                    for (int kx = 0; kx < 4; ++kx) {
+                        o0 = fmaf(win[rr + ky][kx], kf[ky * 4 + kx], o0);
+                        o1 = fmaf(win[rr + ky][1 + kx], kf[ky * 4 + kx], o1);
+                    }
+                const int oy = 2 * m + rr;
+                float v0 = o0 + bv, v1 = o1 + bv;
+                if (noise) {
+                    const float* np = noise + (int64_t)b * noise_bstride + (int64_t)oy * OW + 2 * n;
+                    v0 = fmaf(nw, np[0], v0);
+                    v1 = fmaf(nw, np[1], v1);
+                }
+                if (act) {
+                    v0 = lrelu_gain(v0, slope, gain);
+                    v1 = lrelu_gain(v1, slope, gain);
+                }
+                *reinterpret_cast<float2*>(y + (pl * 2 * H + oy) * OW + 2 * n) = make_float2(v0, v1);
             }
-        const int OW = 2 * W;
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int oy = 2 * m + rr;
-            float2 out;
-            float v0 = o[rr][0] + bv, v1 = o[rr][1] + bv;
-            if (noise) {
-                const float* np = noise + (int64_t)b * noise_bstride + (int64_t)oy * OW + 2 * n;
-                v0 = fmaf(nw, np[0], v0);
-                v1 = fmaf(nw, np[1], v1);
-            }
-            if (act) {
-                v0 = lrelu_gain(v0, slope, gain);
-                v1 = lrelu_gain(v1, slope, gain);
-            }
-            out.x = v0;
-            out.y = v1;
-            *reinterpret_cast<float2*>(y + (pl * 2 * H + oy) * OW + 2 * n) = out;
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int v = 0; v < 5; ++v) win[u][v] = win[u + 2][v];
         }
     }
 }
@@ -162,9 +176,9 @@ extern "C" int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const f
     if (B == 0) return 0;
     SGDFR_REQUIRE(t && fir && y, "blur_bias_act: null pointer");
     SGDFR_REQUIRE(!noise || noise_w, "blur_bias_act: noise without noise_w");
-    const int64_t quads = (int64_t)B * C * H * W;
-    int64_t g = (quads + 255) / 256;
-    if (g > 256 * 16) g = 256 * 16;
+    const int64_t strips = (int64_t)B * C * ((H + BLUR_QV - 1) / BLUR_QV) * W;
+    int64_t g = (strips + 255) / 256;
+    if (g > 256 * 32) g = 256 * 32;
     hipLaunchKernelGGL(blur_bias_act_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), t, fir, noise,
                        noise_bstride, noise_w, bias, y, B, C, H, W, act, slope, gain);
     return check_launch("blur_bias_act");
