@@ -70,6 +70,19 @@ def cpu_baseline(size, cm, budget_s=20.0):
                       '(oracle/sg2_oracle.py), %.1f s' % (reps, B, size, cm, el)}
 
 
+def pmc_traffic(args, B):
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (profiles/traffic_latest.json; PMC
+    counters cannot be collected from inside the timed process).  None when the profile is for another shape."""
+    path = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
+    try:
+        t = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if t.get('config') != {'batch': B, 'cm': args.cm, 'size': args.size}:
+        return None
+    return round(t['bytes_per_launch'])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -160,7 +173,7 @@ def main():
                    'weight_broadcast_bytes': bcast_bytes},
         'roofline': {'bound': 'mfma', 'kernel': 'modconv_mfma_kernel (13 launches/forward)',
                      'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                     'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(args, B),
                      'avg_launch_us': round(conv_s / n_launch * 1e6, 2),
                      'conv_ms_per_step': round(conv_s / args.steps * 1e3, 3),
                      'alg_gflop_per_frame': round(conv_flops / (B * args.steps) / 1e9, 3)},
