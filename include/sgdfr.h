@@ -37,11 +37,13 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 1
+#define SGDFR_ABI_VERSION 2
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
 #define SGDFR_MODE_UP3 1    /* 3x3 transposed stride 2 -> phase planes of size (H+1)x(W+1) (model.py:246-256) */
+#define SGDFR_MODE_DOWN3 2  /* adjoint of UP3: 3x3 stride-2 conv reading phase planes [B,Cin,4,H+1,W+1] -> [B,Cout,H,W]
+                               (the dX of the transposed conv; autograd of model.py:254) */
 
 /* activation codes of sgdfr_linear_f32 */
 #define SGDFR_ACT_NONE 0
@@ -85,8 +87,14 @@ int sgdfr_latent_prepare_f32(const float* w, int w_is_plus, const float* shift, 
                              void* stream);
 
 /* weight [Cout, Cin, k, k] -> wp [Cin, k*k, Cout] = weight * 1/sqrt(Cin*k*k)  and
- *                              q  [Cout, Cin]     = sum_taps wp^2                (q may be NULL) */
-int sgdfr_modconv_prepack_f32(const float* weight, float* wp, float* q, int Cout, int Cin, int k, void* stream);
+ *                              q  [Cout, Cin]     = sum_taps wp^2 ,  qt [Cin, Cout] = q^T   (q, qt may be NULL) */
+int sgdfr_modconv_prepack_f32(const float* weight, float* wp, float* q, float* qt, int Cout, int Cin, int k,
+                              void* stream);
+
+/* weight [Cout, Cin, k, k] -> wt [Cout, k*k, Cin] * 1/sqrt(Cin*k*k), taps reversed when flip != 0: the weight pack of
+ * the ADJOINT convs (dL/dx): sgdfr_modconv2d_fwd_f32 with (Cin, Cout) exchanged, s <- d, d <- s;
+ * PLAIN3 backward uses flip = 1 in mode PLAIN3, UP3 backward uses flip = 0 in mode DOWN3. */
+int sgdfr_modconv_prepack_t_f32(const float* weight, float* wt, int Cout, int Cin, int k, int flip, void* stream);
 
 /* s[b,i] = (sum_j style[b*ld_style + j] * mod_w[i*D + j]) / sqrt(D) + mod_b[i]
  * d[b,o] = rsqrt( sum_i s[b,i]^2 * q[o*Cin + i] + 1e-8 )        (skipped when d == NULL) */
@@ -118,7 +126,10 @@ int sgdfr_styles_batched_f32(const float* latent, int B, int L, int D, const sgd
  * mode UP3:    y [B, Cout, 4, H+1, W+1] = d * conv_transpose2d(x*s, stride 2) split by output parity:
  *              plane ph = 2*(oy&1) + (ox&1) holds T[oy, ox] at [oy>>1, ox>>1]; entries of the odd planes that fall
  *              outside the (2H+1)x(2W+1) result are written as exact zeros.  noise/bias/act are NOT applied
- *              (sgdfr_blur_bias_act_f32 does that after the FIR). */
+ *              (sgdfr_blur_bias_act_f32 does that after the FIR).
+ * mode DOWN3:  x is [B, Cin, 4, H+1, W+1] parity planes (x_bstride = Cin*4*(H+1)*(W+1)), y [B, Cout, H, W]:
+ *              y[b,n,a,c] = d[b,n] * sum_{i,ky,kx} s[b,i] * T_i[2a+ky, 2c+kx] * wp[i][ky*3+kx][n]  (+ bias, act like PLAIN3;
+ *              noise must be NULL).  With wp = transposed pack it is dL/dx of mode UP3. */
 int sgdfr_modconv2d_fwd_f32(const float* x, int64_t x_bstride, const float* wp, const float* s, const float* d,
                             const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
                             float* y, int B, int Cin, int Cout, int H, int W, int mode, int act, float slope,
@@ -134,6 +145,33 @@ int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const float* noise
  *          + (skip ? upfirdn2d(skip[b,j] (H/2 x W/2), fir[4,4], up=2, pad=(2,1))[p] : 0),  j<3 */
 int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, const float* bias, const float* skip,
                         const float* fir, float* y, int B, int Cin, int H, int W, void* stream);
+
+/* ---- backward helpers (autograd of model.py:232-359 as restated in SURVEY.md Appendix C) ------------------------ */
+
+/* Activation gradient + per-(b,c) reductions (op/fused_act.py:19-37 and the adjoints of model.py:287, :240):
+ *   g_pre = g_out * (out > 0 ? 1 : slope) * gain
+ *   sums[b,c,0] = sum g_pre ; sums[b,c,1] = sum g_pre * noise ;
+ *   sums[b,c,2] = sum g_pre * y (want_y != 0), y = lrelu^-1(out) - noise_w*noise - bias[c]  (= d * conv output) */
+int sgdfr_act_grad_reduce_f32(const float* g_out, const float* out, const float* noise, int64_t noise_bstride,
+                              const float* noise_w, const float* bias, float* g_pre, float* sums, int B, int C, int HW,
+                              float slope, float gain, int want_y, void* stream);
+
+/* Adjoint of the FIR of sgdfr_blur_bias_act_f32 (op/upfirdn2d.py:104-121 for pad (1,1)): g [B,C,2H,2W] ->
+ * gt parity planes [B,C,4,H+1,W+1]; with t (forward planes) also asum[b,c] = sum gt * t. */
+int sgdfr_blur_adjoint_f32(const float* g, const float* fir, const float* t, float* gt, float* asum, int B, int C, int H,
+                           int W, void* stream);
+
+/* dx = gu * s[b,c] (dx may alias gu) ; r[b,c] = sum_q x[b,c,q] * gu[b,c,q]   (x_bstride 0 = broadcast constant) */
+int sgdfr_scale_reduce_f32(const float* gu, const float* x, int64_t x_bstride, const float* s, float* dx, float* r, int B,
+                           int C, int HW, void* stream);
+
+/* ToRGB backward: dx[b,i,p] = s[b,i]/sqrt(Cin) * sum_j w_rgb[j,i] g[b,j,p] ; r[b,j,i] = sum_p x[b,i,p] g[b,j,p] */
+int sgdfr_torgb_bwd_f32(const float* x, const float* g, const float* w_rgb, const float* s, float* dx, float* r, int B,
+                        int Cin, int H, int W, void* stream);
+
+/* ds[b,i] = gs[b,i] + s[b,i] * sum_o (-gd[b,o] * d[b,o]^3) * qt[i,o]   (chain rule through d = rsqrt(sum s^2 q + eps)) */
+int sgdfr_demod_grad_f32(const float* gd, const float* d, const float* qt, const float* s, const float* gs, float* ds,
+                         int B, int Cin, int Cout, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libsgdfr_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -26,7 +26,14 @@ SIGNATURES = {
                          ctypes.c_void_p],
     'sgdfr_pixelnorm_f32': [_c_f32p, _c_f32p, _i, _i, _f, ctypes.c_void_p],
     'sgdfr_latent_prepare_f32': [_c_f32p, _i, _c_f32p, _i, _i, _c_f32p, _f, _c_f32p, _i, _i, _i, ctypes.c_void_p],
-    'sgdfr_modconv_prepack_f32': [_c_f32p, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],
+    'sgdfr_modconv_prepack_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],
+    'sgdfr_modconv_prepack_t_f32': [_c_f32p, _c_f32p, _i, _i, _i, _i, ctypes.c_void_p],
+    'sgdfr_act_grad_reduce_f32': [_c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _f,
+                                  _f, _i, ctypes.c_void_p],
+    'sgdfr_blur_adjoint_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i, ctypes.c_void_p],
+    'sgdfr_scale_reduce_f32': [_c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],
+    'sgdfr_torgb_bwd_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i, ctypes.c_void_p],
+    'sgdfr_demod_grad_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_style_demod_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i,
                               ctypes.c_void_p],
     'sgdfr_modconv2d_fwd_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
@@ -49,7 +56,7 @@ class StyleLayer(ctypes.Structure):
 SIGNATURES['sgdfr_styles_batched_f32'] = [_c_f32p, _i, _i, _i, ctypes.POINTER(StyleLayer), _i, ctypes.c_void_p]
 MAX_STYLE_LAYERS = 40
 
-MODE_PLAIN3, MODE_UP3 = 0, 1
+MODE_PLAIN3, MODE_UP3, MODE_DOWN3 = 0, 1, 2
 ACT_NONE, ACT_LRELU = 0, 1
 
 _lib = None

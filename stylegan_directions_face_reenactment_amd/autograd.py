@@ -1,0 +1,233 @@
+"""torch.autograd.Function wrappers of the generator path: forward AND backward run on the HIP library.
+
+Gradient algebra: SURVEY.md Appendix C (verified there in fp64 against autograd of the reference's
+libs/gan/StyleGAN2/model.py:232-273).  With u = x*s, v = conv(u, Wc), y = d*v:
+
+    dL/dx   = s * gu,          gu = conv^T(d * g)        -- the forward MFMA kernel with the transposed weight pack
+                                                            and the roles of s and d exchanged
+    dL/ds   = sum_q x*gu  (+ the demodulation term, applied in StyleFn)
+    dL/dd   = sum_p g*v = (sum_p g*y) / d
+    d       = rsqrt(sum_i s^2 Q + eps)  =>  dL/ds_i += s_i * sum_o (-d^3 dL/dd)[o] * Q[o,i]
+
+Consumers: libs/trainer.py:177-189 (needs dL/dW+ -> A), libs/optimization.py:47-68 (PTI: generator parameters).
+Tiny [B,C]-sized glue (divisions, sums over the batch, transposes) uses torch tensor ops, exactly where the
+reference itself does (e.g. the bias gradient `grad_input.sum(dim)` of op/fused_act.py:32-37).
+"""
+import math
+import warnings
+
+import torch
+from torch.autograd import Function
+
+from . import _native as N
+from . import functional as F_
+
+_warned = set()
+
+
+def _warn_once(key, msg):
+    if key not in _warned:
+        _warned.add(key)
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
+def _t(x):
+    return x.t().contiguous()
+
+
+def _colsum(m):
+    """[R, C] -> [C] column sums through the HIP linear kernel (ones @ m)."""
+    ones = torch.ones(1, m.shape[0], device=m.device, dtype=torch.float32)
+    return F_.linear(ones, _t(m)).view(-1)
+
+
+# ------------------------------------------------------------------ latent preparation
+
+class LatentPrepareFn(Function):
+    """out[b,l] = t + psi*(v - t), v = w[b,(l)] + shift[b,(l)] on the first rows (generic.py:116-135, model.py:494-508)."""
+
+    @staticmethod
+    def forward(ctx, w, shift, trunc, n_latent, shift_layers, psi):
+        ctx.meta = (w.ndim == 3, None if shift is None else shift.ndim == 3, shift_layers, psi, trunc is not None,
+                    None if trunc is None else trunc.shape)
+        if shift is not None and shift.ndim == 3:
+            ctx.meta = ctx.meta[:2] + (shift.shape[1],) + ctx.meta[3:]
+        return F_.latent_prepare(w, n_latent, shift=shift, shift_layers=shift_layers, trunc=trunc, psi=psi)
+
+    @staticmethod
+    def backward(ctx, g):
+        w_plus, shift_plus, layers, psi, has_trunc, tshape = ctx.meta
+        gv = g * psi if has_trunc else g
+        gw = gshift = gtrunc = None
+        if ctx.needs_input_grad[0]:
+            gw = gv if w_plus else gv.sum(1)
+        if shift_plus is not None and ctx.needs_input_grad[1]:
+            gshift = gv[:, :layers] if shift_plus else gv[:, :layers].sum(1)
+        if has_trunc and ctx.needs_input_grad[2]:
+            gtrunc = (g.sum((0, 1)) * (1.0 - psi)).view(tshape)
+        return gw, gshift, gtrunc, None, None, None
+
+
+# ------------------------------------------------------------------ dense layers
+
+class EqualLinearFn(Function):
+    """y = act(x @ W.T * scale + b * lr_mul)  (model.py:148-157)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale, lr_mul, lrelu):
+        y = F_.linear(x, weight, bias, wscale=scale, bscale=lr_mul, lrelu=lrelu)
+        ctx.save_for_backward(x, weight, y if lrelu else None)
+        ctx.cfg = (scale, lr_mul, lrelu, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        scale, lr_mul, lrelu, has_bias = ctx.cfg
+        g2 = N.f32c(g).reshape(-1, weight.shape[0])
+        if lrelu:
+            from .op.fused_act import fused_bias_act
+            g2 = fused_bias_act(g2, None, y.reshape(-1, weight.shape[0]), 3, 1, 0.2, 2 ** 0.5)
+        x2 = x.reshape(-1, weight.shape[1])
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = F_.linear(g2, _t(weight), wscale=scale).view_as(x)
+        if ctx.needs_input_grad[1]:
+            gw = F_.linear(_t(g2), _t(x2), wscale=scale)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = _colsum(g2) * lr_mul
+        return gx, gw, gb, None, None, None
+
+
+class PixelNormFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = F_.pixel_norm(x)
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors          # y = x*r, r = rsqrt(mean x^2 + eps)  =>  dx = r*g - x * r^3 * mean(g*x)
+        r = torch.rsqrt(x.pow(2).mean(1, keepdim=True) + 1e-8)
+        return r * g - x * r.pow(3) * (g * x).mean(1, keepdim=True)
+
+
+class StyleFn(Function):
+    """s = modulation(style) (model.py:235) and d = rsqrt(sum_i s^2 Q + 1e-8) (model.py:238-239)."""
+
+    @staticmethod
+    def forward(ctx, style, mod_w, mod_b, q, qt, cout):
+        s, d = F_.style_demod(style, mod_w, mod_b, q, cout)
+        ctx.save_for_backward(style, mod_w, s, d, qt)
+        ctx.has_d = d is not None
+        if d is None:
+            return s
+        return s, d
+
+    @staticmethod
+    def backward(ctx, gs, gd=None):
+        style, mod_w, s, d, qt = ctx.saved_tensors
+        D = mod_w.shape[1]
+        scale = 1.0 / math.sqrt(D)
+        if gs is None:
+            gs = torch.zeros_like(s)
+        ds = F_.demod_grad(gd, d, qt, s, gs) if (ctx.has_d and gd is not None) else N.f32c(gs)
+        gstyle = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gstyle = F_.linear(ds, _t(mod_w), wscale=scale)
+        if ctx.needs_input_grad[1]:
+            gw = F_.linear(_t(ds), _t(style), wscale=scale)
+        if ctx.needs_input_grad[2]:
+            gb = _colsum(ds)
+        return gstyle, gw, gb, None, None, None
+
+
+# ------------------------------------------------------------------ modulated convs
+
+class StyledConvFn(Function):
+    """act(d * conv(x*s, Wc) + noise_w*noise + bias)  -- StyledConv.forward (model.py:331-337), plain or upsampling.
+    `mod` is the owning ModulatedConv2d (packed weights, FIR taps, shapes); it is not a tensor input."""
+
+    @staticmethod
+    def forward(ctx, x, s, d, weight, noise_w, bias, noise, mod, activate, batch):
+        wp = mod.packed()[0]
+        up = mod.upsample
+        planes = None
+        if up:
+            out, planes = F_.modconv3x3(x, wp, s, d, mod.out_channel, upsample=True, fir=mod.blur.kernel, noise=noise,
+                                        noise_weight=noise_w, bias=bias, activate=activate, batch=batch,
+                                        return_planes=True)
+        else:
+            out = F_.modconv3x3(x, wp, s, d, mod.out_channel, noise=noise, noise_weight=noise_w, bias=bias,
+                                activate=activate, batch=batch)
+        ctx.save_for_backward(x, s, d, out, noise_w, bias, noise, planes)
+        ctx.mod, ctx.activate = mod, activate
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s, d, out, noise_w, bias, noise, planes = ctx.saved_tensors
+        mod, up = ctx.mod, ctx.mod.upsample
+        B, cout = out.shape[0], out.shape[1]
+        cin, H, W = x.shape[1], x.shape[2], x.shape[3]
+        slope, gain = (0.2, 2 ** 0.5) if ctx.activate else (1.0, 1.0)
+        g_pre, sums = F_.act_grad_reduce(g, out, noise, noise_w, bias, want_y=(not up) and d is not None,
+                                         slope=slope, gain=gain)
+        ones_d = d if d is not None else torch.ones(B, cout, device=out.device, dtype=torch.float32)
+        if up:
+            gT, A = F_.blur_adjoint(g_pre, mod.blur.kernel, planes if d is not None else None)
+            gu = F_.modconv_raw(gT, mod.packed_t(), ones_d, None, cin, N.MODE_DOWN3, H, W,
+                                desc='bwd down3 %d->%d @%dx%d' % (cout, cin, H, W))
+        else:
+            A = sums[:, :, 2] if d is not None else None
+            gu = F_.modconv_raw(g_pre, mod.packed_t(), ones_d, None, cin, N.MODE_PLAIN3, H, W,
+                                desc='bwd plain3 %d->%d @%dx%d' % (cout, cin, H, W))
+        dx, r = F_.scale_reduce(gu, x, s)
+        if x.shape[0] == 1 and B != 1:            # broadcast ConstantInput: gradient sums over the batch
+            dx = dx.sum(0, keepdim=True)
+        gx = dx if ctx.needs_input_grad[0] else None
+        gs = r if ctx.needs_input_grad[1] else None
+        gd = (A / d) if (d is not None and ctx.needs_input_grad[2]) else None
+        gweight = None
+        if ctx.needs_input_grad[3]:
+            _warn_once('dW', 'gradients w.r.t. the generator conv weights are not built yet (SURVEY.md §8f-1): '
+                             'they are returned as None; gradients w.r.t. latents / styles / biases / noise strengths '
+                             'are exact')
+        gnw = sums[:, :, 1].sum().view(1) if (noise_w is not None and ctx.needs_input_grad[4]) else None
+        gb = sums[:, :, 0].sum(0) if (bias is not None and ctx.needs_input_grad[5]) else None
+        return gx, gs, gd, gweight, gnw, gb, None, None, None, None
+
+
+class ToRGBFn(Function):
+    """ToRGB.forward (model.py:350-359): 1x1 modconv without demodulation + bias + FIR-upsampled skip."""
+
+    @staticmethod
+    def forward(ctx, x, s, weight, bias, skip, fir):
+        cin = x.shape[1]
+        y = F_.torgb(x, weight.view(3, cin), s, bias=None if bias is None else bias.view(3), skip=skip, fir=fir)
+        ctx.save_for_backward(x, s, weight, fir)
+        ctx.has_skip, ctx.has_bias = skip is not None, bias is not None
+        ctx.bias_shape = None if bias is None else bias.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s, weight, fir = ctx.saved_tensors
+        B, cin = x.shape[0], x.shape[1]
+        w = weight.view(3, cin)
+        scale = 1.0 / math.sqrt(cin)
+        g = N.f32c(g)
+        dx, r = F_.torgb_bwd(x, g, w, s)                       # r[b,j,i] = sum_p x*g_j
+        gx = dx if ctx.needs_input_grad[0] else None
+        gs = (r * w.unsqueeze(0)).sum(1) * scale if ctx.needs_input_grad[1] else None
+        gw = ((r * s.unsqueeze(1)).sum(0) * scale).view_as(weight) if ctx.needs_input_grad[2] else None
+        gb = g.sum((0, 2, 3)).view(ctx.bias_shape) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+        gskip = None
+        if ctx.has_skip and ctx.needs_input_grad[4]:
+            from .op.upfirdn2d import upfirdn2d_native_op
+            H, W = g.shape[2], g.shape[3]
+            # adjoint of upfirdn2d(up=2, pad=(2,1)): flipped taps, down=2, pad (1,1)  (op/upfirdn2d.py:104-117)
+            gskip = upfirdn2d_native_op(g.reshape(B * 3, H, W, 1), torch.flip(fir, [0, 1]), 1, 1, 2, 2, 1, 1, 1, 1)
+            gskip = gskip.view(B, 3, H // 2, W // 2)
+        return gx, gs, gw, gb, gskip, None

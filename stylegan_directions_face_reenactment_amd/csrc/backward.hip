@@ -1,0 +1,259 @@
+// Backward-pass helpers of the generator path.  The heavy part of every gradient --
+// dL/dx of a modulated conv -- is the SAME fp32-MFMA kernel as the forward (csrc/modconv.hip) run with a
+// transposed weight pack and the roles of s and d exchanged; this file holds the HBM-bound pieces around it:
+//   * activation gradient + the per-(b,c) reductions that feed d(bias), d(noise strength), d(demod)
+//   * adjoint of the 4x4 blur, emitted directly as parity planes for MODE_DOWN3
+//   * dx = s * gu with the reduction sum_q x*gu that is d(style) of the modulation
+//   * ToRGB backward (dx and the 3 x Cin reductions that give d(style) and d(w_rgb))
+//   * transposed weight pack
+// Reductions use one wave per (b, c) plane chunk + fp32 atomics into zero-initialised buffers.
+#include "common.h"
+
+namespace sgdfr {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+constexpr int kChunk = 2048;  // elements of one plane handled by one wave
+
+// g_pre = g_out * (out > 0 ? 1 : slope) * gain ;  sums[b,c,0] += sum g_pre ; [1] += sum g_pre*noise ;
+// [2] += sum g_pre * y, with y = act^-1(out) - noise_w*noise - bias  (the demodulated conv output d*v)
+__global__ __launch_bounds__(256) void act_grad_reduce_kernel(const float* __restrict__ g_out,
+                                                             const float* __restrict__ out,
+                                                             const float* __restrict__ noise, int64_t noise_bstride,
+                                                             const float* __restrict__ noise_w,
+                                                             const float* __restrict__ bias, float* __restrict__ g_pre,
+                                                             float* __restrict__ sums, int B, int C, int HW, int chunks,
+                                                             float slope, float gain, int want_y) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t nw_total = (int64_t)B * C * chunks;
+    if (wid >= nw_total) return;
+    const int ch = (int)(wid % chunks);
+    const int64_t pl = wid / chunks;
+    const int c = (int)(pl % C), b = (int)(pl / C);
+    const float nwv = (noise && noise_w) ? noise_w[0] : 0.f;
+    const float bv = bias ? bias[c] : 0.f;
+    const float inv_pos = 1.f / gain, inv_neg = 1.f / (gain * slope);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    const int lo = ch * kChunk, hi = min(HW, lo + kChunk);
+    const int64_t base = pl * HW;
+    for (int p = lo + lane; p < hi; p += 64) {
+        const float o = out[base + p], g = g_out[base + p];
+        const float gp = g * (o > 0.f ? 1.f : slope) * gain;
+        g_pre[base + p] = gp;
+        const float nz = noise ? noise[(int64_t)b * noise_bstride + p] : 0.f;
+        s0 += gp;
+        s1 = fmaf(gp, nz, s1);
+        if (want_y) {
+            const float pre = o * (o > 0.f ? inv_pos : inv_neg);
+            s2 = fmaf(gp, pre - nwv * nz - bv, s2);
+        }
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) {
+        atomicAdd(&sums[pl * 3 + 0], s0);
+        atomicAdd(&sums[pl * 3 + 1], s1);
+        if (want_y) atomicAdd(&sums[pl * 3 + 2], s2);
+    }
+}
+
+// Adjoint of blur_bias_act's FIR: g [planes, 2H, 2W] -> gT parity planes [planes, 4, H+1, W+1]
+//   gT[i,j] = sum_{oy,ox} g[oy,ox] * K[3-(i+1-oy)][3-(j+1-ox)]   (0 <= i+1-oy, j+1-ox <= 3)
+// and, when the forward planes t are given, asum[plane] += sum gT * t  (= d * dL/dd).
+__global__ __launch_bounds__(256) void blur_adjoint_kernel(const float* __restrict__ g, const float* __restrict__ fir,
+                                                          const float* __restrict__ t, float* __restrict__ gt,
+                                                          float* __restrict__ asum, int64_t planes, int H, int W) {
+    float k[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) k[i] = fir[i];
+    const int GH = H + 1, GW = W + 1, OH = 2 * H, OW = 2 * W;
+    const int per_plane = 4 * GH * GW;
+    const int chunks = (per_plane + kChunk - 1) / kChunk;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    if (wid >= planes * chunks) return;
+    const int ch = (int)(wid % chunks);
+    const int64_t pl = wid / chunks;
+    const float* gp = g + pl * (int64_t)OH * OW;
+    float acc_a = 0.f;
+    const int lo = ch * kChunk, hi = min(per_plane, lo + kChunk);
+    for (int e = lo + lane; e < hi; e += 64) {
+        const int ph = e / (GH * GW), r = e - ph * GH * GW;
+        const int a = r / GW, bb = r - a * GW;
+        const int i = 2 * a + (ph >> 1), j = 2 * bb + (ph & 1);
+        float v = 0.f;
+        if (i <= 2 * H && j <= 2 * W) {
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy) {
+                const int oy = i + 1 - dy;           // ky = dy
+                if (oy < 0 || oy >= OH) continue;
+#pragma unroll
+                for (int dx = 0; dx < 4; ++dx) {
+                    const int ox = j + 1 - dx;
+                    if (ox < 0 || ox >= OW) continue;
+                    v = fmaf(gp[oy * OW + ox], k[(3 - dy) * 4 + (3 - dx)], v);
+                }
+            }
+        }
+        gt[pl * per_plane + e] = v;
+        if (t) acc_a = fmaf(v, t[pl * per_plane + e], acc_a);
+    }
+    if (t) {
+        acc_a = wave_sum(acc_a);
+        if (lane == 0) atomicAdd(&asum[pl], acc_a);
+    }
+}
+
+// dx[b,c,q] = gu[b,c,q] * s[b,c]  (may alias gu) ;  r[b,c] += sum_q x[b,c,q] * gu[b,c,q]
+__global__ __launch_bounds__(256) void scale_reduce_kernel(const float* __restrict__ gu, const float* __restrict__ x,
+                                                          int64_t x_bstride, const float* __restrict__ s,
+                                                          float* __restrict__ dx, float* __restrict__ r, int B, int C,
+                                                          int HW, int chunks) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    if (wid >= (int64_t)B * C * chunks) return;
+    const int ch = (int)(wid % chunks);
+    const int64_t pl = wid / chunks;
+    const int c = (int)(pl % C), b = (int)(pl / C);
+    const float sv = s[pl];
+    const float* xp = x + (int64_t)b * x_bstride + (int64_t)c * HW;
+    const int lo = ch * kChunk, hi = min(HW, lo + kChunk);
+    float acc = 0.f;
+    for (int p = lo + lane; p < hi; p += 64) {
+        const float g = gu[pl * HW + p];
+        acc = fmaf(xp[p], g, acc);
+        dx[pl * HW + p] = g * sv;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) atomicAdd(&r[pl], acc);
+}
+
+// ToRGB backward.  One wave per (b, channel i, pixel chunk):
+//   t[p] = scale * sum_j w[j,i] g[b,j,p] ;  dx[b,i,p] = s[b,i] * t[p] ;  r[b,j,i] += sum_p x[b,i,p] * g[b,j,p]
+__global__ __launch_bounds__(256) void torgb_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                       const float* __restrict__ w_rgb, const float* __restrict__ s,
+                                                       float* __restrict__ dx, float* __restrict__ r, int B, int Cin,
+                                                       int HW, int chunks, float scale) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    if (wid >= (int64_t)B * Cin * chunks) return;
+    const int ch = (int)(wid % chunks);
+    const int64_t pl = wid / chunks;
+    const int i = (int)(pl % Cin), b = (int)(pl / Cin);
+    const float c0 = w_rgb[i] * scale, c1 = w_rgb[Cin + i] * scale, c2 = w_rgb[2 * Cin + i] * scale;
+    const float sv = s[pl];
+    const float* gb = g + (int64_t)b * 3 * HW;
+    const int lo = ch * kChunk, hi = min(HW, lo + kChunk);
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    for (int p = lo + lane; p < hi; p += 64) {
+        const float g0 = gb[p], g1 = gb[HW + p], g2 = gb[2 * HW + p];
+        const float xv = x[pl * HW + p];
+        dx[pl * HW + p] = sv * (c0 * g0 + c1 * g1 + c2 * g2);
+        r0 = fmaf(xv, g0, r0);
+        r1 = fmaf(xv, g1, r1);
+        r2 = fmaf(xv, g2, r2);
+    }
+    r0 = wave_sum(r0); r1 = wave_sum(r1); r2 = wave_sum(r2);
+    if (lane == 0) {
+        float* rb = r + (int64_t)b * 3 * Cin;
+        atomicAdd(&rb[i], r0);
+        atomicAdd(&rb[Cin + i], r1);
+        atomicAdd(&rb[2 * Cin + i], r2);
+    }
+}
+
+// w [Cout,Cin,KK] -> wt [Cout, KK, Cin] * scale, taps optionally reversed (flip = 1: the 180-degree rotated
+// kernel that turns the forward correlation into its adjoint)
+__global__ __launch_bounds__(256) void prepack_t_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout,
+                                                       int Cin, int KK, int flip, float scale) {
+    const int64_t n = (int64_t)Cout * Cin * KK;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % Cin);
+        const int64_t r = idx / Cin;
+        const int k = (int)(r % KK);
+        const int o = (int)(r / KK);
+        const int ks = flip ? KK - 1 - k : k;
+        wt[idx] = w[((int64_t)o * Cin + i) * KK + ks] * scale;
+    }
+}
+
+}  // namespace sgdfr
+
+using namespace sgdfr;
+
+static int wave_grid(int64_t waves) { return (int)((waves + 3) / 4); }
+
+extern "C" int sgdfr_act_grad_reduce_f32(const float* g_out, const float* out, const float* noise, int64_t noise_bstride,
+                                         const float* noise_w, const float* bias, float* g_pre, float* sums, int B, int C,
+                                         int HW, float slope, float gain, int want_y, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && C > 0 && HW > 0, "act_grad_reduce: bad shape %d %d %d", B, C, HW);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(g_out && out && g_pre && sums, "act_grad_reduce: null pointer");
+    SGDFR_REQUIRE(!noise || noise_w, "act_grad_reduce: noise without noise_w");
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(sums, 0, sizeof(float) * 3 * (size_t)B * C, st) != hipSuccess) return check_launch("memset");
+    const int chunks = (HW + kChunk - 1) / kChunk;
+    const int64_t waves = (int64_t)B * C * chunks;
+    hipLaunchKernelGGL(act_grad_reduce_kernel, dim3(wave_grid(waves)), dim3(256), 0, st, g_out, out, noise, noise_bstride,
+                       noise_w, bias, g_pre, sums, B, C, HW, chunks, slope, gain, want_y);
+    return check_launch("act_grad_reduce");
+}
+
+extern "C" int sgdfr_blur_adjoint_f32(const float* g, const float* fir, const float* t, float* gt, float* asum, int B,
+                                      int C, int H, int W, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0, "blur_adjoint: bad shape %d %d %d %d", B, C, H, W);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(g && fir && gt, "blur_adjoint: null pointer");
+    SGDFR_REQUIRE(!t || asum, "blur_adjoint: t given without asum");
+    hipStream_t st = as_stream(stream);
+    const int64_t planes = (int64_t)B * C;
+    if (t && hipMemsetAsync(asum, 0, sizeof(float) * (size_t)planes, st) != hipSuccess) return check_launch("memset");
+    const int per_plane = 4 * (H + 1) * (W + 1);
+    const int chunks = (per_plane + kChunk - 1) / kChunk;
+    hipLaunchKernelGGL(blur_adjoint_kernel, dim3(wave_grid(planes * chunks)), dim3(256), 0, st, g, fir, t, gt, asum,
+                       planes, H, W);
+    return check_launch("blur_adjoint");
+}
+
+extern "C" int sgdfr_scale_reduce_f32(const float* gu, const float* x, int64_t x_bstride, const float* s, float* dx,
+                                      float* r, int B, int C, int HW, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && C > 0 && HW > 0, "scale_reduce: bad shape %d %d %d", B, C, HW);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(gu && x && s && dx && r, "scale_reduce: null pointer");
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(r, 0, sizeof(float) * (size_t)B * C, st) != hipSuccess) return check_launch("memset");
+    const int chunks = (HW + kChunk - 1) / kChunk;
+    hipLaunchKernelGGL(scale_reduce_kernel, dim3(wave_grid((int64_t)B * C * chunks)), dim3(256), 0, st, gu, x, x_bstride,
+                       s, dx, r, B, C, HW, chunks);
+    return check_launch("scale_reduce");
+}
+
+extern "C" int sgdfr_torgb_bwd_f32(const float* x, const float* g, const float* w_rgb, const float* s, float* dx, float* r,
+                                   int B, int Cin, int H, int W, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && Cin > 0 && H > 0 && W > 0, "torgb_bwd: bad shape %d %d %d %d", B, Cin, H, W);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(x && g && w_rgb && s && dx && r, "torgb_bwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(r, 0, sizeof(float) * 3 * (size_t)B * Cin, st) != hipSuccess) return check_launch("memset");
+    const int HW = H * W;
+    const int chunks = (HW + kChunk - 1) / kChunk;
+    hipLaunchKernelGGL(torgb_bwd_kernel, dim3(wave_grid((int64_t)B * Cin * chunks)), dim3(256), 0, st, x, g, w_rgb, s, dx,
+                       r, B, Cin, HW, chunks, 1.0f / sqrtf((float)Cin));
+    return check_launch("torgb_bwd");
+}
+
+extern "C" int sgdfr_modconv_prepack_t_f32(const float* weight, float* wt, int Cout, int Cin, int k, int flip,
+                                           void* stream) {
+    SGDFR_REQUIRE(Cout > 0 && Cin > 0 && k > 0, "prepack_t: bad shape %d %d %d", Cout, Cin, k);
+    SGDFR_REQUIRE(weight && wt, "prepack_t: null pointer");
+    const int64_t n = (int64_t)Cout * Cin * k * k;
+    int64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(prepack_t_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), weight, wt, Cout, Cin, k * k, flip,
+                       1.0f / sqrtf((float)Cin * k * k));
+    return check_launch("modconv_prepack_t");
+}

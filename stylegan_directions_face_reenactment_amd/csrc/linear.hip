@@ -12,12 +12,20 @@ constexpr int LBK = 32;
 // (BM/16) x (BN/16) outputs).  Tiles of x and w are staged k-major in LDS (lanes along k for the global
 // reads: 128-byte rows; padded rows make the transposed LDS writes conflict-free).
 // EPI 0: y = act(acc*wscale + bias*bscale);  EPI 1: y = rsqrt(acc + wscale)  (wscale carries eps)
-// SQX: use x^2 instead of x (demodulation: sum_i s^2 q)
-template <bool SQX, int EPI, int BM, int BN>
+// EPI 2: y = add[m,n] + mul[m,n] * (acc*wscale)          (gradient of the demodulation w.r.t. the style)
+// XOP 0: x ; 1: x^2 (demodulation: sum_i s^2 q) ; 2: -x * aux^3 (dL/dd -> dL/d(sum s^2 q) up to the factor 2s)
+struct LinearExtra {
+    const float* xaux;   // [M, K] (ld = ldx) for XOP 2
+    const float* add;    // [M, N] (ld = ldy) for EPI 2
+    const float* mul;    // [M, N] (ld = ldy) for EPI 2
+};
+
+template <int XOP, int EPI, int BM, int BN>
 __device__ __forceinline__ void linear_tile(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
                                             const float* __restrict__ bias, float* __restrict__ y, int64_t ldy, int M,
                                             int N, int K, int m0, int n0, float wscale, float bscale, int act,
-                                            float slope, float gain, float (*xs)[BM + 1], float (*ws)[BN + 1]) {
+                                            float slope, float gain, float (*xs)[BM + 1], float (*ws)[BN + 1],
+                                            LinearExtra ex = LinearExtra{nullptr, nullptr, nullptr}) {
     constexpr int TM = BM / 16, TN = BN / 16;
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
@@ -26,8 +34,15 @@ __device__ __forceinline__ void linear_tile(const float* __restrict__ x, int64_t
         for (int e = tid; e < BM * LBK; e += 256) {
             const int kk = e & (LBK - 1), mm = e >> 5;
             float v = 0.f;
-            if (m0 + mm < M && k0 + kk < K) v = x[(int64_t)(m0 + mm) * ldx + k0 + kk];
-            xs[kk][mm] = SQX ? v * v : v;
+            if (m0 + mm < M && k0 + kk < K) {
+                v = x[(int64_t)(m0 + mm) * ldx + k0 + kk];
+                if (XOP == 1) v = v * v;
+                if (XOP == 2) {
+                    const float a = ex.xaux[(int64_t)(m0 + mm) * ldx + k0 + kk];
+                    v = -v * a * a * a;
+                }
+            }
+            xs[kk][mm] = v;
         }
         for (int e = tid; e < BN * LBK; e += 256) {
             const int kk = e & (LBK - 1), nn = e >> 5;
@@ -62,8 +77,10 @@ __device__ __forceinline__ void linear_tile(const float* __restrict__ x, int64_t
             if (EPI == 0) {
                 v = acc[i][j] * wscale + (bias ? bias[n] * bscale : 0.f);
                 if (act == SGDFR_ACT_LRELU) v = lrelu_gain(v, slope, gain);
-            } else {
+            } else if (EPI == 1) {
                 v = rsqrtf(acc[i][j] + wscale);
+            } else {
+                v = ex.add[(int64_t)m * ldy + n] + ex.mul[(int64_t)m * ldy + n] * (acc[i][j] * wscale);
             }
             y[(int64_t)m * ldy + n] = v;
         }
@@ -72,23 +89,25 @@ __device__ __forceinline__ void linear_tile(const float* __restrict__ x, int64_t
 
 constexpr int LBM = 32, LBN = 32;
 
-template <bool SQX, int EPI>
+template <int XOP, int EPI>
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int64_t ldx,
                                                     const float* __restrict__ w, const float* __restrict__ bias,
                                                     float* __restrict__ y, int64_t ldy, int M, int N, int K,
-                                                    float wscale, float bscale, int act, float slope, float gain) {
+                                                    float wscale, float bscale, int act, float slope, float gain,
+                                                    LinearExtra ex) {
     __shared__ float xs[LBK][LBM + 1];
     __shared__ float ws[LBK][LBN + 1];
-    linear_tile<SQX, EPI, LBM, LBN>(x, ldx, w, bias, y, ldy, M, N, K, blockIdx.y * LBM, blockIdx.x * LBN, wscale,
-                                    bscale, act, slope, gain, xs, ws);
+    linear_tile<XOP, EPI, LBM, LBN>(x, ldx, w, bias, y, ldy, M, N, K, blockIdx.y * LBM, blockIdx.x * LBN, wscale,
+                                    bscale, act, slope, gain, xs, ws, ex);
 }
 
-template <bool SQX, int EPI>
+template <int XOP, int EPI>
 static int launch_linear(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int M,
-                         int N, int K, float wscale, float bscale, int act, float slope, float gain, void* stream) {
+                         int N, int K, float wscale, float bscale, int act, float slope, float gain, void* stream,
+                         LinearExtra ex = LinearExtra{nullptr, nullptr, nullptr}) {
     dim3 grid((N + LBN - 1) / LBN, (M + LBM - 1) / LBM);
-    hipLaunchKernelGGL((linear_kernel<SQX, EPI>), grid, dim3(256), 0, as_stream(stream), x, ldx, w, bias, y, ldy, M, N,
-                       K, wscale, bscale, act, slope, gain);
+    hipLaunchKernelGGL((linear_kernel<XOP, EPI>), grid, dim3(256), 0, as_stream(stream), x, ldx, w, bias, y, ldy, M, N,
+                       K, wscale, bscale, act, slope, gain, ex);
     return check_launch("linear");
 }
 
@@ -115,11 +134,11 @@ __global__ __launch_bounds__(256) void styles_batched_kernel(StyleBatch sb) {
     const int ntn = (N + LBN - 1) / LBN;
     const int m0 = (t / ntn) * LBM, n0 = (t % ntn) * LBN;
     if (STAGE == 0)
-        linear_tile<false, 0, LBM, LBN>(sb.latent + (int64_t)ly.latent_index * sb.D, (int64_t)sb.L * sb.D, ly.mod_w,
+        linear_tile<0, 0, LBM, LBN>(sb.latent + (int64_t)ly.latent_index * sb.D, (int64_t)sb.L * sb.D, ly.mod_w,
                                         ly.mod_b, ly.s, ly.cin, sb.B, ly.cin, sb.D, m0, n0, sb.wscale, 1.f,
                                         SGDFR_ACT_NONE, 0.f, 1.f, xs, ws);
     else
-        linear_tile<true, 1, LBM, LBN>(ly.s, ly.cin, ly.q, nullptr, ly.d, ly.cout, sb.B, ly.cout, ly.cin, m0, n0, 1e-8f,
+        linear_tile<1, 1, LBM, LBN>(ly.s, ly.cin, ly.q, nullptr, ly.d, ly.cout, sb.B, ly.cout, ly.cin, m0, n0, 1e-8f,
                                        0.f, 0, 0.f, 1.f, xs, ws);
 }
 
@@ -135,7 +154,7 @@ extern "C" int sgdfr_linear_f32(const float* x, int64_t ldx, const float* w, con
     SGDFR_REQUIRE(x && w && y, "linear: null pointer");
     SGDFR_REQUIRE(ldx >= K && ldy >= N, "linear: leading dims too small");
     SGDFR_REQUIRE(act == SGDFR_ACT_NONE || act == SGDFR_ACT_LRELU, "linear: unknown act %d", act);
-    return launch_linear<false, 0>(x, ldx, w, bias, y, ldy, M, N, K, wscale, bscale, act, slope, gain, stream);
+    return launch_linear<0, 0>(x, ldx, w, bias, y, ldy, M, N, K, wscale, bscale, act, slope, gain, stream);
 }
 
 extern "C" int sgdfr_style_demod_f32(const float* style, int64_t ld_style, const float* mod_w, const float* mod_b,
@@ -145,11 +164,11 @@ extern "C" int sgdfr_style_demod_f32(const float* style, int64_t ld_style, const
     if (B == 0) return 0;
     SGDFR_REQUIRE(style && mod_w && mod_b && s, "style_demod: null pointer");
     SGDFR_REQUIRE(ld_style >= D, "style_demod: ld_style < D");
-    int rc = launch_linear<false, 0>(style, ld_style, mod_w, mod_b, s, Cin, B, Cin, D, 1.0f / sqrtf((float)D), 1.0f,
+    int rc = launch_linear<0, 0>(style, ld_style, mod_w, mod_b, s, Cin, B, Cin, D, 1.0f / sqrtf((float)D), 1.0f,
                                      SGDFR_ACT_NONE, 0.f, 1.f, stream);
     if (rc || !d) return rc;
     SGDFR_REQUIRE(q && Cout > 0, "style_demod: d requested without q/Cout");
-    return launch_linear<true, 1>(s, Cin, q, nullptr, d, Cout, B, Cout, Cin, 1e-8f, 0.f, 0, 0.f, 1.f, stream);
+    return launch_linear<1, 1>(s, Cin, q, nullptr, d, Cout, B, Cout, Cin, 1e-8f, 0.f, 0, 0.f, 1.f, stream);
 }
 
 extern "C" int sgdfr_styles_batched_f32(const float* latent, int B, int L, int D, const sgdfr_style_layer* layers,
@@ -193,4 +212,14 @@ extern "C" int sgdfr_styles_batched_f32(const float* latent, int B, int L, int D
     sd.n_layers = dl;
     hipLaunchKernelGGL(styles_batched_kernel<1>, dim3(tiles), dim3(256), 0, as_stream(stream), sd);
     return check_launch("styles_batched(demod)");
+}
+
+extern "C" int sgdfr_demod_grad_f32(const float* gd, const float* d, const float* qt, const float* s, const float* gs,
+                                    float* ds, int B, int Cin, int Cout, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cout > 0, "demod_grad: bad shape %d %d %d", B, Cin, Cout);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(gd && d && qt && s && gs && ds, "demod_grad: null pointer");
+    // ds[b,i] = gs[b,i] + s[b,i] * sum_o (-gd[b,o] d[b,o]^3) * Q[o,i]      (qt = Q^T, [Cin, Cout])
+    return launch_linear<2, 2>(gd, Cout, qt, nullptr, ds, Cin, B, Cin, Cout, 1.0f, 0.f, 0, 0.f, 1.f, stream,
+                               LinearExtra{d, gs, s});
 }

@@ -54,18 +54,20 @@ constexpr int CK = 4;  // input channels per LDS stage (2 MFMA k-pairs)
 // and the [CK*9, NT] weight slab.  Issued BEFORE the MFMAs of the previous stage so HBM/L2 latency
 // hides under them; written to LDS after the next barrier (register-staged pipeline).
 // Branch-free per lane: zero-fill positions load a safe address and are masked at store time.
-template <int NT, int EX, int WV>
-__device__ __forceinline__ void load_stage(const ModconvParams& p, int c0, int tid, int n0, int HW, int nex,
-                                           const int64_t (&xoff)[EX], const int (&soff)[EX], float (&xr)[EX][CK],
-                                           float4 (&sr)[EX], float4 (&wr)[WV]) {
+template <int NT, int EX, int WV, int NPL>
+__device__ __forceinline__ void load_stage(const ModconvParams& p, int c0, int tid, int n0, int cstride, int pstride,
+                                           int nex, const int64_t (&xoff)[EX], const int (&soff)[EX],
+                                           float (&xr)[EX][CK * NPL], float4 (&sr)[EX], float4 (&wr)[WV]) {
     constexpr int WF4 = CK * 9 * NT / 4;
 #pragma unroll
     for (int e = 0; e < EX; ++e) {
         if (e < nex) {  // block-uniform
-            const float* xp = p.x + xoff[e] + (int64_t)c0 * HW;
+            const float* xp = p.x + xoff[e] + (int64_t)c0 * cstride;
             sr[e] = *reinterpret_cast<const float4*>(p.s + soff[e] + c0);
 #pragma unroll
-            for (int c = 0; c < CK; ++c) xr[e][c] = xp[(int64_t)c * HW];
+            for (int c = 0; c < CK; ++c)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) xr[e][c * NPL + pl] = xp[(int64_t)c * cstride + pl * pstride];
         }
     }
 #pragma unroll
@@ -81,9 +83,9 @@ __device__ __forceinline__ void load_stage(const ModconvParams& p, int c0, int t
     }
 }
 
-template <int NT, int EX, int WV>
+template <int NT, int EX, int WV, int NPL>
 __device__ __forceinline__ void store_stage(const ModconvParams& p, int tid, int nex, unsigned okmask, float* lx,
-                                            float* lw, const float (&xr)[EX][CK], const float4 (&sr)[EX],
+                                            float* lw, const float (&xr)[EX][CK * NPL], const float4 (&sr)[EX],
                                             const float4 (&wr)[WV]) {
     constexpr int WF4 = CK * 9 * NT / 4;
 #pragma unroll
@@ -92,10 +94,12 @@ __device__ __forceinline__ void store_stage(const ModconvParams& p, int tid, int
             const int j = tid + e * 256;
             const bool ok = (okmask >> e) & 1u;
             if (j < p.xlen) {
-                lx[0 * p.xs + j] = ok ? xr[e][0] * sr[e].x : 0.f;
-                lx[1 * p.xs + j] = ok ? xr[e][1] * sr[e].y : 0.f;
-                lx[2 * p.xs + j] = ok ? xr[e][2] * sr[e].z : 0.f;
-                lx[3 * p.xs + j] = ok ? xr[e][3] * sr[e].w : 0.f;
+                const float sc[4] = {sr[e].x, sr[e].y, sr[e].z, sr[e].w};
+#pragma unroll
+                for (int c = 0; c < CK; ++c)
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl)
+                        lx[(c * NPL + pl) * p.xs + j] = ok ? xr[e][c * NPL + pl] * sc[c] : 0.f;
             }
         }
     }
@@ -110,7 +114,8 @@ template <int MODE, int WM, int WN, int MI, int NI, int EX, int OCC>
 __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p) {
     constexpr int NT = WM * MI * 32;
     constexpr int PT = WN * NI * 32;
-    constexpr int PH = (MODE == SGDFR_MODE_UP3) ? 4 : 1;
+    constexpr int PH = (MODE == SGDFR_MODE_UP3) ? 4 : 1;          // output parity phases (accumulator sets)
+    constexpr int NPL = (MODE == SGDFR_MODE_DOWN3) ? 4 : 1;       // input parity planes
     constexpr int WROWS = CK * 9;
     constexpr int WF4 = WROWS * NT / 4;            // float4 per weight stage
     constexpr int WV = (WF4 + 255) / 256;
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
 
     // two LDS stages: [x: CK*xs][w: CK*9*NT] each
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int stage_floats = CK * p.xs + CK * 9 * NT;
+    const int stage_floats = CK * NPL * p.xs + CK * 9 * NT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -145,6 +150,11 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
         const int rem = p0 - img * HW;
         const int a = rem / p.W, b = rem - a * p.W;
         q0 = (img * p.R + a + 1) * p.P + b + 1 - p.P - 1;
+    } else if (MODE == SGDFR_MODE_DOWN3) {
+        const int img = p0 / HW;
+        const int rem = p0 - img * HW;
+        const int a = rem / p.W, b = rem - a * p.W;
+        q0 = img * RP + a * p.P + b;
     } else {
         q0 = p0;
     }
@@ -164,10 +174,15 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
             const int rem = pix - img * HW;
             const int a = rem / p.W, b = rem - a * p.W;
             qb = (img * p.R + a + 1) * p.P + b + 1;
+        } else if (MODE == SGDFR_MODE_DOWN3) {
+            const int img = pix / HW;
+            const int rem = pix - img * HW;
+            const int a = rem / p.W, b = rem - a * p.W;
+            qb = img * RP + a * p.P + b;
         } else {
             qb = pix;
         }
-        boff[ni] = (qb - q0) + hi * p.xs;
+        boff[ni] = (qb - q0) + hi * NPL * p.xs;
     }
 
     // ---- staging descriptors (fixed for the whole K loop): element offsets into x / s; positions that
@@ -180,12 +195,22 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
     for (int e = 0; e < EX; ++e) {
         const int j = tid + e * 256;
         const int q = q0 + j;
-        const int pir = q / p.P;
-        const int pc = q - pir * p.P;
-        const int img = pir / p.R;
-        const int pr = pir - img * p.R;
-        const bool ok = (j < p.xlen) && pc >= 1 && pr >= 1 && img < p.B;
-        xoff[e] = ok ? (int64_t)img * p.x_bstride + (pr - 1) * p.W + (pc - 1) : 0;
+        bool ok;
+        int img;
+        int64_t off;
+        if (MODE == SGDFR_MODE_DOWN3) {      // input = parity planes [B, Cin, 4, R, P]: every plane entry is real data
+            img = q / RP;
+            ok = (j < p.xlen) && img < p.B;
+            off = (int64_t)img * p.x_bstride + (q - img * RP);
+        } else {
+            const int pir = q / p.P;
+            const int pc = q - pir * p.P;
+            img = pir / p.R;
+            const int pr = pir - img * p.R;
+            ok = (j < p.xlen) && pc >= 1 && pr >= 1 && img < p.B;
+            off = (int64_t)img * p.x_bstride + (pr - 1) * p.W + (pc - 1);
+        }
+        xoff[e] = ok ? off : 0;
         soff[e] = ok ? img * p.Cin : 0;
         okmask |= ok ? (1u << e) : 0u;
     }
@@ -200,7 +225,8 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ph][mi][ni][r] = 0.f;
 
-    float xr[EX][CK];
+    float xr[EX][CK * NPL];
+    const int cstride = (MODE == SGDFR_MODE_DOWN3) ? 4 * RP : HW;   // input channel stride
     float4 sr[EX];
     float4 wr[WV];
 
@@ -211,8 +237,10 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
         const int ky = k / 3, kx = k - ky * 3;
         if (MODE == SGDFR_MODE_PLAIN3)
             tapoff[k] = (ky - 1) * p.P + (kx - 1);
-        else
+        else if (MODE == SGDFR_MODE_UP3)
             tapoff[k] = (ky == 2 ? 0 : p.P) + (kx == 2 ? 0 : 1);
+        else   // DOWN3: T[2a+ky, 2b+kx] lives in plane (ky&1, kx&1) at [a + (ky>>1), b + (kx>>1)]
+            tapoff[k] = (2 * (ky & 1) + (kx & 1)) * p.xs + (ky >> 1) * p.P + (kx >> 1);
     }
     const int aoff = wm * MI * 32 + l31;
 
@@ -220,24 +248,25 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
     // were filled during the previous iteration are written to stage `cur^1` and the global loads of the stage
     // after that are issued (their latency hides under this iteration's MFMAs).
     const int nstage = p.Cin / CK;
-    load_stage<NT, EX, WV>(p, 0, tid, n0, HW, nex, xoff, soff, xr, sr, wr);
-    store_stage<NT, EX, WV>(p, tid, nex, okmask, smem, smem + CK * p.xs, xr, sr, wr);
-    if (nstage > 1) load_stage<NT, EX, WV>(p, CK, tid, n0, HW, nex, xoff, soff, xr, sr, wr);
+    load_stage<NT, EX, WV, NPL>(p, 0, tid, n0, cstride, RP, nex, xoff, soff, xr, sr, wr);
+    store_stage<NT, EX, WV, NPL>(p, tid, nex, okmask, smem, smem + CK * NPL * p.xs, xr, sr, wr);
+    if (nstage > 1) load_stage<NT, EX, WV, NPL>(p, CK, tid, n0, cstride, RP, nex, xoff, soff, xr, sr, wr);
     __syncthreads();
     for (int st = 0; st < nstage; ++st) {
         float* lx = smem + (st & 1) * stage_floats;
-        float* lw = lx + CK * p.xs;
+        float* lw = lx + CK * NPL * p.xs;
         if (st + 1 < nstage) {
             float* nx = smem + ((st + 1) & 1) * stage_floats;
-            store_stage<NT, EX, WV>(p, tid, nex, okmask, nx, nx + CK * p.xs, xr, sr, wr);
-            if (st + 2 < nstage) load_stage<NT, EX, WV>(p, (st + 2) * CK, tid, n0, HW, nex, xoff, soff, xr, sr, wr);
+            store_stage<NT, EX, WV, NPL>(p, tid, nex, okmask, nx, nx + CK * NPL * p.xs, xr, sr, wr);
+            if (st + 2 < nstage)
+                load_stage<NT, EX, WV, NPL>(p, (st + 2) * CK, tid, n0, cstride, RP, nex, xoff, soff, xr, sr, wr);
         }
 #ifdef SGDFR_SETPRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
         for (int cp = 0; cp < CK / 2; ++cp) {
-            const float* lxc = lx + (cp * 2) * p.xs;
+            const float* lxc = lx + (cp * 2) * NPL * p.xs;
             const float* lwc = lw + ((cp * 2 + hi) * 9) * NT + aoff;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
@@ -261,7 +290,7 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
     }
 
     // ---- epilogue.  C/D layout of 32x32: column (pixel) = lane&31, row (cout) = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if (MODE == SGDFR_MODE_PLAIN3) {
+    if (MODE != SGDFR_MODE_UP3) {
         const float nw = (p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -317,7 +346,7 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
 // layouts as the MFMA kernel.
 __global__ __launch_bounds__(256) void modconv_direct_kernel(ModconvParams p, int mode) {
     const int HW = p.H * p.W, RP = p.R * p.P;
-    const int64_t per_img = (mode == SGDFR_MODE_PLAIN3) ? (int64_t)p.Cout * HW : (int64_t)p.Cout * 4 * RP;
+    const int64_t per_img = (mode == SGDFR_MODE_UP3) ? (int64_t)p.Cout * 4 * RP : (int64_t)p.Cout * HW;
     const int64_t total = per_img * p.B;
     const float nw = (p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -327,7 +356,23 @@ __global__ __launch_bounds__(256) void modconv_direct_kernel(ModconvParams p, in
         const float* xb = p.x + img * p.x_bstride;
         const float* sb = p.s + img * p.Cin;
         float acc = 0.f;
-        if (mode == SGDFR_MODE_PLAIN3) {
+        if (mode == SGDFR_MODE_DOWN3) {
+            const int co = (int)(r / HW), rem = (int)(r - (int64_t)co * HW);
+            const int a = rem / p.W, b = rem - a * p.W;
+            for (int i = 0; i < p.Cin; ++i) {
+                float part = 0.f;
+                const float* pl = xb + (int64_t)i * 4 * RP;
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx)
+                        part = fmaf(pl[(2 * (ky & 1) + (kx & 1)) * RP + (a + (ky >> 1)) * p.P + b + (kx >> 1)],
+                                    p.wp[((int64_t)i * 9 + ky * 3 + kx) * p.Cout + co], part);
+                acc = fmaf(part, sb[i], acc);
+            }
+            float v = acc * (p.d ? p.d[img * p.Cout + co] : 1.f);
+            if (p.bias) v += p.bias[co];
+            if (p.act) v = lrelu_gain(v, p.slope, p.gain);
+            p.y[idx] = v;
+        } else if (mode == SGDFR_MODE_PLAIN3) {
             const int co = (int)(r / HW), rem = (int)(r - (int64_t)co * HW);
             const int a = rem / p.W, b = rem - a * p.W;
             for (int i = 0; i < p.Cin; ++i) {
@@ -376,9 +421,10 @@ __global__ __launch_bounds__(256) void modconv_direct_kernel(ModconvParams p, in
 }
 
 // ---------------------------------------------------------------- prepack
-// w [Cout,Cin,KK] -> wp [Cin,KK,Cout] * scale ; q [Cout,Cin] = sum_t (w*scale)^2
+// w [Cout,Cin,KK] -> wp [Cin,KK,Cout] * scale ; q [Cout,Cin] = sum_t (w*scale)^2 ; qt = q^T [Cin,Cout]
 __global__ __launch_bounds__(256) void prepack_kernel(const float* __restrict__ w, float* __restrict__ wp,
-                                                     float* __restrict__ q, int Cout, int Cin, int KK, float scale) {
+                                                     float* __restrict__ q, float* __restrict__ qt, int Cout, int Cin,
+                                                     int KK, float scale) {
     const int64_t n = (int64_t)Cout * Cin;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
         const int o = (int)(idx % Cout);  // o fastest: coalesced wp writes
@@ -391,6 +437,7 @@ __global__ __launch_bounds__(256) void prepack_kernel(const float* __restrict__ 
             ss = fmaf(v, v, ss);
         }
         if (q) q[(int64_t)o * Cin + i] = ss;
+        if (qt) qt[(int64_t)i * Cout + o] = ss;
     }
 }
 
@@ -498,6 +545,11 @@ static int launch_modconv(ModconvParams& p, hipStream_t stream) {
         const int rows_crossed = (p.W % PT == 0) ? 0 : ((PT % p.W == 0) ? PT / p.W - 1 : (PT - 1) / p.W + 1);
         const int imgs_crossed = (HW % PT == 0) ? 0 : ((PT % HW == 0) ? PT / HW - 1 : (PT - 1) / HW + 1);
         xlen = (PT - 1) + rows_crossed + imgs_crossed * p.P + 2 * p.P + 3;
+    } else if (MODE == SGDFR_MODE_DOWN3) {
+        const int HW = p.H * p.W;
+        const int rows_crossed = (p.W % PT == 0) ? 0 : ((PT % p.W == 0) ? PT / p.W - 1 : (PT - 1) / p.W + 1);
+        const int imgs_crossed = (HW % PT == 0) ? 0 : ((PT % HW == 0) ? PT / HW - 1 : (PT - 1) / HW + 1);
+        xlen = (PT - 1) + rows_crossed + imgs_crossed * (p.P + 1) + p.P + 2;
     } else {
         xlen = PT + p.P + 2;
     }
@@ -505,7 +557,8 @@ static int launch_modconv(ModconvParams& p, hipStream_t stream) {
                   p.W);
     p.xlen = xlen;
     p.xs = (xlen + 3) & ~3;
-    const size_t lds = 2 * (size_t)(CK * p.xs + CK * 9 * NT) * sizeof(float);   // double-buffered stages
+    constexpr int NPL = (MODE == SGDFR_MODE_DOWN3) ? 4 : 1;
+    const size_t lds = 2 * (size_t)(CK * NPL * p.xs + CK * 9 * NT) * sizeof(float);   // double-buffered stages
     SGDFR_REQUIRE(p.total_pix + 4ll * p.P + 8 < (1ll << 31), "modconv: batch too large for 32-bit pixel indices");
     const int64_t nblk = (int64_t)p.n_cout_tiles * p.n_pix_tiles;
     SGDFR_REQUIRE(nblk < (1ll << 31), "modconv: grid too large");
@@ -517,14 +570,14 @@ static int launch_modconv(ModconvParams& p, hipStream_t stream) {
 
 using namespace sgdfr;
 
-extern "C" int sgdfr_modconv_prepack_f32(const float* weight, float* wp, float* q, int Cout, int Cin, int k,
+extern "C" int sgdfr_modconv_prepack_f32(const float* weight, float* wp, float* q, float* qt, int Cout, int Cin, int k,
                                          void* stream) {
     SGDFR_REQUIRE(Cout > 0 && Cin > 0 && k > 0, "prepack: bad shape %d %d %d", Cout, Cin, k);
     SGDFR_REQUIRE(weight && wp, "prepack: null pointer");
     const int64_t n = (int64_t)Cout * Cin;
     int64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(prepack_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), weight, wp, q, Cout, Cin, k * k,
+    hipLaunchKernelGGL(prepack_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), weight, wp, q, qt, Cout, Cin, k * k,
                        1.0f / sqrtf((float)Cin * k * k));
     return check_launch("modconv_prepack");
 }
@@ -535,11 +588,14 @@ extern "C" int sgdfr_modconv2d_fwd_f32(const float* x, int64_t x_bstride, const 
                                        int act, float slope, float gain, void* stream) {
     SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "modconv: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B,
                   Cin, Cout, H, W);
-    SGDFR_REQUIRE(mode == SGDFR_MODE_PLAIN3 || mode == SGDFR_MODE_UP3, "modconv: unknown mode %d", mode);
+    SGDFR_REQUIRE(mode == SGDFR_MODE_PLAIN3 || mode == SGDFR_MODE_UP3 || mode == SGDFR_MODE_DOWN3,
+                  "modconv: unknown mode %d", mode);
     if (B == 0) return 0;
     SGDFR_REQUIRE(x && wp && s && y, "modconv: null pointer");
     SGDFR_REQUIRE(!noise || noise_w, "modconv: noise without noise_w");
-    SGDFR_REQUIRE(x_bstride == 0 || x_bstride >= (int64_t)Cin * H * W, "modconv: x_bstride too small");
+    SGDFR_REQUIRE(x_bstride == 0 || x_bstride >= (int64_t)Cin * H * W * (mode == SGDFR_MODE_DOWN3 ? 0 : 1) +
+                                                     (mode == SGDFR_MODE_DOWN3 ? (int64_t)Cin * 4 * (H + 1) * (W + 1) : 0),
+                  "modconv: x_bstride too small");
     ModconvParams p{};
     p.x = x; p.x_bstride = x_bstride; p.wp = wp; p.s = s; p.d = d;
     p.noise = noise; p.noise_bstride = noise_bstride; p.noise_w = noise_w; p.bias = bias; p.y = y;
@@ -549,8 +605,8 @@ extern "C" int sgdfr_modconv2d_fwd_f32(const float* x, int64_t x_bstride, const 
     p.act = act; p.slope = slope; p.gain = gain;
     hipStream_t st = as_stream(stream);
     if (!mfma_ok) {
-        const int64_t total = (mode == SGDFR_MODE_PLAIN3) ? (int64_t)B * Cout * H * W
-                                                          : (int64_t)B * Cout * 4 * (H + 1) * (W + 1);
+        const int64_t total = (mode == SGDFR_MODE_UP3) ? (int64_t)B * Cout * 4 * (H + 1) * (W + 1)
+                                                       : (int64_t)B * Cout * H * W;
         int64_t g = (total + 255) / 256;
         if (g > 256 * 16) g = 256 * 16;
         hipLaunchKernelGGL(modconv_direct_kernel, dim3((int)g), dim3(256), 0, st, p, mode);
@@ -566,6 +622,12 @@ extern "C" int sgdfr_modconv2d_fwd_f32(const float* x, int64_t x_bstride, const 
             return launch_modconv<SGDFR_MODE_PLAIN3, 2, 2, 1, 2, 3, 3>(p, st);                    // NT 64, PT 128
         if (Cout > 32) return launch_modconv<SGDFR_MODE_PLAIN3, 2, 2, 1, 1, 3, 3>(p, st);            // NT 64, PT 64
         return launch_modconv<SGDFR_MODE_PLAIN3, 1, 4, 1, 1, 3, 3>(p, st);                           // NT 32, PT 128
+    } else if (mode == SGDFR_MODE_DOWN3) {
+        p.total_pix = (int64_t)B * H * W;
+        const int64_t big_blocks = ((p.total_pix + 127) / 128) * ((Cout + 127) / 128);
+        if (Cout % 128 == 0 && big_blocks >= 512) return launch_modconv<SGDFR_MODE_DOWN3, 2, 2, 2, 2, 2, 2>(p, st);
+        if (Cout > 32) return launch_modconv<SGDFR_MODE_DOWN3, 2, 2, 1, 1, 2, 2>(p, st);           // NT 64, PT 64
+        return launch_modconv<SGDFR_MODE_DOWN3, 1, 4, 1, 1, 2, 2>(p, st);                          // NT 32, PT 128
     } else {
         p.total_pix = (int64_t)B * (H + 1) * (W + 1);
         const int64_t big_blocks = ((p.total_pix + 63) / 64) * ((Cout + 127) / 128);

@@ -61,7 +61,7 @@ def pixel_norm(x, eps=1e-8):
     x2 = N.f32c(x).reshape(x.shape[0], -1) if x.ndim != 2 else N.f32c(x)
     y = torch.empty_like(x2)
     N.call('sgdfr_pixelnorm_f32', N.ptr(x2), N.ptr(y), x2.shape[0], x2.shape[1], float(eps), N.stream())
-    return forward_only(y.view(x.shape), 'pixel_norm', x)
+    return y.view(x.shape)
 
 
 def linear(x, weight, bias=None, wscale=1.0, bscale=1.0, lrelu=False, slope=0.2, gain=SQRT2):
@@ -114,14 +114,25 @@ def latent_prepare(w, n_latent, shift=None, shift_layers=0, trunc=None, psi=1.0)
 # ------------------------------------------------------------------ modulated conv
 
 def prepack(weight):
-    """weight [1, Cout, Cin, k, k] (model.py:218-220) -> (wp [Cin, k*k, Cout] scaled, q [Cout, Cin])."""
+    """weight [1, Cout, Cin, k, k] (model.py:218-220) -> (wp [Cin, k*k, Cout] scaled, q [Cout, Cin], qt = q^T)."""
     N.require_device(weight)
     w = N.f32c(weight)
     _, cout, cin, k, _ = w.shape
     wp = torch.empty(cin, k * k, cout, device=w.device, dtype=torch.float32)
     q = torch.empty(cout, cin, device=w.device, dtype=torch.float32)
-    N.call('sgdfr_modconv_prepack_f32', N.ptr(w), N.ptr(wp), N.ptr(q), cout, cin, k, N.stream())
-    return wp, q
+    qt = torch.empty(cin, cout, device=w.device, dtype=torch.float32)
+    N.call('sgdfr_modconv_prepack_f32', N.ptr(w), N.ptr(wp), N.ptr(q), N.ptr(qt), cout, cin, k, N.stream())
+    return wp, q, qt
+
+
+def prepack_t(weight, flip):
+    """weight [1, Cout, Cin, k, k] -> [Cout, k*k, Cin] scaled (taps reversed when flip): weight pack of dL/dx."""
+    N.require_device(weight)
+    w = N.f32c(weight)
+    _, cout, cin, k, _ = w.shape
+    wt = torch.empty(cout, k * k, cin, device=w.device, dtype=torch.float32)
+    N.call('sgdfr_modconv_prepack_t_f32', N.ptr(w), N.ptr(wt), cout, cin, k, int(bool(flip)), N.stream())
+    return wt
 
 
 def style_demod(style, mod_weight, mod_bias, q=None, cout=0):
@@ -187,42 +198,60 @@ def _noise_args(noise, B, H, W):
     raise RuntimeError('noise of shape %s does not broadcast to [%d,1,%d,%d]' % (tuple(noise.shape), B, H, W))
 
 
+def modconv_raw(x, wp, s, d, cout, mode, H, W, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2,
+                gain=SQRT2, batch=None, desc=None):
+    """One sgdfr_modconv2d_fwd_f32 launch.  mode PLAIN3: x [B,Cin,H,W] -> [B,cout,H,W]; UP3: -> parity planes
+    [B,cout,4,H+1,W+1]; DOWN3: x = planes [B,Cin,4,H+1,W+1] -> [B,cout,H,W]."""
+    N.require_device(x, wp, s, d, bias, noise_weight)
+    x = N.f32c(x)
+    B = s.shape[0] if batch is None else batch
+    cin = x.shape[1]
+    per_img = x[0].numel()
+    xb = 0 if (x.shape[0] == 1 and B != 1) else per_img
+    if x.shape[0] not in (1, B):
+        raise RuntimeError('input batch %d does not match styles %d' % (x.shape[0], B))
+    if mode == N.MODE_UP3:
+        y = torch.empty(B, cout, 4, H + 1, W + 1, device=x.device, dtype=torch.float32)
+    else:
+        y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+    nz, nzb = _noise_args(noise, B, H, W) if mode == N.MODE_PLAIN3 else (None, 0)
+    st = N.stream()
+    _timed_conv(desc or ('mode%d %d->%d @%dx%d' % (mode, cin, cout, H, W)), B * conv_flops(cin, cout, H, W), lambda: N.call(
+        'sgdfr_modconv2d_fwd_f32', N.ptr(x), xb, N.ptr(wp), N.ptr(s), N.ptr(d), N.ptr(nz), nzb,
+        N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(y), B, cin, cout, H, W, mode,
+        int(activate), float(slope), float(gain), st))
+    return y
+
+
+def blur_bias_act(planes, fir, H, W, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2):
+    """planes [B,C,4,H+1,W+1] -> [B,C,2H,2W]: 4x4 FIR (pad 1,1) + noise + bias + leaky-ReLU."""
+    N.require_device(planes, fir, bias, noise_weight)
+    B, C = planes.shape[0], planes.shape[1]
+    nz, nzb = _noise_args(noise, B, 2 * H, 2 * W)
+    y = torch.empty(B, C, 2 * H, 2 * W, device=planes.device, dtype=torch.float32)
+    N.call('sgdfr_blur_bias_act_f32', N.ptr(planes), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
+           N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(y), B, C, H, W, int(activate),
+           float(slope), float(gain), N.stream())
+    return y
+
+
 def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_weight=None, bias=None,
-               activate=False, slope=0.2, gain=SQRT2, batch=None):
+               activate=False, slope=0.2, gain=SQRT2, batch=None, return_planes=False):
     """Shared-weight modulated 3x3 conv (model.py:232-273) with the StyledConv tail fused in
     (noise model.py:287, bias + leaky-ReLU op/fused_act.py:81-86).
 
     x [B,Cin,H,W], or a [1,Cin,H,W] constant broadcast over `batch` images (ConstantInput,
     model.py:296-300, without materialising the repeat).  upsample=True runs the stride-2 transposed
     conv into parity planes and finishes with the 4x4 FIR pass (model.py:246-257)."""
-    N.require_device(x, wp, s, d, bias, noise_weight, fir)
-    x = N.f32c(x)
-    B = s.shape[0] if batch is None else batch
     _, cin, H, W = x.shape
-    xb = 0 if (x.shape[0] == 1 and B != 1) else cin * H * W
-    if x.shape[0] not in (1, B):
-        raise RuntimeError('input batch %d does not match styles %d' % (x.shape[0], B))
-    st = N.stream()
     if not upsample:
-        nz, nzb = _noise_args(noise, B, H, W)
-        y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
-        _timed_conv('plain3 %d->%d @%dx%d' % (cin, cout, H, W), B * conv_flops(cin, cout, H, W), lambda: N.call(
-            'sgdfr_modconv2d_fwd_f32', N.ptr(x), xb, N.ptr(wp), N.ptr(s), N.ptr(d), N.ptr(nz), nzb,
-            N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(y), B, cin, cout, H, W,
-            N.MODE_PLAIN3, int(activate), float(slope), float(gain), st))
-        return y
+        return modconv_raw(x, wp, s, d, cout, N.MODE_PLAIN3, H, W, noise, noise_weight, bias, activate, slope, gain,
+                           batch, 'plain3 %d->%d @%dx%d' % (cin, cout, H, W))
     if fir is None:
         raise RuntimeError('upsample modconv needs the blur FIR taps')
-    planes = torch.empty(B, cout, 4, H + 1, W + 1, device=x.device, dtype=torch.float32)
-    _timed_conv('up3 %d->%d @%dx%d' % (cin, cout, H, W), B * conv_flops(cin, cout, H, W), lambda: N.call(
-        'sgdfr_modconv2d_fwd_f32', N.ptr(x), xb, N.ptr(wp), N.ptr(s), N.ptr(d), None, 0, None, None,
-        N.ptr(planes), B, cin, cout, H, W, N.MODE_UP3, 0, 0.0, 1.0, st))
-    nz, nzb = _noise_args(noise, B, 2 * H, 2 * W)
-    y = torch.empty(B, cout, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
-    N.call('sgdfr_blur_bias_act_f32', N.ptr(planes), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
-           N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(y), B, cout, H, W, int(activate),
-           float(slope), float(gain), st)
-    return y
+    planes = modconv_raw(x, wp, s, d, cout, N.MODE_UP3, H, W, batch=batch, desc='up3 %d->%d @%dx%d' % (cin, cout, H, W))
+    y = blur_bias_act(planes, fir, H, W, noise, noise_weight, bias, activate, slope, gain)
+    return (y, planes) if return_planes else y
 
 
 def torgb(x, w_rgb, s, bias=None, skip=None, fir=None):
@@ -276,3 +305,65 @@ class _Affine(Function):
 
 def affine(x, weight, bias=None):
     return _Affine.apply(x, weight, bias)
+
+
+# ------------------------------------------------------------------ backward launches
+
+def act_grad_reduce(g_out, out, noise, noise_weight, bias, want_y, slope=0.2, gain=SQRT2):
+    """g_pre and sums [B,C,3] = (sum g_pre, sum g_pre*noise, sum g_pre*y)."""
+    N.require_device(g_out, out, noise_weight, bias)
+    g_out, out = N.f32c(g_out), N.f32c(out)
+    B, C, H, W = out.shape
+    nz, nzb = _noise_args(noise, B, H, W)
+    g_pre = torch.empty_like(out)
+    sums = torch.empty(B, C, 3, device=out.device, dtype=torch.float32)
+    N.call('sgdfr_act_grad_reduce_f32', N.ptr(g_out), N.ptr(out), N.ptr(nz), nzb,
+           N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(g_pre), N.ptr(sums), B, C, H * W,
+           float(slope), float(gain), int(bool(want_y)), N.stream())
+    return g_pre, sums
+
+
+def blur_adjoint(g, fir, planes=None):
+    """g [B,C,2H,2W] -> parity planes of dL/dT [B,C,4,H+1,W+1] (+ asum [B,C] = sum gT*T when planes given)."""
+    N.require_device(g, fir, planes)
+    g = N.f32c(g)
+    B, C, H2, W2 = g.shape
+    H, W = H2 // 2, W2 // 2
+    gt = torch.empty(B, C, 4, H + 1, W + 1, device=g.device, dtype=torch.float32)
+    asum = torch.empty(B, C, device=g.device, dtype=torch.float32) if planes is not None else None
+    N.call('sgdfr_blur_adjoint_f32', N.ptr(g), N.ptr(N.f32c(fir)), N.ptr(planes), N.ptr(gt), N.ptr(asum), B, C, H, W,
+           N.stream())
+    return gt, asum
+
+
+def scale_reduce(gu, x, s):
+    """dx = gu * s[b,c] (in place) and r[b,c] = sum_q x*gu; x may be a [1,C,H,W] broadcast constant."""
+    N.require_device(gu, x, s)
+    x = N.f32c(x)
+    B, C, H, W = gu.shape
+    xb = 0 if (x.shape[0] == 1 and B != 1) else C * H * W
+    r = torch.empty(B, C, device=gu.device, dtype=torch.float32)
+    N.call('sgdfr_scale_reduce_f32', N.ptr(gu), N.ptr(x), xb, N.ptr(s), N.ptr(gu), N.ptr(r), B, C, H * W, N.stream())
+    return gu, r
+
+
+def torgb_bwd(x, g, w_rgb, s):
+    """dx [B,Cin,H,W] and r [B,3,Cin] = sum_p x*g_j."""
+    N.require_device(x, g, w_rgb, s)
+    x, g = N.f32c(x), N.f32c(g)
+    B, cin, H, W = x.shape
+    dx = torch.empty_like(x)
+    r = torch.empty(B, 3, cin, device=x.device, dtype=torch.float32)
+    N.call('sgdfr_torgb_bwd_f32', N.ptr(x), N.ptr(g), N.ptr(N.f32c(w_rgb)), N.ptr(s), N.ptr(dx), N.ptr(r), B, cin, H, W,
+           N.stream())
+    return dx, r
+
+
+def demod_grad(gd, d, qt, s, gs):
+    """ds = gs + s * ((-gd * d^3) @ Q)."""
+    N.require_device(gd, d, qt, s, gs)
+    B, cin = s.shape
+    ds = torch.empty_like(s)
+    N.call('sgdfr_demod_grad_f32', N.ptr(N.f32c(gd)), N.ptr(d), N.ptr(qt), N.ptr(s), N.ptr(N.f32c(gs)), N.ptr(ds), B,
+           cin, d.shape[1], N.stream())
+    return ds

@@ -4,7 +4,14 @@ argument order and return values, so ``run_inference.py:180`` / ``libs/trainer.p
 unchanged.  Shift add, W->W+ broadcast and truncation are one HIP launch (sgdfr_latent_prepare_f32)."""
 import torch
 
+from . import autograd as AG
 from . import functional as F_
+
+
+def _prepare(w, n_latent, shift, shift_layers):
+    if torch.is_grad_enabled() and (w.requires_grad or shift.requires_grad):
+        return AG.LatentPrepareFn.apply(w, shift, None, n_latent, shift_layers, 1.0)
+    return F_.latent_prepare(w, n_latent, shift=shift, shift_layers=shift_layers)
 
 
 def get_shifted_latent_code(G, z, shift, input_is_latent=False, truncation=1, truncation_latent=None,
@@ -13,9 +20,9 @@ def get_shifted_latent_code(G, z, shift, input_is_latent=False, truncation=1, tr
     `truncation*` arguments are accepted and ignored here: truncation happens inside G afterwards."""
     w = z if input_is_latent else G.get_latent(z)
     if w_plus:                       # shift [B, L, 512] added to the first L rows (:133)
-        return F_.latent_prepare(w, G.n_latent, shift=shift)
+        return _prepare(w, G.n_latent, shift, shift.shape[1])
     layers = G.n_latent if num_layers is None else num_layers   # shift [B, 512] (:123-130)
-    return F_.latent_prepare(w, G.n_latent, shift=shift, shift_layers=layers)
+    return _prepare(w, G.n_latent, shift, layers)
 
 
 def generate_image(G, latent_code, truncation, trunc, w_plus=True, num_layers_shift=8, shift_code=None,

@@ -22,6 +22,7 @@ import random
 import torch
 from torch import nn
 
+from . import autograd as AG
 from . import functional as F_
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d  # noqa: F401  (re-exported like model.py:8)
 
@@ -34,9 +35,13 @@ def make_kernel(k):
     return k / k.sum()
 
 
+def _needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
 class PixelNorm(nn.Module):
     def forward(self, input):
-        return F_.pixel_norm(input)
+        return AG.PixelNormFn.apply(input) if _needs_grad(input) else F_.pixel_norm(input)
 
 
 class Upsample(nn.Module):
@@ -82,9 +87,11 @@ class EqualLinear(nn.Module):
         self.lr_mul = lr_mul
 
     def forward(self, input):
-        out = F_.linear(input, self.weight, self.bias, wscale=self.scale, bscale=self.lr_mul,
-                        lrelu=bool(self.activation))
-        return F_.forward_only(out, 'EqualLinear', input, self.weight, self.bias)
+        if _needs_grad(input, self.weight, self.bias):
+            return AG.EqualLinearFn.apply(input, self.weight, self.bias, self.scale, self.lr_mul,
+                                          bool(self.activation))
+        return F_.linear(input, self.weight, self.bias, wscale=self.scale, bscale=self.lr_mul,
+                         lrelu=bool(self.activation))
 
     def __repr__(self):
         return '{}({}, {})'.format(self.__class__.__name__, self.weight.shape[1], self.weight.shape[0])
@@ -120,59 +127,74 @@ class ModulatedConv2d(nn.Module):
         self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
-        self._pack = None          # (key, wp, q): re-packed weights, not part of the state_dict
+        self._pack = None          # (key, wp, q, qt): re-packed weights, not part of the state_dict
+        self._pack_t = None        # (key, wt): adjoint pack for backward
 
     def __repr__(self):
         return '{}({}, {}, {}, upsample={}, downsample={})'.format(
             self.__class__.__name__, self.in_channel, self.out_channel, self.kernel_size, self.upsample,
             self.downsample)
 
-    def packed(self):
-        """[Cin, k*k, Cout] scaled weights and Q[o,i] = sum_taps (scale W)^2, rebuilt when the parameter's
-        storage or version changes (optimizer step, load_state_dict, .cuda())."""
+    def _key(self):
         w = self.weight
-        key = (w.data_ptr(), w._version, w.device)
+        return (w.data_ptr(), w._version, w.device)
+
+    def packed(self):
+        """([Cin, k*k, Cout] scaled weights, Q[o,i] = sum_taps (scale W)^2, Q^T), rebuilt when the parameter's
+        storage or version changes (optimizer step, load_state_dict, .cuda())."""
+        key = self._key()
         if self._pack is None or self._pack[0] != key:
             with torch.no_grad():
-                wp, q = F_.prepack(w.detach())
-            self._pack = (key, wp, q)
-        return self._pack[1], self._pack[2]
+                self._pack = (key,) + F_.prepack(self.weight.detach())
+            self._pack_t = None
+        return self._pack[1], self._pack[2], self._pack[3]
 
-    def _styles(self, style):
-        wp, q = self.packed()
-        mod = self.modulation
-        s, d = F_.style_demod(style, mod.weight, mod.bias, q if self.demodulate else None, self.out_channel)
-        return wp, s, d
+    def packed_t(self):
+        """[Cout, 9, Cin] weight pack of the adjoint conv (dL/dx): taps rotated for the plain conv, as-is for the
+        stride-2 transposed one.  Built lazily, only when a backward pass needs it."""
+        key = self._key()
+        if getattr(self, '_pack_t', None) is None or self._pack_t[0] != key:
+            with torch.no_grad():
+                self._pack_t = (key, F_.prepack_t(self.weight.detach(), flip=not self.upsample))
+        return self._pack_t[1]
 
     def style_spec(self, latent_index):
         """(latent row, modulation weight, bias, Q or None, Cout) for functional.styles_batched."""
-        _, q = self.packed() if self.kernel_size == 3 else (None, None)
-        return (latent_index, self.modulation.weight, self.modulation.bias, q if self.demodulate else None,
-                self.out_channel)
+        q = self.packed()[1] if (self.kernel_size == 3 and self.demodulate) else None
+        return (latent_index, self.modulation.weight, self.modulation.bias, q, self.out_channel)
+
+    def styles(self, style):
+        """(s, d) for one layer; differentiable when anything upstream needs gradients."""
+        mod = self.modulation
+        q = qt = None
+        if self.kernel_size == 3 and self.demodulate:
+            _, q, qt = self.packed()
+        if _needs_grad(style, mod.weight, mod.bias):
+            out = AG.StyleFn.apply(style, mod.weight, mod.bias, q, qt, self.out_channel)
+            return out if q is not None else (out, None)
+        return F_.style_demod(style, mod.weight, mod.bias, q, self.out_channel)
 
     def fused(self, input, style, noise=None, noise_weight=None, bias=None, activate=False, batch=None, sd=None):
         """conv (+ noise + bias + leaky-ReLU) in one pass; what StyledConv.forward calls.
-        `sd` = precomputed (s, d) from the generator's batched style launch."""
-        if sd is None:
-            wp, s, d = self._styles(style)
-        else:
-            wp, (s, d) = self.packed()[0], sd
-        if self.kernel_size == 1:
-            if self.demodulate:
-                raise NotImplementedError('1x1 modulated conv with demodulation is not on the generator path')
-            return F_.torgb(input, self.weight.view(self.out_channel, self.in_channel), s, bias=bias) \
-                if self.out_channel == 3 else self._one_by_one(input, s, bias)
-        return F_.modconv3x3(input, wp, s, d, self.out_channel, upsample=self.upsample,
+        `sd` = precomputed (s, d), e.g. from the generator's batched style launch."""
+        if self.kernel_size != 3:
+            raise NotImplementedError('only the 3x3 modulated conv has a fused StyledConv form (1x1 lives in ToRGB)')
+        s, d = self.styles(style) if sd is None else sd
+        if _needs_grad(input, s, d, self.weight, noise_weight, bias):
+            return AG.StyledConvFn.apply(input, s, d, self.weight, noise_weight, bias, noise, self, activate, batch)
+        return F_.modconv3x3(input, self.packed()[0], s, d, self.out_channel, upsample=self.upsample,
                              fir=self.blur.kernel if self.upsample else None, noise=noise,
                              noise_weight=noise_weight, bias=bias, activate=activate, batch=batch)
 
-    def _one_by_one(self, input, s, bias):
-        raise NotImplementedError('1x1 modulated conv is only built for 3 output channels (ToRGB)')
-
     def forward(self, input, style):
-        out = self.fused(input, style)
-        return F_.forward_only(out, 'ModulatedConv2d', input, style, self.weight, self.modulation.weight,
-                               self.modulation.bias)
+        if self.kernel_size == 1:
+            if self.demodulate or self.out_channel != 3:
+                raise NotImplementedError('1x1 modulated conv is only built as ToRGB (3 outputs, no demodulation)')
+            s, _ = self.styles(style)
+            if _needs_grad(input, s, self.weight):
+                return AG.ToRGBFn.apply(input, s, self.weight, None, None, None)
+            return F_.torgb(input, self.weight.view(3, self.in_channel), s)
+        return self.fused(input, style)
 
 
 class NoiseInjection(nn.Module):
@@ -216,9 +238,8 @@ class StyledConv(nn.Module):
             B = style.shape[0] if sd is None else sd[0].shape[0]
             r = input.shape[-1] * (2 if self.conv.upsample else 1)
             noise = torch.empty(B, 1, r, r, device=input.device, dtype=torch.float32).normal_()
-        out = self.conv.fused(input, style, noise=noise, noise_weight=self.noise.weight, bias=self.activate.bias,
-                              activate=True, batch=batch, sd=sd)
-        return F_.forward_only(out, 'StyledConv', input, style, *self.parameters())
+        return self.conv.fused(input, style, noise=noise, noise_weight=self.noise.weight, bias=self.activate.bias,
+                               activate=True, batch=batch, sd=sd)
 
 
 class ToRGB(nn.Module):
@@ -233,15 +254,16 @@ class ToRGB(nn.Module):
 
     def forward(self, input, style, skip=None, sd=None):
         conv = self.conv
-        s = sd[0] if sd is not None else F_.style_demod(style, conv.modulation.weight, conv.modulation.bias)[0]
+        s = sd[0] if sd is not None else conv.styles(style)[0]
         fir = None
         if skip is not None:
             up = getattr(self, 'upsample', None)
             if up is None or tuple(up.kernel.shape) != (4, 4) or up.pad != (2, 1):
                 raise NotImplementedError('ToRGB skip path is built for the 4-tap 2x Upsample')
             fir = up.kernel
-        out = F_.torgb(input, conv.weight.view(3, conv.in_channel), s, bias=self.bias.view(3), skip=skip, fir=fir)
-        return F_.forward_only(out, 'ToRGB', input, style, skip, *self.parameters())
+        if _needs_grad(input, s, skip, conv.weight, self.bias):
+            return AG.ToRGBFn.apply(input, s, conv.weight, self.bias, skip, fir)
+        return F_.torgb(input, conv.weight.view(3, conv.in_channel), s, bias=self.bias.view(3), skip=skip, fir=fir)
 
 
 class Generator(nn.Module):
@@ -306,24 +328,31 @@ class Generator(nn.Module):
         trunc = truncation_latent if truncation < 1 else None
         if truncation < 1 and truncation_latent is None:
             raise RuntimeError('truncation < 1 needs truncation_latent')
+        grad = _needs_grad(*styles, trunc, *self.parameters())
+
+        def prepare(w, rows):
+            if _needs_grad(w, trunc):
+                return AG.LatentPrepareFn.apply(w, None, trunc, rows, 0, truncation)
+            return F_.latent_prepare(w, rows, trunc=trunc, psi=truncation)
+
         if len(styles) < 2:
             # truncation (also of a full W+ code, as in the reference) + W -> W+ broadcast in one launch
-            latent = F_.latent_prepare(styles[0], self.n_latent, trunc=trunc, psi=truncation)
+            latent = prepare(styles[0], self.n_latent)
         else:   # style mixing (model.py:510-517); unused by the reenactment scripts
             if inject_index is None:
                 inject_index = random.randint(1, self.n_latent - 1)
-            a = F_.latent_prepare(styles[0], inject_index, trunc=trunc, psi=truncation)
-            b = F_.latent_prepare(styles[1], self.n_latent - inject_index, trunc=trunc, psi=truncation)
-            latent = torch.cat([a, b], 1)
+            latent = torch.cat([prepare(styles[0], inject_index), prepare(styles[1], self.n_latent - inject_index)], 1)
         batch = latent.shape[0]
 
-        # every layer's modulation s = A_l(w_l) and demodulation d_l in two launches (instead of 33)
         order = [(self.conv1.conv, 0), (self.to_rgb1.conv, 1)]
         i = 1
         for conv1, conv2, to_rgb in zip(self.convs[::2], self.convs[1::2], self.to_rgbs):
             order += [(conv1.conv, i), (conv2.conv, i + 1), (to_rgb.conv, i + 2)]
             i += 2
-        sd = iter(F_.styles_batched(latent, [m.style_spec(li) for m, li in order]))
+        if grad:   # differentiable per-layer modulation (autograd routes dL/ds back into the latent rows)
+            sd = iter([m.styles(latent[:, li]) for m, li in order])
+        else:      # every layer's s = A_l(w_l) and demodulation d_l in two launches (instead of 33)
+            sd = iter(F_.styles_batched(latent, [m.style_spec(li) for m, li in order]))
 
         # ConstantInput is broadcast inside the kernel (batch stride 0) instead of repeated
         out = self.conv1(self.input.input, None, noise=noise[0], batch=batch, sd=next(sd))
@@ -334,7 +363,4 @@ class Generator(nn.Module):
             out = conv2(out, None, noise=noise2, sd=next(sd))
             skip = to_rgb(out, None, skip, sd=next(sd))
         image = skip
-        if torch.is_grad_enabled():
-            image = F_.forward_only(image, 'Generator.forward', *styles, *self.parameters())
-            latent = F_.forward_only(latent, 'Generator.forward', *styles)
         return (image, latent) if return_latents else (image, None)

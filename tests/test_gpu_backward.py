@@ -1,0 +1,132 @@
+"""GPU parity of the backward pass: HIP gradients vs torch autograd of the CPU oracle (fp64) and
+vs the dL/dA golden captured from the real reference through generate_image (KAT-5)."""
+import pytest
+import torch
+
+from util import O, S, SEED, golden, hip_generator, maxabs, synthetic_state, t
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return maxabs(a, b) / max(float(b.detach().abs().max()), 1e-12)
+
+
+@pytest.mark.parametrize('cin,cout,h,up', [(16, 8, 5, False), (8, 16, 4, True), (64, 128, 8, False), (128, 64, 8, True),
+                                            (256, 128, 16, True), (128, 128, 16, False), (6, 10, 7, False),
+                                            (10, 6, 5, True), (32, 48, 19, True), (64, 64, 40, False)])
+def test_styled_conv_gradients(cin, cout, h, up):
+    from stylegan_directions_face_reenactment_amd.model import StyledConv
+    B = 3
+    key = 'bw.%d.%d.%d.%d' % (cin, cout, h, up)
+    m = StyledConv(cin, cout, 3, 64, upsample=up)
+    sd = {k: S.counter_tensor(21, key + k, tuple(v.shape)) for k, v in m.state_dict().items() if 'kernel' not in k}
+    sd['conv.modulation.bias'] = sd['conv.modulation.bias'] * 0.1 + 1.0
+    sd['noise.weight'] = sd['noise.weight'] * 0.1 + 0.1
+    if up:
+        sd['conv.blur.kernel'] = m.conv.blur.kernel
+    m.load_state_dict(sd)
+    x = S.counter_tensor(21, key + 'x', (B, cin, h, h))
+    st = S.counter_tensor(21, key + 's', (B, 64))
+    r = 2 * h if up else h
+    nz = S.counter_tensor(21, key + 'n', (1, 1, r, r))
+    g = S.counter_tensor(21, key + 'g', (B, cout, r, r))
+    # fp64 oracle + torch autograd
+    P = {'L.' + k: v.double().requires_grad_(k in ('conv.modulation.weight', 'conv.modulation.bias', 'noise.weight',
+                                                    'activate.bias')) for k, v in sd.items()}
+    xr, sr = x.double().requires_grad_(True), st.double().requires_grad_(True)
+    (O.styled_conv(P, 'L', xr, sr, nz.double(), upsample=up) * g.double()).sum().backward()
+    # HIP
+    m = m.cuda()
+    xh, sh = x.cuda().requires_grad_(True), st.cuda().requires_grad_(True)
+    out = m(xh, sh, noise=nz.cuda())
+    (out * g.cuda()).sum().backward()
+    assert _rel(xh.grad, xr.grad) <= 2e-5, 'dx'
+    assert _rel(sh.grad, sr.grad) <= 5e-5, 'dstyle'
+    assert _rel(m.conv.modulation.weight.grad, P['L.conv.modulation.weight'].grad) <= 5e-5
+    assert _rel(m.conv.modulation.bias.grad, P['L.conv.modulation.bias'].grad) <= 5e-5
+    assert _rel(m.noise.weight.grad, P['L.noise.weight'].grad) <= 5e-5
+    assert _rel(m.activate.bias.grad, P['L.activate.bias'].grad) <= 5e-5
+
+
+def test_torgb_gradients():
+    from stylegan_directions_face_reenactment_amd.model import ToRGB
+    for cin, h in ((64, 8), (512, 4), (20, 6), (128, 48)):
+        key = 'bwrgb.%d.%d' % (cin, h)
+        m = ToRGB(cin, 64, upsample=True)
+        sd = {k: S.counter_tensor(22, key + k, tuple(v.shape)) for k, v in m.state_dict().items() if 'kernel' not in k}
+        sd['upsample.kernel'] = m.upsample.kernel
+        m.load_state_dict(sd)
+        x = S.counter_tensor(22, key + 'x', (2, cin, h, h))
+        st = S.counter_tensor(22, key + 's', (2, 64))
+        skip = S.counter_tensor(22, key + 'k', (2, 3, h // 2, h // 2))
+        g = S.counter_tensor(22, key + 'g', (2, 3, h, h))
+        P = {'L.' + k: v.double().requires_grad_('kernel' not in k) for k, v in sd.items()}
+        xr, sr, kr = (v.double().requires_grad_(True) for v in (x, st, skip))
+        (O.to_rgb(P, 'L', xr, sr, kr) * g.double()).sum().backward()
+        m = m.cuda()
+        xh, sh, kh = (v.cuda().requires_grad_(True) for v in (x, st, skip))
+        (m(xh, sh, kh) * g.cuda()).sum().backward()
+        assert _rel(xh.grad, xr.grad) <= 2e-5
+        assert _rel(sh.grad, sr.grad) <= 5e-5
+        assert _rel(kh.grad, kr.grad) <= 2e-5
+        assert _rel(m.conv.weight.grad, P['L.conv.weight'].grad) <= 5e-5
+        assert _rel(m.bias.grad, P['L.bias'].grad) <= 5e-5
+        assert _rel(m.conv.modulation.weight.grad, P['L.conv.modulation.weight'].grad) <= 5e-5
+
+
+def test_mapping_network_gradients():
+    G = hip_generator(32, 1)
+    P = {k: v.double().requires_grad_(k.startswith('style.')) for k, v in synthetic_state(32, 1).items()}
+    z = S.synthetic_z(23, 3, key='bw.z')
+    g = S.counter_tensor(23, 'bw.mg', (3, 512))
+    zr = z.double().requires_grad_(True)
+    (O.mapping(P, zr) * g.double()).sum().backward()
+    zh = z.cuda().requires_grad_(True)
+    (G.get_latent(zh) * g.cuda()).sum().backward()
+    assert _rel(zh.grad, zr.grad) <= 5e-5
+    assert _rel(G.style[1].weight.grad, P['style.1.weight'].grad) <= 5e-5
+    assert _rel(G.style[8].bias.grad, P['style.8.bias'].grad) <= 5e-5
+
+
+def test_generator_gradient_to_latent_small():
+    """dL/dW+ through the whole Generator(64) vs autograd of the fp64 oracle."""
+    G = hip_generator(64, 1)
+    P = {k: v.double() for k, v in synthetic_state(64, 1).items()}
+    w = S.synthetic_latents(24, 2, n_latent=G.n_latent, key='bw.w')
+    tr = S.counter_tensor(24, 'bw.t', (1, 512))
+    wr = w.double().requires_grad_(True)
+    img, _ = O.generator_forward(P, [wr], input_is_latent=True, truncation=0.7, truncation_latent=tr.double())
+    (img ** 2).mean().backward()
+    for p in G.parameters():
+        p.requires_grad_(False)          # only the latent needs gradients here (what the trainer consumes)
+    wh = w.cuda().requires_grad_(True)
+    imgh, _ = G([wh], input_is_latent=True, truncation=0.7, truncation_latent=tr.cuda())
+    assert maxabs(imgh, img) <= 2e-4
+    (imgh ** 2).mean().backward()
+    assert _rel(wh.grad, wr.grad) <= 2e-4
+
+
+def test_direction_matrix_gradient_golden():
+    """KAT-5: dL/dA for L = mean(img^2) through generate_image, z path and W+ path, vs the REAL reference's autograd."""
+    from stylegan_directions_face_reenactment_amd.direction_matrix import DirectionMatrix
+    from stylegan_directions_face_reenactment_amd.generic import generate_image
+    g4, g = golden('kat4_generator256.npz'), golden('kat5_generate_image.npz')
+    G = hip_generator(256, 1)
+    A = DirectionMatrix(512, input_dim=15, out_dim=512, w_plus=True, num_layers=8, verbose=False)
+    A.load_state_dict(S.synthetic_direction_state(SEED))
+    A = A.cuda()
+    trunc = t(g4['cm1.trunc']).cuda()
+    z = S.synthetic_z(SEED, 2, key='kat4.z').cuda()
+    w = S.synthetic_latents(SEED, 2, key='kat4.w').cuda()
+    sv = t(g['sv']).cuda()
+    import warnings
+    for path, code, is_lat in (('z', z, False), ('w', w, True)):
+        A.zero_grad()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')       # G's own parameters keep requires_grad=True like in libs/trainer.py
+            img, lat = generate_image(G, code, 0.7, trunc, shift_code=A(sv), input_is_latent=is_lat, return_latents=True)
+            (img ** 2).mean().backward()
+        ref = t(g['%s.gA' % path])
+        assert _rel(A.linear.weight.grad, ref) <= 5e-4, path
+        assert _rel(A.linear.bias.grad, t(g['%s.gAb' % path])) <= 5e-4, path

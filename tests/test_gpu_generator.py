@@ -154,6 +154,3 @@ def test_module_protocol_on_gpu():
         P = {k: v.cpu() for k, v in G2.state_dict().items()}
         ref, _ = O.generator_forward(P, [w.cpu()], input_is_latent=True)
         assert maxabs(c, ref) <= 2e-4
-    with pytest.raises(NotImplementedError):
-        img, _ = G([w.clone().requires_grad_(True)], input_is_latent=True)
-        img.sum().backward()
