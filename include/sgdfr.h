@@ -173,6 +173,18 @@ int sgdfr_torgb_bwd_f32(const float* x, const float* g, const float* w_rgb, cons
 int sgdfr_demod_grad_f32(const float* gd, const float* d, const float* qt, const float* s, const float* gs, float* ds,
                          int B, int Cin, int Cout, void* stream);
 
+/* Weight gradient of the modulated conv in the packed layout (split-K fp32 MFMA, atomically accumulated):
+ *   dwp[i][ky*3+kx][o] = sum_{b,p} (d*g)[b,o,shifted p] * (x*s)[b,i,p]
+ * mode PLAIN3: g = activation-gradient [B,Cout,H,W];  mode UP3: g = parity planes [B,Cout,4,H+1,W+1] from
+ * sgdfr_blur_adjoint_f32.  x [B,Cin,H,W] (x_bstride 0 = broadcast), dwp [Cin,9,Cout] (zeroed here). */
+int sgdfr_modconv_wgrad_f32(const float* g, const float* d, const float* x, int64_t x_bstride, const float* s, float* dwp,
+                            int B, int Cin, int Cout, int H, int W, int mode, void* stream);
+
+/* dweight[o][i][k] = (dwp[i][k][o] + 2 * wp[i][k][o] * dq[o][i]) / sqrt(9*Cin):  un-pack, add the demodulation path
+ * (dq = dL/dQ [Cout,Cin], NULL without demodulation) and apply the equalised-lr scale of model.py:215,236. */
+int sgdfr_modconv_wgrad_finish_f32(const float* dwp, const float* wp, const float* dq, float* dweight, int Cout, int Cin,
+                                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

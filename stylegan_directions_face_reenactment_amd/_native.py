@@ -33,6 +33,8 @@ SIGNATURES = {
     'sgdfr_blur_adjoint_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_scale_reduce_f32': [_c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_torgb_bwd_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i, ctypes.c_void_p],
+    'sgdfr_modconv_wgrad_f32': [_c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _i, _i, _i, _i, _i, _i, ctypes.c_void_p],
+    'sgdfr_modconv_wgrad_finish_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, ctypes.c_void_p],
     'sgdfr_demod_grad_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_style_demod_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i,
                               ctypes.c_void_p],

@@ -191,9 +191,11 @@ class StyledConvFn(Function):
         gd = (A / d) if (d is not None and ctx.needs_input_grad[2]) else None
         gweight = None
         if ctx.needs_input_grad[3]:
-            _warn_once('dW', 'gradients w.r.t. the generator conv weights are not built yet (SURVEY.md §8f-1): '
-                             'they are returned as None; gradients w.r.t. latents / styles / biases / noise strengths '
-                             'are exact')
+            dq = None
+            if d is not None:      # dL/dQ[o,i] = sum_b dL/dd * (-d^3/2) * s^2   (d = rsqrt(sum_i s^2 Q + eps))
+                coeff = (A / d) * d.pow(3) * -0.5
+                dq = F_.linear(_t(coeff), _t(s * s))
+            gweight = F_.wgrad(gT if up else g_pre, d, x, s, cout, up, wp=mod.packed()[0], dq=dq)
         gnw = sums[:, :, 1].sum().view(1) if (noise_w is not None and ctx.needs_input_grad[4]) else None
         gb = sums[:, :, 0].sum(0) if (bias is not None and ctx.needs_input_grad[5]) else None
         return gx, gs, gd, gweight, gnw, gb, None, None, None, None

@@ -1,0 +1,235 @@
+// Weight gradient of the shared-weight modulated conv (needed by PTI, libs/optimization.py:32-68):
+//     dWc[o,i,ky,kx] = sum_{b,p} (d*g)[b,o, shifted p] * (x*s)[b,i,p]
+// as a split-K fp32-MFMA GEMM: rows = output channels o, columns = input channels i, nine accumulators
+// (one per tap), reduction over pixels.  The pixel stream is cut into chunks of PC pixels inside one image
+// row; per chunk the block stages the style-scaled input row segment [64 i][PC] and the demod-scaled gradient
+// neighbourhood [64 o][segments][PC+2]:
+//     PLAIN3: 3 segments = gradient rows y+1, y, y-1  (tap (ky,kx) reads row 2-ky at column j+2-kx)
+//     UP3   : 8 segments = 4 parity planes x 2 plane rows (tap (ky,kx) reads plane (ky&1,kx&1), row y+(ky>>1),
+//             column j+(kx>>1)) -- the planes produced by sgdfr_blur_adjoint_f32
+// Channel strides in LDS are odd so the MFMA fragment reads (32 lanes = 32 channels) are conflict-free.
+// Blocks own a (64 o x 64 i) tile and a contiguous range of chunks; partial sums are added to the packed
+// gradient dwp[Cin][9][Cout] with fp32 atomics.
+#include "common.h"
+
+namespace sgdfr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradParams {
+    const float* g;
+    const float* d;
+    const float* x;
+    int64_t x_bstride;
+    const float* s;
+    float* dwp;
+    int B, Cin, Cout, H, W, P, R;
+    int PC, chunks_per_row, total_chunks, chunks_per_block, n_ot, n_it;
+};
+
+template <int MODE, int PCMAX>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
+    constexpr int NSEG = (MODE == SGDFR_MODE_UP3) ? 8 : 3;
+    constexpr int SEG = PCMAX + 2;
+    constexpr int GST = (NSEG * SEG) | 1;   // odd channel stride
+    constexpr int UST = PCMAX | 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* lu = smem;                 // [64][UST]
+    float* lg = smem + 64 * UST;      // [64][GST]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wo = wave >> 1, wi = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ntile = p.n_ot * p.n_it;
+    const int tile = blockIdx.x % ntile, ks = blockIdx.x / ntile;
+    const int ot = tile / p.n_it, it = tile - ot * p.n_it;
+    const int HW = p.H * p.W, RP = p.R * p.P;
+    const int PC = p.PC;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    const int c_lo = ks * p.chunks_per_block;
+    const int c_hi = min(p.total_chunks, c_lo + p.chunks_per_block);
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int img = c / (p.H * p.chunks_per_row);
+        const int rem = c - img * p.H * p.chunks_per_row;
+        const int y = rem / p.chunks_per_row;
+        const int x0 = (rem - y * p.chunks_per_row) * PC;
+        __syncthreads();   // previous chunk's fragments are consumed
+        // ---- style-scaled inputs  u[i][j] = x[img,i,y,x0+j] * s[img,i]
+        for (int e = tid; e < 64 * PC; e += 256) {
+            const int il = e / PC, j = e - il * PC;
+            const int i = it * 64 + il;
+            float v = 0.f;
+            if (i < p.Cin) v = p.x[(int64_t)img * p.x_bstride + (int64_t)i * HW + y * p.W + x0 + j] * p.s[img * p.Cin + i];
+            lu[il * UST + j] = v;
+        }
+        // ---- demod-scaled gradient neighbourhood
+        const int seglen = (MODE == SGDFR_MODE_UP3) ? PC + 1 : PC + 2;
+        for (int e = tid; e < 64 * NSEG * seglen; e += 256) {
+            const int ol = e / (NSEG * seglen);
+            const int r2 = e - ol * NSEG * seglen;
+            const int sg = r2 / seglen, ci = r2 - sg * seglen;
+            const int o = ot * 64 + ol;
+            float v = 0.f;
+            if (o < p.Cout) {
+                const float dv = p.d ? p.d[img * p.Cout + o] : 1.f;
+                if (MODE == SGDFR_MODE_UP3) {
+                    const int plane = sg >> 1, row = y + (sg & 1), col = x0 + ci;
+                    v = p.g[(((int64_t)img * p.Cout + o) * 4 + plane) * RP + row * p.P + col] * dv;
+                } else {
+                    const int yy = y + sg - 1, xx = x0 - 1 + ci;
+                    if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
+                        v = p.g[((int64_t)img * p.Cout + o) * HW + yy * p.W + xx] * dv;
+                }
+            }
+            lg[ol * GST + sg * SEG + ci] = v;
+        }
+        __syncthreads();
+        const float* lub = lu + (wi * 32 + l31) * UST + hi;
+        const float* lgb = lg + (wo * 32 + l31) * GST + hi;
+        for (int j = 0; j < PC; j += 2) {
+            const float b = lub[j];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int ky = k / 3, kx = k - ky * 3;
+                int off;
+                if (MODE == SGDFR_MODE_UP3)
+                    off = ((2 * (ky & 1) + (kx & 1)) * 2 + (ky >> 1)) * SEG + (kx >> 1);
+                else
+                    off = (2 - ky) * SEG + 2 - kx;
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(lgb[off + j], b, acc[k], 0, 0, 0);
+            }
+        }
+    }
+    // ---- split-K combine: dwp[i][tap][o] += acc
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = ot * 64 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int i = it * 64 + wi * 32 + l31;
+            if (o < p.Cout && i < p.Cin) atomicAdd(&p.dwp[((int64_t)i * 9 + k) * p.Cout + o], acc[k][r]);
+        }
+}
+
+// Any shape (odd widths, channel counts that are not multiples of 4 ...): one thread per (i, tap, o).
+__global__ __launch_bounds__(256) void wgrad_direct_kernel(WgradParams p, int mode) {
+    const int64_t total = (int64_t)p.Cin * 9 * p.Cout;
+    const int HW = p.H * p.W, RP = p.R * p.P;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(idx % p.Cout);
+        const int k = (int)((idx / p.Cout) % 9);
+        const int i = (int)(idx / ((int64_t)p.Cout * 9));
+        const int ky = k / 3, kx = k - ky * 3;
+        float acc = 0.f;
+        for (int b = 0; b < p.B; ++b) {
+            const float sc = p.s[b * p.Cin + i] * (p.d ? p.d[b * p.Cout + o] : 1.f);
+            const float* xp = p.x + (int64_t)b * p.x_bstride + (int64_t)i * HW;
+            float part = 0.f;
+            for (int y = 0; y < p.H; ++y)
+                for (int x = 0; x < p.W; ++x) {
+                    float gv;
+                    if (mode == SGDFR_MODE_UP3) {
+                        gv = p.g[(((int64_t)b * p.Cout + o) * 4 + 2 * (ky & 1) + (kx & 1)) * RP + (y + (ky >> 1)) * p.P + x +
+                                 (kx >> 1)];
+                    } else {
+                        const int yy = y + 1 - ky, xx = x + 1 - kx;
+                        if (yy < 0 || yy >= p.H || xx < 0 || xx >= p.W) continue;
+                        gv = p.g[((int64_t)b * p.Cout + o) * HW + yy * p.W + xx];
+                    }
+                    part = fmaf(xp[y * p.W + x], gv, part);
+                }
+            acc = fmaf(part, sc, acc);
+        }
+        p.dwp[idx] = acc;
+    }
+}
+
+// dW[o][i][k] = scale * ( dwp[i][k][o] + 2 * wp[i][k][o] * dq[o][i] )      (dq = dL/dQ from the demodulation, may be NULL)
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ dwp, const float* __restrict__ wp,
+                                                          const float* __restrict__ dq, float* __restrict__ dw, int Cout,
+                                                          int Cin, float scale) {
+    const int64_t total = (int64_t)Cout * Cin * 9;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(idx % Cout);     // o fastest: coalesced reads of the packed tensors
+        const int k = (int)((idx / Cout) % 9);
+        const int i = (int)(idx / ((int64_t)Cout * 9));
+        float v = dwp[idx];
+        if (dq) v = fmaf(2.f * wp[idx], dq[(int64_t)o * Cin + i], v);
+        dw[((int64_t)o * Cin + i) * 9 + k] = v * scale;
+    }
+}
+
+template <int MODE, int PCMAX>
+static int launch_wgrad(WgradParams& p, hipStream_t st) {
+    constexpr int NSEG = (MODE == SGDFR_MODE_UP3) ? 8 : 3;
+    constexpr int GST = (NSEG * (PCMAX + 2)) | 1, UST = PCMAX | 1;
+    p.n_ot = (p.Cout + 63) / 64;
+    p.n_it = (p.Cin + 63) / 64;
+    const int ntile = p.n_ot * p.n_it;
+    // split K so that ~1024 blocks exist, but keep at least 4 chunks per block
+    int ksplit = (1024 + ntile - 1) / ntile;
+    int maxsplit = (p.total_chunks + 3) / 4;
+    if (maxsplit < 1) maxsplit = 1;
+    if (ksplit > maxsplit) ksplit = maxsplit;
+    p.chunks_per_block = (p.total_chunks + ksplit - 1) / ksplit;
+    ksplit = (p.total_chunks + p.chunks_per_block - 1) / p.chunks_per_block;
+    const size_t lds = (size_t)(64 * UST + 64 * GST) * sizeof(float);
+    auto kern = wgrad_mfma_kernel<MODE, PCMAX>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return check_launch("wgrad(lds attribute)");
+    }
+    hipLaunchKernelGGL(kern, dim3(ntile * ksplit), dim3(256), lds, st, p);
+    return check_launch("modconv_wgrad");
+}
+
+}  // namespace sgdfr
+
+using namespace sgdfr;
+
+extern "C" int sgdfr_modconv_wgrad_f32(const float* g, const float* d, const float* x, int64_t x_bstride, const float* s,
+                                       float* dwp, int B, int Cin, int Cout, int H, int W, int mode, void* stream) {
+    SGDFR_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "wgrad: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin,
+                  Cout, H, W);
+    SGDFR_REQUIRE(mode == SGDFR_MODE_PLAIN3 || mode == SGDFR_MODE_UP3, "wgrad: mode must be PLAIN3 or UP3, got %d", mode);
+    SGDFR_REQUIRE(g && x && s && dwp, "wgrad: null pointer");
+    hipStream_t st = as_stream(stream);
+    WgradParams p{};
+    p.g = g; p.d = d; p.x = x; p.x_bstride = x_bstride; p.s = s; p.dwp = dwp;
+    p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.P = W + 1; p.R = H + 1;
+    const int pcmax = (mode == SGDFR_MODE_UP3) ? 32 : 64;
+    const int PC = W < pcmax ? W : pcmax;
+    const bool mfma_ok = (W % PC == 0) && (PC % 2 == 0);
+    if (!mfma_ok) {
+        const int64_t total = (int64_t)Cin * 9 * Cout;
+        int64_t gsz = (total + 255) / 256;
+        if (gsz > 256 * 16) gsz = 256 * 16;
+        hipLaunchKernelGGL(wgrad_direct_kernel, dim3((int)gsz), dim3(256), 0, st, p, mode);
+        return check_launch("modconv_wgrad(direct)");
+    }
+    if (hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cin * 9 * Cout, st) != hipSuccess) return check_launch("memset");
+    p.PC = PC;
+    p.chunks_per_row = W / PC;
+    p.total_chunks = B * H * p.chunks_per_row;
+    if (mode == SGDFR_MODE_UP3) return launch_wgrad<SGDFR_MODE_UP3, 32>(p, st);
+    return launch_wgrad<SGDFR_MODE_PLAIN3, 64>(p, st);
+}
+
+extern "C" int sgdfr_modconv_wgrad_finish_f32(const float* dwp, const float* wp, const float* dq, float* dweight, int Cout,
+                                              int Cin, void* stream) {
+    SGDFR_REQUIRE(Cout > 0 && Cin > 0, "wgrad_finish: bad shape %d %d", Cout, Cin);
+    SGDFR_REQUIRE(dwp && dweight && (wp || !dq), "wgrad_finish: null pointer");
+    const int64_t total = (int64_t)Cout * Cin * 9;
+    int64_t gsz = (total + 255) / 256;
+    if (gsz > 4096) gsz = 4096;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((int)gsz), dim3(256), 0, as_stream(stream), dwp, wp, dq, dweight, Cout,
+                       Cin, 1.0f / sqrtf((float)Cin * 9));
+    return check_launch("modconv_wgrad_finish");
+}

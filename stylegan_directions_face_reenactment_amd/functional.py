@@ -367,3 +367,19 @@ def demod_grad(gd, d, qt, s, gs):
     N.call('sgdfr_demod_grad_f32', N.ptr(N.f32c(gd)), N.ptr(d), N.ptr(qt), N.ptr(s), N.ptr(N.f32c(gs)), N.ptr(ds), B,
            cin, d.shape[1], N.stream())
     return ds
+
+
+def wgrad(g, d, x, s, cout, upsample, wp=None, dq=None):
+    """dL/dW [1,Cout,Cin,3,3] of a modulated 3x3 conv.  g: activation gradient [B,Cout,H,W] (plain) or the
+    parity planes of dL/dT [B,Cout,4,H+1,W+1] (upsample); x [B or 1,Cin,H,W]; dq [Cout,Cin] = dL/dQ or None."""
+    N.require_device(g, d, x, s, wp, dq)
+    x, g = N.f32c(x), N.f32c(g)
+    B = s.shape[0]
+    _, cin, H, W = x.shape
+    xb = 0 if (x.shape[0] == 1 and B != 1) else cin * H * W
+    dwp = torch.empty(cin, 9, cout, device=x.device, dtype=torch.float32)
+    N.call('sgdfr_modconv_wgrad_f32', N.ptr(g), N.ptr(d), N.ptr(x), xb, N.ptr(s), N.ptr(dwp), B, cin, cout, H, W,
+           N.MODE_UP3 if upsample else N.MODE_PLAIN3, N.stream())
+    dw = torch.empty(1, cout, cin, 3, 3, device=x.device, dtype=torch.float32)
+    N.call('sgdfr_modconv_wgrad_finish_f32', N.ptr(dwp), N.ptr(wp), N.ptr(dq), N.ptr(dw), cout, cin, N.stream())
+    return dw

@@ -130,3 +130,59 @@ def test_direction_matrix_gradient_golden():
         ref = t(g['%s.gA' % path])
         assert _rel(A.linear.weight.grad, ref) <= 5e-4, path
         assert _rel(A.linear.bias.grad, t(g['%s.gAb' % path])) <= 5e-4, path
+
+
+@pytest.mark.parametrize('cin,cout,h,up,B', [(16, 8, 8, False, 3), (8, 16, 4, True, 3), (64, 128, 16, False, 2),
+                                              (128, 64, 16, True, 2), (64, 64, 64, False, 1), (32, 64, 64, True, 1),
+                                              (6, 10, 7, False, 2), (10, 6, 5, True, 2), (64, 64, 128, False, 1)])
+def test_conv_weight_gradient(cin, cout, h, up, B):
+    """dL/dW of the modulated conv (what PTI optimises, libs/optimization.py:32-35), incl. the demodulation path."""
+    from stylegan_directions_face_reenactment_amd.model import StyledConv
+    key = 'wg.%d.%d.%d.%d' % (cin, cout, h, up)
+    m = StyledConv(cin, cout, 3, 64, upsample=up)
+    sd = {k: S.counter_tensor(25, key + k, tuple(v.shape)) for k, v in m.state_dict().items() if 'kernel' not in k}
+    sd['conv.modulation.bias'] = sd['conv.modulation.bias'] * 0.1 + 1.0
+    if up:
+        sd['conv.blur.kernel'] = m.conv.blur.kernel
+    m.load_state_dict(sd)
+    x = S.counter_tensor(25, key + 'x', (B, cin, h, h))
+    st = S.counter_tensor(25, key + 's', (B, 64))
+    r = 2 * h if up else h
+    nz = S.counter_tensor(25, key + 'n', (1, 1, r, r))
+    g = S.counter_tensor(25, key + 'g', (B, cout, r, r))
+    P = {'L.' + k: v.double().requires_grad_(k == 'conv.weight') for k, v in sd.items()}
+    (O.styled_conv(P, 'L', x.double(), st.double(), nz.double(), upsample=up) * g.double()).sum().backward()
+    m = m.cuda()
+    (m(x.cuda(), st.cuda(), noise=nz.cuda()) * g.cuda()).sum().backward()
+    assert m.conv.weight.grad is not None and m.conv.weight.grad.shape == (1, cout, cin, 3, 3)
+    assert _rel(m.conv.weight.grad, P['L.conv.weight'].grad) <= 1e-4
+
+
+def test_pti_style_step_updates_generator():
+    """One optimiser step on convs[4..11] parameters as in libs/optimization.py:32-68 (B=1, MSE to a target)."""
+    import copy
+    G = hip_generator(64, 1)
+    P = {k: v.double() for k, v in synthetic_state(64, 1).items()}
+    names = [n for n, _ in G.named_parameters() if n.startswith('convs.4.') or n.startswith('convs.7.')]
+    for k in P:
+        P[k].requires_grad_(k in names)
+    w = S.synthetic_latents(26, 1, n_latent=G.n_latent, key='pti.w')
+    target = S.counter_tensor(26, 'pti.t', (1, 3, 64, 64))
+    img, _ = O.generator_forward(P, [w.double()], input_is_latent=True)
+    ((img - target.double()) ** 2).mean().backward()
+    G2 = copy.deepcopy(G).train()
+    params = [p for n, p in G2.named_parameters() if n in names]
+    opt = torch.optim.Adam(params, lr=3e-4)
+    imgh, _ = G2([w.cuda()], input_is_latent=True)
+    loss = ((imgh - target.cuda()) ** 2).mean()
+    loss.backward()
+    for n, p in G2.named_parameters():
+        if n in names:
+            assert p.grad is not None, n
+            assert _rel(p.grad, P[n].grad) <= 5e-4, n
+    before = G2.convs[4].conv.weight.detach().clone()
+    opt.step()
+    assert float((G2.convs[4].conv.weight - before).abs().max()) > 0
+    with torch.no_grad():
+        img2, _ = G2([w.cuda()], input_is_latent=True)      # repacked weights are picked up
+    assert float(((img2 - target.cuda()) ** 2).mean()) < float(loss)
