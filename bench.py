@@ -13,7 +13,8 @@ generates its own 64-latent shard of the global batch; rank 0's weights are broa
 before the timed region and there is no collective inside it.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline      fp32-MFMA conv kernel (modconv_mfma_kernel): algorithmic FLOPs / HIP-event time on the
+  roofline      the fp32-MFMA conv kernels (direct modconv_mfma_kernel + Winograd wino_mfma_kernel): ALGORITHMIC FLOPs
+                (2*9*Cin*Cout per input pixel, whatever multiplies the kernel really issues) / HIP-event time on the
                 launch stream, vs the 157.3 TFLOP/s fp32 MFMA peak of MI355X
   cpu_baseline  the oracle (CPU PyTorch restatement of the reference generator, kind "port") timed on this
                 host's cores on a bounded sample of the same workload (N=1 only)
@@ -171,7 +172,7 @@ def main():
                    'per_gpu_batch': B, 'global_batch': B * world, 'resolution': args.size,
                    'channel_multiplier': args.cm, 'parallelism': 'batch-sharded x%d, no data-path collective' % world,
                    'weight_broadcast_bytes': bcast_bytes},
-        'roofline': {'bound': 'mfma', 'kernel': 'modconv_mfma_kernel (13 launches/forward)',
+        'roofline': {'bound': 'mfma', 'kernel': 'wino_mfma_kernel (5 plain 3x3 layers) + modconv_mfma_kernel (2 plain, 6 transposed): 13 conv launches/forward',
                      'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(args, B),
                      'avg_launch_us': round(conv_s / n_launch * 1e6, 2),

@@ -136,8 +136,9 @@ int sgdfr_modconv2d_fwd_f32(const float* x, int64_t x_bstride, const float* wp, 
                             float gain, void* stream);
 
 /* Winograd F(2x2,3x3) form of mode PLAIN3 (same result up to fp32 rounding, 2.25x fewer MFMA ops).
- *   sgdfr_modconv_prepack_wino_f32: weight [Cout,Cin,3,3] -> u [Cin][16][Cout] = (G g G^T) / sqrt(9*Cin);
- *       transpose_flip != 0 packs the ADJOINT conv instead: u [Cout][16][Cin] of the 180-degree rotated, transposed kernel
+ *   sgdfr_modconv_prepack_wino_f32: weight [Cout,Cin,3,3] -> u [Cin][Cout][16] = (G g G^T) / sqrt(9*Cin), the four 16-byte
+ *       quads of each 16-vector stored at slot (quad ^ (cout & 3)) (LDS bank swizzle, opaque to callers);
+ *       transpose_flip != 0 packs the ADJOINT conv instead: u [Cout][Cin][16] of the 180-degree rotated, transposed kernel
  *   sgdfr_modconv2d_wino_supported: 1 when the shape can use it (Cin % 8 == 0, Cout % 64 == 0, H and W even)
  *   sgdfr_modconv2d_wino_f32: arguments as sgdfr_modconv2d_fwd_f32(mode PLAIN3) with u in place of wp, plus `zeros`:
  *       a device buffer of >= 16 zero bytes (the global->LDS DMA reads padding positions from it) */

@@ -14,7 +14,10 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libsgdfr_hip.so')
 ARCH = 'gfx950'
-FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=on', '-Wall', '-Wno-unused-function']
+# -fno-slp-vectorize: packed f32 VALU (v_pk_add_f32 / v_pk_mul_f32) beside MFMAs costs more issue time than the
+# scalar pair it replaces (cdna_hip_programming.md, "price of one filler beside MFMAs")
+FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=on', '-fno-slp-vectorize', '-Wall',
+         '-Wno-unused-function']
 
 
 def _hipcc():

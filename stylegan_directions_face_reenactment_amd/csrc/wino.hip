@@ -11,9 +11,12 @@
 //     Y = A^T M A          2x2 outputs per tile, per lane, straight from the accumulators; then the usual
 //                          d * Y + noise + bias -> leaky-ReLU epilogue, float2 stores.
 //
-// Staging is the same padded-flat q-space trick as csrc/modconv.hip: the 4x4 patch of tile (img, ty, tx) starts at
-// q = (img*(H+1) + 2ty)*(W+1) + 2tx and its rows are P = W+1 apart, so a block's 64 consecutive tiles need one
-// contiguous q-range per channel.  One barrier per K stage (8 input channels = 64 MFMAs per wave), LDS stages
+// Staging is the padded-flat q-space trick of csrc/modconv.hip with an EVEN row pitch P = W+2 (a zero column on both
+// sides of every row, one shared zero row between images): the 4x4 patch of tile (img, ty, tx) starts at the even index
+// q = (img*(H+1) + 2ty)*P + 2tx and its rows are P apart, so a block's 64 consecutive tiles need one contiguous q-range
+// per channel, and every patch row is two 8-byte aligned ds_read_b64 (lanes = consecutive tiles = consecutive 8-byte
+// words: conflict-free).  The weight fragments are stored [cin][cout][16] with the four 16-byte quads of a cout row
+// XOR-swizzled by (cout & 3), so a lane fetches its 16 Winograd-domain weights with four conflict-free ds_read_b128.  One barrier per K stage (8 input channels = 64 MFMAs per wave), LDS stages
 // double-buffered, next stage prefetched into registers under the MFMAs.
 #include "common.h"
 
@@ -38,13 +41,17 @@ struct WinoParams {
     int n_t_tiles, n_o_tiles;
     int total_tiles;
     int xs, xlen;
+    int simgs;           // images a block of 64 tiles can touch
     int act;
     float slope, gain;
 };
 
-constexpr int WCK = 8;    // input channels per LDS stage
+constexpr int WCK = 8;    // input channels per LDS stage (4 when three 8-channel stages do not fit in LDS)
 constexpr int WNT = 64;   // couts per block
 constexpr int WTT = 64;   // tiles per block
+#ifndef WINO_SPLIT
+#define WINO_SPLIT 4
+#endif
 constexpr int WEX = 4;    // staged q elements per thread per channel (xlen <= 1024)
 
 __device__ __forceinline__ int wino_qbase(const WinoParams& p, int t) {
@@ -55,8 +62,32 @@ __device__ __forceinline__ int wino_qbase(const WinoParams& p, int t) {
     return (img * p.R + 2 * ty) * p.P + 2 * tx;
 }
 
+// One k-pair's operands from LDS: the lane's 4x4 input patch (8 x ds_read_b64) and its 16 Winograd-domain weights
+// (4 x ds_read_b128, quads un-swizzled by usw = cout & 3).
+__device__ __forceinline__ void wino_fetch(const float* px, int P, const float* pu, int usw, float (&uu)[16],
+                                           float (&dd)[4][4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 q = *reinterpret_cast<const float4*>(pu + ((j ^ usw) << 2));
+        uu[4 * j + 0] = q.x; uu[4 * j + 1] = q.y; uu[4 * j + 2] = q.z; uu[4 * j + 3] = q.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float2 a = *reinterpret_cast<const float2*>(px + r * P);
+        const float2 b = *reinterpret_cast<const float2*>(px + r * P + 2);
+        dd[r][0] = a.x; dd[r][1] = a.y; dd[r][2] = b.x; dd[r][3] = b.y;
+    }
+}
+
 // V = sc * B^T d B for one 4x4 patch (32 add/sub + 16 mul per patch)
 __device__ __forceinline__ void wino_input_transform(const float (&dd)[4][4], float sc, float (&vv)[16]) {
+#ifdef WINO_NO_TRANSFORM   // timing experiment only (wrong results): how much do the 64 VALU ops per k-pair cost?
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) vv[a * 4 + c] = dd[a][c];
+    return;
+#endif
     float tmp[4][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {   // B^T d  (rows)
@@ -74,9 +105,34 @@ __device__ __forceinline__ void wino_input_transform(const float (&dd)[4][4], fl
     }
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// wait until at most `per_stage * stages_in_flight` DMA instructions of this wave are outstanding
+template <int CKK>
+__device__ __forceinline__ void wait_dma(bool one_stage_in_flight) {
+    // weight-slab DMA instructions per stage and wave: CKK (16-byte pieces of 1 KiB per wave)
+    if (one_stage_in_flight) wait_vmcnt<CKK>();
+    else wait_vmcnt<0>();
+}
+
+// CKK input channels per K stage, two LDS stages.  The k-pair pipeline runs CONTINUOUSLY across stages: the fragments
+// of k-pair n+1 are fetched from LDS before the 16 MFMAs of k-pair n are issued, also when n+1 is the first k-pair of
+// the next stage.  The single rendezvous per stage sits right before that cross-stage fetch; at that point every
+// wave already holds the last fragments of stage st in registers, so the buffer of stage st is immediately free to
+// receive stage st+2 (inputs: dword loads issued a whole stage earlier, then ds_write; weights: 16-byte LDS DMA,
+// retired by a counted vmcnt at the next rendezvous).  With one wave per SIMD (16 accumulators = 256 registers)
+// this keeps the matrix pipe from draining at stage boundaries.
+template <int CKK, int NEX>
 __global__ __launch_bounds__(256, 1) void wino_mfma_kernel(WinoParams p) {
+    constexpr int NBUF = 2;
+    constexpr int NKP = CKK / 2;   // MFMA k-pairs per stage
+    constexpr int UV = CKK;   // weight-slab DMA pieces per wave and stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int stage_floats = WCK * p.xs + WCK * 16 * WNT;
+    const int stage_floats = CKK * p.xs + CKK * 16 * WNT;
+    float* ls = smem + NBUF * stage_floats;            // styles of the images this block touches: [simgs][Cin]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wo = wave >> 1, wt = wave & 1;
@@ -93,30 +149,30 @@ __global__ __launch_bounds__(256, 1) void wino_mfma_kernel(WinoParams p) {
     const int n0 = ct * WNT;
     const int t0 = tt * WTT;
     const int q0 = wino_qbase(p, t0);
+    const int per_img = p.TW * p.TH;
+    const int img0 = t0 / per_img;
 
     // this lane's tile (column of the B operand) and its patch origin inside the staged range
     int tile = t0 + wt * 32 + l31;
     const bool tile_ok = tile < p.total_tiles;
     if (!tile_ok) tile = p.total_tiles - 1;
     const int boff = wino_qbase(p, tile) - q0;
+    const float* lsp = ls + (tile / per_img - img0) * p.Cin + hi;   // this lane's style row (+ channel parity)
+    const int uoff = (wo * 32 + l31) * 16, usw = l31 & 3;           // this lane's cout row in a [64][16] weight tile
 
     // staging descriptors: padding positions of the q-range read a zero word instead of x
-    const float* xsrc[WEX];
-    const int nex = (p.xlen + 255) >> 8;
+    const float* xsrc[NEX];
 #pragma unroll
-    for (int e = 0; e < WEX; ++e) {
+    for (int e = 0; e < NEX; ++e) {
         const int j = tid + e * 256;
         const int q = q0 + j;
         const int pir = q / p.P;
         const int pc = q - pir * p.P;
         const int img = pir / p.R;
         const int pr = pir - img * p.R;
-        const bool ok = (j < p.xlen) && pc >= 1 && pr >= 1 && img < p.B;
+        const bool ok = (j < p.xlen) && pc >= 1 && pc <= p.W && pr >= 1 && img < p.B;
         xsrc[e] = ok ? p.x + (int64_t)img * p.x_bstride + (pr - 1) * p.W + (pc - 1) : nullptr;
     }
-    // style of this lane's tile image, for channel (.. + hi) of each k-pair
-    const int simg = (wino_qbase(p, tile) / p.P) / p.R;
-    const float* sp = p.s + (int64_t)simg * p.Cin + hi;
 
     f32x16 acc[16];
 #pragma unroll
@@ -129,91 +185,109 @@ __global__ __launch_bounds__(256, 1) void wino_mfma_kernel(WinoParams p) {
 
     // Global -> LDS by DMA (no staging registers, no arithmetic: the style scale is applied after the input
     // transform, which is linear).  dwordx4 for the weight slab, dword for the q-range (zero word for padding).
-    auto issue_stage = [&](int c0, float* lx, float* lu) {
+    // Staging.  Weight slab: global -> LDS DMA in 16-byte pieces (1 KiB per wave instruction, no registers).
+    // q-range of the inputs: ordinary dword loads into registers two stages ahead, written to LDS after the MFMAs
+    // (a 4-byte DMA piece costs as much issue time as a 16-byte one, so the narrow gather goes through VGPRs).
+    float xr[NEX][CKK];
+    auto load_x = [&](int st) {
+        const int c0 = st * CKK;
 #pragma unroll
-        for (int e = 0; e < WEX; ++e) {
-            if (e < nex) {
-                const int j0 = (tid & ~63) + e * 256;   // wave-uniform LDS base; the DMA adds lane*4
+        for (int e = 0; e < NEX; ++e) {
+            const float* src = xsrc[e] ? xsrc[e] + (int64_t)c0 * HW : p.zeros;
+            const int64_t cs = xsrc[e] ? HW : 0;
 #pragma unroll
-                for (int c = 0; c < WCK; ++c) {
-                    const float* src = xsrc[e] ? xsrc[e] + (int64_t)(c0 + c) * HW : p.zeros;
-                    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(lx + c * p.xs + j0), 4, 0, 0);
-                }
-            }
+            for (int c = 0; c < CKK; ++c) xr[e][c] = src[c * cs];
         }
+    };
+    auto store_x = [&](int st) {
+        float* lx = smem + (st % NBUF) * stage_floats;
 #pragma unroll
-        for (int v = 0; v < 8; ++v) {
-            const int f = tid + v * 256;
-            const int row = f >> 4, col = (f & 15) * 4;   // WNT/4 = 16 float4 per row
-            const float* src = p.u + ((int64_t)c0 * 16 + row) * p.Cout + n0 + col;
+        for (int e = 0; e < NEX; ++e)
+#pragma unroll
+            for (int c = 0; c < CKK; ++c) lx[c * p.xs + tid + e * 256] = xr[e][c];
+    };
+    auto issue_u = [&](int st) {
+        const int c0 = st * CKK;
+        float* lu = smem + (st % NBUF) * stage_floats + CKK * p.xs;
+#pragma unroll
+        for (int v = 0; v < UV; ++v) {
+            const int f = tid + v * 256;                  // float4 index inside the stage slab: 256 per channel
+            const int row = f >> 8, col = (f & 255) * 4;
+            const float* src = p.u + (((int64_t)(c0 + row) * p.Cout + n0) << 4) + col;
             __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(lu + (size_t)((tid & ~63) + v * 256) * 4), 16, 0, 0);
         }
     };
 
-    const int nstage = p.Cin / WCK;
+    const int nstage = p.Cin / CKK;
     const int P = p.P;
-    issue_stage(0, smem, smem + WCK * p.xs);
-    float sv[WCK / 2];
-#pragma unroll
-    for (int cp = 0; cp < WCK / 2; ++cp) sv[cp] = sp[cp * 2];
-    __syncthreads();
+    // styles of the block's images -> LDS (plain loads: retired by the first wait below)
+    for (int e = tid; e < p.simgs * p.Cin; e += 256) {
+        const int m = e / p.Cin;
+        ls[e] = (img0 + m < p.B) ? p.s[(int64_t)(img0 + m) * p.Cin + (e - m * p.Cin)] : 0.f;
+    }
+    load_x(0);
+    store_x(0);
+    issue_u(0);
+    if (nstage > 1) {
+        load_x(1);
+        store_x(1);
+        issue_u(1);
+        wait_vmcnt<CKK>();     // stage 0's weight DMA landed; stage 1's may still fly
+    } else {
+        wait_vmcnt<0>();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // style rows + staged inputs written above
+    __builtin_amdgcn_s_barrier();
+
+    // Input transform of the upcoming k-pair:  V = s * B^T x B   (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1])
+    float uc[16], vc[16], un[16], dn[4][4];
+    {
+        wino_fetch(smem + hi * p.xs + boff, P, smem + CKK * p.xs + hi * (16 * WNT) + uoff, usw, uc, dn);
+        wino_input_transform(dn, lsp[0], vc);
+    }
     for (int st = 0; st < nstage; ++st) {
-        float* lx = smem + (st & 1) * stage_floats;
-        float* lu = lx + WCK * p.xs;
-        float sn[WCK / 2];
-        if (st + 1 < nstage) {
-            float* nx = smem + ((st + 1) & 1) * stage_floats;
-            issue_stage((st + 1) * WCK, nx, nx + WCK * p.xs);
+        const bool more = st + 2 < nstage, next_stage = st + 1 < nstage;
+        if (more) load_x(st + 2);                      // global -> registers, consumed after the rendezvous below
 #pragma unroll
-            for (int cp = 0; cp < WCK / 2; ++cp) sn[cp] = sp[(st + 1) * WCK + cp * 2];
-        }
-        // Software-pipelined over the 4 k-pairs of the stage: the LDS reads (16 weight fragments + the 4x4 patch)
-        // of k-pair n+1 are issued BEFORE the 16 MFMAs of k-pair n, and its input transform
-        //     V = s * B^T x B     (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1])
-        // is free to interleave with those MFMAs, so the matrix pipe does not wait on LDS latency.
-        float uc[16], vc[16], un[16], dn[4][4];
-        {
-            const float* px = lx + hi * p.xs + boff;
-            const float* pu = lu + (hi * 16) * WNT + wo * 32 + l31;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) uc[k] = pu[k * WNT];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) dn[r][c] = px[r * P + c];
-            wino_input_transform(dn, sv[0], vc);
-        }
-#pragma unroll
-        for (int cp = 0; cp < WCK / 2; ++cp) {
-            if (cp + 1 < WCK / 2) {
-                const float* px = lx + ((cp + 1) * 2 + hi) * p.xs + boff;
-                const float* pu = lu + (((cp + 1) * 2 + hi) * 16) * WNT + wo * 32 + l31;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) un[k] = pu[k * WNT];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) dn[r][c] = px[r * P + c];
-                __builtin_amdgcn_sched_barrier(0);   // keep the reads above the MFMAs
+        for (int cp = 0; cp < NKP; ++cp) {
+            const bool cross = (cp == NKP - 1);
+            const bool fetch = !cross || next_stage;
+            float sn = 0.f;
+            if (cross && next_stage) {
+                // rendezvous: stage st+1 complete for every wave (weights: DMA issued one stage ago; inputs: ds_write)
+                if (more) wait_vmcnt<NEX * CKK>();      // all but the input loads issued at the top of this iteration
+                else wait_vmcnt<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (more) {                             // buffer of stage st is free: every wave has its last fragments
+                    store_x(st + 2);
+                    issue_u(st + 2);
+                }
             }
+            if (fetch) {
+                const int fst = cross ? st + 1 : st, fcp = cross ? 0 : cp + 1;
+                const float* lx = smem + (fst % NBUF) * stage_floats;
+                wino_fetch(lx + (fcp * 2 + hi) * p.xs + boff, P, lx + CKK * p.xs + (fcp * 2 + hi) * (16 * WNT) + uoff, usw, un,
+                           dn);
+                sn = lsp[fst * CKK + fcp * 2];
+            }
+            __builtin_amdgcn_sched_barrier(0);           // keep the fetches above the MFMAs
 #pragma unroll
-            for (int k = 0; k < 16; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(uc[k], vc[k], acc[k], 0, 0, 0);
-            if (cp + 1 < WCK / 2) {
-                wino_input_transform(dn, sv[cp + 1], vc);
+            for (int k = 0; k < WINO_SPLIT; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(uc[k], vc[k], acc[k], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);           // first use of the fetched fragments comes after these MFMAs
+            float vn[16];
+            if (fetch) wino_input_transform(dn, sn, vn);
 #pragma unroll
-                for (int k = 0; k < 16; ++k) uc[k] = un[k];
+            for (int k = WINO_SPLIT; k < 16; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(uc[k], vc[k], acc[k], 0, 0, 0);
+            if (fetch) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { uc[k] = un[k]; vc[k] = vn[k]; }
             }
         }
-        if (st + 1 < nstage) {
-#pragma unroll
-            for (int cp = 0; cp < WCK / 2; ++cp) sv[cp] = sn[cp];
-        }
-        __syncthreads();   // stage st consumed by every wave; stage st+1's DMA has landed (vmcnt(0) before the barrier)
     }
 
     // ---- output transform Y = A^T M A per lane, then the StyledConv epilogue
     if (!tile_ok) return;
-    const int per_img = p.TW * p.TH;
     const int64_t img = tile / per_img;
     const int rem = tile - (int)img * per_img;
     const int ty = rem / p.TW, tx = rem - ty * p.TW;
@@ -259,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void wino_mfma_kernel(WinoParams p) {
     }
 }
 
-// U[i][xi][o] = (G g G^T)[xi] * scale,  g = weight[o][i][3][3]  (optionally rotated 180 degrees and read
+// U[i][o][xi] = (G g G^T)[xi] * scale (quads swizzled, see file header),  g = weight[o][i][3][3]  (optionally rotated 180 degrees and read
 // transposed, which turns the pack into the one of the adjoint conv: weight is then indexed [i][o])
 __global__ __launch_bounds__(256) void prepack_wino_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout,
                                                           int Cin, int transpose_flip, float scale) {
@@ -284,14 +358,16 @@ __global__ __launch_bounds__(256) void prepack_wino_kernel(const float* __restri
             t[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
             t[3][c] = g[2][c];
         }
+        // row of 16 Winograd-domain weights for (i, o); quad a is stored at slot a ^ (o & 3)
+        float* dst = u + (((int64_t)i * n_out + o) << 4);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const float u0 = t[a][0];
-            const float u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
-            const float u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
-            const float u3 = t[a][2];
-            float* dst = u + ((int64_t)i * 16 + a * 4) * n_out + o;
-            dst[0] = u0; dst[n_out] = u1; dst[2 * (int64_t)n_out] = u2; dst[3 * (int64_t)n_out] = u3;
+            float4 q;
+            q.x = t[a][0];
+            q.y = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+            q.z = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+            q.w = t[a][2];
+            *reinterpret_cast<float4*>(dst + ((a ^ (o & 3)) << 2)) = q;
         }
     }
 }
@@ -302,7 +378,7 @@ using namespace sgdfr;
 
 // Largest q-distance between the first and last patch origin of 64 consecutive tiles starting at a multiple of 64.
 static int wino_span(int H, int W) {
-    const int TW = W / 2, TH = H / 2, P = W + 1;
+    const int TW = W / 2, TH = H / 2, P = W + 2;
     const int per_img = TW * TH;
     if (TW % WTT == 0) return 2 * (WTT - 1);                                            // inside one tile row
     if (WTT % TW == 0 && per_img % WTT == 0) return (WTT / TW - 1) * 2 * P + 2 * (TW - 1);  // whole tile rows of one image
@@ -325,7 +401,7 @@ extern "C" int sgdfr_modconv_prepack_wino_f32(const float* weight, float* u, int
 extern "C" int sgdfr_modconv2d_wino_supported(int B, int Cin, int Cout, int H, int W) {
     if (Cin % WCK != 0 || Cout % WNT != 0 || (H & 1) || (W & 1) || H < 2 || W < 2) return 0;
     // staged q-range of 64 consecutive tiles must fit WEX*256 elements
-    return (wino_span(H, W) + 3 * (W + 1) + 4) <= WEX * 256 ? 1 : 0;
+    return (wino_span(H, W) + 3 * (W + 2) + 4) <= WEX * 256 ? 1 : 0;
 }
 
 extern "C" int sgdfr_modconv2d_wino_f32(const float* x, int64_t x_bstride, const float* u, const float* s, const float* d,
@@ -344,7 +420,7 @@ extern "C" int sgdfr_modconv2d_wino_f32(const float* x, int64_t x_bstride, const
     WinoParams p{};
     p.x = x; p.x_bstride = x_bstride; p.u = u; p.s = s; p.d = d; p.noise = noise; p.noise_bstride = noise_bstride;
     p.noise_w = noise_w; p.bias = bias; p.zeros = zeros; p.y = y;
-    p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.P = W + 1; p.R = H + 1;
+    p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.P = W + 2; p.R = H + 1;
     p.TW = W / 2; p.TH = H / 2;
     p.total_tiles = B * p.TW * p.TH;
     SGDFR_REQUIRE((int64_t)B * p.R * p.P + 4ll * p.P + 8 < (1ll << 31), "modconv_wino: batch too large for 32-bit indices");
@@ -353,11 +429,22 @@ extern "C" int sgdfr_modconv2d_wino_f32(const float* x, int64_t x_bstride, const
     p.xlen = wino_span(H, W) + 3 * p.P + 4;
     p.xs = (p.xlen + 255) & ~255;   // whole 256-element DMA rows: stray lanes of the last row stay inside the channel
     p.act = act; p.slope = slope; p.gain = gain;
-    const size_t lds = 2 * (size_t)(WCK * p.xs + WCK * 16 * WNT) * sizeof(float);
+    const int per_img = p.TW * p.TH;
+    p.simgs = (per_img % WTT == 0) ? 1 : (WTT - 1) / per_img + 2;
+    const size_t s_bytes = (size_t)((p.simgs * Cin + 3) & ~3) * sizeof(float);
+    const int nex = (p.xlen + 255) / 256;
+    p.xs = nex * 256;                               // the q-range is staged in whole 256-element rows
+    const size_t lds8 = 2 * (size_t)(8 * p.xs + 8 * 16 * WNT) * sizeof(float) + s_bytes;
+    const size_t lds4 = 2 * (size_t)(4 * p.xs + 4 * 16 * WNT) * sizeof(float) + s_bytes;
+    const bool use8 = lds8 <= 160 * 1024;
+    const size_t lds = use8 ? lds8 : lds4;
     SGDFR_REQUIRE(lds <= 160 * 1024, "modconv_wino: LDS request %zu too large", lds);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
+    void (*kern)(WinoParams);
+    if (use8) kern = nex <= 1 ? wino_mfma_kernel<8, 1> : nex == 2 ? wino_mfma_kernel<8, 2> : nex == 3 ? wino_mfma_kernel<8, 3> : wino_mfma_kernel<8, 4>;
+    else kern = nex <= 2 ? wino_mfma_kernel<4, 2> : nex == 3 ? wino_mfma_kernel<4, 3> : wino_mfma_kernel<4, 4>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
         return check_launch("modconv_wino(lds attribute)");
-    hipLaunchKernelGGL(wino_mfma_kernel, dim3(p.n_t_tiles * p.n_o_tiles), dim3(256), lds, as_stream(stream), p);
+    hipLaunchKernelGGL(kern, dim3(p.n_t_tiles * p.n_o_tiles), dim3(256), lds, as_stream(stream), p);
     return check_launch("modconv2d_wino");
 }

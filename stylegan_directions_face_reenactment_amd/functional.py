@@ -211,12 +211,12 @@ def _zero_words(device):
 
 
 def prepack_wino(weight, adjoint=False):
-    """weight [1,Cout,Cin,3,3] -> Winograd-domain pack U [Cin][16][Cout] (adjoint: [Cout][16][Cin] of the rotated,
-    transposed kernel = the pack of dL/dx)."""
+    """weight [1,Cout,Cin,3,3] -> Winograd-domain pack U [Cin][Cout][16] (16-byte quads XOR-swizzled by cout & 3;
+    adjoint: [Cout][Cin][16] of the rotated, transposed kernel = the pack of dL/dx)."""
     N.require_device(weight)
     w = N.f32c(weight)
     _, cout, cin, k, _ = w.shape
-    u = torch.empty((cout if adjoint else cin), 16, (cin if adjoint else cout), device=w.device, dtype=torch.float32)
+    u = torch.empty((cout if adjoint else cin), (cin if adjoint else cout), 16, device=w.device, dtype=torch.float32)
     N.call('sgdfr_modconv_prepack_wino_f32', N.ptr(w), N.ptr(u), cout, cin, int(bool(adjoint)), N.stream())
     return u
 
