@@ -261,9 +261,6 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
             if (st + 2 < nstage)
                 load_stage<NT, EX, WV, NPL>(p, (st + 2) * CK, tid, n0, cstride, RP, nex, xoff, soff, xr, sr, wr);
         }
-#ifdef SGDFR_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int cp = 0; cp < CK / 2; ++cp) {
             const float* lxc = lx + (cp * 2) * NPL * p.xs;
@@ -283,9 +280,6 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
                         acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[ph][mi][ni], 0, 0, 0);
             }
         }
-#ifdef SGDFR_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         __syncthreads();  // stage st fully consumed, stage st+1 fully written
     }
 

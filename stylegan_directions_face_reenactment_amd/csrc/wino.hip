@@ -49,9 +49,7 @@ struct WinoParams {
 constexpr int WCK = 8;    // input channels per LDS stage (4 when three 8-channel stages do not fit in LDS)
 constexpr int WNT = 64;   // couts per block
 constexpr int WTT = 64;   // tiles per block
-#ifndef WINO_SPLIT
-#define WINO_SPLIT 4
-#endif
+constexpr int WINO_SPLIT = 4;   // MFMAs issued before the first use of the prefetched fragments
 constexpr int WEX = 4;    // staged q elements per thread per channel (xlen <= 1024)
 
 __device__ __forceinline__ int wino_qbase(const WinoParams& p, int t) {
@@ -81,13 +79,6 @@ __device__ __forceinline__ void wino_fetch(const float* px, int P, const float* 
 
 // V = sc * B^T d B for one 4x4 patch (32 add/sub + 16 mul per patch)
 __device__ __forceinline__ void wino_input_transform(const float (&dd)[4][4], float sc, float (&vv)[16]) {
-#ifdef WINO_NO_TRANSFORM   // timing experiment only (wrong results): how much do the 64 VALU ops per k-pair cost?
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) vv[a * 4 + c] = dd[a][c];
-    return;
-#endif
     float tmp[4][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {   // B^T d  (rows)
