@@ -160,6 +160,10 @@ int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const float* noise
 int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, const float* bias, const float* skip,
                         const float* fir, float* y, int B, int Cin, int H, int W, void* stream);
 
+/* x [B,3,H,W] fp32 -> y [B,H,W,3] uint8:  trunc( (clamp(x,-1,1) + 1) / (2 + 1e-5) * 255 )
+ * (libs/utilities/image_utils.py:87-110 tensor_to_image / torch_range_1_to_255, then the writers' uint8 cast) */
+int sgdfr_image_to_u8_f32(const float* x, unsigned char* y, int B, int H, int W, void* stream);
+
 /* ---- backward helpers (autograd of model.py:232-359 as restated in SURVEY.md Appendix C) ------------------------ */
 
 /* Activation gradient + per-(b,c) reductions (op/fused_act.py:19-37 and the adjoints of model.py:287, :240):

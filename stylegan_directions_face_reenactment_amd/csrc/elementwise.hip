@@ -112,6 +112,26 @@ __global__ __launch_bounds__(256) void latent_prepare_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------- output conversion
+// [B,3,H,W] fp32 in [-1,1] -> [B,H,W,3] uint8 with the reference's scaling
+// (libs/utilities/image_utils.py:87-110: clamp to [-1,1], (v+1)/(2+1e-5)*255, then the uint8 truncation of the writers)
+__global__ __launch_bounds__(256) void image_to_u8_kernel(const float* __restrict__ x, unsigned char* __restrict__ y, int B,
+                                                         int HW) {
+    const int64_t n = (int64_t)B * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW;
+        const int p = (int)(i - b * HW);
+        const float* xp = x + b * 3 * HW + p;
+        unsigned char* yp = y + i * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = fminf(fmaxf(xp[(int64_t)c * HW], -1.f), 1.f);
+            v = (v + 1.f) / (2.f + 1e-5f) * 255.f;
+            yp[c] = (unsigned char)v;
+        }
+    }
+}
+
 }  // namespace sgdfr
 
 using namespace sgdfr;
@@ -166,4 +186,13 @@ extern "C" int sgdfr_latent_prepare_f32(const float* w, int w_is_plus, const flo
     hipLaunchKernelGGL(latent_prepare_kernel, dim3(grid_for((int64_t)B * L * D)), dim3(256), 0, as_stream(stream), w,
                        w_is_plus, shift, shift_is_plus, shift_layers, trunc, psi, out, B, L, D);
     return check_launch("latent_prepare");
+}
+
+extern "C" int sgdfr_image_to_u8_f32(const float* x, unsigned char* y, int B, int H, int W, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && H > 0 && W > 0, "image_to_u8: bad shape %d %d %d", B, H, W);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(x && y, "image_to_u8: null pointer");
+    hipLaunchKernelGGL(image_to_u8_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, as_stream(stream), x, y, B,
+                       H * W);
+    return check_launch("image_to_u8");
 }

@@ -156,3 +156,34 @@ def test_module_protocol_on_gpu():
         P = {k: v.cpu() for k, v in G2.state_dict().items()}
         ref, _ = O.generator_forward(P, [w.cpu()], input_is_latent=True)
         assert maxabs(c, ref) <= 2e-4
+
+
+def test_batched_reenactment_equals_per_frame_loop():
+    """N frames in batches == the reference's one-generate_image-per-frame loop (run_inference.py:170-181),
+    and the GPU uint8 conversion == the reference's tensor_to_image scaling + uint8 cast."""
+    from stylegan_directions_face_reenactment_amd.direction_matrix import DirectionMatrix
+    from stylegan_directions_face_reenactment_amd.generic import generate_image
+    from stylegan_directions_face_reenactment_amd.reenact import ReenactmentSession, images_to_uint8
+    G = hip_generator(64, 1)
+    A = DirectionMatrix(512, input_dim=15, out_dim=512, w_plus=True, num_layers=8, verbose=False)
+    A.load_state_dict(S.synthetic_direction_state(SEED))
+    A = A.cuda()
+    src = S.synthetic_latents(41, 1, n_latent=G.n_latent, key='re.src').cuda()
+    trunc = S.counter_tensor(41, 're.t', (1, 512)).cuda()
+    sv = S.counter_tensor(41, 're.sv', (7, 15), 0.0, 3.0).cuda()
+    sess = ReenactmentSession(G, A, src, 0.7, trunc, batch=3)
+    out = sess.render(sv)
+    assert out.shape == (7, 3, 64, 64)
+    with torch.no_grad():
+        for i in range(7):
+            ref = generate_image(G, src, 0.7, trunc, shift_code=A(sv[i:i + 1]), input_is_latent=True)
+            assert maxabs(out[i:i + 1], ref) <= 1e-5
+    u8 = sess.render(sv, as_uint8=True)
+    assert u8.shape == (7, 64, 64, 3) and u8.dtype == torch.uint8
+    x = out.cpu().clone()
+    x.clamp_(-1, 1).add_(1).div_(2 + 1e-5)
+    expect = x.mul(255.0).numpy().transpose(0, 2, 3, 1).astype('uint8')
+    diff = (u8.cpu().numpy().astype(int) - expect.astype(int))
+    assert abs(diff).max() <= 1 and (diff != 0).mean() < 1e-3      # identical up to fp32 rounding at integer boundaries
+    assert images_to_uint8(torch.full((1, 3, 2, 2), 5.0).cuda()).max() == 254 and \
+        images_to_uint8(torch.full((1, 3, 2, 2), -5.0).cuda()).max() == 0
