@@ -35,6 +35,17 @@ def make_kernel(k):
     return k / k.sum()
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One side HIP stream per device (module-level: streams must not live on nn.Modules that get deep-copied)."""
+    st = _SIDE_STREAMS.get(device)
+    if st is None:
+        st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _needs_grad(*tensors):
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
@@ -313,6 +324,7 @@ class Generator(nn.Module):
             self.to_rgbs.append(ToRGB(out_channel, style_dim))
             in_channel = out_channel
         self.n_latent = self.log_size * 2 - 2
+        self.overlap_rgb = True     # run the ToRGB chain on a side stream in no-grad forwards
 
     # ---- latent-side helpers (model.py:449-469)
     def make_noise(self):
@@ -369,11 +381,27 @@ class Generator(nn.Module):
 
         # ConstantInput is broadcast inside the kernel (batch stride 0) instead of repeated
         out = self.conv1(self.input.input, None, noise=noise[0], batch=batch, sd=next(sd))
-        skip = self.to_rgb1(out, None, sd=next(sd))
+        # The RGB branch (HBM-bound ToRGB kernels, a chain over `skip`) runs on a side HIP stream next to the
+        # MFMA-bound conv chain of the main stream; it joins before the image is returned.  No-grad path only.
+        side = _side_stream(out.device) if (self.overlap_rgb and not grad) else None
+        main = torch.cuda.current_stream() if side is not None else None
+
+        def rgb(layer, x, skip_in, sdl):
+            if side is None:
+                return layer(x, None, skip_in, sd=sdl)
+            side.wait_stream(main)                 # x (and this forward's styles) are ready
+            x.record_stream(side)
+            with torch.cuda.stream(side):
+                return layer(x, None, skip_in, sd=sdl)
+
+        skip = rgb(self.to_rgb1, out, None, next(sd))
         for conv1, conv2, noise1, noise2, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2],
                                                         noise[2::2], self.to_rgbs):
             out = conv1(out, None, noise=noise1, sd=next(sd))
             out = conv2(out, None, noise=noise2, sd=next(sd))
-            skip = to_rgb(out, None, skip, sd=next(sd))
+            skip = rgb(to_rgb, out, skip, next(sd))
+        if side is not None:
+            main.wait_stream(side)
+            skip.record_stream(main)
         image = skip
         return (image, latent) if return_latents else (image, None)
