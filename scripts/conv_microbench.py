@@ -18,6 +18,14 @@ def main():
     B = 64
     shapes = [(512, 512, 16), (512, 512, 32), (256, 256, 64), (128, 128, 128), (64, 64, 256)]
     which = sys.argv[1:] or ['direct', 'wino']
+    if 'up' in which:
+        for cin, cout, h in [(512, 512, 16), (512, 256, 32), (256, 128, 64), (128, 64, 128)]:
+            w = torch.randn(1, cout, cin, 3, 3, device='cuda'); x = torch.randn(B, cin, h, h, device='cuda')
+            s = torch.randn(B, cin, device='cuda'); d = torch.rand(B, cout, device='cuda') + 0.5
+            wp, q, qt = F_.prepack(w); fl = B * F_.conv_flops(cin, cout, h, h)
+            t = bench(lambda: F_.modconv_raw(x, wp, s, d, cout, N.MODE_UP3, h, h))
+            print('up %4d->%4d @%3d: %7.1f us %6.1f TF' % (cin, cout, h, t * 1e6, fl / t / 1e12), flush=True)
+        return
     for cin, cout, h in shapes:
         w = torch.randn(1, cout, cin, 3, 3, device='cuda')
         x = torch.randn(B, cin, h, h, device='cuda')
