@@ -168,8 +168,8 @@ def main():
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
-        'config': {'workload': '1xMI355X HIP synthesis-only: Generator(%d,512,8,cm=%d), random w+ [%d,14,512] per GPU, '
-                               'fixed noise, psi=1' % (args.size, args.cm, B),
+        'config': {'workload': '%dxMI355X HIP synthesis-only: Generator(%d,512,8,cm=%d), random w+ [%d,14,512] per GPU, '
+                               'fixed noise, psi=1' % (world, args.size, args.cm, B),
                    'per_gpu_batch': B, 'global_batch': B * world, 'resolution': args.size,
                    'channel_multiplier': args.cm, 'parallelism': 'batch-sharded x%d, no data-path collective' % world,
                    'weight_broadcast_bytes': bcast_bytes},
