@@ -18,6 +18,8 @@
 // words: conflict-free).  The weight fragments are stored [cin][cout][16] with the four 16-byte quads of a cout row
 // XOR-swizzled by (cout & 3), so a lane fetches its 16 Winograd-domain weights with four conflict-free ds_read_b128.  One barrier per K stage (8 input channels = 64 MFMAs per wave), LDS stages
 // double-buffered, next stage prefetched into registers under the MFMAs.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace sgdfr {
@@ -324,6 +326,245 @@ __global__ __launch_bounds__(256, 1) void wino_mfma_kernel(WinoParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Split-xi variant: 8 waves per block, TWO waves per SIMD.  A pair of waves shares one (32 cout x 32 tile) quadrant
+// and splits the 16 Winograd-domain positions: half h owns rows a = 2h, 2h+1 of the 4x4 domain, i.e. 8 accumulators
+// (128 registers) instead of 16.  An in-order wave pays for its own LDS reads / transform VALU / staging with matrix
+// issue slots, but a SIMD partner's work overlaps perfectly (scripts/mfma_probe.hip), so two 8-accumulator waves per
+// SIMD keep the fp32 matrix pipe busier than one 16-accumulator wave.  Each half needs only two rows of B^T x B
+// (24 VALU instead of 80 per k-pair) and two of the four weight quads.  The output transform is linear in the domain
+// rows, so each half reduces its rows to a partial 2x2 result; half 1 hands it to half 0 through LDS once, after the K
+// loop.
+__device__ __forceinline__ void wino_fetch_half(const float* px, int P, const float* pu, int usw, int half, float (&uu)[8],
+                                                float (&dd)[4][4]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float4 q = *reinterpret_cast<const float4*>(pu + (((2 * half + j) ^ usw) << 2));
+        uu[4 * j + 0] = q.x; uu[4 * j + 1] = q.y; uu[4 * j + 2] = q.z; uu[4 * j + 3] = q.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float2 a = *reinterpret_cast<const float2*>(px + r * P);
+        const float2 b = *reinterpret_cast<const float2*>(px + r * P + 2);
+        dd[r][0] = a.x; dd[r][1] = a.y; dd[r][2] = b.x; dd[r][3] = b.y;
+    }
+}
+
+// rows a = 2*half, 2*half+1 of  sc * B^T d B
+__device__ __forceinline__ void wino_input_transform_half(const float (&dd)[4][4], float sc, int half, float (&vv)[8]) {
+    float t0[4], t1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        t0[c] = half ? dd[2][c] - dd[1][c] : dd[0][c] - dd[2][c];
+        t1[c] = half ? dd[1][c] - dd[3][c] : dd[1][c] + dd[2][c];
+    }
+    vv[0] = (t0[0] - t0[2]) * sc; vv[1] = (t0[1] + t0[2]) * sc; vv[2] = (t0[2] - t0[1]) * sc; vv[3] = (t0[1] - t0[3]) * sc;
+    vv[4] = (t1[0] - t1[2]) * sc; vv[5] = (t1[1] + t1[2]) * sc; vv[6] = (t1[2] - t1[1]) * sc; vv[7] = (t1[1] - t1[3]) * sc;
+}
+
+template <int CKK, int NEX>   // NEX: 512-element rows of the staged q-range per channel
+__global__ __launch_bounds__(512, 2) void wino2_mfma_kernel(WinoParams p) {
+    constexpr int NBUF = 2;
+    constexpr int NKP = CKK / 2;
+    constexpr int UV = CKK / 2;   // weight-slab DMA pieces per wave and stage (CKK*16*64 floats / 4 / 512 threads)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int stage_floats = CKK * p.xs + CKK * 16 * WNT;
+    float* ls = smem + NBUF * stage_floats;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int quad = wave & 3, half = __builtin_amdgcn_readfirstlane(wave >> 2);
+    const int wo = quad >> 1, wt = quad & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int HW = p.H * p.W;
+
+    int lid;
+    {
+        const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int ct = lid / p.n_t_tiles, tt = lid - ct * p.n_t_tiles;
+    const int n0 = ct * WNT;
+    const int t0 = tt * WTT;
+    const int q0 = wino_qbase(p, t0);
+    const int per_img = p.TW * p.TH;
+    const int img0 = t0 / per_img;
+
+    int tile = t0 + wt * 32 + l31;
+    const bool tile_ok = tile < p.total_tiles;
+    if (!tile_ok) tile = p.total_tiles - 1;
+    const int boff = wino_qbase(p, tile) - q0;
+    const float* lsp = ls + (tile / per_img - img0) * p.Cin + hi;
+    const int uoff = (wo * 32 + l31) * 16, usw = l31 & 3;
+
+    const float* xsrc[NEX];
+#pragma unroll
+    for (int e = 0; e < NEX; ++e) {
+        const int j = tid + e * 512;
+        const int q = q0 + j;
+        const int pir = q / p.P;
+        const int pc = q - pir * p.P;
+        const int img = pir / p.R;
+        const int pr = pir - img * p.R;
+        const bool ok = (j < p.xlen) && pc >= 1 && pc <= p.W && pr >= 1 && img < p.B;
+        xsrc[e] = ok ? p.x + (int64_t)img * p.x_bstride + (pr - 1) * p.W + (pc - 1) : nullptr;
+    }
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    float xr[NEX][CKK];
+    auto load_x = [&](int st) {
+        const int c0 = st * CKK;
+#pragma unroll
+        for (int e = 0; e < NEX; ++e) {
+            const float* src = xsrc[e] ? xsrc[e] + (int64_t)c0 * HW : p.zeros;
+            const int64_t cs = xsrc[e] ? HW : 0;
+#pragma unroll
+            for (int c = 0; c < CKK; ++c) xr[e][c] = src[c * cs];
+        }
+    };
+    auto store_x = [&](int st) {
+        float* lx = smem + (st % NBUF) * stage_floats;
+#pragma unroll
+        for (int e = 0; e < NEX; ++e)
+#pragma unroll
+            for (int c = 0; c < CKK; ++c) lx[c * p.xs + tid + e * 512] = xr[e][c];
+    };
+    auto issue_u = [&](int st) {
+        const int c0 = st * CKK;
+        float* lu = smem + (st % NBUF) * stage_floats + CKK * p.xs;
+#pragma unroll
+        for (int v = 0; v < UV; ++v) {
+            const int f = tid + v * 512;                  // float4 index inside the stage slab: 256 per channel
+            const int row = f >> 8, col = (f & 255) * 4;
+            const float* src = p.u + (((int64_t)(c0 + row) * p.Cout + n0) << 4) + col;
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(lu + (size_t)((tid & ~63) + v * 512) * 4), 16, 0, 0);
+        }
+    };
+
+    const int nstage = p.Cin / CKK;
+    const int P = p.P;
+    for (int e = tid; e < p.simgs * p.Cin; e += 512) {
+        const int m = e / p.Cin;
+        ls[e] = (img0 + m < p.B) ? p.s[(int64_t)(img0 + m) * p.Cin + (e - m * p.Cin)] : 0.f;
+    }
+    load_x(0);
+    store_x(0);
+    issue_u(0);
+    if (nstage > 1) {
+        load_x(1);
+        store_x(1);
+        issue_u(1);
+        wait_vmcnt<UV>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    float uc[8], vc[8], un[8], dn[4][4];
+    wino_fetch_half(smem + hi * p.xs + boff, P, smem + CKK * p.xs + hi * (16 * WNT) + uoff, usw, half, uc, dn);
+    wino_input_transform_half(dn, lsp[0], half, vc);
+    for (int st = 0; st < nstage; ++st) {
+        const bool more = st + 2 < nstage, next_stage = st + 1 < nstage;
+        if (more) load_x(st + 2);
+#pragma unroll
+        for (int cp = 0; cp < NKP; ++cp) {
+            const bool cross = (cp == NKP - 1);
+            const bool fetch = !cross || next_stage;
+            float sn = 0.f;
+            if (cross && next_stage) {
+                if (more) wait_vmcnt<NEX * CKK>();
+                else wait_vmcnt<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (more) {
+                    store_x(st + 2);
+                    issue_u(st + 2);
+                }
+            }
+            if (fetch) {
+                const int fst = cross ? st + 1 : st, fcp = cross ? 0 : cp + 1;
+                const float* lx = smem + (fst % NBUF) * stage_floats;
+                wino_fetch_half(lx + (fcp * 2 + hi) * p.xs + boff, P, lx + CKK * p.xs + (fcp * 2 + hi) * (16 * WNT) + uoff, usw,
+                                half, un, dn);
+                sn = lsp[fst * CKK + fcp * 2];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(uc[k], vc[k], acc[k], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            float vn[8];
+            if (fetch) wino_input_transform_half(dn, sn, half, vn);
+#pragma unroll
+            for (int k = 2; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(uc[k], vc[k], acc[k], 0, 0, 0);
+            if (fetch) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { uc[k] = un[k]; vc[k] = vn[k]; }
+            }
+        }
+    }
+
+    // ---- partial output transform of this half's two domain rows:  Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1]
+    //      half 0 (rows 0,1): ra0 = m0 + m1, ra1 = m1 ;  half 1 (rows 2,3): ra0 = m2, ra1 = -m2 - m3
+    float py[16][4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float ra0[4], ra1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float ma = acc[c][r], mb = acc[4 + c][r];
+            ra0[c] = half ? ma : ma + mb;
+            ra1[c] = half ? -ma - mb : mb;
+        }
+        py[r][0] = ra0[0] + ra0[1] + ra0[2];
+        py[r][1] = ra0[1] - ra0[2] - ra0[3];
+        py[r][2] = ra1[0] + ra1[1] + ra1[2];
+        py[r][3] = ra1[1] - ra1[2] - ra1[3];
+    }
+    __syncthreads();                       // every wave is done with the staging buffers
+    float* ex = smem + quad * (64 * 64);   // [r*4+i][lane] per quadrant: 16 KB
+    if (half) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ex[(r * 4 + i) * 64 + lane] = py[r][i];
+    }
+    __syncthreads();
+    if (half || !tile_ok) return;
+    const int64_t img = tile / per_img;
+    const int rem = tile - (int)img * per_img;
+    const int ty = rem / p.TW, tx = rem - ty * p.TW;
+    const float nw = (p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
+    float nz[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.noise) {
+        const float* np = p.noise + img * p.noise_bstride + (2 * ty) * p.W + 2 * tx;
+        nz[0] = nw * np[0]; nz[1] = nw * np[1]; nz[2] = nw * np[p.W]; nz[3] = nw * np[p.W + 1];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = n0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (co >= p.Cout) continue;
+        const float dv = p.d ? p.d[img * p.Cout + co] : 1.f;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+        float* dst = p.y + (img * p.Cout + co) * HW + (2 * ty) * p.W + 2 * tx;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = (py[r][i] + ex[(r * 4 + i) * 64 + lane]) * dv + nz[i] + bv;
+            if (p.act) v[i] = lrelu_gain(v[i], p.slope, p.gain);
+        }
+        *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
+        *reinterpret_cast<float2*>(dst + p.W) = make_float2(v[2], v[3]);
+    }
+}
+
 // U[i][o][xi] = (G g G^T)[xi] * scale (quads swizzled, see file header),  g = weight[o][i][3][3]  (optionally rotated 180 degrees and read
 // transposed, which turns the pack into the one of the adjoint conv: weight is then indexed [i][o])
 __global__ __launch_bounds__(256) void prepack_wino_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout,
@@ -423,19 +664,32 @@ extern "C" int sgdfr_modconv2d_wino_f32(const float* x, int64_t x_bstride, const
     const int per_img = p.TW * p.TH;
     p.simgs = (per_img % WTT == 0) ? 1 : (WTT - 1) / per_img + 2;
     const size_t s_bytes = (size_t)((p.simgs * Cin + 3) & ~3) * sizeof(float);
-    const int nex = (p.xlen + 255) / 256;
-    p.xs = nex * 256;                               // the q-range is staged in whole 256-element rows
-    const size_t lds8 = 2 * (size_t)(8 * p.xs + 8 * 16 * WNT) * sizeof(float) + s_bytes;
-    const size_t lds4 = 2 * (size_t)(4 * p.xs + 4 * 16 * WNT) * sizeof(float) + s_bytes;
-    const bool use8 = lds8 <= 160 * 1024;
-    const size_t lds = use8 ? lds8 : lds4;
-    SGDFR_REQUIRE(lds <= 160 * 1024, "modconv_wino: LDS request %zu too large", lds);
+    static const int variant = getenv("SGDFR_WINO") ? atoi(getenv("SGDFR_WINO")) : 2;   // 1: one 16-accumulator wave per SIMD
     void (*kern)(WinoParams);
-    if (use8) kern = nex <= 1 ? wino_mfma_kernel<8, 1> : nex == 2 ? wino_mfma_kernel<8, 2> : nex == 3 ? wino_mfma_kernel<8, 3> : wino_mfma_kernel<8, 4>;
-    else kern = nex <= 2 ? wino_mfma_kernel<4, 2> : nex == 3 ? wino_mfma_kernel<4, 3> : wino_mfma_kernel<4, 4>;
+    size_t lds;
+    int threads;
+    if (variant == 1) {
+        const int nex = (p.xlen + 255) / 256;
+        p.xs = nex * 256;                               // the q-range is staged in whole 256-element rows
+        const size_t lds8 = 2 * (size_t)(8 * p.xs + 8 * 16 * WNT) * sizeof(float) + s_bytes;
+        const size_t lds4 = 2 * (size_t)(4 * p.xs + 4 * 16 * WNT) * sizeof(float) + s_bytes;
+        const bool use8 = lds8 <= 160 * 1024;
+        lds = use8 ? lds8 : lds4;
+        if (use8) kern = nex <= 1 ? wino_mfma_kernel<8, 1> : nex == 2 ? wino_mfma_kernel<8, 2> : nex == 3 ? wino_mfma_kernel<8, 3> : wino_mfma_kernel<8, 4>;
+        else kern = nex <= 2 ? wino_mfma_kernel<4, 2> : nex == 3 ? wino_mfma_kernel<4, 3> : wino_mfma_kernel<4, 4>;
+        threads = 256;
+    } else {
+        const int nex = (p.xlen + 511) / 512;           // 512 staging threads
+        p.xs = nex * 512;
+        lds = 2 * (size_t)(8 * p.xs + 8 * 16 * WNT) * sizeof(float) + s_bytes;
+        if (lds < 4 * 64 * 64 * sizeof(float)) lds = 4 * 64 * 64 * sizeof(float);   // half-exchange area of the epilogue
+        kern = nex <= 1 ? wino2_mfma_kernel<8, 1> : wino2_mfma_kernel<8, 2>;
+        threads = 512;
+    }
+    SGDFR_REQUIRE(lds <= 160 * 1024, "modconv_wino: LDS request %zu too large", lds);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess)
         return check_launch("modconv_wino(lds attribute)");
-    hipLaunchKernelGGL(kern, dim3(p.n_t_tiles * p.n_o_tiles), dim3(256), lds, as_stream(stream), p);
+    hipLaunchKernelGGL(kern, dim3(p.n_t_tiles * p.n_o_tiles), dim3(threads), lds, as_stream(stream), p);
     return check_launch("modconv2d_wino");
 }
