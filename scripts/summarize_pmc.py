@@ -3,7 +3,7 @@ committed summaries under profiles/:  python scripts/summarize_pmc.py r1c r01_c"
 import collections, csv, json, shutil, sys
 
 tag, out = sys.argv[1], sys.argv[2]
-CONV = ('modconv_mfma', 'wino_mfma')
+CONV = ('modconv_mfma', 'wino_mfma', 'wino2_mfma')
 
 
 def load(dirn):
