@@ -42,6 +42,7 @@ struct ModconvParams {
     int n_pix_tiles, n_cout_tiles;
     int xs;               // LDS floats per staged channel (multiple of 4, >= xlen)
     int xlen;             // q-range length staged per channel
+    int seglen, segpitch; // PLAIN3 on wide images: the range is 3 row segments of seglen, segpitch (= P) apart; else (xlen, 0)
     int64_t total_pix;    // PLAIN: B*H*W dense pixels ; UP: B*R*P super-pixels
     int act;
     float slope, gain;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
         } else {
             qb = pix;
         }
-        boff[ni] = (qb - q0) + hi * NPL * p.xs;
+        boff[ni] = (p.segpitch ? (pix - p0) + p.seglen + 1 : (qb - q0)) + hi * NPL * p.xs;
     }
 
     // ---- staging descriptors (fixed for the whole K loop): element offsets into x / s; positions that
@@ -194,7 +195,8 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
 #pragma unroll
     for (int e = 0; e < EX; ++e) {
         const int j = tid + e * 256;
-        const int q = q0 + j;
+        const int sg = j / p.seglen;
+        const int q = q0 + sg * p.segpitch + (j - sg * p.seglen);
         bool ok;
         int img;
         int64_t off;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
     for (int k = 0; k < 9; ++k) {
         const int ky = k / 3, kx = k - ky * 3;
         if (MODE == SGDFR_MODE_PLAIN3)
-            tapoff[k] = (ky - 1) * p.P + (kx - 1);
+            tapoff[k] = (ky - 1) * (p.segpitch ? p.seglen : p.P) + (kx - 1);
         else if (MODE == SGDFR_MODE_UP3)
             tapoff[k] = (ky == 2 ? 0 : p.P) + (kx == 2 ? 0 : 1);
         else   // DOWN3: T[2a+ky, 2b+kx] lives in plane (ky&1, kx&1) at [a + (ky>>1), b + (kx>>1)]
@@ -547,6 +549,14 @@ static int launch_modconv(ModconvParams& p, hipStream_t stream) {
     } else {
         xlen = PT + p.P + 2;
     }
+    p.seglen = xlen;
+    p.segpitch = 0;
+    if (MODE == SGDFR_MODE_PLAIN3 && p.W % PT == 0 && 3 * (PT + 2) < xlen) {
+        // wide image: a tile is a piece of ONE row, so stage just the three row segments it touches
+        p.seglen = PT + 2;
+        p.segpitch = p.P;
+        xlen = 3 * (PT + 2);
+    }
     SGDFR_REQUIRE(xlen <= EX * 256, "modconv: staged range %d exceeds %d (W=%d too wide for this tile)", xlen, EX * 256,
                   p.W);
     p.xlen = xlen;
@@ -556,6 +566,11 @@ static int launch_modconv(ModconvParams& p, hipStream_t stream) {
     SGDFR_REQUIRE(p.total_pix + 4ll * p.P + 8 < (1ll << 31), "modconv: batch too large for 32-bit pixel indices");
     const int64_t nblk = (int64_t)p.n_cout_tiles * p.n_pix_tiles;
     SGDFR_REQUIRE(nblk < (1ll << 31), "modconv: grid too large");
+    SGDFR_REQUIRE(lds <= 160 * 1024, "modconv: LDS request %zu too large", lds);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_mfma_kernel<MODE, WM, WN, MI, NI, EX, OCC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return check_launch("modconv(lds attribute)");
     hipLaunchKernelGGL((modconv_mfma_kernel<MODE, WM, WN, MI, NI, EX, OCC>), dim3((unsigned)nblk), dim3(256), lds, stream, p);
     return check_launch("modconv2d_fwd");
 }
@@ -619,15 +634,15 @@ extern "C" int sgdfr_modconv2d_fwd_f32(const float* x, int64_t x_bstride, const 
     } else if (mode == SGDFR_MODE_DOWN3) {
         p.total_pix = (int64_t)B * H * W;
         const int64_t big_blocks = ((p.total_pix + 127) / 128) * ((Cout + 127) / 128);
-        if (Cout % 128 == 0 && big_blocks >= 512) return launch_modconv<SGDFR_MODE_DOWN3, 2, 2, 2, 2, 2, 2>(p, st);
-        if (Cout > 32) return launch_modconv<SGDFR_MODE_DOWN3, 2, 2, 1, 1, 2, 2>(p, st);           // NT 64, PT 64
-        return launch_modconv<SGDFR_MODE_DOWN3, 1, 4, 1, 1, 2, 2>(p, st);                          // NT 32, PT 128
+        if (Cout % 128 == 0 && big_blocks >= 512) return launch_modconv<SGDFR_MODE_DOWN3, 2, 2, 2, 2, 3, 2>(p, st);
+        if (Cout > 32) return launch_modconv<SGDFR_MODE_DOWN3, 2, 2, 1, 1, 3, 2>(p, st);           // NT 64, PT 64
+        return launch_modconv<SGDFR_MODE_DOWN3, 1, 4, 1, 1, 3, 2>(p, st);                          // NT 32, PT 128
     } else {
         p.total_pix = (int64_t)B * (H + 1) * (W + 1);
         const int64_t big_blocks = ((p.total_pix + 63) / 64) * ((Cout + 127) / 128);
-        if (Cout % 128 == 0 && big_blocks >= 512) return launch_modconv<SGDFR_MODE_UP3, 4, 1, 1, 2, 2, 2>(p, st);  // NT 128, PT 64
-        if (Cout > 32) return launch_modconv<SGDFR_MODE_UP3, 2, 2, 1, 1, 2, 3>(p, st);               // NT 64, PT 64
-        return launch_modconv<SGDFR_MODE_UP3, 1, 4, 1, 1, 2, 3>(p, st);                              // NT 32, PT 128
+        if (Cout % 128 == 0 && big_blocks >= 512) return launch_modconv<SGDFR_MODE_UP3, 4, 1, 1, 2, 3, 2>(p, st);  // NT 128, PT 64
+        if (Cout > 32) return launch_modconv<SGDFR_MODE_UP3, 2, 2, 1, 1, 3, 3>(p, st);               // NT 64, PT 64
+        return launch_modconv<SGDFR_MODE_UP3, 1, 4, 1, 1, 3, 3>(p, st);                              // NT 32, PT 128
     }
 }
 

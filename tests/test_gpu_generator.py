@@ -187,3 +187,41 @@ def test_batched_reenactment_equals_per_frame_loop():
     assert abs(diff).max() <= 1 and (diff != 0).mean() < 1e-3      # identical up to fp32 rounding at integer boundaries
     assert images_to_uint8(torch.full((1, 3, 2, 2), 5.0).cuda()).max() == 254 and \
         images_to_uint8(torch.full((1, 3, 2, 2), -5.0).cuda()).max() == 0
+
+
+def test_wide_layers_and_1024_generator():
+    """Resolutions above 256 (the reference also ships ffhq-1024, libs/configs/config_models.py:16-20, pooled to 256 by
+    generate_image): wide rows switch the conv staging to row segments; checked per layer and end to end."""
+    from stylegan_directions_face_reenactment_amd.model import Generator, StyledConv
+    from stylegan_directions_face_reenactment_amd.generic import generate_image
+    for cin, cout, h, up in ((8, 32, 512, False), (16, 64, 1024, False), (8, 8, 256, True), (8, 16, 512, True)):
+        key = 'wide.%d.%d.%d.%d' % (cin, cout, h, up)
+        m = StyledConv(cin, cout, 3, 64, upsample=up)
+        sd = {k: S.counter_tensor(51, key + k, tuple(v.shape)) for k, v in m.state_dict().items() if 'kernel' not in k}
+        sd['conv.modulation.bias'] = sd['conv.modulation.bias'] * 0.1 + 1.0
+        if up:
+            sd['conv.blur.kernel'] = m.conv.blur.kernel
+        m.load_state_dict(sd)
+        x = S.counter_tensor(51, key + 'x', (1, cin, h, h))
+        st = S.counter_tensor(51, key + 's', (1, 64))
+        r = 2 * h if up else h
+        nz = S.counter_tensor(51, key + 'n', (1, 1, r, r))
+        ref = O.styled_conv({'L.' + k: v for k, v in sd.items()}, 'L', x, st, nz, upsample=up)
+        with torch.no_grad():
+            y = m.cuda()(x.cuda(), st.cuda(), noise=nz.cuda())
+        assert maxabs(y, ref) <= 3e-5, key
+    G = Generator(1024, 512, 8, channel_multiplier=2)
+    P = S.synthetic_state_dict(O.template_state(1024, 512, 8, 2), seed=SEED)
+    G.load_state_dict(P)
+    G = G.eval().cuda()
+    assert G.n_latent == 18
+    w = S.synthetic_latents(52, 1, n_latent=18, key='g1024.w')
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        img, _ = G([w.cuda()], input_is_latent=True)
+        ref, _ = O.generator_forward(P, [w], input_is_latent=True)
+        assert img.shape == (1, 3, 1024, 1024)
+        assert maxabs(img, ref) <= IMG_TOL
+        small = generate_image(G, w.cuda(), 1.0, None, input_is_latent=True)       # pooled to 256 like the reference
+        assert small.shape == (1, 3, 256, 256)
+        assert maxabs(small, torch.nn.functional.adaptive_avg_pool2d(ref, (256, 256))) <= IMG_TOL
