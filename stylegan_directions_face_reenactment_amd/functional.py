@@ -28,31 +28,6 @@ def _timed_conv(desc, flops, launch):
     CONV_TIMING.append((e0, e1, flops, desc))
 
 
-# ------------------------------------------------------------------ autograd guard
-
-class _BackwardNotBuilt(Function):
-    """Marks a forward-only result: usable outside no_grad(), fails loudly if differentiated."""
-
-    @staticmethod
-    def forward(ctx, out, what, *deps):
-        ctx.what = what
-        return out.view_as(out)
-
-    @staticmethod
-    def backward(ctx, grad):
-        raise NotImplementedError(
-            '%s: the HIP backward of this op (SURVEY.md §8 a17) is not built yet; there is no PyTorch '
-            'fallback on purpose. Run the generator under torch.no_grad().' % ctx.what)
-
-
-def forward_only(out, what, *deps):
-    if torch.is_grad_enabled():
-        live = [t for t in deps if isinstance(t, torch.Tensor) and t.requires_grad]
-        if live:
-            return _BackwardNotBuilt.apply(out, what, *live)
-    return out
-
-
 # ------------------------------------------------------------------ small dense ops
 
 def pixel_norm(x, eps=1e-8):
