@@ -135,6 +135,16 @@ int sgdfr_modconv2d_fwd_f32(const float* x, int64_t x_bstride, const float* wp, 
                             float* y, int B, int Cin, int Cout, int H, int W, int mode, int act, float slope,
                             float gain, void* stream);
 
+/* K-sliced form of sgdfr_modconv2d_fwd_f32 (modes PLAIN3 / UP3) for launches too small to fill the chip (single-frame
+ * reenactment, 4x4 / 8x8 layers): `splits` replicas of the tile grid each reduce a slice of the input channels into
+ * partials [splits][elements of y]; a second launch adds them in a fixed order (deterministic) and applies the epilogue.
+ * sgdfr_modconv2d_splitk_hint returns the recommended number of slices (1 = use the plain entry point). */
+int sgdfr_modconv2d_splitk_hint(int B, int Cin, int Cout, int H, int W, int mode);
+int sgdfr_modconv2d_splitk_f32(const float* x, int64_t x_bstride, const float* wp, const float* s, const float* d,
+                               const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias, float* y,
+                               float* partials, int splits, int B, int Cin, int Cout, int H, int W, int mode, int act,
+                               float slope, float gain, void* stream);
+
 /* Winograd F(2x2,3x3) form of mode PLAIN3 (same result up to fp32 rounding, 2.25x fewer MFMA ops).
  *   sgdfr_modconv_prepack_wino_f32: weight [Cout,Cin,3,3] -> u [Cin][Cout][16] = (G g G^T) / sqrt(9*Cin), the four 16-byte
  *       quads of each 16-vector stored at slot (quad ^ (cout & 3)) (LDS bank swizzle, opaque to callers);

@@ -40,6 +40,9 @@ SIGNATURES = {
     'sgdfr_modconv2d_wino_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
                                  _c_f32p, _i, _i, _i, _i, _i, _i, _f, _f, ctypes.c_void_p],
     'sgdfr_image_to_u8_f32': [_c_f32p, ctypes.c_void_p, _i, _i, _i, ctypes.c_void_p],
+    'sgdfr_modconv2d_splitk_hint': [_i, _i, _i, _i, _i, _i],
+    'sgdfr_modconv2d_splitk_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
+                                   _c_f32p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, ctypes.c_void_p],
     'sgdfr_demod_grad_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_style_demod_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i,
                               ctypes.c_void_p],

@@ -46,6 +46,8 @@ struct ModconvParams {
     int64_t total_pix;    // PLAIN: B*H*W dense pixels ; UP: B*R*P super-pixels
     int act;
     float slope, gain;
+    int ksplit;           // K (input-channel) slices; > 1: every slice writes d*partial sums to y + slice*split_stride
+    int64_t split_stride; // and sgdfr's reduce kernel adds them up and applies noise / bias / activation
 };
 
 constexpr int CK = 4;  // input channels per LDS stage (2 MFMA k-pairs)
@@ -140,7 +142,10 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
-    const int ct = lid / p.n_pix_tiles, pt = lid - ct * p.n_pix_tiles;
+    const int tiles_per_slice = p.n_pix_tiles * p.n_cout_tiles;
+    const int ks = lid / tiles_per_slice;                 // K slice of this block (0 when ksplit == 1)
+    const int lt = lid - ks * tiles_per_slice;
+    const int ct = lt / p.n_pix_tiles, pt = lt - ct * p.n_pix_tiles;
     const int n0 = ct * NT;
     const int p0 = pt * PT;      // host guarantees every pixel / q index fits int32
 
@@ -249,10 +254,12 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
     // Software pipeline, ONE barrier per K stage: while the MFMAs consume LDS stage `cur`, the registers that
     // were filled during the previous iteration are written to stage `cur^1` and the global loads of the stage
     // after that are issued (their latency hides under this iteration's MFMAs).
-    const int nstage = p.Cin / CK;
-    load_stage<NT, EX, WV, NPL>(p, 0, tid, n0, cstride, RP, nex, xoff, soff, xr, sr, wr);
+    const int nstage_all = p.Cin / CK;
+    const int st0 = (int)((int64_t)nstage_all * ks / p.ksplit), st1 = (int)((int64_t)nstage_all * (ks + 1) / p.ksplit);
+    const int nstage = st1 - st0;                          // stages of this K slice
+    load_stage<NT, EX, WV, NPL>(p, st0 * CK, tid, n0, cstride, RP, nex, xoff, soff, xr, sr, wr);
     store_stage<NT, EX, WV, NPL>(p, tid, nex, okmask, smem, smem + CK * NPL * p.xs, xr, sr, wr);
-    if (nstage > 1) load_stage<NT, EX, WV, NPL>(p, CK, tid, n0, cstride, RP, nex, xoff, soff, xr, sr, wr);
+    if (nstage > 1) load_stage<NT, EX, WV, NPL>(p, (st0 + 1) * CK, tid, n0, cstride, RP, nex, xoff, soff, xr, sr, wr);
     __syncthreads();
     for (int st = 0; st < nstage; ++st) {
         float* lx = smem + (st & 1) * stage_floats;
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
             float* nx = smem + ((st + 1) & 1) * stage_floats;
             store_stage<NT, EX, WV, NPL>(p, tid, nex, okmask, nx, nx + CK * NPL * p.xs, xr, sr, wr);
             if (st + 2 < nstage)
-                load_stage<NT, EX, WV, NPL>(p, (st + 2) * CK, tid, n0, cstride, RP, nex, xoff, soff, xr, sr, wr);
+                load_stage<NT, EX, WV, NPL>(p, (st0 + st + 2) * CK, tid, n0, cstride, RP, nex, xoff, soff, xr, sr, wr);
         }
 #pragma unroll
         for (int cp = 0; cp < CK / 2; ++cp) {
@@ -286,15 +293,17 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
     }
 
     // ---- epilogue.  C/D layout of 32x32: column (pixel) = lane&31, row (cout) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* const yout = p.y + (int64_t)ks * p.split_stride;
+    const bool whole = p.ksplit == 1;      // K slices only scale by d; noise / bias / activation follow the reduction
     if (MODE != SGDFR_MODE_UP3) {
-        const float nw = (p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
+        const float nw = (whole && p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int pix = pixv[ni];
             if (pix >= total_pix) continue;
             const int64_t img = pix / HW;
             const int rem = pix - (int)img * HW;
-            const float nz = p.noise ? nw * p.noise[img * p.noise_bstride + rem] : 0.f;
+            const float nz = (whole && p.noise) ? nw * p.noise[img * p.noise_bstride + rem] : 0.f;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -304,9 +313,9 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
                         float v = acc[0][mi][ni][r];
                         if (p.d) v *= p.d[img * p.Cout + co];
                         v += nz;
-                        if (p.bias) v += p.bias[co];
-                        if (p.act) v = lrelu_gain(v, p.slope, p.gain);
-                        p.y[(img * p.Cout + co) * HW + rem] = v;
+                        if (whole && p.bias) v += p.bias[co];
+                        if (whole && p.act) v = lrelu_gain(v, p.slope, p.gain);
+                        yout[(img * p.Cout + co) * HW + rem] = v;
                     }
                 }
             }
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
                     const int co = n0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     if (co < p.Cout) {
                         const float dv = p.d ? p.d[img * p.Cout + co] : 1.f;
-                        float* dst = p.y + ((img * p.Cout + co) * 4) * RP + rem;
+                        float* dst = yout + ((img * p.Cout + co) * 4) * RP + rem;
 #pragma unroll
                         for (int ph = 0; ph < PH; ++ph) dst[(int64_t)ph * RP] = acc[ph][mi][ni][r] * dv;
                     }
@@ -335,6 +344,26 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
     }
 }
 
+
+// ---------------------------------------------------------------- split-K reduction
+// y[i] = act( sum_s part[s][i] + noise_w*noise + bias[c] ), fixed summation order (deterministic, no atomics)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t stride,
+                                                           const float* __restrict__ noise, int64_t noise_bstride,
+                                                           const float* __restrict__ noise_w,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           int64_t n, int C, int inner, int act, float slope, float gain) {
+    const float nw = (noise && noise_w) ? noise_w[0] : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < splits; ++s) v += part[s * stride + i];
+        const int64_t pl = i / inner;
+        const int rem = (int)(i - pl * inner);
+        if (noise) v = fmaf(nw, noise[(pl / C) * noise_bstride + rem], v);
+        if (bias) v += bias[pl % C];
+        if (act) v = lrelu_gain(v, slope, gain);
+        y[i] = v;
+    }
+}
 
 // ---------------------------------------------------------------- odd-shape path
 // Channel counts that are not multiples of 4 never occur in the generator (512..16 channels) but the
@@ -564,7 +593,7 @@ static int launch_modconv(ModconvParams& p, hipStream_t stream) {
     constexpr int NPL = (MODE == SGDFR_MODE_DOWN3) ? 4 : 1;
     const size_t lds = 2 * (size_t)(CK * NPL * p.xs + CK * 9 * NT) * sizeof(float);   // double-buffered stages
     SGDFR_REQUIRE(p.total_pix + 4ll * p.P + 8 < (1ll << 31), "modconv: batch too large for 32-bit pixel indices");
-    const int64_t nblk = (int64_t)p.n_cout_tiles * p.n_pix_tiles;
+    const int64_t nblk = (int64_t)p.n_cout_tiles * p.n_pix_tiles * p.ksplit;
     SGDFR_REQUIRE(nblk < (1ll << 31), "modconv: grid too large");
     SGDFR_REQUIRE(lds <= 160 * 1024, "modconv: LDS request %zu too large", lds);
     if (lds > 64 * 1024 &&
@@ -612,6 +641,7 @@ extern "C" int sgdfr_modconv2d_fwd_f32(const float* x, int64_t x_bstride, const 
     const bool mfma_ok = (Cin % 4 == 0) && (Cout % 4 == 0) &&
                          (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(wp)) & 15) == 0);
     p.act = act; p.slope = slope; p.gain = gain;
+    p.ksplit = 1; p.split_stride = 0;
     hipStream_t st = as_stream(stream);
     if (!mfma_ok) {
         const int64_t total = (mode == SGDFR_MODE_UP3) ? (int64_t)B * Cout * 4 * (H + 1) * (W + 1)
@@ -668,4 +698,61 @@ extern "C" int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const flo
         hipLaunchKernelGGL(torgb_kernel<1>, grid, dim3(256), 0, as_stream(stream), x, w_rgb, s, bias, skip, fir, y, B,
                            Cin, H, W, QB, sh, scale);
     return check_launch("torgb_fwd");
+}
+
+// ---- K-sliced variant for launches that cannot fill the chip (small batch x small resolution) --------------------
+// The (64 cout x 64 pixel)-tile grid is replicated `splits` times; slice k accumulates input channels
+// [k*Cin/splits, (k+1)*Cin/splits) and writes d * partial sums to partials[k]; a second launch adds the slices in a
+// fixed order and applies noise / bias / activation (PLAIN3) or just adds (UP3 planes).
+extern "C" int sgdfr_modconv2d_splitk_hint(int B, int Cin, int Cout, int H, int W, int mode) {
+    if (Cin % 4 || Cout % 4 || Cout <= 32 || mode == SGDFR_MODE_DOWN3) return 1;
+    const int64_t pix = (mode == SGDFR_MODE_UP3) ? (int64_t)B * (H + 1) * (W + 1) : (int64_t)B * H * W;
+    const int64_t blocks = ((pix + 63) / 64) * ((Cout + 63) / 64);
+    if (blocks >= 192) return 1;
+    int s = (int)(384 / blocks);
+    const int max_by_k = Cin / CK / 8;      // keep at least 8 stages per slice
+    if (s > max_by_k) s = max_by_k;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : s;
+}
+
+extern "C" int sgdfr_modconv2d_splitk_f32(const float* x, int64_t x_bstride, const float* wp, const float* s,
+                                          const float* d, const float* noise, int64_t noise_bstride,
+                                          const float* noise_w, const float* bias, float* y, float* partials, int splits,
+                                          int B, int Cin, int Cout, int H, int W, int mode, int act, float slope, float gain,
+                                          void* stream) {
+    SGDFR_REQUIRE(B > 0 && Cin > 0 && Cout > 32 && H > 0 && W > 0, "modconv_splitk: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B,
+                  Cin, Cout, H, W);
+    SGDFR_REQUIRE(mode == SGDFR_MODE_PLAIN3 || mode == SGDFR_MODE_UP3, "modconv_splitk: mode must be PLAIN3 or UP3");
+    SGDFR_REQUIRE(splits >= 2 && splits <= Cin / CK, "modconv_splitk: splits %d not in 2..%d", splits, Cin / CK);
+    SGDFR_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "modconv_splitk: Cin and Cout must be multiples of 4");
+    SGDFR_REQUIRE(x && wp && s && y && partials, "modconv_splitk: null pointer");
+    SGDFR_REQUIRE(!noise || noise_w, "modconv_splitk: noise without noise_w");
+    ModconvParams p{};
+    p.x = x; p.x_bstride = x_bstride; p.wp = wp; p.s = s; p.d = d;
+    p.y = partials;
+    p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.P = W + 1; p.R = H + 1;
+    p.ksplit = splits;
+    hipStream_t st = as_stream(stream);
+    int64_t n;
+    int rc;
+    if (mode == SGDFR_MODE_PLAIN3) {
+        p.total_pix = (int64_t)B * H * W;
+        n = (int64_t)B * Cout * H * W;
+        p.split_stride = n;
+        rc = launch_modconv<SGDFR_MODE_PLAIN3, 2, 2, 1, 1, 3, 3>(p, st);
+    } else {
+        p.total_pix = (int64_t)B * (H + 1) * (W + 1);
+        n = (int64_t)B * Cout * 4 * (H + 1) * (W + 1);
+        p.split_stride = n;
+        rc = launch_modconv<SGDFR_MODE_UP3, 2, 2, 1, 1, 3, 3>(p, st);
+    }
+    if (rc) return rc;
+    int64_t g = (n + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    const bool plain = mode == SGDFR_MODE_PLAIN3;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, st, partials, splits, n, plain ? noise : nullptr,
+                       noise_bstride, noise_w, plain ? bias : nullptr, y, n, Cout, plain ? H * W : 1, plain ? act : 0, slope,
+                       gain);
+    return check_launch("modconv2d_splitk(reduce)");
 }

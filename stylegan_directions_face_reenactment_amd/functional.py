@@ -173,6 +173,7 @@ def _noise_args(noise, B, H, W):
     raise RuntimeError('noise of shape %s does not broadcast to [%d,1,%d,%d]' % (tuple(noise.shape), B, H, W))
 
 
+USE_SPLITK = True            # K-sliced launches for convs that cannot fill the chip (small batch / 4x4, 8x8 layers)
 USE_WINOGRAD = True          # plain 3x3 layers: Winograd F(2x2,3x3) MFMA kernel when the shape allows it
 WINOGRAD_MIN_BLOCKS = 256    # below this many (64 cout x 64 tile) blocks the direct kernel's smaller tiles win
 _zeros = {}
@@ -240,6 +241,14 @@ def modconv_raw(x, wp, s, d, cout, mode, H, W, noise=None, noise_weight=None, bi
         y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
     nz, nzb = _noise_args(noise, B, H, W) if mode == N.MODE_PLAIN3 else (None, 0)
     st = N.stream()
+    splits = N.load().sgdfr_modconv2d_splitk_hint(B, cin, cout, H, W, mode) if USE_SPLITK else 1
+    if splits > 1:      # too few tiles to fill the chip: slice K across extra blocks, reduce deterministically
+        partials = torch.empty((splits,) + tuple(y.shape), device=x.device, dtype=torch.float32)
+        _timed_conv((desc or 'conv') + ' splitK%d' % splits, B * conv_flops(cin, cout, H, W), lambda: N.call(
+            'sgdfr_modconv2d_splitk_f32', N.ptr(x), xb, N.ptr(wp), N.ptr(s), N.ptr(d), N.ptr(nz), nzb,
+            N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(y), N.ptr(partials), splits, B, cin, cout,
+            H, W, mode, int(activate), float(slope), float(gain), st))
+        return y
     _timed_conv(desc or ('mode%d %d->%d @%dx%d' % (mode, cin, cout, H, W)), B * conv_flops(cin, cout, H, W), lambda: N.call(
         'sgdfr_modconv2d_fwd_f32', N.ptr(x), xb, N.ptr(wp), N.ptr(s), N.ptr(d), N.ptr(nz), nzb,
         N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(y), B, cin, cout, H, W, mode,
