@@ -122,24 +122,46 @@ struct StyleBatch {
     float wscale;   // 1/sqrt(D), computed on the host like the single-layer entry point
 };
 
+// One WAVE per output column n of one layer: the wave keeps the weight row (K <= 512: 8 floats per lane) in registers,
+// then walks the batch: dot(x[b,:], w[n,:]) by 8 FMAs per lane + a 6-step butterfly, lane 0 stores.  K-serial tiles
+// (the generic linear kernel) need ~70 us for these skinny GEMMs whatever the batch; this form needs ~10 us.
 template <int STAGE>
 __global__ __launch_bounds__(256) void styles_batched_kernel(StyleBatch sb) {
-    __shared__ float xs[LBK][LBM + 1];
-    __shared__ float ws[LBK][LBN + 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + wave;                      // global output column over all layers
     int li = 0;
-    while (li + 1 < sb.n_layers && (int)blockIdx.x >= sb.tile_start[li + 1]) ++li;
+    while (li + 1 < sb.n_layers && col >= sb.tile_start[li + 1]) ++li;
+    if (col >= sb.tile_start[sb.n_layers]) return;
     const sgdfr_style_layer& ly = sb.layer[li];
-    const int t = blockIdx.x - sb.tile_start[li];
-    const int N = STAGE == 0 ? ly.cin : ly.cout;
-    const int ntn = (N + LBN - 1) / LBN;
-    const int m0 = (t / ntn) * LBM, n0 = (t % ntn) * LBN;
-    if (STAGE == 0)
-        linear_tile<0, 0, LBM, LBN>(sb.latent + (int64_t)ly.latent_index * sb.D, (int64_t)sb.L * sb.D, ly.mod_w,
-                                        ly.mod_b, ly.s, ly.cin, sb.B, ly.cin, sb.D, m0, n0, sb.wscale, 1.f,
-                                        SGDFR_ACT_NONE, 0.f, 1.f, xs, ws);
-    else
-        linear_tile<1, 1, LBM, LBN>(ly.s, ly.cin, ly.q, nullptr, ly.d, ly.cout, sb.B, ly.cout, ly.cin, m0, n0, 1e-8f,
-                                       0.f, 0, 0.f, 1.f, xs, ws);
+    const int n = col - sb.tile_start[li];
+    const int K = STAGE == 0 ? sb.D : ly.cin;
+    const float* wrow = (STAGE == 0 ? ly.mod_w : ly.q) + (int64_t)n * K;
+    const float* xb = STAGE == 0 ? sb.latent + (int64_t)ly.latent_index * sb.D : ly.s;
+    const int64_t ldx = STAGE == 0 ? (int64_t)sb.L * sb.D : ly.cin;
+    float* out = STAGE == 0 ? ly.s : ly.d;
+    const int ldo = STAGE == 0 ? ly.cin : ly.cout;
+    constexpr int KPL = 8;                                       // K <= 512 -> at most 8 elements per lane
+    float w[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        const int k = lane + 64 * j;
+        w[j] = k < K ? wrow[k] : 0.f;
+    }
+    const float bias = STAGE == 0 ? ly.mod_b[n] : 0.f;
+    for (int b = 0; b < sb.B; ++b) {
+        const float* xr = xb + b * ldx;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const int k = lane + 64 * j;
+            float v = k < K ? xr[k] : 0.f;
+            if (STAGE == 1) v *= v;
+            acc = fmaf(v, w[j], acc);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) out[(int64_t)b * ldo + n] = STAGE == 0 ? acc * sb.wscale + bias : rsqrtf(acc + 1e-8f);
+    }
 }
 
 }  // namespace sgdfr
@@ -181,8 +203,8 @@ extern "C" int sgdfr_styles_batched_f32(const float* latent, int B, int L, int D
     StyleBatch sb{};
     sb.n_layers = n_layers; sb.latent = latent; sb.B = B; sb.L = L; sb.D = D;
     sb.wscale = 1.0f / sqrtf((float)D);
-    const int mt = (B + LBM - 1) / LBM;
-    int tiles = 0, dl = 0;
+    SGDFR_REQUIRE(D <= 512, "styles_batched: style_dim %d > 512", D);
+    int tiles = 0, dl = 0;     // tile_start[] holds prefix sums of output COLUMNS (one wave each)
     for (int i = 0; i < n_layers; ++i) {
         const sgdfr_style_layer& ly = layers[i];
         SGDFR_REQUIRE(ly.mod_w && ly.mod_b && ly.s && ly.cin > 0, "styles_batched: layer %d incomplete", i);
@@ -190,11 +212,12 @@ extern "C" int sgdfr_styles_batched_f32(const float* latent, int B, int L, int D
                       i, ly.latent_index);
         SGDFR_REQUIRE(!ly.d || (ly.q && ly.cout > 0), "styles_batched: layer %d wants d without q", i);
         sb.layer[i] = ly;
+        SGDFR_REQUIRE(ly.cin <= 512 || !ly.d, "styles_batched: layer %d has %d input channels (> 512)", i, ly.cin);
         sb.tile_start[i] = tiles;
-        tiles += mt * ((ly.cin + LBN - 1) / LBN);
+        tiles += ly.cin;
     }
     sb.tile_start[n_layers] = tiles;
-    hipLaunchKernelGGL(styles_batched_kernel<0>, dim3(tiles), dim3(256), 0, as_stream(stream), sb);
+    hipLaunchKernelGGL(styles_batched_kernel<0>, dim3((tiles + 3) / 4), dim3(256), 0, as_stream(stream), sb);
     if (int rc = check_launch("styles_batched(modulation)")) return rc;
     // demodulation coefficients: only layers that asked for d
     StyleBatch sd{};
@@ -204,13 +227,13 @@ extern "C" int sgdfr_styles_batched_f32(const float* latent, int B, int L, int D
         if (!layers[i].d) continue;
         sd.layer[dl] = layers[i];
         sd.tile_start[dl] = tiles;
-        tiles += mt * ((layers[i].cout + LBN - 1) / LBN);
+        tiles += layers[i].cout;
         ++dl;
     }
     if (dl == 0) return 0;
     sd.tile_start[dl] = tiles;
     sd.n_layers = dl;
-    hipLaunchKernelGGL(styles_batched_kernel<1>, dim3(tiles), dim3(256), 0, as_stream(stream), sd);
+    hipLaunchKernelGGL(styles_batched_kernel<1>, dim3((tiles + 3) / 4), dim3(256), 0, as_stream(stream), sd);
     return check_launch("styles_batched(demod)");
 }
 

@@ -709,7 +709,7 @@ extern "C" int sgdfr_modconv2d_splitk_hint(int B, int Cin, int Cout, int H, int 
     const int64_t pix = (mode == SGDFR_MODE_UP3) ? (int64_t)B * (H + 1) * (W + 1) : (int64_t)B * H * W;
     const int64_t blocks = ((pix + 63) / 64) * ((Cout + 63) / 64);
     if (blocks >= 192) return 1;
-    int s = (int)(384 / blocks);
+    int s = (int)(1024 / blocks);           // aim at ~4 K-slice blocks per CU
     const int max_by_k = Cin / CK / 8;      // keep at least 8 stages per slice
     if (s > max_by_k) s = max_by_k;
     if (s > 16) s = 16;
