@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 2
+#define SGDFR_ABI_VERSION 3
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -173,6 +173,15 @@ int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, cons
 /* x [B,3,H,W] fp32 -> y [B,H,W,3] uint8:  trunc( (clamp(x,-1,1) + 1) / (2 + 1e-5) * 255 )
  * (libs/utilities/image_utils.py:87-110 tensor_to_image / torch_range_1_to_255, then the writers' uint8 cast) */
 int sgdfr_image_to_u8_f32(const float* x, unsigned char* y, int B, int H, int W, void* stream);
+
+/* K panels [B,3,H,W] fp32 side by side -> y [B,H,K*W,3] uint8 video frames, same scaling as above.
+ * `panels` / `bstrides` are HOST arrays of K device pointers / batch strides in floats (0 = the same image in
+ * every frame, e.g. the source).  Batched generate_grid_image + tensor_to_image + np.uint8
+ * (libs/utilities/utils_inference.py:11-33, run_inference.py:188-194); swap_rb != 0 also applies that path's
+ * cv2.cvtColor(.., COLOR_BGR2RGB) channel swap. */
+#define SGDFR_MAX_GRID_PANELS 4
+int sgdfr_grid_to_u8_f32(const float* const* panels, const int64_t* bstrides, int K, unsigned char* y, int B, int H,
+                         int W, int swap_rb, void* stream);
 
 /* ---- backward helpers (autograd of model.py:232-359 as restated in SURVEY.md Appendix C) ------------------------ */
 

@@ -19,6 +19,7 @@ the HIP kernels use, so agreement between the two is a real check.
 """
 import math
 
+import numpy
 import torch
 import torch.nn.functional as F
 
@@ -301,3 +302,25 @@ def template_state(size=256, style_dim=512, n_mlp=8, channel_multiplier=2):
 
 def cast_state(P, dtype):
     return {k: v.to(dtype) for k, v in P.items()}
+
+
+def tensor_to_uint8_hwc(images):
+    """[B,3,H,W] in [-1,1] -> [B,H,W,3] uint8: tensor_to_image (libs/utilities/image_utils.py:97-110: clamp, +1,
+    /(2+1e-5), *255) followed by the np.uint8 truncation of generate_video (libs/utilities/utils_inference.py:16)."""
+    x = images.detach().to(torch.float32).clone()
+    x.clamp_(min=-1, max=1).add_(1).div_(2 + 1e-5)
+    x = x.mul(255.0)
+    return x.permute(0, 2, 3, 1).contiguous().numpy().astype('uint8')
+
+
+def grid_video_frames(source, target, reenacted, swap_rb=True):
+    """Per frame i: generate_grid_image(source, target[i], reenacted[i]) puts the three images side by side
+    (utils_inference.py:20-29, called with batch 1 at run_inference.py:188), tensor_to_image + cvtColor(BGR2RGB)
+    (run_inference.py:193) turn it into the frame handed to the video writer.  -> [N,H,3W,3] uint8."""
+    n = reenacted.shape[0]
+    frames = []
+    for i in range(n):
+        grid = torch.cat([source[0], target[i], reenacted[i]], dim=2)      # [3,H,3W]
+        f = tensor_to_uint8_hwc(grid.unsqueeze(0))[0]
+        frames.append(f[:, :, ::-1].copy() if swap_rb else f)
+    return numpy.stack(frames, 0)

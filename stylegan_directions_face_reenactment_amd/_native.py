@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libsgdfr_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -40,6 +40,8 @@ SIGNATURES = {
     'sgdfr_modconv2d_wino_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
                                  _c_f32p, _i, _i, _i, _i, _i, _i, _f, _f, ctypes.c_void_p],
     'sgdfr_image_to_u8_f32': [_c_f32p, ctypes.c_void_p, _i, _i, _i, ctypes.c_void_p],
+    'sgdfr_grid_to_u8_f32': [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), _i, ctypes.c_void_p, _i, _i, _i,
+                             _i, ctypes.c_void_p],
     'sgdfr_modconv2d_splitk_hint': [_i, _i, _i, _i, _i, _i],
     'sgdfr_modconv2d_splitk_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
                                    _c_f32p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, ctypes.c_void_p],

@@ -132,6 +132,35 @@ __global__ __launch_bounds__(256) void image_to_u8_kernel(const float* __restric
     }
 }
 
+// K panels [B,3,H,W] (batch stride 0 = one image shown in every row) side by side -> video frames [B,H,K*W,3] uint8:
+// generate_grid_image + tensor_to_image + the np.uint8 of generate_video (libs/utilities/utils_inference.py:11-33,
+// run_inference.py:188-194) for a whole batch of frames.  swap_rb: the cvtColor(.., COLOR_BGR2RGB) before VideoWriter.
+struct GridPanels {
+    const float* x[SGDFR_MAX_GRID_PANELS];
+    int64_t bstride[SGDFR_MAX_GRID_PANELS];
+};
+
+__global__ __launch_bounds__(256) void grid_to_u8_kernel(GridPanels g, unsigned char* __restrict__ y, int B, int H, int W,
+                                                        int K, int swap_rb) {
+    const int64_t n = (int64_t)B * H * K * W;
+    const int HW = H * W, KW = K * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % KW);
+        const int64_t br = i / KW;
+        const int row = (int)(br % H);
+        const int64_t b = br / H;
+        const int k = col / W, c0 = col - k * W;
+        const float* xp = g.x[k] + b * g.bstride[k] + row * W + c0;
+        unsigned char* yp = y + i * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = fminf(fmaxf(xp[(int64_t)c * HW], -1.f), 1.f);
+            v = (v + 1.f) / (2.f + 1e-5f) * 255.f;
+            yp[swap_rb ? 2 - c : c] = (unsigned char)v;
+        }
+    }
+}
+
 }  // namespace sgdfr
 
 using namespace sgdfr;
@@ -195,4 +224,21 @@ extern "C" int sgdfr_image_to_u8_f32(const float* x, unsigned char* y, int B, in
     hipLaunchKernelGGL(image_to_u8_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(256), 0, as_stream(stream), x, y, B,
                        H * W);
     return check_launch("image_to_u8");
+}
+
+extern "C" int sgdfr_grid_to_u8_f32(const float* const* panels, const int64_t* bstrides, int K, unsigned char* y, int B,
+                                    int H, int W, int swap_rb, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && H > 0 && W > 0, "grid_to_u8: bad shape %d %d %d", B, H, W);
+    SGDFR_REQUIRE(K >= 1 && K <= SGDFR_MAX_GRID_PANELS, "grid_to_u8: %d panels (1..%d)", K, SGDFR_MAX_GRID_PANELS);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(panels && bstrides && y, "grid_to_u8: null pointer");
+    GridPanels g;
+    for (int k = 0; k < SGDFR_MAX_GRID_PANELS; ++k) {
+        g.x[k] = k < K ? panels[k] : nullptr;
+        g.bstride[k] = k < K ? bstrides[k] : 0;
+        SGDFR_REQUIRE(k >= K || g.x[k], "grid_to_u8: panel %d is null", k);
+    }
+    hipLaunchKernelGGL(grid_to_u8_kernel, dim3(grid_for((int64_t)B * H * K * W)), dim3(256), 0, as_stream(stream), g, y,
+                       B, H, W, K, swap_rb);
+    return check_launch("grid_to_u8");
 }

@@ -9,6 +9,10 @@ batch.  `ReenactmentSession.frames` chunks the shift vectors, broadcasts the sou
 ``sgdfr_latent_prepare_f32`` (shift add + truncation in the same launch) and yields [b,3,H,W] images, optionally
 converted on the GPU to the uint8 HWC layout the reference writes (libs/utilities/image_utils.py:97-110).
 """
+import ctypes
+import os
+
+import numpy as np
 import torch
 
 from . import _native as N
@@ -25,6 +29,57 @@ def images_to_uint8(images):
     y = torch.empty(B, H, W, 3, device=x.device, dtype=torch.uint8)
     N.call('sgdfr_image_to_u8_f32', N.ptr(x), N.ptr(y), B, H, W, N.stream())
     return y
+
+
+def grid_frames_uint8(panels, swap_rb=False):
+    """Side-by-side video frames for a batch: panels = list of [B,3,H,W] or [1,3,H,W] (shown in every frame) fp32
+    images in [-1,1] -> [B,H,K*W,3] uint8.  One launch for what the reference does per frame with
+    generate_grid_image + tensor_to_image + np.uint8 (utils_inference.py:11-33, run_inference.py:188-194);
+    swap_rb applies that path's cvtColor channel swap."""
+    if not 1 <= len(panels) <= 4:
+        raise RuntimeError('grid_frames_uint8 takes 1..4 panels, got %d' % len(panels))
+    xs = []
+    for x in panels:
+        N.require_device(x)
+        xs.append(N.f32c(x if x.ndim == 4 else x.unsqueeze(0)))
+    B = max(x.shape[0] for x in xs)
+    _, C, H, W = xs[0].shape
+    for x in xs:
+        if x.shape[1:] != (3, H, W) or x.shape[0] not in (1, B):
+            raise RuntimeError('grid panels must be [B or 1,3,%d,%d], got %s' % (H, W, tuple(x.shape)))
+    K = len(xs)
+    ptrs = (ctypes.c_void_p * K)(*[x.data_ptr() for x in xs])
+    strides = (ctypes.c_int64 * K)(*[0 if (x.shape[0] == 1 and B > 1) else 3 * H * W for x in xs])
+    y = torch.empty(B, H, K * W, 3, device=xs[0].device, dtype=torch.uint8)
+    N.call('sgdfr_grid_to_u8_f32', ptrs, strides, K, N.ptr(y), B, H, W, int(bool(swap_rb)), N.stream())
+    return y
+
+
+def save_latent_codes(directory, names, latents):
+    """The reference's W+ latent store: one `<name>.npy` holding a [n_latent,512] fp32 array per frame
+    (invert_images.py:119-125).  `latents` [B,n_latent,512] comes back to the host in ONE copy."""
+    lat = latents.detach().to('cpu', torch.float32).numpy()
+    if lat.ndim != 3 or len(names) != lat.shape[0]:
+        raise RuntimeError('save_latent_codes: %d names for latents of shape %s' % (len(names), tuple(lat.shape)))
+    os.makedirs(directory, exist_ok=True)
+    paths = []
+    for name, code in zip(names, lat):
+        path = os.path.join(directory, os.path.splitext(name)[0] + '.npy')
+        np.save(path, code)
+        paths.append(path)
+    return paths
+
+
+def load_latent_codes(paths, device=None):
+    """Read per-frame `.npy` codes back into one [B,n_latent,512] tensor (pinned staging, one H2D copy)."""
+    codes = [np.load(p) for p in paths]
+    for p, c in zip(paths, codes):
+        if c.ndim != 2 or c.shape != codes[0].shape or c.dtype != np.float32:
+            raise RuntimeError('latent store %s: expected fp32 %s, got %s %s' % (p, codes[0].shape, c.dtype, c.shape))
+    host = torch.from_numpy(np.stack(codes, 0))
+    if device is None or torch.device(device).type == 'cpu':
+        return host
+    return host.pin_memory().to(device, non_blocking=True)
 
 
 class ReenactmentSession:
@@ -57,3 +112,12 @@ class ReenactmentSession:
 
     def render(self, shift_vectors, as_uint8=False):
         return torch.cat(list(self.frames(shift_vectors, as_uint8=as_uint8)), 0)
+
+    @torch.no_grad()
+    def video_frames(self, source_image, target_images, shift_vectors, swap_rb=True):
+        """source | target | reenacted frames [N,H,3W,3] uint8 (the --save_video output of run_inference.py:186-198)."""
+        out, lo = [], 0
+        for img in self.frames(shift_vectors):
+            out.append(grid_frames_uint8([source_image, target_images[lo:lo + img.shape[0]], img], swap_rb=swap_rb))
+            lo += img.shape[0]
+        return torch.cat(out, 0)

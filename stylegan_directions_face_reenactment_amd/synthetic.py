@@ -118,3 +118,35 @@ def synthetic_direction_state(seed, input_dim=15, out_dim=512, num_layers=8, w_p
         'linear.weight': counter_tensor(seed, 'A.linear.weight', (rows, input_dim), 0.0, 0.03),
         'linear.bias': counter_tensor(seed, 'A.linear.bias', (rows,), 0.0, 0.02),
     }
+
+
+def synthetic_encoder_state(template, seed=0):
+    """Fill an Encoder4Editing-shaped state_dict (psp_encoders.py:122-160 key set) with synthetic values:
+    conv filters ~ N(0, gain/fan_in) so activations stay O(1) through the 24 residual units and the style heads, BatchNorm statistics near
+    (0, 1) with positive variances, PReLU slopes near 0.25, randn EqualLinear weights (lr_mul=1)."""
+    out = {}
+    for key, t in template.items():
+        shape = tuple(t.shape)
+        if key.endswith('num_batches_tracked'):
+            out[key] = torch.zeros(shape, dtype=torch.int64)
+        elif key.endswith('running_var'):
+            v = counter_normal(seed, key, int(np.prod(shape))) * 0.2 + 1.0
+            out[key] = torch.from_numpy(np.maximum(v, 0.3).astype(np.float32).reshape(shape))
+        elif key.endswith('running_mean'):
+            out[key] = counter_tensor(seed, key, shape, 0.0, 0.1)
+        elif len(shape) == 4:                                     # conv filters [Cout,Cin/groups,kh,kw]
+            fan_in = shape[1] * shape[2] * shape[3]
+            gain = 2.0 if key.startswith('styles.') else 0.7     # heads: plain LeakyReLU chains; trunk: residual sums
+            out[key] = counter_tensor(seed, key, shape, 0.0, float(np.sqrt(gain / fan_in)))
+        elif len(shape) == 2:                                     # EqualLinear weight
+            out[key] = counter_tensor(seed, key, shape, 0.0, 1.0)
+        elif '.linear.' in key:                                   # EqualLinear bias
+            out[key] = counter_tensor(seed, key, shape, 0.0, 0.1)
+        elif key.endswith('.bias'):                               # BatchNorm shift / conv bias
+            out[key] = counter_tensor(seed, key, shape, 0.0, 0.05)
+        elif key.endswith('.weight'):                             # 1-D: BatchNorm scale or PReLU slope
+            is_prelu = key.endswith('input_layer.2.weight') or key.endswith('res_layer.2.weight')
+            out[key] = counter_tensor(seed, key, shape, 0.25 if is_prelu else 1.0, 0.05 if is_prelu else 0.1)
+        else:
+            raise KeyError(key)
+    return out

@@ -150,3 +150,22 @@ def test_shard_range_and_flops_table():
         fl += F_.conv_flops(cin, ch[r], r // 2, r // 2, upsample=True) + F_.conv_flops(ch[r], ch[r], r, r)
         cin = ch[r]
     assert abs(fl / 1e9 - 29.746) < 0.01
+
+
+def test_latent_store_roundtrip(tmp_path):
+    """W+ latent store = one [14,512] fp32 .npy per frame (invert_images.py:119-125)."""
+    import numpy as np
+    from stylegan_directions_face_reenactment_amd.reenact import save_latent_codes, load_latent_codes
+    lat = S.synthetic_latents(3, 5)
+    names = ['%06d.png' % i for i in range(5)]
+    paths = save_latent_codes(str(tmp_path / 'latent_codes'), names, lat)
+    assert [p.split('/')[-1] for p in paths] == ['%06d.npy' % i for i in range(5)]
+    one = np.load(paths[2])
+    assert one.shape == (14, 512) and one.dtype == np.float32 and np.array_equal(one, lat[2].numpy())
+    back = load_latent_codes(paths)
+    assert back.shape == (5, 14, 512) and torch.equal(back, lat)
+    with pytest.raises(RuntimeError):
+        save_latent_codes(str(tmp_path / 'x'), names[:2], lat)
+    np.save(str(tmp_path / 'bad.npy'), np.zeros((3, 512), np.float32))
+    with pytest.raises(RuntimeError):
+        load_latent_codes([paths[0], str(tmp_path / 'bad.npy')])

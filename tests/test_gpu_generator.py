@@ -189,6 +189,27 @@ def test_batched_reenactment_equals_per_frame_loop():
         images_to_uint8(torch.full((1, 3, 2, 2), -5.0).cuda()).max() == 0
 
 
+def test_video_grid_frames_match_reference_packing():
+    """source|target|reenacted uint8 frames for a whole batch in one launch == the reference's per-frame
+    generate_grid_image + tensor_to_image + cvtColor + np.uint8 (utils_inference.py:11-33, run_inference.py:188-194)."""
+    from stylegan_directions_face_reenactment_amd.reenact import grid_frames_uint8
+    src = S.counter_tensor(5, 'grid.src', (1, 3, 16, 24), 0.0, 0.8)
+    tgt = S.counter_tensor(5, 'grid.tgt', (6, 3, 16, 24), 0.0, 0.8)
+    ren = S.counter_tensor(5, 'grid.ren', (6, 3, 16, 24), 0.0, 0.8)
+    for swap in (True, False):
+        got = grid_frames_uint8([src.cuda(), tgt.cuda(), ren.cuda()], swap_rb=swap)
+        assert got.shape == (6, 16, 72, 3) and got.dtype == torch.uint8
+        expect = O.grid_video_frames(src, tgt, ren, swap_rb=swap)
+        diff = got.cpu().numpy().astype(int) - expect.astype(int)
+        assert abs(diff).max() <= 1 and (diff != 0).mean() < 1e-3      # fp32 rounding at integer boundaries only
+    one = grid_frames_uint8([tgt.cuda()])
+    assert (one.cpu().numpy().astype(int) - O.tensor_to_uint8_hwc(tgt).astype(int)).__abs__().max() <= 1
+    with pytest.raises(RuntimeError):
+        grid_frames_uint8([src.cuda()] * 5)
+    with pytest.raises(RuntimeError):
+        grid_frames_uint8([src.cuda(), tgt[:, :, :8].cuda()])
+
+
 def test_wide_layers_and_1024_generator():
     """Resolutions above 256 (the reference also ships ffhq-1024, libs/configs/config_models.py:16-20, pooled to 256 by
     generate_image): wide rows switch the conv staging to row segments; checked per layer and end to end."""
