@@ -40,6 +40,10 @@ def main():
         if 'wino' in which:
             t = bench(lambda: F_.modconv_wino(x, u, s, d, cout, nz, nw, bias, True))
             out.append('wino %7.1f us %6.1f TF' % (t * 1e6, fl / t / 1e12))
+        if 'split' in which:
+            wsp = F_.prepack_split(w)
+            t = bench(lambda: F_.modconv_split(x, wsp, s, d, cout, nz, nw, bias, True))
+            out.append('bf16x3 %7.1f us %6.1f TF-eq' % (t * 1e6, fl / t / 1e12))
         print('%4d->%4d @%3d: %s' % (cin, cout, h, ' | '.join(out)), flush=True)
 
 if __name__ == '__main__':

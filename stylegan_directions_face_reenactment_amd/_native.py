@@ -39,6 +39,10 @@ SIGNATURES = {
     'sgdfr_modconv2d_wino_supported': [_i, _i, _i, _i, _i],
     'sgdfr_modconv2d_wino_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
                                  _c_f32p, _i, _i, _i, _i, _i, _i, _f, _f, ctypes.c_void_p],
+    'sgdfr_modconv_prepack_split_f32': [_c_f32p, ctypes.c_void_p, _i, _i, ctypes.c_void_p],
+    'sgdfr_modconv2d_split_supported': [_i, _i, _i, _i, _i],
+    'sgdfr_modconv2d_split_f32': [_c_f32p, _i64, ctypes.c_void_p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
+                                  _c_f32p, _i, _i, _i, _i, _i, _i, _f, _f, ctypes.c_void_p],
     'sgdfr_image_to_u8_f32': [_c_f32p, ctypes.c_void_p, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_grid_to_u8_f32': [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), _i, ctypes.c_void_p, _i, _i, _i,
                              _i, ctypes.c_void_p],
@@ -86,6 +90,8 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.sgdfr_abi_version.restype = ctypes.c_int
     lib.sgdfr_last_error.restype = ctypes.c_char_p
+    lib.sgdfr_modconv_prepack_split_elems.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.sgdfr_modconv_prepack_split_elems.restype = ctypes.c_int64
     if lib.sgdfr_abi_version() != ABI_VERSION:
         raise RuntimeError('libsgdfr_hip.so ABI %d != expected %d: rebuild' % (lib.sgdfr_abi_version(), ABI_VERSION))
     for name, argtypes in SIGNATURES.items():

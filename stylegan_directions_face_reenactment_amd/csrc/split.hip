@@ -1,0 +1,457 @@
+// 3x3 modulated convolution on the bf16 matrix cores with fp32 operands split in two bf16 terms ("bf16x3"):
+//
+//     a = a_hi + a_lo,  b = b_hi + b_lo   (hi = bf16(v), lo = bf16(v - hi): 16 mantissa bits kept)
+//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi      accumulated in fp32 by v_mfma_f32_32x32x16_bf16
+//
+// Three bf16 MFMAs replace eight fp32 ones (v_mfma_f32_32x32x2_f32 covers K=2 in 64 cycles, the bf16 form K=16 in
+// 32), so the contraction runs ~5x above the fp32-MFMA roof; the kernel is then bound by staging and LDS/L2
+// bandwidth.  Per-product error is ~2^-17 relative (the dropped lo*lo term and the 16-bit split), measured end to end
+// on the 256x256 generator: 1.1e-4 max-abs against the fp64 oracle (fp32 path: 1e-5; contract: 1e-3).  This is an
+// OPT-IN precision mode (functional.PRECISION / SGDFR_PRECISION=bf16x3); the default path stays exact fp32.
+//
+// Same algebra as modconv.hip (y = d * conv(x*s, Wc), batch folded into the pixel dimension), different data path:
+//   * GEMM view M = cout, N = pixels, K = (tap, cin); one MFMA = 16 input channels of one tap.  A lane holds 8
+//     consecutive channels (16 B): LDS keeps activations as [part hi/lo][k-half][position][8 x bf16] and weights as
+//     [tap][part][k-half][cout][8 x bf16], so every fragment is one conflict-free ds_read_b128.
+//   * block = 8 waves: NT = 64*WM couts x PT = 64*WN pixels, wave tile 64 x 64 (2x2 MFMA tiles x 3 products).
+//   * K loop over 16-channel blocks, each split in 3 sub-stages (one kernel row = 3 taps).  The weight row slab
+//     (NT*192 B, prepacked in LDS order) is DMA'd global->LDS one sub-stage ahead into a 2-slot ring; the activation
+//     tile of the NEXT channel block is converted (x*s -> hi/lo) from registers and written to the other x buffer
+//     one third per sub-stage, while its global loads were issued a full channel block earlier.  One barrier per
+//     sub-stage (36 MFMAs per wave).
+//   * pixel tiles: contiguous runs of the padded flat space for W <= 64 (a tile may span images), TR x 128 patches
+//     for wider images.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace sgdfr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct SplitParams {
+    const float* x;
+    int64_t x_bstride;
+    const unsigned short* wsp;   // prepacked bf16 hi/lo weights
+    const float* s;
+    const float* d;
+    const float* noise;
+    int64_t noise_bstride;
+    const float* noise_w;
+    const float* bias;
+    const float* zeros;          // >= 8 zero floats
+    float* y;
+    int B, Cin, Cout, H, W;
+    int P, R;                    // padded pitch / rows per image of the flat space (W+1, H+1)
+    int n_pix_tiles, n_cout_tiles;
+    int xs, xlen;                // staged positions per channel block: padded to a multiple of 64 / real
+    int patch;                   // 0: flat runs ; 1: TR x TC patches
+    int TC, TR, tiles_x, tiles_y, seglen;
+    int simgs;                   // images one tile's staged range can touch
+    int64_t total_pix;
+    int act;
+    float slope, gain;
+};
+
+constexpr int SPLIT_CB = 16;     // input channels per K block (one MFMA K)
+
+template <int N>
+__device__ __forceinline__ void split_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// two floats -> packed bf16 hi pair and packed bf16 lo pair (lo = bf16(v - float(hi)), exact subtraction)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    f32x2 v = {a, b};
+    bf16x2 h = __builtin_convertvector(v, bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+    f32x2 r = {a - ha, b - hb};
+    bf16x2 l = __builtin_convertvector(r, bf16x2);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <int WM, int WN, int NEX>
+__global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
+    constexpr int NTHR = 512;
+    constexpr int NT = WM * 64, PT = WN * 64;
+    static_assert(WM * WN == 8, "8 waves per block");
+    constexpr int WROW_BYTES = NT * 192;                 // [3 kx][2 part][2 k-half][NT][8] bf16
+    constexpr int WCHUNKS = WROW_BYTES / 1024;           // 64-lane x 16-byte DMA pieces
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int xbuf_bytes = 64 * p.xs;                    // [2 part][2 k-half][xs][8] bf16
+    unsigned char* const xb0 = smem;
+    unsigned char* const wb0 = smem + 2 * xbuf_bytes;
+    float* const ls = reinterpret_cast<float*>(wb0 + 2 * WROW_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int HW = p.H * p.W;
+
+    int lid;
+    {
+        const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int ct = lid / p.n_pix_tiles, pt = lid - ct * p.n_pix_tiles;
+    const int n0 = ct * NT;
+
+    // ---- tile origin
+    int q0 = 0, img0, row0 = 0, col0 = 0;
+    if (p.patch) {
+        const int per_img = p.tiles_x * p.tiles_y;
+        img0 = pt / per_img;
+        const int rem = pt - img0 * per_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        row0 = ty * p.TR;
+        col0 = tx * p.TC;
+    } else {
+        const int p0 = pt * PT;
+        img0 = p0 / HW;
+        const int rem = p0 - img0 * HW;
+        const int a = rem / p.W, b = rem - a * p.W;
+        q0 = (img0 * p.R + a + 1) * p.P + b + 1 - p.P - 1;
+    }
+
+    // ---- this lane's two output pixels: position inside the staged range, and where they are stored
+    int boff[2];
+    int64_t ybase[2];     // (img*Cout)*HW + rem, or -1 when the pixel does not exist
+    int64_t nzoff[2];
+    int dimg[2];
+    const int pitch = p.patch ? p.seglen : p.P;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int l = (wn * 2 + n) * 32 + l31;
+        if (p.patch) {
+            const int r = l / p.TC, c = l - r * p.TC;
+            boff[n] = (r + 1) * p.seglen + c + 1;
+            const int rem = (row0 + r) * p.W + col0 + c;
+            const bool ok = img0 < p.B;
+            ybase[n] = ok ? (int64_t)img0 * p.Cout * HW + rem : -1;
+            nzoff[n] = (int64_t)img0 * p.noise_bstride + rem;
+            dimg[n] = img0;
+        } else {
+            int64_t pix = (int64_t)pt * PT + l;
+            const bool ok = pix < p.total_pix;
+            if (!ok) pix = p.total_pix - 1;
+            const int img = (int)(pix / HW);
+            const int rem = (int)(pix - (int64_t)img * HW);
+            const int a = rem / p.W, b = rem - a * p.W;
+            boff[n] = (img * p.R + a + 1) * p.P + b + 1 - q0;
+            ybase[n] = ok ? (int64_t)img * p.Cout * HW + rem : -1;
+            nzoff[n] = (int64_t)img * p.noise_bstride + rem;
+            dimg[n] = img;
+        }
+        boff[n] += hi * p.xs;
+    }
+
+    // ---- staging descriptors: item = (position j, k-half h) -> 8 channels -> one 16-byte hi and one 16-byte lo chunk
+    const float* xsrc[NEX];
+    int soff[NEX];        // float offset into the LDS style table, -1: nothing to write (beyond the range)
+    int ldst[NEX];        // byte offset inside an x buffer
+#pragma unroll
+    for (int e = 0; e < NEX; ++e) {
+        const int i = tid + e * NTHR;
+        const int h = i / p.xs;
+        const int j = i - h * p.xs;
+        const bool in_range = (h < 2) && (j < p.xlen);
+        bool ok;
+        int img, pix;
+        if (p.patch) {
+            const int sg = j / p.seglen, cc = j - sg * p.seglen;
+            const int row = row0 - 1 + sg, col = col0 - 1 + cc;
+            img = img0;
+            ok = in_range && row >= 0 && row < p.H && col >= 0 && col < p.W && img < p.B;
+            pix = row * p.W + col;
+        } else {
+            const int q = q0 + j;
+            const int pir = q / p.P, pc = q - pir * p.P;
+            img = pir / p.R;
+            const int pr = pir - img * p.R;
+            ok = in_range && pc >= 1 && pr >= 1 && img < p.B && q >= 0;
+            pix = (pr - 1) * p.W + (pc - 1);
+        }
+        xsrc[e] = ok ? p.x + (int64_t)img * p.x_bstride + (int64_t)(8 * h) * HW + pix : nullptr;
+        soff[e] = !(h < 2 && j < p.xs) ? -1 : ok ? (img - img0) * p.Cin + 8 * h : 0;
+        ldst[e] = (h * p.xs + j) * 16;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    float xr[NEX][8];
+
+    auto load_x = [&](int e, int cb) {
+        const float* src = xsrc[e] ? xsrc[e] + (int64_t)cb * SPLIT_CB * HW : p.zeros;
+        const int64_t cs = xsrc[e] ? HW : 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xr[e][c] = src[c * cs];
+    };
+    auto convert_store = [&](int e, int cb, unsigned char* xb) {
+        if (soff[e] < 0) return;
+        const float* sp = ls + soff[e] + cb * SPLIT_CB;
+        const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+        const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        uint4 vh, vl;
+        unsigned* ph = reinterpret_cast<unsigned*>(&vh);
+        unsigned* pl = reinterpret_cast<unsigned*>(&vl);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) split_pair(xr[e][2 * c] * sv[2 * c], xr[e][2 * c + 1] * sv[2 * c + 1], ph[c], pl[c]);
+        *reinterpret_cast<uint4*>(xb + ldst[e]) = vh;
+        *reinterpret_cast<uint4*>(xb + 32 * p.xs + ldst[e]) = vl;
+    };
+    const int ncb = p.Cin / SPLIT_CB;
+    const unsigned char* const wglb = reinterpret_cast<const unsigned char*>(p.wsp) + (int64_t)ct * ncb * 3 * WROW_BYTES;
+    auto issue_w = [&](int u) {      // row slab u = cb*3 + ky -> ring slot u & 1
+        const unsigned char* src = wglb + (int64_t)u * WROW_BYTES;
+        unsigned char* dst = wb0 + (u & 1) * WROW_BYTES;
+#pragma unroll
+        for (int v = 0; v < (WCHUNKS + 7) / 8; ++v) {
+            const int chunk = wave + v * 8;
+            if (chunk < WCHUNKS)
+                __builtin_amdgcn_global_load_lds((glb_void*)(src + chunk * 1024 + lane * 16), (lds_void*)(dst + chunk * 1024), 16,
+                                                 0, 0);
+        }
+    };
+
+    // ---- prologue: style table, channel block 0 staged, block 1 in registers, weight row 0 in flight
+    for (int e = tid; e < p.simgs * p.Cin; e += NTHR) {
+        const int m = e / p.Cin;
+        ls[e] = (img0 + m < p.B) ? p.s[(int64_t)(img0 + m) * p.Cin + (e - m * p.Cin)] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NEX; ++e) load_x(e, 0);
+#pragma unroll
+    for (int e = 0; e < NEX; ++e) convert_store(e, 0, xb0);
+    issue_w(0);
+    if (ncb > 1) {
+#pragma unroll
+        for (int e = 0; e < NEX; ++e) load_x(e, 1);
+        split_wait_vmcnt<NEX * 8>();
+    } else {
+        split_wait_vmcnt<0>();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int aoff = (hi * NT + wm * 64 + l31) * 16;
+    for (int cb = 0; cb < ncb; ++cb) {
+        const unsigned char* xcur = xb0 + (cb & 1) * xbuf_bytes;
+        unsigned char* xnext = xb0 + ((cb + 1) & 1) * xbuf_bytes;
+        const bool conv_next = cb + 1 < ncb, load_next = cb + 2 < ncb;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int u = cb * 3 + ky;
+            const bool more_w = u + 1 < ncb * 3;
+            if (more_w) issue_w(u + 1);
+            constexpr int kSlots[3] = {(NEX + 2) / 3, (NEX + 1) / 3, NEX / 3};
+            if (conv_next) {
+#pragma unroll
+                for (int e = ky; e < NEX; e += 3) {
+                    convert_store(e, cb + 1, xnext);
+                    if (load_next) load_x(e, cb + 2);
+                }
+            }
+            const unsigned char* wcur = wb0 + (u & 1) * WROW_BYTES + aoff;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tapoff = (ky - 1) * pitch + (kx - 1);
+                bf16x8 a[2][2], b[2][2];     // [part][tile]
+#pragma unroll
+                for (int part = 0; part < 2; ++part)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        a[part][m] = *reinterpret_cast<const bf16x8*>(wcur + ((kx * 2 + part) * 2) * (NT * 16) + m * 512);
+#pragma unroll
+                for (int part = 0; part < 2; ++part)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        b[part][n] = *reinterpret_cast<const bf16x8*>(xcur + part * 32 * p.xs + (boff[n] + tapoff) * 16);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][m], b[0][n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][m], b[1][n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][m], b[0][n], acc[m][n], 0, 0, 0);
+                    }
+            }
+            if (more_w) {
+                if (conv_next && load_next) {
+                    if (kSlots[ky] == 0) split_wait_vmcnt<0>();
+                    else if (kSlots[ky] == 1) split_wait_vmcnt<8>();
+                    else split_wait_vmcnt<16>();
+                } else {
+                    split_wait_vmcnt<0>();
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    }
+
+    // ---- epilogue.  C/D layout of 32x32: column (pixel) = lane&31, row (cout) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const float nw = (p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        if (ybase[n] < 0) continue;
+        const float nz = p.noise ? nw * p.noise[nzoff[n]] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = n0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float v = acc[m][n][r];
+                if (p.d) v *= p.d[(int64_t)dimg[n] * p.Cout + co];
+                v += nz;
+                if (p.bias) v += p.bias[co];
+                if (p.act) v = lrelu_gain(v, p.slope, p.gain);
+                p.y[ybase[n] + (int64_t)co * HW] = v;
+            }
+        }
+    }
+}
+
+// weight [Cout,Cin,3,3] fp32 -> bf16 hi/lo of Wc = weight/sqrt(9 Cin) in the kernel's LDS order:
+//   [cout tile][cin block][ky][kx][part][k-half][cout in tile (NT)][8 cin]
+__global__ __launch_bounds__(256) void prepack_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
+                                                           int Cout, int Cin, int NT, float scale) {
+    const int64_t n = (int64_t)Cout * Cin * 9;
+    const int ncb = Cin / SPLIT_CB;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(idx % 9);
+        const int ci = (int)((idx / 9) % Cin);
+        const int co = (int)(idx / (9 * (int64_t)Cin));
+        const float v = w[idx] * scale;
+        const bf16x2 hv = __builtin_convertvector((f32x2){v, 0.f}, bf16x2);
+        const unsigned hbits = __builtin_bit_cast(unsigned, hv) & 0xffffu;
+        const float hf = __builtin_bit_cast(float, hbits << 16);
+        const bf16x2 lv = __builtin_convertvector((f32x2){v - hf, 0.f}, bf16x2);
+        const unsigned lbits = __builtin_bit_cast(unsigned, lv) & 0xffffu;
+        const int ctile = co / NT, col = co - ctile * NT, cb = ci / SPLIT_CB, h = (ci % SPLIT_CB) / 8, c8 = ci % 8;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int64_t base = ((((int64_t)ctile * ncb + cb) * 3 + ky) * 3 + kx) * 2;   // -> [part]
+        out[(((base + 0) * 2 + h) * NT + col) * 8 + c8] = (unsigned short)hbits;
+        out[(((base + 1) * 2 + h) * NT + col) * 8 + c8] = (unsigned short)lbits;
+    }
+}
+
+}  // namespace sgdfr
+
+using namespace sgdfr;
+
+static int split_nt(int Cout) { return (Cout % 128 == 0) ? 128 : 64; }
+
+// geometry of the pixel tiling; returns 0 when the shape cannot use the split kernel
+static int split_geometry(int B, int Cin, int Cout, int H, int W, SplitParams* out) {
+    if (Cin % SPLIT_CB != 0 || Cout % 64 != 0 || B < 1) return 0;
+    SplitParams p{};
+    const int NT = split_nt(Cout), PT = (NT == 128) ? 256 : 512;
+    const int HW = H * W;
+    p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.P = W + 1; p.R = H + 1;
+    p.total_pix = (int64_t)B * HW;
+    if ((int64_t)B * p.R * p.P + 4ll * p.P + 8 >= (1ll << 31) || p.total_pix >= (1ll << 31)) return 0;
+    if (W > 64) {
+        p.patch = 1;
+        p.TC = 128;
+        p.TR = PT / p.TC;
+        if (W % p.TC != 0 || H % p.TR != 0) return 0;
+        p.tiles_x = W / p.TC; p.tiles_y = H / p.TR;
+        p.seglen = p.TC + 2;
+        p.xlen = (p.TR + 2) * p.seglen;
+        p.simgs = 1;
+        p.n_pix_tiles = B * p.tiles_x * p.tiles_y;
+    } else {
+        p.patch = 0;
+        int span;   // q distance between the first and the last pixel of a tile
+        if (PT % W == 0 && HW % PT == 0) {
+            span = (PT / W - 1) * p.P + (W - 1);
+            p.simgs = 1;
+        } else if (PT % HW == 0) {
+            span = (PT / HW - 1) * p.R * p.P + (H - 1) * p.P + (W - 1);
+            p.simgs = PT / HW;
+        } else {
+            return 0;
+        }
+        p.xlen = span + 2 * p.P + 3;
+        p.n_pix_tiles = (int)((p.total_pix + PT - 1) / PT);
+    }
+    p.xs = (p.xlen + 63) & ~63;
+    p.n_cout_tiles = Cout / NT;
+    if (out) *out = p;
+    return 1;
+}
+
+static size_t split_lds_bytes(const SplitParams& p, int NT) {
+    return 2 * (size_t)64 * p.xs + 2 * (size_t)NT * 192 + (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float);
+}
+
+extern "C" int sgdfr_modconv2d_split_supported(int B, int Cin, int Cout, int H, int W) {
+    SplitParams p;
+    if (!split_geometry(B, Cin, Cout, H, W, &p)) return 0;
+    if ((2 * p.xs + 511) / 512 > 4) return 0;
+    return split_lds_bytes(p, split_nt(Cout)) <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin) { return (int64_t)Cout * Cin * 9 * 2; }
+
+extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, void* stream) {
+    SGDFR_REQUIRE(Cout > 0 && Cin > 0 && Cin % SPLIT_CB == 0 && Cout % 64 == 0,
+                  "prepack_split: needs Cin %% 16 == 0 and Cout %% 64 == 0, got Cin=%d Cout=%d", Cin, Cout);
+    SGDFR_REQUIRE(weight && wsp, "prepack_split: null pointer");
+    const int64_t n = (int64_t)Cout * Cin * 9;
+    int64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(prepack_split_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), weight, wsp, Cout, Cin,
+                       split_nt(Cout), 1.0f / sqrtf((float)Cin * 9));
+    return check_launch("modconv_prepack_split");
+}
+
+template <int WM, int WN>
+static int launch_split(const SplitParams& p, hipStream_t st) {
+    const int nex = (2 * p.xs + 511) / 512;
+    void (*kern)(SplitParams) = nex <= 2 ? split_mfma_kernel<WM, WN, 2> : nex == 3 ? split_mfma_kernel<WM, WN, 3>
+                                                                                   : split_mfma_kernel<WM, WN, 4>;
+    const size_t lds = split_lds_bytes(p, WM * 64);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+        return check_launch("modconv_split(lds attribute)");
+    hipLaunchKernelGGL(kern, dim3(p.n_pix_tiles * p.n_cout_tiles), dim3(512), lds, st, p);
+    return check_launch("modconv2d_split");
+}
+
+extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned short* wsp, const float* s,
+                                         const float* d, const float* noise, int64_t noise_bstride, const float* noise_w,
+                                         const float* bias, const float* zeros, float* y, int B, int Cin, int Cout, int H,
+                                         int W, int act, float slope, float gain, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "modconv_split: bad shape B=%d Cin=%d Cout=%d H=%d W=%d",
+                  B, Cin, Cout, H, W);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(sgdfr_modconv2d_split_supported(B, Cin, Cout, H, W),
+                  "modconv_split: shape B=%d Cin=%d Cout=%d H=%d W=%d not supported; use sgdfr_modconv2d_fwd_f32", B, Cin,
+                  Cout, H, W);
+    SGDFR_REQUIRE(x && wsp && s && y && zeros, "modconv_split: null pointer");
+    SGDFR_REQUIRE(!noise || noise_w, "modconv_split: noise without noise_w");
+    SGDFR_REQUIRE(((reinterpret_cast<uintptr_t>(wsp) | reinterpret_cast<uintptr_t>(s)) & 15) == 0,
+                  "modconv_split: wsp and s must be 16-byte aligned");
+    SplitParams p;
+    split_geometry(B, Cin, Cout, H, W, &p);
+    p.x = x; p.x_bstride = x_bstride; p.wsp = wsp; p.s = s; p.d = d; p.noise = noise; p.noise_bstride = noise_bstride;
+    p.noise_w = noise_w; p.bias = bias; p.zeros = zeros; p.y = y;
+    p.act = act; p.slope = slope; p.gain = gain;
+    hipStream_t st = as_stream(stream);
+    return split_nt(Cout) == 128 ? launch_split<2, 4>(p, st) : launch_split<1, 8>(p, st);
+}

@@ -5,6 +5,7 @@ nothing here computes with torch ops.  Reference lines each function stands for 
 (paths relative to the reference's libs/gan/StyleGAN2/).
 """
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -176,7 +177,18 @@ def _noise_args(noise, B, H, W):
 USE_SPLITK = True            # K-sliced launches for convs that cannot fill the chip (small batch / 4x4, 8x8 layers)
 USE_WINOGRAD = True          # plain 3x3 layers: Winograd F(2x2,3x3) MFMA kernel when the shape allows it
 WINOGRAD_MIN_BLOCKS = 256    # below this many (64 cout x 64 tile) blocks the direct kernel's smaller tiles win
+# Arithmetic of the plain 3x3 modulated convs.  'fp32' (default): fp32 MFMA, exact products.  'bf16x3': OPT-IN split
+# mode (csrc/split.hip): operands split in bf16 hi+lo, hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32
+# accumulation; ~1e-4 max-abs on the 256x256 generator (contract 1e-3).  Inference (no-grad) path only.
+PRECISION = os.environ.get('SGDFR_PRECISION', 'fp32')
 _zeros = {}
+
+
+def set_precision(mode):
+    global PRECISION
+    if mode not in ('fp32', 'bf16x3'):
+        raise ValueError("precision must be 'fp32' or 'bf16x3', got %r" % (mode,))
+    PRECISION = mode
 
 
 def _zero_words(device):
@@ -218,6 +230,41 @@ def modconv_wino(x, u, s, d, cout, noise=None, noise_weight=None, bias=None, act
     st = N.stream()
     _timed_conv(desc or ('wino3 %d->%d @%dx%d' % (cin, cout, H, W)), B * conv_flops(cin, cout, H, W), lambda: N.call(
         'sgdfr_modconv2d_wino_f32', N.ptr(x), xb, N.ptr(u), N.ptr(s), N.ptr(d), N.ptr(nz), nzb,
+        N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(_zero_words(x.device)), N.ptr(y), B, cin,
+        cout, H, W, int(activate), float(slope), float(gain), st))
+    return y
+
+
+def prepack_split(weight):
+    """weight [1,Cout,Cin,3,3] -> uint16 buffer of bf16 hi/lo terms of weight/sqrt(9 Cin) in split.hip's LDS order."""
+    N.require_device(weight)
+    w = N.f32c(weight)
+    _, cout, cin, k, _ = w.shape
+    n = N.load().sgdfr_modconv_prepack_split_elems(cout, cin)
+    wsp = torch.empty(n, device=w.device, dtype=torch.int16)
+    N.call('sgdfr_modconv_prepack_split_f32', N.ptr(w), N.ptr(wsp), cout, cin, N.stream())
+    return wsp
+
+
+def split_ok(B, cin, cout, H, W):
+    return PRECISION == 'bf16x3' and bool(N.load().sgdfr_modconv2d_split_supported(B, cin, cout, H, W))
+
+
+def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2,
+                  batch=None, desc=None):
+    """Plain 3x3 modulated conv in the bf16x3 split arithmetic (same contract as modconv_raw(mode PLAIN3))."""
+    N.require_device(x, s, d, bias, noise_weight)
+    if not wsp.is_cuda or wsp.dtype != torch.int16:
+        raise RuntimeError('modconv_split: wsp must be the int16 device buffer made by prepack_split')
+    x = N.f32c(x)
+    B = s.shape[0] if batch is None else batch
+    _, cin, H, W = x.shape
+    xb = 0 if (x.shape[0] == 1 and B != 1) else cin * H * W
+    nz, nzb = _noise_args(noise, B, H, W)
+    y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+    st = N.stream()
+    _timed_conv(desc or ('split3 %d->%d @%dx%d' % (cin, cout, H, W)), B * conv_flops(cin, cout, H, W), lambda: N.call(
+        'sgdfr_modconv2d_split_f32', N.ptr(x), xb, N.ptr(wsp), N.ptr(s), N.ptr(d), N.ptr(nz), nzb,
         N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(_zero_words(x.device)), N.ptr(y), B, cin,
         cout, H, W, int(activate), float(slope), float(gain), st))
     return y
@@ -269,7 +316,7 @@ def blur_bias_act(planes, fir, H, W, noise=None, noise_weight=None, bias=None, a
 
 
 def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_weight=None, bias=None,
-               activate=False, slope=0.2, gain=SQRT2, batch=None, return_planes=False, wino=None):
+               activate=False, slope=0.2, gain=SQRT2, batch=None, return_planes=False, wino=None, split=None):
     """Shared-weight modulated 3x3 conv (model.py:232-273) with the StyledConv tail fused in
     (noise model.py:287, bias + leaky-ReLU op/fused_act.py:81-86).
 
@@ -279,6 +326,9 @@ def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_we
     _, cin, H, W = x.shape
     if not upsample:
         B = s.shape[0] if batch is None else batch
+        if split is not None and split_ok(B, cin, cout, H, W):
+            return modconv_split(x, split() if callable(split) else split, s, d, cout, noise, noise_weight, bias,
+                                 activate, slope, gain, batch)
         if wino is not None and wino_ok(B, cin, cout, H, W):
             return modconv_wino(x, wino() if callable(wino) else wino, s, d, cout, noise, noise_weight, bias, activate,
                                 slope, gain, batch)

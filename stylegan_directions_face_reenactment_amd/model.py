@@ -181,6 +181,15 @@ class ModulatedConv2d(nn.Module):
                 cache[1 + int(adjoint)] = F_.prepack_wino(self.weight.detach(), adjoint=adjoint)
         return cache[1 + int(adjoint)]
 
+    def packed_split(self):
+        """bf16 hi/lo weight pack of the opt-in bf16x3 mode (functional.PRECISION), cached per weight version."""
+        key = self._key()
+        cache = getattr(self, '_pack_s', None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                cache = self._pack_s = (key, F_.prepack_split(self.weight.detach()))
+        return cache[1]
+
     def style_spec(self, latent_index):
         """(latent row, modulation weight, bias, Q or None, Cout) for functional.styles_batched."""
         q = self.packed()[1] if (self.kernel_size == 3 and self.demodulate) else None
@@ -208,7 +217,8 @@ class ModulatedConv2d(nn.Module):
         return F_.modconv3x3(input, self.packed()[0], s, d, self.out_channel, upsample=self.upsample,
                              fir=self.blur.kernel if self.upsample else None, noise=noise,
                              noise_weight=noise_weight, bias=bias, activate=activate, batch=batch,
-                             wino=None if self.upsample else self.packed_wino)
+                             wino=None if self.upsample else self.packed_wino,
+                             split=None if self.upsample else self.packed_split)
 
     def forward(self, input, style):
         if self.kernel_size == 1:

@@ -1,0 +1,68 @@
+"""Opt-in bf16x3 precision mode (csrc/split.hip): the plain 3x3 modulated conv with fp32 operands split into bf16
+hi + lo terms on the bf16 matrix cores.  Tolerances are those of the arithmetic (2^-17 per product), checked against
+the fp64 oracle per layer and end to end against the north-star contract (1e-3 max-abs; measured ~1e-4)."""
+import pytest
+import torch
+
+from util import O, S, SEED, hip_generator, maxabs, synthetic_state
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # cin, cout, H, B
+    (64, 64, 16, 3),      # NT=64 / PT=512: two images per tile, ragged batch
+    (128, 128, 32, 2),    # NT=128 / PT=256 inside one image
+    (64, 128, 4, 20),     # 16 images per tile, partial last tile
+    (32, 64, 8, 5),
+    (48, 192, 64, 1),     # 3 channel blocks, NT=64 with 3 cout tiles
+    (64, 64, 128, 1),     # 4 x 128 patches
+    (32, 128, 128, 2),    # 2 x 128 patches
+    (16, 64, 256, 1),     # patches on a 256-wide image
+]
+
+
+def _oracle(x, w, s, d, noise, nw, bias):
+    x, w, s, d = x.double().cpu(), w.double().cpu(), s.double().cpu(), d.double().cpu()
+    cin = x.shape[1]
+    y = torch.nn.functional.conv2d(x * s[:, :, None, None], w[0] / (cin * 9) ** 0.5, padding=1) * d[:, :, None, None]
+    y = y + nw.double().cpu() * noise.double().cpu() + bias.double().cpu().view(1, -1, 1, 1)
+    return torch.nn.functional.leaky_relu(y, 0.2) * 2 ** 0.5
+
+
+@pytest.mark.parametrize('cin,cout,H,B', CASES)
+def test_split_conv_matches_fp64_oracle(cin, cout, H, B):
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    key = 'split.%d.%d.%d.%d' % (cin, cout, H, B)
+    w = S.counter_tensor(3, key + '.w', (1, cout, cin, 3, 3)).cuda()
+    x = S.counter_tensor(3, key + '.x', (B, cin, H, H)).cuda()
+    s = S.counter_tensor(3, key + '.s', (B, cin), 1.0, 0.3).cuda()
+    d = S.counter_tensor(3, key + '.d', (B, cout), 1.0, 0.2).cuda()
+    noise = S.counter_tensor(3, key + '.n', (1, 1, H, H)).cuda()
+    nw = torch.full((1,), 0.1).cuda()
+    bias = S.counter_tensor(3, key + '.b', (cout,), 0.0, 0.1).cuda()
+    assert F_.N.load().sgdfr_modconv2d_split_supported(B, cin, cout, H, H)
+    y = F_.modconv_split(x, F_.prepack_split(w), s, d, cout, noise, nw, bias, True)
+    ref = _oracle(x, w, s, d, noise, nw, bias)
+    err = maxabs(y, ref)
+    assert err <= 1e-4 * max(1.0, float(ref.abs().max())), err
+    # and it really is more than a single bf16 product (which would be ~4e-3)
+    assert err < 5e-5 * float(ref.abs().max()) + 1e-5
+
+
+def test_split_generator_within_contract():
+    """End to end at 64x64 and 256x256: bf16x3 plain convs (transposed convs stay fp32) vs the fp64 oracle."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    for size, B in ((64, 3), (256, 2)):
+        G = hip_generator(size, 1)
+        w = S.synthetic_latents(SEED, B, n_latent=G.n_latent, key='split.w').cuda()
+        P64 = O.cast_state(synthetic_state(size, 1), torch.float64)
+        with torch.no_grad():
+            ref, _ = O.generator_forward(P64, [w.double().cpu()], input_is_latent=True)
+            exact, _ = G([w], input_is_latent=True)
+            F_.set_precision('bf16x3')
+            try:
+                fast, _ = G([w], input_is_latent=True)
+            finally:
+                F_.set_precision('fp32')
+        e_exact, e_fast = maxabs(exact, ref), maxabs(fast, ref)
+        assert e_exact <= 1e-4 and e_fast <= 5e-4, (size, e_exact, e_fast)      # contract: 1e-3
+        assert e_fast > 0 and not torch.equal(fast, exact)                       # the split kernels really ran
