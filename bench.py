@@ -94,6 +94,10 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--layers', action='store_true', help='also print the per-layer conv table to stderr')
+    ap.add_argument('--precision', choices=('fp32', 'bf16x3'), default='fp32',
+                    help="arithmetic of the 3x3 convs for the HEADLINE value: exact fp32 MFMA (default) or the opt-in split "
+                         "mode (bf16 hi+lo operands on the bf16 matrix cores, fp32 accumulation)")
+    ap.add_argument('--no-alt', action='store_true', help='skip the extra bf16x3 leg of the default fp32 run')
     args = ap.parse_args()
 
     rank, local_rank, world = D.init_from_env()
@@ -121,6 +125,7 @@ def main():
         img, _ = G([w], input_is_latent=True)
         return img
 
+    F_.set_precision(args.precision)
     with torch.no_grad():
         for _ in range(max(args.warmup, 1)):
             img = step()
@@ -141,6 +146,31 @@ def main():
             step()
         torch.cuda.synchronize()
         rec, F_.CONV_TIMING = F_.CONV_TIMING, None
+
+        # ---- extra leg (fp32 runs only): the same steps in the opt-in bf16x3 mode + its deviation from the fp32 images
+        alt = None
+        if args.precision == 'fp32' and not args.no_alt:
+            exact = step()
+            F_.set_precision('bf16x3')
+            try:
+                for _ in range(max(args.warmup, 1)):
+                    fast = step()
+                D.barrier()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                D.barrier()
+                alt_elapsed = D.max_over_ranks(time.perf_counter() - t1, dev)
+            finally:
+                F_.set_precision('fp32')
+            alt = {'value': round(B * world * args.steps / alt_elapsed, 2), 'unit': 'frames/s',
+                   'ms_per_step': round(alt_elapsed / args.steps * 1e3, 3),
+                   'max_abs_vs_fp32_path': float((fast - exact).abs().max()),
+                   'note': 'opt-in SGDFR_PRECISION=bf16x3: 3x3 conv operands split in bf16 hi+lo, hi*hi+hi*lo+lo*hi on '
+                           'v_mfma_f32_32x32x16_bf16, fp32 accumulate; contract is 1e-3 max-abs, uint8 step is 7.8e-3; '
+                           'NOT the headline value'}
     per_layer = {}
     for e0, e1, flops, desc in rec:
         a = per_layer.setdefault(desc, [0.0, 0.0, 0])
@@ -166,7 +196,7 @@ def main():
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f32',
+        'dtype': 'f32' if args.precision == 'fp32' else 'bf16x3 split of f32 (f32 accumulate)',
         'data': 'synthetic',
         'config': {'workload': '%dxMI355X HIP synthesis-only: Generator(%d,512,8,cm=%d), random w+ [%d,14,512] per GPU, '
                                'fixed noise, psi=1' % (world, args.size, args.cm, B),
@@ -180,6 +210,13 @@ def main():
                      'conv_ms_per_step': round(conv_s / args.steps * 1e3, 3),
                      'alg_gflop_per_frame': round(conv_flops / (B * args.steps) / 1e9, 3)},
     }
+    if alt is not None:
+        out['alt_precision_bf16x3'] = alt
+    if args.precision != 'fp32':
+        # algorithmic fp32 FLOPs over time, against the dense bf16 MFMA peak / 3 products (SURVEY.md §8d rule)
+        out['roofline'].update({'kernel': 'split_mfma_kernel (13 conv launches/forward, bf16x3)', 'peak': round(2500.0 / 3, 1),
+                                'frac': round(achieved / (2500.0 / 3), 4), 'traffic': None,
+                                'peak_note': 'dense bf16 MFMA peak 2.5 PFLOP/s / 3 split products'})
     if args.layers:
         for desc, (sec, fl, n) in per_layer.items():
             sys.stderr.write('%-28s %8.1f us/launch %7.1f TFLOP/s\n' % (desc, sec / n * 1e6, fl / sec / 1e12))

@@ -170,21 +170,27 @@ int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const float* noise
 int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, const float* bias, const float* skip,
                         const float* fir, float* y, int B, int Cin, int H, int W, void* stream);
 
-/* Opt-in "bf16x3" precision mode of the plain 3x3 modulated conv (same contract as sgdfr_modconv2d_fwd_f32 mode PLAIN3,
+/* Opt-in "bf16x3" precision mode of the 3x3 modulated convs (same contract as sgdfr_modconv2d_fwd_f32 modes PLAIN3 / UP3,
  * ModulatedConv2d.forward model.py:232-273): fp32 operands are split into bf16 hi + lo terms and contracted as
  * hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~2^-17 relative error per product; the
  * whole 256x256 generator stays within 1.1e-4 max-abs of the fp64 oracle, contract 1e-3).  Never selected implicitly.
  *   sgdfr_modconv_prepack_split_elems: uint16 elements of the packed weight buffer (= 2*9*Cout*Cin)
  *   sgdfr_modconv_prepack_split_f32:   weight [Cout,Cin,3,3] -> bf16 hi/lo of weight/sqrt(9 Cin) in kernel order
  *   sgdfr_modconv2d_split_supported:   1 when the shape can use it (Cin % 16 == 0, Cout % 64 == 0, tileable H x W)
- *   sgdfr_modconv2d_split_f32:         arguments as sgdfr_modconv2d_wino_f32 with wsp in place of u */
+ *   sgdfr_modconv2d_split_f32:         arguments as sgdfr_modconv2d_wino_f32 with wsp in place of u, plus mode:
+ *                                      PLAIN3, or UP3 = stride-2 transposed conv into parity planes
+ *                                      [B,Cout,4,H+1,W+1] exactly as sgdfr_modconv2d_fwd_f32(mode UP3) writes them;
+ *                                      ksplit > 1 (see ..._ksplit_hint; layers too small to fill the chip) slices the
+ *                                      channel blocks over extra thread blocks into `partials` [ksplit][numel(y)] and
+ *                                      reduces them in fixed order (deterministic) */
 int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin);
 int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, void* stream);
-int sgdfr_modconv2d_split_supported(int B, int Cin, int Cout, int H, int W);
+int sgdfr_modconv2d_split_supported(int B, int Cin, int Cout, int H, int W, int mode);
 int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned short* wsp, const float* s, const float* d,
                               const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
-                              const float* zeros, float* y, int B, int Cin, int Cout, int H, int W, int act, float slope,
-                              float gain, void* stream);
+                              const float* zeros, float* y, float* partials, int ksplit, int B, int Cin, int Cout, int H,
+                              int W, int mode, int act, float slope, float gain, void* stream);
+int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, int mode);
 
 /* x [B,3,H,W] fp32 -> y [B,H,W,3] uint8:  trunc( (clamp(x,-1,1) + 1) / (2 + 1e-5) * 255 )
  * (libs/utilities/image_utils.py:87-110 tensor_to_image / torch_range_1_to_255, then the writers' uint8 cast) */

@@ -24,7 +24,9 @@ def main():
             s = torch.randn(B, cin, device='cuda'); d = torch.rand(B, cout, device='cuda') + 0.5
             wp, q, qt = F_.prepack(w); fl = B * F_.conv_flops(cin, cout, h, h)
             t = bench(lambda: F_.modconv_raw(x, wp, s, d, cout, N.MODE_UP3, h, h))
-            print('up %4d->%4d @%3d: %7.1f us %6.1f TF' % (cin, cout, h, t * 1e6, fl / t / 1e12), flush=True)
+            wsp = F_.prepack_split(w)
+            t2 = bench(lambda: F_.modconv_split(x, wsp, s, d, cout, mode=N.MODE_UP3))
+            print('up %4d->%4d @%3d: fp32 %7.1f us %6.1f TF | bf16x3 %7.1f us %6.1f TF-eq' % (cin, cout, h, t * 1e6, fl / t / 1e12, t2 * 1e6, fl / t2 / 1e12), flush=True)
         return
     for cin, cout, h in shapes:
         w = torch.randn(1, cout, cin, 3, 3, device='cuda')

@@ -23,6 +23,11 @@ int check_launch(const char* what);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// y = act( sum_s partials[s] + noise_w*noise + bias ), fixed order (modconv.hip); `inner` = elements per (b, c) plane
+int launch_splitk_reduce(const float* partials, int splits, int64_t n, const float* noise, int64_t noise_bstride,
+                         const float* noise_w, const float* bias, float* y, int C, int inner, int act, float slope, float gain,
+                         hipStream_t st);
+
 constexpr int kWave = 64;  // gfx950 wavefront
 
 __device__ __forceinline__ float lrelu_gain(float v, float slope, float gain) {

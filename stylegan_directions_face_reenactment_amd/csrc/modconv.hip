@@ -365,6 +365,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+int launch_splitk_reduce(const float* partials, int splits, int64_t n, const float* noise, int64_t noise_bstride,
+                         const float* noise_w, const float* bias, float* y, int C, int inner, int act, float slope, float gain,
+                         hipStream_t st) {
+    int64_t g = (n + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, st, partials, splits, n, noise, noise_bstride, noise_w,
+                       bias, y, n, C, inner, act, slope, gain);
+    return check_launch("splitk_reduce");
+}
+
 // ---------------------------------------------------------------- odd-shape path
 // Channel counts that are not multiples of 4 never occur in the generator (512..16 channels) but the
 // ModulatedConv2d API accepts them: one thread per output element, same packed weights, same output
@@ -748,11 +758,7 @@ extern "C" int sgdfr_modconv2d_splitk_f32(const float* x, int64_t x_bstride, con
         rc = launch_modconv<SGDFR_MODE_UP3, 2, 2, 1, 1, 3, 3>(p, st);
     }
     if (rc) return rc;
-    int64_t g = (n + 255) / 256;
-    if (g > 256 * 16) g = 256 * 16;
     const bool plain = mode == SGDFR_MODE_PLAIN3;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, st, partials, splits, n, plain ? noise : nullptr,
-                       noise_bstride, noise_w, plain ? bias : nullptr, y, n, Cout, plain ? H * W : 1, plain ? act : 0, slope,
-                       gain);
-    return check_launch("modconv2d_splitk(reduce)");
+    return launch_splitk_reduce(partials, splits, n, plain ? noise : nullptr, noise_bstride, noise_w, plain ? bias : nullptr, y,
+                                Cout, plain ? H * W : 1, plain ? act : 0, slope, gain, st);
 }

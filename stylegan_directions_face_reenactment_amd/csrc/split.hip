@@ -54,6 +54,9 @@ struct SplitParams {
     int64_t total_pix;
     int act;
     float slope, gain;
+    int ksplit;                  // K (channel-block) slices; > 1: slice ks writes d * partial sums to y + ks*split_stride
+    int64_t split_stride;
+    int stagger;                 // which waves run MFMAs before staging inside a sub-stage (0 none, 1 waves 4-7, 2 odd waves)
 };
 
 constexpr int SPLIT_CB = 16;     // input channels per K block (one MFMA K)
@@ -74,10 +77,15 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
     lo = __builtin_bit_cast(unsigned, l);
 }
 
-template <int WM, int WN, int NEX>
+// MODE PLAIN3: y = conv3x3(x*s) * d (+ noise, bias, activation).  MODE UP3: stride-2 transposed conv into the four
+// output-parity planes T[B,Cout,4,H+1,W+1] (same contract as modconv.hip): one "pixel" is a super-pixel of the padded
+// flat space, each of the 9 taps feeds the accumulator set of its parity phase.
+template <int MODE, int WM, int WN, int MI, int NI, int NEX>
 __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
     constexpr int NTHR = 512;
-    constexpr int NT = WM * 64, PT = WN * 64;
+    constexpr int NT = WM * MI * 32, PT = WN * NI * 32;
+    constexpr bool UP = (MODE == SGDFR_MODE_UP3);
+    constexpr int PH = UP ? 4 : 1;
     static_assert(WM * WN == 8, "8 waves per block");
     constexpr int WROW_BYTES = NT * 192;                 // [3 kx][2 part][2 k-half][NT][8] bf16
     constexpr int WCHUNKS = WROW_BYTES / 1024;           // 64-lane x 16-byte DMA pieces
@@ -98,7 +106,10 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
-    const int ct = lid / p.n_pix_tiles, pt = lid - ct * p.n_pix_tiles;
+    const int tiles_per_slice = p.n_pix_tiles * p.n_cout_tiles;
+    const int ks = lid / tiles_per_slice;                 // K slice of this block (0 when ksplit == 1)
+    const int lt = lid - ks * tiles_per_slice;
+    const int ct = lt / p.n_pix_tiles, pt = lt - ct * p.n_pix_tiles;
     const int n0 = ct * NT;
 
     // ---- tile origin
@@ -110,6 +121,9 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
         row0 = ty * p.TR;
         col0 = tx * p.TC;
+    } else if (UP) {
+        q0 = pt * PT;                       // super-pixels ARE positions of the padded flat space
+        img0 = q0 / (p.R * p.P);
     } else {
         const int p0 = pt * PT;
         img0 = p0 / HW;
@@ -119,15 +133,26 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
     }
 
     // ---- this lane's two output pixels: position inside the staged range, and where they are stored
-    int boff[2];
-    int64_t ybase[2];     // (img*Cout)*HW + rem, or -1 when the pixel does not exist
-    int64_t nzoff[2];
-    int dimg[2];
+    int boff[NI];
+    int64_t ybase[NI];    // (img*Cout)*HW + rem (UP3: (img*Cout*4)*RP + rem), or -1 when the pixel does not exist
+    int64_t nzoff[NI];
+    int dimg[NI];
     const int pitch = p.patch ? p.seglen : p.P;
+    const int RP = p.R * p.P;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int l = (wn * 2 + n) * 32 + l31;
-        if (p.patch) {
+    for (int n = 0; n < NI; ++n) {
+        const int l = (wn * NI + n) * 32 + l31;
+        if (UP) {
+            int64_t pix = (int64_t)pt * PT + l;
+            const bool ok = pix < p.total_pix;
+            if (!ok) pix = p.total_pix - 1;
+            const int img = (int)(pix / RP);
+            const int rem = (int)(pix - (int64_t)img * RP);
+            boff[n] = l;
+            ybase[n] = ok ? (int64_t)img * p.Cout * 4 * RP + rem : -1;
+            nzoff[n] = 0;
+            dimg[n] = img;
+        } else if (p.patch) {
             const int r = l / p.TC, c = l - r * p.TC;
             boff[n] = (r + 1) * p.seglen + c + 1;
             const int rem = (row0 + r) * p.W + col0 + c;
@@ -181,13 +206,15 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
         ldst[e] = (h * p.xs + j) * 16;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[PH][MI][NI];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int ph = 0; ph < PH; ++ph)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int m = 0; m < MI; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+            for (int n = 0; n < NI; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ph][m][n][r] = 0.f;
 
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
@@ -212,8 +239,9 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
         *reinterpret_cast<uint4*>(xb + ldst[e]) = vh;
         *reinterpret_cast<uint4*>(xb + 32 * p.xs + ldst[e]) = vl;
     };
-    const int ncb = p.Cin / SPLIT_CB;
-    const unsigned char* const wglb = reinterpret_cast<const unsigned char*>(p.wsp) + (int64_t)ct * ncb * 3 * WROW_BYTES;
+    const int ncb_all = p.Cin / SPLIT_CB;
+    const int cb0 = (int)((int64_t)ncb_all * ks / p.ksplit), ncb = (int)((int64_t)ncb_all * (ks + 1) / p.ksplit);
+    const unsigned char* const wglb = reinterpret_cast<const unsigned char*>(p.wsp) + (int64_t)ct * ncb_all * 3 * WROW_BYTES;
     auto issue_w = [&](int u) {      // row slab u = cb*3 + ky -> ring slot u & 1
         const unsigned char* src = wglb + (int64_t)u * WROW_BYTES;
         unsigned char* dst = wb0 + (u & 1) * WROW_BYTES;
@@ -233,13 +261,13 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < NEX; ++e) load_x(e, 0);
+    for (int e = 0; e < NEX; ++e) load_x(e, cb0);
 #pragma unroll
-    for (int e = 0; e < NEX; ++e) convert_store(e, 0, xb0);
-    issue_w(0);
-    if (ncb > 1) {
+    for (int e = 0; e < NEX; ++e) convert_store(e, cb0, xb0 + (cb0 & 1) * xbuf_bytes);
+    issue_w(cb0 * 3);
+    if (ncb > cb0 + 1) {
 #pragma unroll
-        for (int e = 0; e < NEX; ++e) load_x(e, 1);
+        for (int e = 0; e < NEX; ++e) load_x(e, cb0 + 1);
         split_wait_vmcnt<NEX * 8>();
     } else {
         split_wait_vmcnt<0>();
@@ -247,8 +275,10 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    const int aoff = (hi * NT + wm * 64 + l31) * 16;
-    for (int cb = 0; cb < ncb; ++cb) {
+    const int aoff = (hi * NT + wm * (MI * 32) + l31) * 16;
+    const bool stagger = (p.stagger & 3) == 1 ? (wave >= 4) : (p.stagger & 3) == 2 ? (wave & 1) : false;
+    const bool dbg_nowait = p.stagger & 8, dbg_nostage = p.stagger & 16, dbg_nomfma = p.stagger & 32;
+    for (int cb = cb0; cb < ncb; ++cb) {
         const unsigned char* xcur = xb0 + (cb & 1) * xbuf_bytes;
         unsigned char* xnext = xb0 + ((cb + 1) & 1) * xbuf_bytes;
         const bool conv_next = cb + 1 < ncb, load_next = cb + 2 < ncb;
@@ -257,40 +287,114 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
             const int u = cb * 3 + ky;
             const bool more_w = u + 1 < ncb * 3;
             if (more_w) issue_w(u + 1);
+            __builtin_amdgcn_sched_barrier(0);
             constexpr int kSlots[3] = {(NEX + 2) / 3, (NEX + 1) / 3, NEX / 3};
-            if (conv_next) {
+            // one third of the next channel block's activations: registers -> hi/lo -> LDS, then refill the registers
+            auto stage_part = [&]() {
+                if (conv_next) {
 #pragma unroll
-                for (int e = ky; e < NEX; e += 3) {
-                    convert_store(e, cb + 1, xnext);
-                    if (load_next) load_x(e, cb + 2);
-                }
-            }
-            const unsigned char* wcur = wb0 + (u & 1) * WROW_BYTES + aoff;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int tapoff = (ky - 1) * pitch + (kx - 1);
-                bf16x8 a[2][2], b[2][2];     // [part][tile]
-#pragma unroll
-                for (int part = 0; part < 2; ++part)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        a[part][m] = *reinterpret_cast<const bf16x8*>(wcur + ((kx * 2 + part) * 2) * (NT * 16) + m * 512);
-#pragma unroll
-                for (int part = 0; part < 2; ++part)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        b[part][n] = *reinterpret_cast<const bf16x8*>(xcur + part * 32 * p.xs + (boff[n] + tapoff) * 16);
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][m], b[0][n], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][m], b[1][n], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][m], b[0][n], acc[m][n], 0, 0, 0);
+                    for (int e = ky; e < NEX; e += 3) {
+                        convert_store(e, cb + 1, xnext);
+                        if (load_next) load_x(e, cb + 2);
                     }
-            }
+                }
+            };
+            const unsigned char* wcur = wb0 + (u & 1) * WROW_BYTES + aoff;
+            auto mfma_part = [&]() {
+                if (UP) {
+                    // taps (ky, kx): x[a-(ky==2), b-(kx==2)] -> offsets rowoff + {1, 1, 0}; phase = 2*(ky&1) + (kx&1).
+                    // The row's 8 activation fragments are read once; weight fragments of tap kx+1 are requested
+                    // while the MFMAs of tap kx run.
+                    const int rowoff = (ky == 2) ? 0 : p.P;
+                    bf16x8 b[2][2][NI];   // [column offset 0/1][part][tile]
+                    bf16x8 a[2][2][MI];   // [set][part][tile]
+                    auto fetch_a = [&](int set, int kx) {
+#pragma unroll
+                        for (int part = 0; part < 2; ++part)
+#pragma unroll
+                            for (int m = 0; m < MI; ++m)
+                                a[set][part][m] =
+                                    *reinterpret_cast<const bf16x8*>(wcur + ((kx * 2 + part) * 2) * (NT * 16) + m * 512);
+                    };
+                    fetch_a(0, 0);
+#pragma unroll
+                    for (int part = 0; part < 2; ++part)
+#pragma unroll
+                        for (int o = 1; o >= 0; --o)
+#pragma unroll
+                            for (int n = 0; n < NI; ++n)
+                                b[o][part][n] =
+                                    *reinterpret_cast<const bf16x8*>(xcur + part * 32 * p.xs + (boff[n] + rowoff + o) * 16);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int ph = 2 * (ky & 1) + (kx & 1);
+                        const int o = (kx == 2) ? 0 : 1;
+                        const int cur = kx & 1;
+                        if (kx < 2) fetch_a(cur ^ 1, kx + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)          // product term outermost: dependent MFMAs are MI*NI apart
+#pragma unroll
+                            for (int m = 0; m < MI; ++m)
+#pragma unroll
+                                for (int n = 0; n < NI; ++n)
+                                    acc[ph][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][t == 2][m], b[o][t == 1][n],
+                                                                                            acc[ph][m][n], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    // software pipeline over the 3 taps of the row: after the hi*hi MFMAs of tap kx are issued, the
+                    // fragments of tap kx+1 are requested (second register set) and land behind the other 8 MFMAs
+                    bf16x8 a[2][2][MI], b[2][2][NI];     // [set][part][tile]
+                    auto fetch = [&](int set, int kx) {
+                        const int tapoff = (ky - 1) * pitch + (kx - 1);
+#pragma unroll
+                        for (int part = 0; part < 2; ++part) {
+#pragma unroll
+                            for (int m = 0; m < MI; ++m)
+                                a[set][part][m] =
+                                    *reinterpret_cast<const bf16x8*>(wcur + ((kx * 2 + part) * 2) * (NT * 16) + m * 512);
+#pragma unroll
+                            for (int n = 0; n < NI; ++n)
+                                b[set][part][n] =
+                                    *reinterpret_cast<const bf16x8*>(xcur + part * 32 * p.xs + (boff[n] + tapoff) * 16);
+                        }
+                    };
+                    fetch(0, 0);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int cur = kx & 1;
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int m = 0; m < MI; ++m)
+#pragma unroll
+                            for (int n = 0; n < NI; ++n)
+                                acc[0][m][n] =
+                                    __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0][m], b[cur][0][n], acc[0][m][n], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (kx < 2) fetch(cur ^ 1, kx + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 1; t < 3; ++t)
+#pragma unroll
+                            for (int m = 0; m < MI; ++m)
+#pragma unroll
+                                for (int n = 0; n < NI; ++n)
+                                    acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][t == 2][m], b[cur][t == 1][n],
+                                                                                           acc[0][m][n], 0, 0, 0);
+                    }
+                }
+            };
+            // the two waves of a SIMD (w, w+4) run the two parts in opposite order, so one converts while the other
+            // keeps the matrix core busy
+            if (!stagger && !dbg_nostage) stage_part();
+            __builtin_amdgcn_sched_barrier(0);
+            if (!dbg_nomfma) mfma_part();
+            __builtin_amdgcn_sched_barrier(0);
+            if (stagger && !dbg_nostage) stage_part();
             if (more_w) {
-                if (conv_next && load_next) {
+                if (dbg_nowait) {
+                } else if (conv_next && load_next) {
                     if (kSlots[ky] == 0) split_wait_vmcnt<0>();
                     else if (kSlots[ky] == 1) split_wait_vmcnt<8>();
                     else split_wait_vmcnt<16>();
@@ -304,22 +408,42 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
     }
 
     // ---- epilogue.  C/D layout of 32x32: column (pixel) = lane&31, row (cout) = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const float nw = (p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
+    if (UP) {
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
+        for (int n = 0; n < NI; ++n) {
+            if (ybase[n] < 0) continue;
+#pragma unroll
+            for (int m = 0; m < MI; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = n0 + wm * (MI * 32) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float dv = p.d ? p.d[(int64_t)dimg[n] * p.Cout + co] : 1.f;
+                    float* dst = p.y + (int64_t)ks * p.split_stride + ybase[n] + (int64_t)co * 4 * RP;
+#pragma unroll
+                    for (int ph = 0; ph < PH; ++ph) dst[(int64_t)ph * RP] = acc[ph][m][n][r] * dv;
+                }
+            }
+        }
+        return;
+    }
+    const bool whole = p.ksplit == 1;     // K slices only scale by d; noise / bias / activation follow the reduction
+    float* const yout = p.y + (int64_t)ks * p.split_stride;
+    const float nw = (whole && p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
         if (ybase[n] < 0) continue;
-        const float nz = p.noise ? nw * p.noise[nzoff[n]] : 0.f;
+        const float nz = (whole && p.noise) ? nw * p.noise[nzoff[n]] : 0.f;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < MI; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = n0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                float v = acc[m][n][r];
+                const int co = n0 + wm * (MI * 32) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float v = acc[0][m][n][r];
                 if (p.d) v *= p.d[(int64_t)dimg[n] * p.Cout + co];
                 v += nz;
-                if (p.bias) v += p.bias[co];
-                if (p.act) v = lrelu_gain(v, p.slope, p.gain);
-                p.y[ybase[n] + (int64_t)co * HW] = v;
+                if (whole && p.bias) v += p.bias[co];
+                if (whole && p.act) v = lrelu_gain(v, p.slope, p.gain);
+                yout[ybase[n] + (int64_t)co * HW] = v;
             }
         }
     }
@@ -356,15 +480,25 @@ using namespace sgdfr;
 static int split_nt(int Cout) { return (Cout % 128 == 0) ? 128 : 64; }
 
 // geometry of the pixel tiling; returns 0 when the shape cannot use the split kernel
-static int split_geometry(int B, int Cin, int Cout, int H, int W, SplitParams* out) {
+static int split_up_pt(int Cout) { return split_nt(Cout) == 128 ? 128 : 256; }
+
+static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, SplitParams* out) {
     if (Cin % SPLIT_CB != 0 || Cout % 64 != 0 || B < 1) return 0;
+    if (mode != SGDFR_MODE_PLAIN3 && mode != SGDFR_MODE_UP3) return 0;
     SplitParams p{};
     const int NT = split_nt(Cout), PT = (NT == 128) ? 256 : 512;
     const int HW = H * W;
     p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.P = W + 1; p.R = H + 1;
     p.total_pix = (int64_t)B * HW;
     if ((int64_t)B * p.R * p.P + 4ll * p.P + 8 >= (1ll << 31) || p.total_pix >= (1ll << 31)) return 0;
-    if (W > 64) {
+    if (mode == SGDFR_MODE_UP3) {
+        const int UPT = split_up_pt(Cout);
+        p.patch = 0;
+        p.total_pix = (int64_t)B * p.R * p.P;            // super-pixels
+        p.xlen = UPT + p.P + 2;
+        p.simgs = (p.xlen - 1) / (p.R * p.P) + 2;
+        p.n_pix_tiles = (int)((p.total_pix + UPT - 1) / UPT);
+    } else if (W > 64) {
         p.patch = 1;
         p.TC = 128;
         p.TR = PT / p.TC;
@@ -399,11 +533,23 @@ static size_t split_lds_bytes(const SplitParams& p, int NT) {
     return 2 * (size_t)64 * p.xs + 2 * (size_t)NT * 192 + (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float);
 }
 
-extern "C" int sgdfr_modconv2d_split_supported(int B, int Cin, int Cout, int H, int W) {
+extern "C" int sgdfr_modconv2d_split_supported(int B, int Cin, int Cout, int H, int W, int mode) {
     SplitParams p;
-    if (!split_geometry(B, Cin, Cout, H, W, &p)) return 0;
-    if ((2 * p.xs + 511) / 512 > 4) return 0;
+    if (!split_geometry(B, Cin, Cout, H, W, mode, &p)) return 0;
+    if ((2 * p.xs + 511) / 512 > (mode == SGDFR_MODE_UP3 ? 3 : 4)) return 0;
     return split_lds_bytes(p, split_nt(Cout)) <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, int mode) {
+    SplitParams p;
+    if (!split_geometry(B, Cin, Cout, H, W, mode, &p)) return 1;
+    const int blocks = p.n_pix_tiles * p.n_cout_tiles;
+    if (blocks >= 192) return 1;
+    int s = 512 / blocks;                       // aim at ~2 resident-size waves of blocks
+    const int max_by_k = (Cin / SPLIT_CB) / 2;  // at least 2 channel blocks per slice
+    if (s > max_by_k) s = max_by_k;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : s;
 }
 
 extern "C" int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin) { return (int64_t)Cout * Cin * 9 * 2; }
@@ -420,38 +566,63 @@ extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned sho
     return check_launch("modconv_prepack_split");
 }
 
-template <int WM, int WN>
+template <int MODE, int WM, int WN, int MI, int NI>
 static int launch_split(const SplitParams& p, hipStream_t st) {
     const int nex = (2 * p.xs + 511) / 512;
-    void (*kern)(SplitParams) = nex <= 2 ? split_mfma_kernel<WM, WN, 2> : nex == 3 ? split_mfma_kernel<WM, WN, 3>
-                                                                                   : split_mfma_kernel<WM, WN, 4>;
-    const size_t lds = split_lds_bytes(p, WM * 64);
+    constexpr int NEX_MAX = (MODE == SGDFR_MODE_UP3) ? 3 : 4;   // UP3 stages at most PT + P + 2 positions
+    SGDFR_REQUIRE(nex <= NEX_MAX, "modconv_split: staged range %d too long for mode %d", p.xlen, MODE);
+    void (*kern)(SplitParams) = nex <= 2   ? split_mfma_kernel<MODE, WM, WN, MI, NI, 2>
+                                : nex == 3 ? split_mfma_kernel<MODE, WM, WN, MI, NI, 3>
+                                           : split_mfma_kernel<MODE, WM, WN, MI, NI, NEX_MAX>;
+    const size_t lds = split_lds_bytes(p, WM * MI * 32);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess)
         return check_launch("modconv_split(lds attribute)");
-    hipLaunchKernelGGL(kern, dim3(p.n_pix_tiles * p.n_cout_tiles), dim3(512), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(p.n_pix_tiles * p.n_cout_tiles * p.ksplit), dim3(512), lds, st, p);
     return check_launch("modconv2d_split");
 }
 
 extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned short* wsp, const float* s,
                                          const float* d, const float* noise, int64_t noise_bstride, const float* noise_w,
-                                         const float* bias, const float* zeros, float* y, int B, int Cin, int Cout, int H,
-                                         int W, int act, float slope, float gain, void* stream) {
+                                         const float* bias, const float* zeros, float* y, float* partials, int ksplit,
+                                         int B, int Cin, int Cout, int H, int W, int mode, int act, float slope, float gain,
+                                         void* stream) {
     SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "modconv_split: bad shape B=%d Cin=%d Cout=%d H=%d W=%d",
                   B, Cin, Cout, H, W);
     if (B == 0) return 0;
-    SGDFR_REQUIRE(sgdfr_modconv2d_split_supported(B, Cin, Cout, H, W),
-                  "modconv_split: shape B=%d Cin=%d Cout=%d H=%d W=%d not supported; use sgdfr_modconv2d_fwd_f32", B, Cin,
-                  Cout, H, W);
+    SGDFR_REQUIRE(sgdfr_modconv2d_split_supported(B, Cin, Cout, H, W, mode),
+                  "modconv_split: shape B=%d Cin=%d Cout=%d H=%d W=%d mode=%d not supported; use sgdfr_modconv2d_fwd_f32", B,
+                  Cin, Cout, H, W, mode);
+    SGDFR_REQUIRE(mode == SGDFR_MODE_PLAIN3 || (!noise && !bias && !act), "modconv_split: UP3 writes raw parity planes "
+                  "(noise / bias / activation belong to sgdfr_blur_bias_act_f32)");
     SGDFR_REQUIRE(x && wsp && s && y && zeros, "modconv_split: null pointer");
     SGDFR_REQUIRE(!noise || noise_w, "modconv_split: noise without noise_w");
     SGDFR_REQUIRE(((reinterpret_cast<uintptr_t>(wsp) | reinterpret_cast<uintptr_t>(s)) & 15) == 0,
                   "modconv_split: wsp and s must be 16-byte aligned");
     SplitParams p;
-    split_geometry(B, Cin, Cout, H, W, &p);
+    split_geometry(B, Cin, Cout, H, W, mode, &p);
     p.x = x; p.x_bstride = x_bstride; p.wsp = wsp; p.s = s; p.d = d; p.noise = noise; p.noise_bstride = noise_bstride;
     p.noise_w = noise_w; p.bias = bias; p.zeros = zeros; p.y = y;
     p.act = act; p.slope = slope; p.gain = gain;
+    if (ksplit < 1) ksplit = 1;
+    SGDFR_REQUIRE(ksplit == 1 || (partials && ksplit <= Cin / SPLIT_CB), "modconv_split: ksplit %d needs a partials buffer "
+                  "and at most %d slices", ksplit, Cin / SPLIT_CB);
+    const int64_t n_out = (mode == SGDFR_MODE_UP3) ? (int64_t)B * Cout * 4 * p.R * p.P : (int64_t)B * Cout * H * W;
+    p.ksplit = ksplit;
+    p.split_stride = n_out;
+    if (ksplit > 1) p.y = partials;
+    static const int stagger = getenv("SGDFR_SPLIT_STAGGER") ? atoi(getenv("SGDFR_SPLIT_STAGGER")) : 1;
+    p.stagger = stagger;
     hipStream_t st = as_stream(stream);
-    return split_nt(Cout) == 128 ? launch_split<2, 4>(p, st) : launch_split<1, 8>(p, st);
+    int rc;
+    if (mode == SGDFR_MODE_UP3)
+        rc = split_nt(Cout) == 128 ? launch_split<SGDFR_MODE_UP3, 4, 2, 1, 2>(p, st)      // 128 couts x 128 super-pixels
+                                   : launch_split<SGDFR_MODE_UP3, 2, 4, 1, 2>(p, st);     //  64 couts x 256 super-pixels
+    else
+        rc = split_nt(Cout) == 128 ? launch_split<SGDFR_MODE_PLAIN3, 2, 4, 2, 2>(p, st)   // 128 couts x 256 pixels
+                                   : launch_split<SGDFR_MODE_PLAIN3, 1, 8, 2, 2>(p, st);  //  64 couts x 512 pixels
+    if (rc || ksplit == 1) return rc;
+    const bool plain = mode == SGDFR_MODE_PLAIN3;
+    return launch_splitk_reduce(partials, ksplit, n_out, plain ? noise : nullptr, noise_bstride, noise_w, plain ? bias : nullptr, y,
+                                Cout, plain ? H * W : 1, plain ? act : 0, slope, gain, st);
 }

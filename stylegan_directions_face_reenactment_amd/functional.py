@@ -246,13 +246,13 @@ def prepack_split(weight):
     return wsp
 
 
-def split_ok(B, cin, cout, H, W):
-    return PRECISION == 'bf16x3' and bool(N.load().sgdfr_modconv2d_split_supported(B, cin, cout, H, W))
+def split_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
+    return PRECISION == 'bf16x3' and bool(N.load().sgdfr_modconv2d_split_supported(B, cin, cout, H, W, mode))
 
 
 def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2,
-                  batch=None, desc=None):
-    """Plain 3x3 modulated conv in the bf16x3 split arithmetic (same contract as modconv_raw(mode PLAIN3))."""
+                  batch=None, desc=None, mode=N.MODE_PLAIN3):
+    """3x3 modulated conv in the bf16x3 split arithmetic (same contract as modconv_raw, modes PLAIN3 and UP3)."""
     N.require_device(x, s, d, bias, noise_weight)
     if not wsp.is_cuda or wsp.dtype != torch.int16:
         raise RuntimeError('modconv_split: wsp must be the int16 device buffer made by prepack_split')
@@ -260,13 +260,20 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
     B = s.shape[0] if batch is None else batch
     _, cin, H, W = x.shape
     xb = 0 if (x.shape[0] == 1 and B != 1) else cin * H * W
-    nz, nzb = _noise_args(noise, B, H, W)
-    y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+    if mode == N.MODE_UP3:
+        nz, nzb = None, 0
+        y = torch.empty(B, cout, 4, H + 1, W + 1, device=x.device, dtype=torch.float32)
+    else:
+        nz, nzb = _noise_args(noise, B, H, W)
+        y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
     st = N.stream()
-    _timed_conv(desc or ('split3 %d->%d @%dx%d' % (cin, cout, H, W)), B * conv_flops(cin, cout, H, W), lambda: N.call(
+    ks = N.load().sgdfr_modconv2d_split_ksplit_hint(B, cin, cout, H, W, mode) if USE_SPLITK else 1
+    partials = torch.empty((ks,) + tuple(y.shape), device=x.device, dtype=torch.float32) if ks > 1 else None
+    _timed_conv(desc or ('split mode%d %d->%d @%dx%d%s' % (mode, cin, cout, H, W, ' K/%d' % ks if ks > 1 else '')),
+                B * conv_flops(cin, cout, H, W), lambda: N.call(
         'sgdfr_modconv2d_split_f32', N.ptr(x), xb, N.ptr(wsp), N.ptr(s), N.ptr(d), N.ptr(nz), nzb,
-        N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(_zero_words(x.device)), N.ptr(y), B, cin,
-        cout, H, W, int(activate), float(slope), float(gain), st))
+        N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(_zero_words(x.device)), N.ptr(y),
+        N.ptr(partials), ks, B, cin, cout, H, W, mode, int(activate), float(slope), float(gain), st))
     return y
 
 
@@ -336,7 +343,11 @@ def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_we
                            batch, 'plain3 %d->%d @%dx%d' % (cin, cout, H, W))
     if fir is None:
         raise RuntimeError('upsample modconv needs the blur FIR taps')
-    planes = modconv_raw(x, wp, s, d, cout, N.MODE_UP3, H, W, batch=batch, desc='up3 %d->%d @%dx%d' % (cin, cout, H, W))
+    Bu = s.shape[0] if batch is None else batch
+    if split is not None and split_ok(Bu, cin, cout, H, W, N.MODE_UP3):
+        planes = modconv_split(x, split() if callable(split) else split, s, d, cout, batch=batch, mode=N.MODE_UP3)
+    else:
+        planes = modconv_raw(x, wp, s, d, cout, N.MODE_UP3, H, W, batch=batch, desc='up3 %d->%d @%dx%d' % (cin, cout, H, W))
     y = blur_bias_act(planes, fir, H, W, noise, noise_weight, bias, activate, slope, gain)
     return (y, planes) if return_planes else y
 

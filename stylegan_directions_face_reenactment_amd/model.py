@@ -218,7 +218,7 @@ class ModulatedConv2d(nn.Module):
                              fir=self.blur.kernel if self.upsample else None, noise=noise,
                              noise_weight=noise_weight, bias=bias, activate=activate, batch=batch,
                              wino=None if self.upsample else self.packed_wino,
-                             split=None if self.upsample else self.packed_split)
+                             split=self.packed_split)
 
     def forward(self, input, style):
         if self.kernel_size == 1:

@@ -39,7 +39,7 @@ def test_split_conv_matches_fp64_oracle(cin, cout, H, B):
     noise = S.counter_tensor(3, key + '.n', (1, 1, H, H)).cuda()
     nw = torch.full((1,), 0.1).cuda()
     bias = S.counter_tensor(3, key + '.b', (cout,), 0.0, 0.1).cuda()
-    assert F_.N.load().sgdfr_modconv2d_split_supported(B, cin, cout, H, H)
+    assert F_.N.load().sgdfr_modconv2d_split_supported(B, cin, cout, H, H, 0)
     y = F_.modconv_split(x, F_.prepack_split(w), s, d, cout, noise, nw, bias, True)
     ref = _oracle(x, w, s, d, noise, nw, bias)
     err = maxabs(y, ref)
@@ -48,8 +48,36 @@ def test_split_conv_matches_fp64_oracle(cin, cout, H, B):
     assert err < 5e-5 * float(ref.abs().max()) + 1e-5
 
 
+UP_CASES = [(64, 64, 16, 3), (128, 128, 8, 5), (32, 128, 4, 9), (64, 64, 64, 2), (32, 64, 128, 1), (48, 256, 32, 2)]
+
+
+@pytest.mark.parametrize('cin,cout,H,B', UP_CASES)
+def test_split_transposed_conv_matches_fp64_oracle(cin, cout, H, B):
+    """UP3: parity planes of the stride-2 transposed conv, then the shared FIR pass == model.py:246-257."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    key = 'splitup.%d.%d.%d.%d' % (cin, cout, H, B)
+    w = S.counter_tensor(4, key + '.w', (1, cout, cin, 3, 3)).cuda()
+    x = S.counter_tensor(4, key + '.x', (B, cin, H, H)).cuda()
+    s = S.counter_tensor(4, key + '.s', (B, cin), 1.0, 0.3).cuda()
+    d = S.counter_tensor(4, key + '.d', (B, cout), 1.0, 0.2).cuda()
+    assert F_.N.load().sgdfr_modconv2d_split_supported(B, cin, cout, H, H, 1)
+    planes = F_.modconv_split(x, F_.prepack_split(w), s, d, cout, mode=F_.N.MODE_UP3)
+    wp, _, _ = F_.prepack(w)
+    exact = F_.modconv_raw(x, wp, s, d, cout, F_.N.MODE_UP3, H, H)            # fp32 kernel, same plane layout
+    assert planes.shape == exact.shape
+    # fp64 transposed conv, read back in plane form: T[2a+py, 2b+px] = planes[py*2+px][a][b]
+    wt = (w[0].double().cpu() / (cin * 9) ** 0.5).transpose(0, 1)
+    T = torch.nn.functional.conv_transpose2d(x.double().cpu() * s.double().cpu()[:, :, None, None], wt, stride=2)
+    T = T * d.double().cpu()[:, :, None, None]                                 # [B,cout,2H+1,2H+1]
+    T = torch.nn.functional.pad(T, (0, 1, 0, 1))                               # -> 2(H+1) square
+    ref = torch.stack([T[:, :, py::2, px::2] for py in (0, 1) for px in (0, 1)], 2)
+    scale = max(1.0, float(ref.abs().max()))
+    assert maxabs(exact, ref) <= 2e-5 * scale
+    assert maxabs(planes, ref) <= 1e-4 * scale
+
+
 def test_split_generator_within_contract():
-    """End to end at 64x64 and 256x256: bf16x3 plain convs (transposed convs stay fp32) vs the fp64 oracle."""
+    """End to end at 64x64 and 256x256: every 3x3 conv (plain and transposed) in bf16x3 vs the fp64 oracle."""
     from stylegan_directions_face_reenactment_amd import functional as F_
     for size, B in ((64, 3), (256, 2)):
         G = hip_generator(size, 1)
