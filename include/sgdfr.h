@@ -183,13 +183,16 @@ int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, cons
  *                                      ksplit > 1 (see ..._ksplit_hint; layers too small to fill the chip) slices the
  *                                      channel blocks over extra thread blocks into `partials` [ksplit][numel(y)] and
  *                                      reduces them in fixed order (deterministic) */
+#define SGDFR_SPLIT_BF16 0   /* bf16 hi+lo: 16 mantissa bits, fp32 range   (~1e-4 on the 256x256 generator) */
+#define SGDFR_SPLIT_FP16 1   /* fp16 hi+lo: 22 mantissa bits = fp32-grade; operands range-shifted by exact powers of two,
+                                |x*s| saturates at 1.04e6 */
 int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin);
-int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, void* stream);
+int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int arith, void* stream);
 int sgdfr_modconv2d_split_supported(int B, int Cin, int Cout, int H, int W, int mode);
 int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned short* wsp, const float* s, const float* d,
                               const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
                               const float* zeros, float* y, float* partials, int ksplit, int B, int Cin, int Cout, int H,
-                              int W, int mode, int act, float slope, float gain, void* stream);
+                              int W, int mode, int arith, int act, float slope, float gain, void* stream);
 int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, int mode);
 
 /* x [B,3,H,W] fp32 -> y [B,H,W,3] uint8:  trunc( (clamp(x,-1,1) + 1) / (2 + 1e-5) * 255 )

@@ -24,9 +24,9 @@ def main():
             s = torch.randn(B, cin, device='cuda'); d = torch.rand(B, cout, device='cuda') + 0.5
             wp, q, qt = F_.prepack(w); fl = B * F_.conv_flops(cin, cout, h, h)
             t = bench(lambda: F_.modconv_raw(x, wp, s, d, cout, N.MODE_UP3, h, h))
-            wsp = F_.prepack_split(w)
-            t2 = bench(lambda: F_.modconv_split(x, wsp, s, d, cout, mode=N.MODE_UP3))
-            print('up %4d->%4d @%3d: fp32 %7.1f us %6.1f TF | bf16x3 %7.1f us %6.1f TF-eq' % (cin, cout, h, t * 1e6, fl / t / 1e12, t2 * 1e6, fl / t2 / 1e12), flush=True)
+            wsp = F_.prepack_split(w, 'fp16x3')
+            t2 = bench(lambda: F_.modconv_split(x, wsp, s, d, cout, mode=N.MODE_UP3, arith='fp16x3'))
+            print('up %4d->%4d @%3d: fp32 %7.1f us %6.1f TF | fp16x3 %7.1f us %6.1f TF-eq' % (cin, cout, h, t * 1e6, fl / t / 1e12, t2 * 1e6, fl / t2 / 1e12), flush=True)
         return
     for cin, cout, h in shapes:
         w = torch.randn(1, cout, cin, 3, 3, device='cuda')
@@ -43,9 +43,10 @@ def main():
             t = bench(lambda: F_.modconv_wino(x, u, s, d, cout, nz, nw, bias, True))
             out.append('wino %7.1f us %6.1f TF' % (t * 1e6, fl / t / 1e12))
         if 'split' in which:
-            wsp = F_.prepack_split(w)
-            t = bench(lambda: F_.modconv_split(x, wsp, s, d, cout, nz, nw, bias, True))
-            out.append('bf16x3 %7.1f us %6.1f TF-eq' % (t * 1e6, fl / t / 1e12))
+            for ar in ('bf16x3', 'fp16x3'):
+                wsp = F_.prepack_split(w, ar)
+                t = bench(lambda: F_.modconv_split(x, wsp, s, d, cout, nz, nw, bias, True, arith=ar))
+                out.append('%s %7.1f us %6.1f TF-eq' % (ar, t * 1e6, fl / t / 1e12))
         print('%4d->%4d @%3d: %s' % (cin, cout, h, ' | '.join(out)), flush=True)
 
 if __name__ == '__main__':

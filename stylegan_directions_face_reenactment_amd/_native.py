@@ -39,10 +39,10 @@ SIGNATURES = {
     'sgdfr_modconv2d_wino_supported': [_i, _i, _i, _i, _i],
     'sgdfr_modconv2d_wino_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
                                  _c_f32p, _i, _i, _i, _i, _i, _i, _f, _f, ctypes.c_void_p],
-    'sgdfr_modconv_prepack_split_f32': [_c_f32p, ctypes.c_void_p, _i, _i, ctypes.c_void_p],
+    'sgdfr_modconv_prepack_split_f32': [_c_f32p, ctypes.c_void_p, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_modconv2d_split_supported': [_i, _i, _i, _i, _i, _i],
     'sgdfr_modconv2d_split_f32': [_c_f32p, _i64, ctypes.c_void_p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
-                                  _c_f32p, _c_f32p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, ctypes.c_void_p],
+                                  _c_f32p, _c_f32p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, ctypes.c_void_p],
     'sgdfr_modconv2d_split_ksplit_hint': [_i, _i, _i, _i, _i, _i],
     'sgdfr_image_to_u8_f32': [_c_f32p, ctypes.c_void_p, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_grid_to_u8_f32': [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), _i, ctypes.c_void_p, _i, _i, _i,
@@ -74,6 +74,7 @@ SIGNATURES['sgdfr_styles_batched_f32'] = [_c_f32p, _i, _i, _i, ctypes.POINTER(St
 MAX_STYLE_LAYERS = 40
 
 MODE_PLAIN3, MODE_UP3, MODE_DOWN3 = 0, 1, 2
+SPLIT_BF16, SPLIT_FP16 = 0, 1
 ACT_NONE, ACT_LRELU = 0, 1
 
 _lib = None

@@ -30,7 +30,21 @@ namespace sgdfr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int frag128 __attribute__((ext_vector_type(4)));   // 8 x 16-bit operand elements of one lane
+
+// ET: element type of the split terms.  SGDFR_SPLIT_BF16: 8+8 mantissa bits, fp32 range.  SGDFR_SPLIT_FP16: 11+11 bits
+// (the 22-bit sum is fp32-grade), fp16 range: activations are pre-scaled by 2^-4 and clamped to +-65504 before the
+// split, weights by 2^6 in the pack, and the epilogue multiplies by 2^-2 (all exact powers of two).
+template <int ET>
+__device__ __forceinline__ f32x16 split_mfma(frag128 a, frag128 b, f32x16 c) {
+    if (ET == SGDFR_SPLIT_FP16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+constexpr float SPLIT_F16_XSCALE = 0.0625f, SPLIT_F16_WSCALE = 64.f, SPLIT_F16_OUT = 0.25f, SPLIT_F16_MAX = 65504.f;
 
 struct SplitParams {
     const float* x;
@@ -66,21 +80,34 @@ __device__ __forceinline__ void split_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// two floats -> packed bf16 hi pair and packed bf16 lo pair (lo = bf16(v - float(hi)), exact subtraction)
+// two floats -> packed hi pair and packed lo pair (lo = round(v - float(hi)), the subtraction is exact)
+template <int ET>
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
-    f32x2 v = {a, b};
-    bf16x2 h = __builtin_convertvector(v, bf16x2);
-    hi = __builtin_bit_cast(unsigned, h);
-    const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
-    f32x2 r = {a - ha, b - hb};
-    bf16x2 l = __builtin_convertvector(r, bf16x2);
-    lo = __builtin_bit_cast(unsigned, l);
+    if (ET == SGDFR_SPLIT_FP16) {
+        a = __builtin_amdgcn_fmed3f(a, -SPLIT_F16_MAX, SPLIT_F16_MAX);
+        b = __builtin_amdgcn_fmed3f(b, -SPLIT_F16_MAX, SPLIT_F16_MAX);
+        f32x2 v = {a, b};
+        f16x2 h = __builtin_convertvector(v, f16x2);
+        hi = __builtin_bit_cast(unsigned, h);
+        f32x2 hf = __builtin_convertvector(h, f32x2);
+        f32x2 r = {a - hf[0], b - hf[1]};
+        f16x2 l = __builtin_convertvector(r, f16x2);
+        lo = __builtin_bit_cast(unsigned, l);
+    } else {
+        f32x2 v = {a, b};
+        bf16x2 h = __builtin_convertvector(v, bf16x2);
+        hi = __builtin_bit_cast(unsigned, h);
+        const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+        f32x2 r = {a - ha, b - hb};
+        bf16x2 l = __builtin_convertvector(r, bf16x2);
+        lo = __builtin_bit_cast(unsigned, l);
+    }
 }
 
 // MODE PLAIN3: y = conv3x3(x*s) * d (+ noise, bias, activation).  MODE UP3: stride-2 transposed conv into the four
 // output-parity planes T[B,Cout,4,H+1,W+1] (same contract as modconv.hip): one "pixel" is a super-pixel of the padded
 // flat space, each of the 9 taps feeds the accumulator set of its parity phase.
-template <int MODE, int WM, int WN, int MI, int NI, int NEX>
+template <int MODE, int ET, int WM, int WN, int MI, int NI, int NEX>
 __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
     constexpr int NTHR = 512;
     constexpr int NT = WM * MI * 32, PT = WN * NI * 32;
@@ -235,7 +262,7 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
         unsigned* ph = reinterpret_cast<unsigned*>(&vh);
         unsigned* pl = reinterpret_cast<unsigned*>(&vl);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split_pair(xr[e][2 * c] * sv[2 * c], xr[e][2 * c + 1] * sv[2 * c + 1], ph[c], pl[c]);
+        for (int c = 0; c < 4; ++c) split_pair<ET>(xr[e][2 * c] * sv[2 * c], xr[e][2 * c + 1] * sv[2 * c + 1], ph[c], pl[c]);
         *reinterpret_cast<uint4*>(xb + ldst[e]) = vh;
         *reinterpret_cast<uint4*>(xb + 32 * p.xs + ldst[e]) = vl;
     };
@@ -257,7 +284,7 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
     // ---- prologue: style table, channel block 0 staged, block 1 in registers, weight row 0 in flight
     for (int e = tid; e < p.simgs * p.Cin; e += NTHR) {
         const int m = e / p.Cin;
-        ls[e] = (img0 + m < p.B) ? p.s[(int64_t)(img0 + m) * p.Cin + (e - m * p.Cin)] : 0.f;
+        ls[e] = (img0 + m < p.B) ? p.s[(int64_t)(img0 + m) * p.Cin + (e - m * p.Cin)] * (ET == SGDFR_SPLIT_FP16 ? SPLIT_F16_XSCALE : 1.f) : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -306,15 +333,15 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
                     // The row's 8 activation fragments are read once; weight fragments of tap kx+1 are requested
                     // while the MFMAs of tap kx run.
                     const int rowoff = (ky == 2) ? 0 : p.P;
-                    bf16x8 b[2][2][NI];   // [column offset 0/1][part][tile]
-                    bf16x8 a[2][2][MI];   // [set][part][tile]
+                    frag128 b[2][2][NI];   // [column offset 0/1][part][tile]
+                    frag128 a[2][2][MI];   // [set][part][tile]
                     auto fetch_a = [&](int set, int kx) {
 #pragma unroll
                         for (int part = 0; part < 2; ++part)
 #pragma unroll
                             for (int m = 0; m < MI; ++m)
                                 a[set][part][m] =
-                                    *reinterpret_cast<const bf16x8*>(wcur + ((kx * 2 + part) * 2) * (NT * 16) + m * 512);
+                                    *reinterpret_cast<const frag128*>(wcur + ((kx * 2 + part) * 2) * (NT * 16) + m * 512);
                     };
                     fetch_a(0, 0);
 #pragma unroll
@@ -324,7 +351,7 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
 #pragma unroll
                             for (int n = 0; n < NI; ++n)
                                 b[o][part][n] =
-                                    *reinterpret_cast<const bf16x8*>(xcur + part * 32 * p.xs + (boff[n] + rowoff + o) * 16);
+                                    *reinterpret_cast<const frag128*>(xcur + part * 32 * p.xs + (boff[n] + rowoff + o) * 16);
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const int ph = 2 * (ky & 1) + (kx & 1);
@@ -338,14 +365,13 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
                             for (int m = 0; m < MI; ++m)
 #pragma unroll
                                 for (int n = 0; n < NI; ++n)
-                                    acc[ph][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][t == 2][m], b[o][t == 1][n],
-                                                                                            acc[ph][m][n], 0, 0, 0);
+                                    acc[ph][m][n] = split_mfma<ET>(a[cur][t == 2][m], b[o][t == 1][n], acc[ph][m][n]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
                     // software pipeline over the 3 taps of the row: after the hi*hi MFMAs of tap kx are issued, the
                     // fragments of tap kx+1 are requested (second register set) and land behind the other 8 MFMAs
-                    bf16x8 a[2][2][MI], b[2][2][NI];     // [set][part][tile]
+                    frag128 a[2][2][MI], b[2][2][NI];     // [set][part][tile]
                     auto fetch = [&](int set, int kx) {
                         const int tapoff = (ky - 1) * pitch + (kx - 1);
 #pragma unroll
@@ -353,11 +379,11 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
 #pragma unroll
                             for (int m = 0; m < MI; ++m)
                                 a[set][part][m] =
-                                    *reinterpret_cast<const bf16x8*>(wcur + ((kx * 2 + part) * 2) * (NT * 16) + m * 512);
+                                    *reinterpret_cast<const frag128*>(wcur + ((kx * 2 + part) * 2) * (NT * 16) + m * 512);
 #pragma unroll
                             for (int n = 0; n < NI; ++n)
                                 b[set][part][n] =
-                                    *reinterpret_cast<const bf16x8*>(xcur + part * 32 * p.xs + (boff[n] + tapoff) * 16);
+                                    *reinterpret_cast<const frag128*>(xcur + part * 32 * p.xs + (boff[n] + tapoff) * 16);
                         }
                     };
                     fetch(0, 0);
@@ -370,7 +396,7 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
 #pragma unroll
                             for (int n = 0; n < NI; ++n)
                                 acc[0][m][n] =
-                                    __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][0][m], b[cur][0][n], acc[0][m][n], 0, 0, 0);
+                                    split_mfma<ET>(a[cur][0][m], b[cur][0][n], acc[0][m][n]);
                         __builtin_amdgcn_sched_barrier(0);
                         if (kx < 2) fetch(cur ^ 1, kx + 1);
                         __builtin_amdgcn_sched_barrier(0);
@@ -380,8 +406,7 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
                             for (int m = 0; m < MI; ++m)
 #pragma unroll
                                 for (int n = 0; n < NI; ++n)
-                                    acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][t == 2][m], b[cur][t == 1][n],
-                                                                                           acc[0][m][n], 0, 0, 0);
+                                    acc[0][m][n] = split_mfma<ET>(a[cur][t == 2][m], b[cur][t == 1][n], acc[0][m][n]);
                     }
                 }
             };
@@ -417,7 +442,7 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = n0 + wm * (MI * 32) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float dv = p.d ? p.d[(int64_t)dimg[n] * p.Cout + co] : 1.f;
+                    const float dv = (p.d ? p.d[(int64_t)dimg[n] * p.Cout + co] : 1.f) * (ET == SGDFR_SPLIT_FP16 ? SPLIT_F16_OUT : 1.f);
                     float* dst = p.y + (int64_t)ks * p.split_stride + ybase[n] + (int64_t)co * 4 * RP;
 #pragma unroll
                     for (int ph = 0; ph < PH; ++ph) dst[(int64_t)ph * RP] = acc[ph][m][n][r] * dv;
@@ -438,7 +463,7 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = n0 + wm * (MI * 32) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                float v = acc[0][m][n][r];
+                float v = acc[0][m][n][r] * (ET == SGDFR_SPLIT_FP16 ? SPLIT_F16_OUT : 1.f);
                 if (p.d) v *= p.d[(int64_t)dimg[n] * p.Cout + co];
                 v += nz;
                 if (whole && p.bias) v += p.bias[co];
@@ -452,19 +477,18 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
 // weight [Cout,Cin,3,3] fp32 -> bf16 hi/lo of Wc = weight/sqrt(9 Cin) in the kernel's LDS order:
 //   [cout tile][cin block][ky][kx][part][k-half][cout in tile (NT)][8 cin]
 __global__ __launch_bounds__(256) void prepack_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                                           int Cout, int Cin, int NT, float scale) {
+                                                           int Cout, int Cin, int NT, float scale, int et) {
     const int64_t n = (int64_t)Cout * Cin * 9;
     const int ncb = Cin / SPLIT_CB;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
         const int tap = (int)(idx % 9);
         const int ci = (int)((idx / 9) % Cin);
         const int co = (int)(idx / (9 * (int64_t)Cin));
-        const float v = w[idx] * scale;
-        const bf16x2 hv = __builtin_convertvector((f32x2){v, 0.f}, bf16x2);
-        const unsigned hbits = __builtin_bit_cast(unsigned, hv) & 0xffffu;
-        const float hf = __builtin_bit_cast(float, hbits << 16);
-        const bf16x2 lv = __builtin_convertvector((f32x2){v - hf, 0.f}, bf16x2);
-        const unsigned lbits = __builtin_bit_cast(unsigned, lv) & 0xffffu;
+        const float v = w[idx] * scale;          // fp16 packs: scale already carries the 2^6 range shift
+        unsigned hp, lp;
+        if (et == SGDFR_SPLIT_FP16) split_pair<SGDFR_SPLIT_FP16>(v, 0.f, hp, lp);
+        else split_pair<SGDFR_SPLIT_BF16>(v, 0.f, hp, lp);
+        const unsigned hbits = hp & 0xffffu, lbits = lp & 0xffffu;
         const int ctile = co / NT, col = co - ctile * NT, cb = ci / SPLIT_CB, h = (ci % SPLIT_CB) / 8, c8 = ci % 8;
         const int ky = tap / 3, kx = tap - ky * 3;
         const int64_t base = ((((int64_t)ctile * ncb + cb) * 3 + ky) * 3 + kx) * 2;   // -> [part]
@@ -554,7 +578,9 @@ extern "C" int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H
 
 extern "C" int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin) { return (int64_t)Cout * Cin * 9 * 2; }
 
-extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, void* stream) {
+extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int arith,
+                                               void* stream) {
+    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "prepack_split: arith must be SGDFR_SPLIT_BF16/FP16");
     SGDFR_REQUIRE(Cout > 0 && Cin > 0 && Cin % SPLIT_CB == 0 && Cout % 64 == 0,
                   "prepack_split: needs Cin %% 16 == 0 and Cout %% 64 == 0, got Cin=%d Cout=%d", Cin, Cout);
     SGDFR_REQUIRE(weight && wsp, "prepack_split: null pointer");
@@ -562,18 +588,18 @@ extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned sho
     int64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(prepack_split_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), weight, wsp, Cout, Cin,
-                       split_nt(Cout), 1.0f / sqrtf((float)Cin * 9));
+                       split_nt(Cout), (arith == SGDFR_SPLIT_FP16 ? SPLIT_F16_WSCALE : 1.f) / sqrtf((float)Cin * 9), arith);
     return check_launch("modconv_prepack_split");
 }
 
-template <int MODE, int WM, int WN, int MI, int NI>
+template <int MODE, int ET, int WM, int WN, int MI, int NI>
 static int launch_split(const SplitParams& p, hipStream_t st) {
     const int nex = (2 * p.xs + 511) / 512;
     constexpr int NEX_MAX = (MODE == SGDFR_MODE_UP3) ? 3 : 4;   // UP3 stages at most PT + P + 2 positions
     SGDFR_REQUIRE(nex <= NEX_MAX, "modconv_split: staged range %d too long for mode %d", p.xlen, MODE);
-    void (*kern)(SplitParams) = nex <= 2   ? split_mfma_kernel<MODE, WM, WN, MI, NI, 2>
-                                : nex == 3 ? split_mfma_kernel<MODE, WM, WN, MI, NI, 3>
-                                           : split_mfma_kernel<MODE, WM, WN, MI, NI, NEX_MAX>;
+    void (*kern)(SplitParams) = nex <= 2   ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 2>
+                                : nex == 3 ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 3>
+                                           : split_mfma_kernel<MODE, ET, WM, WN, MI, NI, NEX_MAX>;
     const size_t lds = split_lds_bytes(p, WM * MI * 32);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess)
@@ -585,8 +611,9 @@ static int launch_split(const SplitParams& p, hipStream_t st) {
 extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned short* wsp, const float* s,
                                          const float* d, const float* noise, int64_t noise_bstride, const float* noise_w,
                                          const float* bias, const float* zeros, float* y, float* partials, int ksplit,
-                                         int B, int Cin, int Cout, int H, int W, int mode, int act, float slope, float gain,
-                                         void* stream) {
+                                         int B, int Cin, int Cout, int H, int W, int mode, int arith, int act, float slope,
+                                         float gain, void* stream) {
+    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "modconv_split: arith must be SGDFR_SPLIT_BF16/FP16");
     SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "modconv_split: bad shape B=%d Cin=%d Cout=%d H=%d W=%d",
                   B, Cin, Cout, H, W);
     if (B == 0) return 0;
@@ -615,12 +642,22 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
     p.stagger = stagger;
     hipStream_t st = as_stream(stream);
     int rc;
-    if (mode == SGDFR_MODE_UP3)
-        rc = split_nt(Cout) == 128 ? launch_split<SGDFR_MODE_UP3, 4, 2, 1, 2>(p, st)      // 128 couts x 128 super-pixels
-                                   : launch_split<SGDFR_MODE_UP3, 2, 4, 1, 2>(p, st);     //  64 couts x 256 super-pixels
-    else
-        rc = split_nt(Cout) == 128 ? launch_split<SGDFR_MODE_PLAIN3, 2, 4, 2, 2>(p, st)   // 128 couts x 256 pixels
-                                   : launch_split<SGDFR_MODE_PLAIN3, 1, 8, 2, 2>(p, st);  //  64 couts x 512 pixels
+    const bool wide = split_nt(Cout) == 128;
+    if (arith == SGDFR_SPLIT_FP16) {
+        if (mode == SGDFR_MODE_UP3)
+            rc = wide ? launch_split<SGDFR_MODE_UP3, SGDFR_SPLIT_FP16, 4, 2, 1, 2>(p, st)      // 128 couts x 128 super-pixels
+                      : launch_split<SGDFR_MODE_UP3, SGDFR_SPLIT_FP16, 2, 4, 1, 2>(p, st);     //  64 couts x 256 super-pixels
+        else
+            rc = wide ? launch_split<SGDFR_MODE_PLAIN3, SGDFR_SPLIT_FP16, 2, 4, 2, 2>(p, st)   // 128 couts x 256 pixels
+                      : launch_split<SGDFR_MODE_PLAIN3, SGDFR_SPLIT_FP16, 1, 8, 2, 2>(p, st);  //  64 couts x 512 pixels
+    } else {
+        if (mode == SGDFR_MODE_UP3)
+            rc = wide ? launch_split<SGDFR_MODE_UP3, SGDFR_SPLIT_BF16, 4, 2, 1, 2>(p, st)
+                      : launch_split<SGDFR_MODE_UP3, SGDFR_SPLIT_BF16, 2, 4, 1, 2>(p, st);
+        else
+            rc = wide ? launch_split<SGDFR_MODE_PLAIN3, SGDFR_SPLIT_BF16, 2, 4, 2, 2>(p, st)
+                      : launch_split<SGDFR_MODE_PLAIN3, SGDFR_SPLIT_BF16, 1, 8, 2, 2>(p, st);
+    }
     if (rc || ksplit == 1) return rc;
     const bool plain = mode == SGDFR_MODE_PLAIN3;
     return launch_splitk_reduce(partials, ksplit, n_out, plain ? noise : nullptr, noise_bstride, noise_w, plain ? bias : nullptr, y,

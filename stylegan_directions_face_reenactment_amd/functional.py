@@ -177,17 +177,21 @@ def _noise_args(noise, B, H, W):
 USE_SPLITK = True            # K-sliced launches for convs that cannot fill the chip (small batch / 4x4, 8x8 layers)
 USE_WINOGRAD = True          # plain 3x3 layers: Winograd F(2x2,3x3) MFMA kernel when the shape allows it
 WINOGRAD_MIN_BLOCKS = 256    # below this many (64 cout x 64 tile) blocks the direct kernel's smaller tiles win
-# Arithmetic of the plain 3x3 modulated convs.  'fp32' (default): fp32 MFMA, exact products.  'bf16x3': OPT-IN split
-# mode (csrc/split.hip): operands split in bf16 hi+lo, hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32
-# accumulation; ~1e-4 max-abs on the 256x256 generator (contract 1e-3).  Inference (no-grad) path only.
-PRECISION = os.environ.get('SGDFR_PRECISION', 'fp32')
+# Arithmetic of the 3x3 modulated convs on the no-grad (inference) path:
+#   'fp16x3' (default)  fp32 operands split into fp16 hi + lo (11+11 mantissa bits; range-shifted by exact powers of two,
+#                       |x*s| saturates at 1.04e6), hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulation
+#                       (csrc/split.hip).  fp32-grade: measured 7.7e-6 max-abs vs the fp64 oracle on 256x256 images
+#                       (fp32 MFMA kernels: 9.5e-6) and held to the same per-layer bound by tests/test_gpu_split.py.
+#   'fp32'              fp32 MFMA kernels (direct + Winograd): what the autograd path always uses.
+#   'bf16x3'            as fp16x3 with bf16 terms: full fp32 range, 8+8 bits (~1e-4 on images; contract 1e-3).
+PRECISION = os.environ.get('SGDFR_PRECISION', 'fp16x3')
 _zeros = {}
 
 
 def set_precision(mode):
     global PRECISION
-    if mode not in ('fp32', 'bf16x3'):
-        raise ValueError("precision must be 'fp32' or 'bf16x3', got %r" % (mode,))
+    if mode not in ('fp32', 'fp16x3', 'bf16x3'):
+        raise ValueError("precision must be 'fp32', 'fp16x3' or 'bf16x3', got %r" % (mode,))
     PRECISION = mode
 
 
@@ -235,24 +239,31 @@ def modconv_wino(x, u, s, d, cout, noise=None, noise_weight=None, bias=None, act
     return y
 
 
-def prepack_split(weight):
-    """weight [1,Cout,Cin,3,3] -> uint16 buffer of bf16 hi/lo terms of weight/sqrt(9 Cin) in split.hip's LDS order."""
+_SPLIT_ARITH = {'bf16x3': N.SPLIT_BF16, 'fp16x3': N.SPLIT_FP16}
+
+
+def prepack_split(weight, arith=None):
+    """weight [1,Cout,Cin,3,3] -> uint16 buffer of 16-bit hi/lo terms of weight/sqrt(9 Cin) in split.hip's LDS order
+    (arith: 'bf16x3' or 'fp16x3', default = the current PRECISION)."""
+    arith = _SPLIT_ARITH[arith or PRECISION]
     N.require_device(weight)
     w = N.f32c(weight)
     _, cout, cin, k, _ = w.shape
     n = N.load().sgdfr_modconv_prepack_split_elems(cout, cin)
     wsp = torch.empty(n, device=w.device, dtype=torch.int16)
-    N.call('sgdfr_modconv_prepack_split_f32', N.ptr(w), N.ptr(wsp), cout, cin, N.stream())
+    N.call('sgdfr_modconv_prepack_split_f32', N.ptr(w), N.ptr(wsp), cout, cin, arith, N.stream())
     return wsp
 
 
 def split_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
-    return PRECISION == 'bf16x3' and bool(N.load().sgdfr_modconv2d_split_supported(B, cin, cout, H, W, mode))
+    return PRECISION in _SPLIT_ARITH and bool(N.load().sgdfr_modconv2d_split_supported(B, cin, cout, H, W, mode))
 
 
 def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2,
-                  batch=None, desc=None, mode=N.MODE_PLAIN3):
-    """3x3 modulated conv in the bf16x3 split arithmetic (same contract as modconv_raw, modes PLAIN3 and UP3)."""
+                  batch=None, desc=None, mode=N.MODE_PLAIN3, arith=None):
+    """3x3 modulated conv in a split arithmetic (same contract as modconv_raw, modes PLAIN3 and UP3); `wsp` must have
+    been packed for the same `arith`."""
+    arith = _SPLIT_ARITH[arith or PRECISION]
     N.require_device(x, s, d, bias, noise_weight)
     if not wsp.is_cuda or wsp.dtype != torch.int16:
         raise RuntimeError('modconv_split: wsp must be the int16 device buffer made by prepack_split')
@@ -273,7 +284,7 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
                 B * conv_flops(cin, cout, H, W), lambda: N.call(
         'sgdfr_modconv2d_split_f32', N.ptr(x), xb, N.ptr(wsp), N.ptr(s), N.ptr(d), N.ptr(nz), nzb,
         N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(_zero_words(x.device)), N.ptr(y),
-        N.ptr(partials), ks, B, cin, cout, H, W, mode, int(activate), float(slope), float(gain), st))
+        N.ptr(partials), ks, B, cin, cout, H, W, mode, arith, int(activate), float(slope), float(gain), st))
     return y
 
 

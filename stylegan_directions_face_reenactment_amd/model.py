@@ -182,8 +182,8 @@ class ModulatedConv2d(nn.Module):
         return cache[1 + int(adjoint)]
 
     def packed_split(self):
-        """bf16 hi/lo weight pack of the opt-in bf16x3 mode (functional.PRECISION), cached per weight version."""
-        key = self._key()
+        """16-bit hi/lo weight pack of the split precision modes (functional.PRECISION), cached per weight version and mode."""
+        key = self._key() + (F_.PRECISION,)
         cache = getattr(self, '_pack_s', None)
         if cache is None or cache[0] != key:
             with torch.no_grad():

@@ -7,6 +7,16 @@ import torch
 
 from util import O, S, SEED, golden, hip_generator, image_digest, maxabs, synthetic_state, t
 
+
+@pytest.fixture(autouse=True, params=['fp16x3', 'fp32'])
+def _both_arithmetics(request):
+    """Every generator-level check runs twice: default split-fp16 conv kernels and the fp32 MFMA / Winograd kernels."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    default = F_.PRECISION
+    F_.set_precision(request.param)
+    yield
+    F_.set_precision(default)
+
 pytestmark = pytest.mark.gpu
 
 IMG_TOL = 2e-4      # |image| <= ~10, 14 layers of K<=4608 fp32 accumulations; north_star allows 1e-3
