@@ -180,7 +180,7 @@ WINOGRAD_MIN_BLOCKS = 256    # below this many (64 cout x 64 tile) blocks the di
 # Arithmetic of the 3x3 modulated convs on the no-grad (inference) path:
 #   'fp16x3' (default)  fp32 operands split into fp16 hi + lo (11+11 mantissa bits; range-shifted by exact powers of two,
 #                       |x*s| saturates at 1.04e6), hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulation
-#                       (csrc/split.hip).  fp32-grade: measured 7.7e-6 max-abs vs the fp64 oracle on 256x256 images
+#                       (csrc/split.hip).  fp32-grade: measured 7.7e-6 max-abs vs an fp64 evaluation on 256x256 images
 #                       (fp32 MFMA kernels: 9.5e-6) and held to the same per-layer bound by tests/test_gpu_split.py.
 #   'fp32'              fp32 MFMA kernels (direct + Winograd): what the autograd path always uses.
 #   'bf16x3'            as fp16x3 with bf16 terms: full fp32 range, 8+8 bits (~1e-4 on images; contract 1e-3).
