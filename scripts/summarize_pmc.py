@@ -1,9 +1,10 @@
 """Turns the rocprofv3 outputs of one profiling session (gpurun_out/prof_<tag>, pmc_<tag>_{fetch,write,sq}) into the
-committed summaries under profiles/:  python scripts/summarize_pmc.py r1c r01_c"""
+committed summaries under profiles/:  python scripts/summarize_pmc.py r1e r01_e [fp16x3|fp32]"""
 import collections, csv, json, shutil, sys
 
 tag, out = sys.argv[1], sys.argv[2]
-CONV = ('modconv_mfma', 'wino_mfma', 'wino2_mfma')
+CONV = ('modconv_mfma', 'wino_mfma', 'wino2_mfma', 'split_mfma')
+precision = sys.argv[3] if len(sys.argv) > 3 else 'fp16x3'
 
 
 def load(dirn):
@@ -33,7 +34,7 @@ ff, ww = last(f, 'FETCH_SIZE'), last(w, 'WRITE_SIZE')
 L = ['# rocprofv3 PMC passes (%s)\n' % out,
      'Each counter set in its own pass with `--kernel-trace --output-format csv` only: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`,',
      '`--pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE`,',
-     'command `python bench.py --steps 2 --warmup 1 --no-cpu-baseline` (B=64, 256x256, cm=1).  Kernel-trace stats of the',
+     'command `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt --precision %s` (B=64, 256x256, cm=1).  Kernel-trace stats of the' % precision,
      'timing run (`--kernel-trace --stats`, `--steps 10 --warmup 3`): `profiles/%s_kernel_stats.csv`.\n' % out,
      'FETCH_SIZE / WRITE_SIZE are KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 128-B requests',
      'as 64 B, so read bytes = 2 x FETCH_SIZE; WRITE_SIZE equals the algorithmic output bytes of every launch exactly.\n',
@@ -66,7 +67,7 @@ for (name, grid), (disp, c) in seen.items():
         name, grid, dur / 1e3, gui / dur if dur else 0, 100 * c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (gui * 1024) if gui else 0,
         c.get('SQ_WAIT_INST_ANY', 0) / wc, c.get('SQ_WAIT_ANY', 0) / wc, c.get('SQ_LDS_BANK_CONFLICT', 0)))
 open('profiles/%s_pmc.md' % out, 'w').write('\n'.join(L) + '\n')
-json.dump({'config': {'batch': 64, 'cm': 1, 'size': 256}, 'conv_launches_per_forward': 13, 'read_bytes_per_forward': tr,
+json.dump({'config': {'batch': 64, 'cm': 1, 'size': 256, 'precision': precision}, 'conv_launches_per_forward': 13, 'read_bytes_per_forward': tr,
            'write_bytes_per_forward': tw, 'bytes_per_launch': (tr + tw) / 13,
            'source': 'profiles/%s_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)' % out},
           open('profiles/traffic_latest.json', 'w'), indent=1)
