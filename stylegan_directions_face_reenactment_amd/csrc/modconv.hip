@@ -295,45 +295,54 @@ __global__ __launch_bounds__(256, OCC) void modconv_mfma_kernel(ModconvParams p)
     // ---- epilogue.  C/D layout of 32x32: column (pixel) = lane&31, row (cout) = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* const yout = p.y + (int64_t)ks * p.split_stride;
     const bool whole = p.ksplit == 1;      // K slices only scale by d; noise / bias / activation follow the reduction
-    if (MODE != SGDFR_MODE_UP3) {
-        const float nw = (whole && p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
+    // Loads and stores share the in-order vmcnt counter: a `d` / bias load between two stores would make the wave wait
+    // for the previous store's HBM round trip.  The coefficients go through LDS (lgkmcnt), noise into registers first.
+    const int unit = (MODE == SGDFR_MODE_UP3) ? RP : HW;           // "pixels" per image of this mode
+    const int img0 = p0 / unit;
+    int nimg;
+    {
+        int last = p0 + PT - 1;
+        if (last >= total_pix) last = total_pix - 1;
+        nimg = last / unit - img0 + 1;
+    }
+    float* const dl = smem;                 // [nimg][NT]; the K loop ended on a barrier, the stage buffers are free
+    float* const bl = smem + nimg * NT;     // [NT]
+    for (int e = tid; e < nimg * NT; e += 256) {
+        const int m = e / NT, c = e - m * NT;
+        dl[e] = (p.d && n0 + c < p.Cout) ? p.d[(int64_t)(img0 + m) * p.Cout + n0 + c] : 1.f;
+    }
+    for (int e = tid; e < NT; e += 256) bl[e] = (whole && p.bias && n0 + e < p.Cout) ? p.bias[n0 + e] : 0.f;
+    float nzv[NI];
+    {
+        const float nw = (MODE != SGDFR_MODE_UP3 && whole && p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const int pix = pixv[ni];
-            if (pix >= total_pix) continue;
-            const int64_t img = pix / HW;
-            const int rem = pix - (int)img * HW;
-            const float nz = (whole && p.noise) ? nw * p.noise[img * p.noise_bstride + rem] : 0.f;
+            const int pix = pixv[ni] < total_pix ? pixv[ni] : total_pix - 1;
+            const int64_t img = pix / unit;
+            nzv[ni] = (MODE != SGDFR_MODE_UP3 && whole && p.noise) ? nw * p.noise[img * p.noise_bstride + (pix - (int)img * unit)] : 0.f;
+        }
+    }
+    __syncthreads();
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
+    for (int ni = 0; ni < NI; ++ni) {
+        const int pix = pixv[ni];
+        if (pix >= total_pix) continue;
+        const int64_t img = pix / unit;
+        const int rem = pix - (int)img * unit;
+        const float* dln = dl + ((int)img - img0) * NT;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = n0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (co < p.Cout) {
-                        float v = acc[0][mi][ni][r];
-                        if (p.d) v *= p.d[img * p.Cout + co];
-                        v += nz;
-                        if (whole && p.bias) v += p.bias[co];
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int co = n0 + cl;
+                if (co < p.Cout) {
+                    const float dv = dln[cl];
+                    if (MODE != SGDFR_MODE_UP3) {
+                        float v = acc[0][mi][ni][r] * dv + nzv[ni] + bl[cl];
                         if (whole && p.act) v = lrelu_gain(v, p.slope, p.gain);
                         yout[(img * p.Cout + co) * HW + rem] = v;
-                    }
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int pix = pixv[ni];
-            if (pix >= total_pix) continue;
-            const int64_t img = pix / RP;
-            const int rem = pix - (int)img * RP;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = n0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (co < p.Cout) {
-                        const float dv = p.d ? p.d[img * p.Cout + co] : 1.f;
+                    } else {
                         float* dst = yout + ((img * p.Cout + co) * 4) * RP + rem;
 #pragma unroll
                         for (int ph = 0; ph < PH; ++ph) dst[(int64_t)ph * RP] = acc[ph][mi][ni][r] * dv;

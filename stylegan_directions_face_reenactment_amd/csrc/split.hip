@@ -107,15 +107,22 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
 // MODE PLAIN3: y = conv3x3(x*s) * d (+ noise, bias, activation).  MODE UP3: stride-2 transposed conv into the four
 // output-parity planes T[B,Cout,4,H+1,W+1] (same contract as modconv.hip): one "pixel" is a super-pixel of the padded
 // flat space, each of the 9 taps feeds the accumulator set of its parity phase.
-template <int MODE, int ET, int WM, int WN, int MI, int NI, int NEX>
-__global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
-    constexpr int NTHR = 512;
+// NSS: barrier-delimited sub-stages per 16-channel block: 3 = one kernel row (3 taps) each, 1 = all 9 taps.
+template <int MODE, int ET, int WM, int WN, int MI, int NI, int NEX, int NSS>
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma_kernel(SplitParams p) {
+    constexpr int NW = WM * WN;            // 8 waves, one block per CU (4-wave blocks, two per CU, measured slower: more
+                                           // halo staging and 1.0 ds_read per MFMA)
+    constexpr int NTHR = NW * 64;
     constexpr int NT = WM * MI * 32, PT = WN * NI * 32;
     constexpr bool UP = (MODE == SGDFR_MODE_UP3);
     constexpr int PH = UP ? 4 : 1;
-    static_assert(WM * WN == 8, "8 waves per block");
-    constexpr int WROW_BYTES = NT * 192;                 // [3 kx][2 part][2 k-half][NT][8] bf16
-    constexpr int WCHUNKS = WROW_BYTES / 1024;           // 64-lane x 16-byte DMA pieces
+    static_assert(NW == 8 || NW == 4, "4 or 8 waves per block");
+    static_assert(NT % 64 == 0 && (NSS == 1 || NSS == 3), "cout tiles are packed 64 wide");
+    constexpr int RPS = 3 / NSS;                          // kernel rows per sub-stage
+    constexpr int WT = NT / 64;                           // 64-cout pack tiles per block
+    constexpr int WROW64 = 64 * 192;                      // one kernel row of one pack tile: [3 kx][2 part][2 k-half][64][8] x 16 bit
+    constexpr int WROW_BYTES = WT * RPS * WROW64;         // weight bytes of one sub-stage: [pack tile][row][kx][part][k-half][64][8]
+    constexpr int WCHUNKS = WROW_BYTES / 1024;            // 64-lane x 16-byte DMA pieces
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int xbuf_bytes = 64 * p.xs;                    // [2 part][2 k-half][xs][8] bf16
     unsigned char* const xb0 = smem;
@@ -268,16 +275,16 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
     };
     const int ncb_all = p.Cin / SPLIT_CB;
     const int cb0 = (int)((int64_t)ncb_all * ks / p.ksplit), ncb = (int)((int64_t)ncb_all * (ks + 1) / p.ksplit);
-    const unsigned char* const wglb = reinterpret_cast<const unsigned char*>(p.wsp) + (int64_t)ct * ncb_all * 3 * WROW_BYTES;
-    auto issue_w = [&](int u) {      // row slab u = cb*3 + ky -> ring slot u & 1
-        const unsigned char* src = wglb + (int64_t)u * WROW_BYTES;
+    const unsigned char* const wglb = reinterpret_cast<const unsigned char*>(p.wsp) + (int64_t)ct * WT * ncb_all * 3 * WROW64;
+    constexpr int WV = (WCHUNKS + NW - 1) / NW; // DMA pieces per wave and sub-stage (every wave issues exactly WV)
+    auto issue_w = [&](int u) {      // sub-stage u = cb*NSS + ss -> ring slot u & 1
         unsigned char* dst = wb0 + (u & 1) * WROW_BYTES;
 #pragma unroll
-        for (int v = 0; v < (WCHUNKS + 7) / 8; ++v) {
-            const int chunk = wave + v * 8;
-            if (chunk < WCHUNKS)
-                __builtin_amdgcn_global_load_lds((glb_void*)(src + chunk * 1024 + lane * 16), (lds_void*)(dst + chunk * 1024), 16,
-                                                 0, 0);
+        for (int v = 0; v < WV; ++v) {
+            const int chunk = (wave + v * NW) % WCHUNKS;          // wrap: a duplicate piece rewrites identical bytes
+            const int tile = chunk / (RPS * 12), within = chunk - tile * (RPS * 12);
+            const unsigned char* src = wglb + ((int64_t)tile * ncb_all * 3 + (int64_t)u * RPS) * WROW64 + within * 1024;
+            __builtin_amdgcn_global_load_lds((glb_void*)(src + lane * 16), (lds_void*)(dst + chunk * 1024), 16, 0, 0);
         }
     };
 
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
     for (int e = 0; e < NEX; ++e) load_x(e, cb0);
 #pragma unroll
     for (int e = 0; e < NEX; ++e) convert_store(e, cb0, xb0 + (cb0 & 1) * xbuf_bytes);
-    issue_w(cb0 * 3);
+    issue_w(cb0 * NSS);
     if (ncb > cb0 + 1) {
 #pragma unroll
         for (int e = 0; e < NEX; ++e) load_x(e, cb0 + 1);
@@ -302,32 +309,39 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    const int aoff = (hi * NT + wm * (MI * 32) + l31) * 16;
-    const bool stagger = (p.stagger & 3) == 1 ? (wave >= 4) : (p.stagger & 3) == 2 ? (wave & 1) : false;
+    // A fragment (m) of kernel row r (inside the sub-stage), tap kx, part: aoff[m] + r*WROW64 + (kx*2+part)*2048
+    int aoff[MI];
+#pragma unroll
+    for (int m = 0; m < MI; ++m) {
+        const int col = wm * (MI * 32) + m * 32;
+        aoff[m] = (col / 64) * (RPS * WROW64) + (hi * 64 + (col % 64) + l31) * 16;
+    }
+    const bool stagger = NW == 8 && ((p.stagger & 3) == 1 ? (wave >= 4) : (p.stagger & 3) == 2 ? (wave & 1) : false);
     const bool dbg_nowait = p.stagger & 8, dbg_nostage = p.stagger & 16, dbg_nomfma = p.stagger & 32;
     for (int cb = cb0; cb < ncb; ++cb) {
         const unsigned char* xcur = xb0 + (cb & 1) * xbuf_bytes;
         unsigned char* xnext = xb0 + ((cb + 1) & 1) * xbuf_bytes;
         const bool conv_next = cb + 1 < ncb, load_next = cb + 2 < ncb;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int u = cb * 3 + ky;
-            const bool more_w = u + 1 < ncb * 3;
+        for (int ss = 0; ss < NSS; ++ss) {
+            const int u = cb * NSS + ss;
+            const bool more_w = u + 1 < ncb * NSS;
             if (more_w) issue_w(u + 1);
             __builtin_amdgcn_sched_barrier(0);
-            constexpr int kSlots[3] = {(NEX + 2) / 3, (NEX + 1) / 3, NEX / 3};
-            // one third of the next channel block's activations: registers -> hi/lo -> LDS, then refill the registers
+            constexpr int kSlots[3] = {(NEX + NSS - 1) / NSS, NSS == 3 ? (NEX + 1) / 3 : 0, NSS == 3 ? NEX / 3 : 0};
+            // 1/NSS of the next channel block's activations: registers -> hi/lo -> LDS, then refill the registers
             auto stage_part = [&]() {
                 if (conv_next) {
 #pragma unroll
-                    for (int e = ky; e < NEX; e += 3) {
+                    for (int e = ss; e < NEX; e += NSS) {
                         convert_store(e, cb + 1, xnext);
                         if (load_next) load_x(e, cb + 2);
                     }
                 }
             };
-            const unsigned char* wcur = wb0 + (u & 1) * WROW_BYTES + aoff;
-            auto mfma_part = [&]() {
+            const unsigned char* wslot = wb0 + (u & 1) * WROW_BYTES;
+            auto mfma_row = [&](int ky) {
+                const unsigned char* wcur = wslot + (ky - ss * RPS) * WROW64;
                 if (UP) {
                     // taps (ky, kx): x[a-(ky==2), b-(kx==2)] -> offsets rowoff + {1, 1, 0}; phase = 2*(ky&1) + (kx&1).
                     // The row's 8 activation fragments are read once; weight fragments of tap kx+1 are requested
@@ -341,7 +355,7 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
 #pragma unroll
                             for (int m = 0; m < MI; ++m)
                                 a[set][part][m] =
-                                    *reinterpret_cast<const frag128*>(wcur + ((kx * 2 + part) * 2) * (NT * 16) + m * 512);
+                                    *reinterpret_cast<const frag128*>(wcur + aoff[m] + (kx * 2 + part) * 2048);
                     };
                     fetch_a(0, 0);
 #pragma unroll
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
 #pragma unroll
                             for (int m = 0; m < MI; ++m)
                                 a[set][part][m] =
-                                    *reinterpret_cast<const frag128*>(wcur + ((kx * 2 + part) * 2) * (NT * 16) + m * 512);
+                                    *reinterpret_cast<const frag128*>(wcur + aoff[m] + (kx * 2 + part) * 2048);
 #pragma unroll
                             for (int n = 0; n < NI; ++n)
                                 b[set][part][n] =
@@ -410,6 +424,10 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
                     }
                 }
             };
+            auto mfma_part = [&]() {
+#pragma unroll
+                for (int r = 0; r < RPS; ++r) mfma_row(ss * RPS + r);
+            };
             // the two waves of a SIMD (w, w+4) run the two parts in opposite order, so one converts while the other
             // keeps the matrix core busy
             if (!stagger && !dbg_nostage) stage_part();
@@ -420,9 +438,9 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
             if (more_w) {
                 if (dbg_nowait) {
                 } else if (conv_next && load_next) {
-                    if (kSlots[ky] == 0) split_wait_vmcnt<0>();
-                    else if (kSlots[ky] == 1) split_wait_vmcnt<8>();
-                    else split_wait_vmcnt<16>();
+                    if (ss == 0) split_wait_vmcnt<8 * kSlots[0]>();
+                    else if (ss == 1) split_wait_vmcnt<8 * kSlots[1]>();
+                    else split_wait_vmcnt<8 * kSlots[2]>();
                 } else {
                     split_wait_vmcnt<0>();
                 }
@@ -432,43 +450,50 @@ __global__ __launch_bounds__(512) void split_mfma_kernel(SplitParams p) {
         }
     }
 
-    // ---- epilogue.  C/D layout of 32x32: column (pixel) = lane&31, row (cout) = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if (UP) {
-#pragma unroll
-        for (int n = 0; n < NI; ++n) {
-            if (ybase[n] < 0) continue;
-#pragma unroll
-            for (int m = 0; m < MI; ++m) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = n0 + wm * (MI * 32) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float dv = (p.d ? p.d[(int64_t)dimg[n] * p.Cout + co] : 1.f) * (ET == SGDFR_SPLIT_FP16 ? SPLIT_F16_OUT : 1.f);
-                    float* dst = p.y + (int64_t)ks * p.split_stride + ybase[n] + (int64_t)co * 4 * RP;
-#pragma unroll
-                    for (int ph = 0; ph < PH; ++ph) dst[(int64_t)ph * RP] = acc[ph][m][n][r] * dv;
-                }
-            }
-        }
-        return;
-    }
+    // ---- epilogue.  C/D layout of 32x32: column (pixel) = lane&31, row (cout) = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Loads and stores share the in-order vmcnt counter: a per-output `d` / bias load between two stores makes the
+    // wave wait for the previous store's HBM round trip.  So every coefficient the stores need is first brought into
+    // LDS (whose reads count on lgkmcnt) and the noise values into registers; after that the wave only issues stores.
+    if ((p.stagger & 64) && acc[0][0][0][0] != 123.456f) return;     // debug: skip the stores
     const bool whole = p.ksplit == 1;     // K slices only scale by d; noise / bias / activation follow the reduction
+    __syncthreads();                      // every wave is done with the staging buffers
+    float* const dl = reinterpret_cast<float*>(smem);          // [simgs][NT]  d * output scale
+    float* const bl = dl + p.simgs * NT;                        // [NT]         bias
+    const float oscale = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_OUT : 1.f;
+    for (int e = tid; e < p.simgs * NT; e += NTHR) {
+        const int m = e / NT, c = e - m * NT;
+        dl[e] = (p.d && img0 + m < p.B) ? p.d[(int64_t)(img0 + m) * p.Cout + n0 + c] * oscale : oscale;
+    }
+    for (int e = tid; e < NT; e += NTHR) bl[e] = (whole && p.bias) ? p.bias[n0 + e] : 0.f;
+    float nz[NI];
+    {
+        const float nw = (whole && p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
+#pragma unroll
+        for (int n = 0; n < NI; ++n) nz[n] = (!UP && whole && p.noise && ybase[n] >= 0) ? nw * p.noise[nzoff[n]] : 0.f;
+    }
+    __syncthreads();
     float* const yout = p.y + (int64_t)ks * p.split_stride;
-    const float nw = (whole && p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
         if (ybase[n] < 0) continue;
-        const float nz = (whole && p.noise) ? nw * p.noise[nzoff[n]] : 0.f;
+        const float* dln = dl + (dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi;
+        const float* bln = bl + wm * (MI * 32) + 4 * hi;
 #pragma unroll
         for (int m = 0; m < MI; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = n0 + wm * (MI * 32) + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                float v = acc[0][m][n][r] * (ET == SGDFR_SPLIT_FP16 ? SPLIT_F16_OUT : 1.f);
-                if (p.d) v *= p.d[(int64_t)dimg[n] * p.Cout + co];
-                v += nz;
-                if (whole && p.bias) v += p.bias[co];
-                if (whole && p.act) v = lrelu_gain(v, p.slope, p.gain);
-                yout[ybase[n] + (int64_t)co * HW] = v;
+                const int cl = m * 32 + (r & 3) + 8 * (r >> 2);          // cout inside the wave's rows (without 4*hi)
+                const int co = n0 + wm * (MI * 32) + cl + 4 * hi;
+                const float dv = dln[cl];
+                if (UP) {
+                    float* dst = yout + ybase[n] + (int64_t)co * 4 * RP;
+#pragma unroll
+                    for (int ph = 0; ph < PH; ++ph) dst[(int64_t)ph * RP] = acc[ph][m][n][r] * dv;
+                } else {
+                    float v = acc[0][m][n][r] * dv + nz[n] + bln[cl];
+                    if (whole && p.act) v = lrelu_gain(v, p.slope, p.gain);
+                    yout[ybase[n] + (int64_t)co * HW] = v;
+                }
             }
         }
     }
@@ -501,27 +526,33 @@ __global__ __launch_bounds__(256) void prepack_split_kernel(const float* __restr
 
 using namespace sgdfr;
 
-static int split_nt(int Cout) { return (Cout % 128 == 0) ? 128 : 64; }
 
-// geometry of the pixel tiling; returns 0 when the shape cannot use the split kernel
-static int split_up_pt(int Cout) { return split_nt(Cout) == 128 ? 128 : 256; }
+// ---- tiling plans.  A plan = (NT couts, PT pixels, NSS sub-stages per channel block); `cfg` indexes the kernel
+// instantiations in launch_plan().
+struct SplitPlan {
+    int cfg, nt, pt, nss, nw;
+};
+static const SplitPlan kPlanPlainWide = {0, 128, 256, 3, 8};    // plain: 128 couts x 256 pixels, row sub-stages
+static const SplitPlan kPlanPlainNarrow = {1, 64, 512, 3, 8};   // plain, Cout % 128 != 0: 64 x 512
+static const SplitPlan kPlanUpWide = {2, 128, 128, 3, 8};       // transposed: 128 couts x 128 super-pixels, row sub-stages
+static const SplitPlan kPlanUpNarrow = {3, 64, 256, 3, 8};      // transposed, Cout % 128 != 0 (or as a fallback): 64 x 256
+static const SplitPlan kPlanUpDeep = {4, 64, 256, 1, 8};        // transposed: 64 x 256, all 9 taps between barriers
 
-static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, SplitParams* out) {
-    if (Cin % SPLIT_CB != 0 || Cout % 64 != 0 || B < 1) return 0;
-    if (mode != SGDFR_MODE_PLAIN3 && mode != SGDFR_MODE_UP3) return 0;
+// geometry of the pixel tiling for one plan; returns 0 when the shape cannot use it
+static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, const SplitPlan& plan, SplitParams* out) {
+    if (Cin % SPLIT_CB != 0 || Cout % plan.nt != 0 || B < 1) return 0;
     SplitParams p{};
-    const int NT = split_nt(Cout), PT = (NT == 128) ? 256 : 512;
+    const int PT = plan.pt;
     const int HW = H * W;
     p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.P = W + 1; p.R = H + 1;
     p.total_pix = (int64_t)B * HW;
     if ((int64_t)B * p.R * p.P + 4ll * p.P + 8 >= (1ll << 31) || p.total_pix >= (1ll << 31)) return 0;
     if (mode == SGDFR_MODE_UP3) {
-        const int UPT = split_up_pt(Cout);
         p.patch = 0;
         p.total_pix = (int64_t)B * p.R * p.P;            // super-pixels
-        p.xlen = UPT + p.P + 2;
+        p.xlen = PT + p.P + 2;
         p.simgs = (p.xlen - 1) / (p.R * p.P) + 2;
-        p.n_pix_tiles = (int)((p.total_pix + UPT - 1) / UPT);
+        p.n_pix_tiles = (int)((p.total_pix + PT - 1) / PT);
     } else if (W > 64) {
         p.patch = 1;
         p.TC = 128;
@@ -547,26 +578,48 @@ static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, Spli
         p.xlen = span + 2 * p.P + 3;
         p.n_pix_tiles = (int)((p.total_pix + PT - 1) / PT);
     }
-    p.xs = (p.xlen + 63) & ~63;
-    p.n_cout_tiles = Cout / NT;
+    p.xs = plan.nw == 8 ? (p.xlen + 63) & ~63 : (p.xlen + 7) & ~7;
+    p.n_cout_tiles = Cout / plan.nt;
+    const int nthr = plan.nw * 64;
+    if ((2 * p.xs + nthr - 1) / nthr > (mode == SGDFR_MODE_UP3 ? 3 : 4)) return 0;                 // staging slots
+    const size_t lds = 2 * (size_t)64 * p.xs + 2 * (size_t)plan.nt * 192 * (3 / plan.nss) +
+                       (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float);
+    if (lds > (plan.nw == 8 ? 160 : 80) * 1024) return 0;
     if (out) *out = p;
     return 1;
 }
 
-static size_t split_lds_bytes(const SplitParams& p, int NT) {
-    return 2 * (size_t)64 * p.xs + 2 * (size_t)NT * 192 + (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float);
+// the plan used for a shape (first that fits), or nullptr
+static const SplitPlan* split_plan(int B, int Cin, int Cout, int H, int W, int mode, SplitParams* out) {
+    static const int deep = getenv("SGDFR_SPLIT_DEEP") ? atoi(getenv("SGDFR_SPLIT_DEEP")) : 1;
+    const SplitPlan* order[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n = 0;
+    if (mode == SGDFR_MODE_UP3) {
+        // deep stages need enough blocks per 64-cout tile to fill the chip; small layers keep the row sub-stages + K slices
+        if (deep && (int64_t)B * (H + 1) * (W + 1) * (Cout / 64) >= 256 * 256) order[n++] = &kPlanUpDeep;
+        if (Cout % 128 == 0) order[n++] = &kPlanUpWide;
+        order[n++] = &kPlanUpNarrow;
+    } else if (mode == SGDFR_MODE_PLAIN3) {
+        if (Cout % 128 == 0) order[n++] = &kPlanPlainWide;
+        order[n++] = &kPlanPlainNarrow;
+    }
+    for (int i = 0; i < n; ++i)
+        if (split_geometry(B, Cin, Cout, H, W, mode, *order[i], out)) return order[i];
+    return nullptr;
+}
+
+static size_t split_lds_bytes(const SplitParams& p, int NT, int nss) {
+    return 2 * (size_t)64 * p.xs + 2 * (size_t)NT * 192 * (3 / nss) + (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float);
 }
 
 extern "C" int sgdfr_modconv2d_split_supported(int B, int Cin, int Cout, int H, int W, int mode) {
     SplitParams p;
-    if (!split_geometry(B, Cin, Cout, H, W, mode, &p)) return 0;
-    if ((2 * p.xs + 511) / 512 > (mode == SGDFR_MODE_UP3 ? 3 : 4)) return 0;
-    return split_lds_bytes(p, split_nt(Cout)) <= 160 * 1024 ? 1 : 0;
+    return split_plan(B, Cin, Cout, H, W, mode, &p) ? 1 : 0;
 }
 
 extern "C" int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, int mode) {
     SplitParams p;
-    if (!split_geometry(B, Cin, Cout, H, W, mode, &p)) return 1;
+    if (!split_plan(B, Cin, Cout, H, W, mode, &p)) return 1;
     const int blocks = p.n_pix_tiles * p.n_cout_tiles;
     if (blocks >= 192) return 1;
     int s = 512 / blocks;                       // aim at ~2 resident-size waves of blocks
@@ -588,24 +641,36 @@ extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned sho
     int64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(prepack_split_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), weight, wsp, Cout, Cin,
-                       split_nt(Cout), (arith == SGDFR_SPLIT_FP16 ? SPLIT_F16_WSCALE : 1.f) / sqrtf((float)Cin * 9), arith);
+                       64, (arith == SGDFR_SPLIT_FP16 ? SPLIT_F16_WSCALE : 1.f) / sqrtf((float)Cin * 9), arith);
     return check_launch("modconv_prepack_split");
 }
 
-template <int MODE, int ET, int WM, int WN, int MI, int NI>
+template <int MODE, int ET, int WM, int WN, int MI, int NI, int NSS = 3>
 static int launch_split(const SplitParams& p, hipStream_t st) {
-    const int nex = (2 * p.xs + 511) / 512;
+    constexpr int NTHR = WM * WN * 64;
+    const int nex = (2 * p.xs + NTHR - 1) / NTHR;
     constexpr int NEX_MAX = (MODE == SGDFR_MODE_UP3) ? 3 : 4;   // UP3 stages at most PT + P + 2 positions
     SGDFR_REQUIRE(nex <= NEX_MAX, "modconv_split: staged range %d too long for mode %d", p.xlen, MODE);
-    void (*kern)(SplitParams) = nex <= 2   ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 2>
-                                : nex == 3 ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 3>
-                                           : split_mfma_kernel<MODE, ET, WM, WN, MI, NI, NEX_MAX>;
-    const size_t lds = split_lds_bytes(p, WM * MI * 32);
+    void (*kern)(SplitParams) = nex <= 2   ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 2, NSS>
+                                : nex == 3 ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 3, NSS>
+                                           : split_mfma_kernel<MODE, ET, WM, WN, MI, NI, NEX_MAX, NSS>;
+    const size_t lds = split_lds_bytes(p, WM * MI * 32, NSS);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess)
         return check_launch("modconv_split(lds attribute)");
-    hipLaunchKernelGGL(kern, dim3(p.n_pix_tiles * p.n_cout_tiles * p.ksplit), dim3(512), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(p.n_pix_tiles * p.n_cout_tiles * p.ksplit), dim3(NTHR), lds, st, p);
     return check_launch("modconv2d_split");
+}
+
+template <int ET>
+static int launch_plan(int cfg, const SplitParams& p, hipStream_t st) {
+    switch (cfg) {
+        case 0: return launch_split<SGDFR_MODE_PLAIN3, ET, 2, 4, 2, 2, 3>(p, st);
+        case 1: return launch_split<SGDFR_MODE_PLAIN3, ET, 1, 8, 2, 2, 3>(p, st);
+        case 2: return launch_split<SGDFR_MODE_UP3, ET, 4, 2, 1, 2, 3>(p, st);
+        case 3: return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 3>(p, st);
+        default: return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 1>(p, st);
+    }
 }
 
 extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned short* wsp, const float* s,
@@ -627,7 +692,7 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
     SGDFR_REQUIRE(((reinterpret_cast<uintptr_t>(wsp) | reinterpret_cast<uintptr_t>(s)) & 15) == 0,
                   "modconv_split: wsp and s must be 16-byte aligned");
     SplitParams p;
-    split_geometry(B, Cin, Cout, H, W, mode, &p);
+    const SplitPlan* plan = split_plan(B, Cin, Cout, H, W, mode, &p);
     p.x = x; p.x_bstride = x_bstride; p.wsp = wsp; p.s = s; p.d = d; p.noise = noise; p.noise_bstride = noise_bstride;
     p.noise_w = noise_w; p.bias = bias; p.zeros = zeros; p.y = y;
     p.act = act; p.slope = slope; p.gain = gain;
@@ -641,23 +706,8 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
     static const int stagger = getenv("SGDFR_SPLIT_STAGGER") ? atoi(getenv("SGDFR_SPLIT_STAGGER")) : 1;
     p.stagger = stagger;
     hipStream_t st = as_stream(stream);
-    int rc;
-    const bool wide = split_nt(Cout) == 128;
-    if (arith == SGDFR_SPLIT_FP16) {
-        if (mode == SGDFR_MODE_UP3)
-            rc = wide ? launch_split<SGDFR_MODE_UP3, SGDFR_SPLIT_FP16, 4, 2, 1, 2>(p, st)      // 128 couts x 128 super-pixels
-                      : launch_split<SGDFR_MODE_UP3, SGDFR_SPLIT_FP16, 2, 4, 1, 2>(p, st);     //  64 couts x 256 super-pixels
-        else
-            rc = wide ? launch_split<SGDFR_MODE_PLAIN3, SGDFR_SPLIT_FP16, 2, 4, 2, 2>(p, st)   // 128 couts x 256 pixels
-                      : launch_split<SGDFR_MODE_PLAIN3, SGDFR_SPLIT_FP16, 1, 8, 2, 2>(p, st);  //  64 couts x 512 pixels
-    } else {
-        if (mode == SGDFR_MODE_UP3)
-            rc = wide ? launch_split<SGDFR_MODE_UP3, SGDFR_SPLIT_BF16, 4, 2, 1, 2>(p, st)
-                      : launch_split<SGDFR_MODE_UP3, SGDFR_SPLIT_BF16, 2, 4, 1, 2>(p, st);
-        else
-            rc = wide ? launch_split<SGDFR_MODE_PLAIN3, SGDFR_SPLIT_BF16, 2, 4, 2, 2>(p, st)
-                      : launch_split<SGDFR_MODE_PLAIN3, SGDFR_SPLIT_BF16, 1, 8, 2, 2>(p, st);
-    }
+    const int rc = arith == SGDFR_SPLIT_FP16 ? launch_plan<SGDFR_SPLIT_FP16>(plan->cfg, p, st)
+                                             : launch_plan<SGDFR_SPLIT_BF16>(plan->cfg, p, st);
     if (rc || ksplit == 1) return rc;
     const bool plain = mode == SGDFR_MODE_PLAIN3;
     return launch_splitk_reduce(partials, ksplit, n_out, plain ? noise : nullptr, noise_bstride, noise_w, plain ? bias : nullptr, y,

@@ -536,23 +536,35 @@ __global__ __launch_bounds__(512, 2) void wino2_mfma_kernel(WinoParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) ex[(r * 4 + i) * 64 + lane] = py[r][i];
     }
-    __syncthreads();
-    if (half || !tile_ok) return;
+    // coefficients of the epilogue go through LDS too: a global `d` / bias load between two stores would make the
+    // wave wait for the previous store's HBM round trip (loads and stores share the in-order vmcnt counter)
+    float* const dl = smem + 4 * 64 * 64;      // [simgs][WNT]
+    float* const bl = dl + p.simgs * WNT;      // [WNT]
+    for (int e = tid; e < p.simgs * WNT; e += 512) {
+        const int m = e / WNT, c = e - m * WNT;
+        dl[e] = (p.d && img0 + m < p.B && n0 + c < p.Cout) ? p.d[(int64_t)(img0 + m) * p.Cout + n0 + c] : 1.f;
+    }
+    for (int e = tid; e < WNT; e += 512) bl[e] = (p.bias && n0 + e < p.Cout) ? p.bias[n0 + e] : 0.f;
     const int64_t img = tile / per_img;
     const int rem = tile - (int)img * per_img;
     const int ty = rem / p.TW, tx = rem - ty * p.TW;
     const float nw = (p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
     float nz[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.noise) {
+    if (p.noise && !half) {
         const float* np = p.noise + img * p.noise_bstride + (2 * ty) * p.W + 2 * tx;
         nz[0] = nw * np[0]; nz[1] = nw * np[1]; nz[2] = nw * np[p.W]; nz[3] = nw * np[p.W + 1];
     }
+    __syncthreads();
+    if (half || !tile_ok) return;
+    const float* dln = dl + ((int)img - img0) * WNT + wo * 32 + 4 * hi;
+    const float* bln = bl + wo * 32 + 4 * hi;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int co = n0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int cl = (r & 3) + 8 * (r >> 2);
+        const int co = n0 + wo * 32 + cl + 4 * hi;
         if (co >= p.Cout) continue;
-        const float dv = p.d ? p.d[img * p.Cout + co] : 1.f;
-        const float bv = p.bias ? p.bias[co] : 0.f;
+        const float dv = dln[cl];
+        const float bv = bln[cl];
         float* dst = p.y + (img * p.Cout + co) * HW + (2 * ty) * p.W + 2 * tx;
         float v[4];
 #pragma unroll
@@ -682,7 +694,8 @@ extern "C" int sgdfr_modconv2d_wino_f32(const float* x, int64_t x_bstride, const
         const int nex = (p.xlen + 511) / 512;           // 512 staging threads
         p.xs = nex * 512;
         lds = 2 * (size_t)(8 * p.xs + 8 * 16 * WNT) * sizeof(float) + s_bytes;
-        if (lds < 4 * 64 * 64 * sizeof(float)) lds = 4 * 64 * 64 * sizeof(float);   // half-exchange area of the epilogue
+        const size_t epi = (4 * 64 * 64 + (size_t)(p.simgs + 1) * WNT) * sizeof(float);   // half-exchange area + d / bias rows of the epilogue
+        if (lds < epi) lds = epi;
         kern = nex <= 1 ? wino2_mfma_kernel<8, 1> : wino2_mfma_kernel<8, 2>;
         threads = 512;
     }

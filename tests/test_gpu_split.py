@@ -19,6 +19,8 @@ CASES = [  # cin, cout, H, B
     (64, 64, 128, 1),     # 4 x 128 patches
     (32, 128, 128, 2),    # 2 x 128 patches
     (16, 64, 256, 1),     # patches on a 256-wide image
+    (16, 64, 256, 2),
+    (32, 128, 128, 8),
 ]
 
 
@@ -52,7 +54,8 @@ def test_split_conv_matches_fp64_oracle(cin, cout, H, B, arith):
     assert err <= TOL[arith] * max(1.0, float(ref.abs().max())), err
 
 
-UP_CASES = [(64, 64, 16, 3), (128, 128, 8, 5), (32, 128, 4, 9), (64, 64, 64, 2), (32, 64, 128, 1), (48, 256, 32, 2)]
+UP_CASES = [(64, 64, 16, 3), (128, 128, 8, 5), (32, 128, 4, 9), (64, 64, 64, 2), (32, 64, 128, 1), (48, 256, 32, 2),
+            (32, 64, 128, 8), (16, 128, 64, 33)]
 
 
 @pytest.mark.parametrize('arith', ['fp16x3', 'bf16x3'])
