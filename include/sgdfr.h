@@ -175,7 +175,9 @@ int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, cons
  * hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~2^-17 relative error per product; the
  * whole 256x256 generator stays within 1.1e-4 max-abs of the fp64 oracle, contract 1e-3).  Never selected implicitly.
  *   sgdfr_modconv_prepack_split_elems: uint16 elements of the packed weight buffer (= 2*9*Cout*Cin)
- *   sgdfr_modconv_prepack_split_f32:   weight [Cout,Cin,3,3] -> bf16 hi/lo of weight/sqrt(9 Cin) in kernel order
+ *   sgdfr_modconv_prepack_split_f32:   weight [Cout,Cin,3,3] -> 16-bit hi/lo of weight/sqrt(9 Cin) in kernel order;
+ *                                      transpose_flip != 0 packs the adjoint conv (Cin outputs, Cout inputs, taps rotated):
+ *                                      dL/dx of the plain conv is then the same PLAIN3 kernel
  *   sgdfr_modconv2d_split_supported:   1 when the shape can use it (Cin % 16 == 0, Cout % 64 == 0, tileable H x W)
  *   sgdfr_modconv2d_split_f32:         arguments as sgdfr_modconv2d_wino_f32 with wsp in place of u, plus mode:
  *                                      PLAIN3, or UP3 = stride-2 transposed conv into parity planes
@@ -187,7 +189,8 @@ int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, cons
 #define SGDFR_SPLIT_FP16 1   /* fp16 hi+lo: 22 mantissa bits = fp32-grade; operands range-shifted by exact powers of two,
                                 |x*s| saturates at 1.04e6 */
 int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin);
-int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int arith, void* stream);
+int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int arith, int transpose_flip,
+                                    void* stream);
 int sgdfr_modconv2d_split_supported(int B, int Cin, int Cout, int H, int W, int mode);
 int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned short* wsp, const float* s, const float* d,
                               const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,

@@ -157,10 +157,10 @@ class StyledConvFn(Function):
         if up:
             out, planes = F_.modconv3x3(x, wp, s, d, mod.out_channel, upsample=True, fir=mod.blur.kernel, noise=noise,
                                         noise_weight=noise_w, bias=bias, activate=activate, batch=batch,
-                                        return_planes=True)
+                                        return_planes=True, split=mod.packed_split)
         else:
             out = F_.modconv3x3(x, wp, s, d, mod.out_channel, noise=noise, noise_weight=noise_w, bias=bias,
-                                activate=activate, batch=batch, wino=mod.packed_wino)
+                                activate=activate, batch=batch, wino=mod.packed_wino, split=mod.packed_split)
         ctx.save_for_backward(x, s, d, out, noise_w, bias, noise, planes)
         ctx.mod, ctx.activate = mod, activate
         return out
@@ -181,7 +181,12 @@ class StyledConvFn(Function):
                                 desc='bwd down3 %d->%d @%dx%d' % (cout, cin, H, W))
         else:
             A = sums[:, :, 2] if d is not None else None
-            if F_.wino_ok(B, cout, cin, H, W):     # dL/dx of a plain conv is a plain conv: same Winograd kernel
+            if F_.split_ok(B, cout, cin, H, W):    # dL/dx of a plain conv is a plain conv: same kernels, adjoint packs.
+                # Gradients have no natural scale (1e-8 is as likely as 1e+3), so the range-shifted fp16 terms do not
+                # apply: the backward conv always splits into bf16 terms (fp32 range, 2^-17 per product).
+                gu = F_.modconv_split(g_pre, mod.packed_split(adjoint=True, arith='bf16x3'), ones_d, None, cin,
+                                      desc='bwd split3 %d->%d @%dx%d' % (cout, cin, H, W), arith='bf16x3')
+            elif F_.wino_ok(B, cout, cin, H, W):
                 gu = F_.modconv_wino(g_pre, mod.packed_wino(adjoint=True), ones_d, None, cin,
                                      desc='bwd wino3 %d->%d @%dx%d' % (cout, cin, H, W))
             else:

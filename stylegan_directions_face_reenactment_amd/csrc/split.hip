@@ -502,14 +502,17 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 // weight [Cout,Cin,3,3] fp32 -> bf16 hi/lo of Wc = weight/sqrt(9 Cin) in the kernel's LDS order:
 //   [cout tile][cin block][ky][kx][part][k-half][cout in tile (NT)][8 cin]
 __global__ __launch_bounds__(256) void prepack_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                                           int Cout, int Cin, int NT, float scale, int et) {
-    const int64_t n = (int64_t)Cout * Cin * 9;
-    const int ncb = Cin / SPLIT_CB;
+                                                           int Cout, int Cin, int NT, float scale, int et, int transpose_flip) {
+    // packed conv: n_out x n_in channels.  transpose_flip: the adjoint conv (dL/dx of the plain conv): channels swapped, taps
+    // rotated by 180 degrees; weight stays indexed [Cout][Cin][3][3]
+    const int n_out = transpose_flip ? Cin : Cout, n_in = transpose_flip ? Cout : Cin;
+    const int64_t n = (int64_t)n_out * n_in * 9;
+    const int ncb = n_in / SPLIT_CB;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
         const int tap = (int)(idx % 9);
-        const int ci = (int)((idx / 9) % Cin);
-        const int co = (int)(idx / (9 * (int64_t)Cin));
-        const float v = w[idx] * scale;          // fp16 packs: scale already carries the 2^6 range shift
+        const int ci = (int)((idx / 9) % n_in);
+        const int co = (int)(idx / (9 * (int64_t)n_in));
+        const float v = (transpose_flip ? w[((int64_t)ci * Cin + co) * 9 + (8 - tap)] : w[idx]) * scale;   // fp16: scale carries 2^6
         unsigned hp, lp;
         if (et == SGDFR_SPLIT_FP16) split_pair<SGDFR_SPLIT_FP16>(v, 0.f, hp, lp);
         else split_pair<SGDFR_SPLIT_BF16>(v, 0.f, hp, lp);
@@ -632,16 +635,17 @@ extern "C" int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H
 extern "C" int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin) { return (int64_t)Cout * Cin * 9 * 2; }
 
 extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int arith,
-                                               void* stream) {
+                                               int transpose_flip, void* stream) {
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "prepack_split: arith must be SGDFR_SPLIT_BF16/FP16");
-    SGDFR_REQUIRE(Cout > 0 && Cin > 0 && Cin % SPLIT_CB == 0 && Cout % 64 == 0,
-                  "prepack_split: needs Cin %% 16 == 0 and Cout %% 64 == 0, got Cin=%d Cout=%d", Cin, Cout);
+    const int n_out = transpose_flip ? Cin : Cout, n_in = transpose_flip ? Cout : Cin;
+    SGDFR_REQUIRE(Cout > 0 && Cin > 0 && n_in % SPLIT_CB == 0 && n_out % 64 == 0,
+                  "prepack_split: needs in-channels %% 16 == 0 and out-channels %% 64 == 0, got in=%d out=%d", n_in, n_out);
     SGDFR_REQUIRE(weight && wsp, "prepack_split: null pointer");
     const int64_t n = (int64_t)Cout * Cin * 9;
     int64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(prepack_split_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), weight, wsp, Cout, Cin,
-                       64, (arith == SGDFR_SPLIT_FP16 ? SPLIT_F16_WSCALE : 1.f) / sqrtf((float)Cin * 9), arith);
+                       64, (arith == SGDFR_SPLIT_FP16 ? SPLIT_F16_WSCALE : 1.f) / sqrtf((float)Cin * 9), arith, transpose_flip);
     return check_launch("modconv_prepack_split");
 }
 

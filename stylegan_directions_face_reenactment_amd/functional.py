@@ -177,12 +177,13 @@ def _noise_args(noise, B, H, W):
 USE_SPLITK = True            # K-sliced launches for convs that cannot fill the chip (small batch / 4x4, 8x8 layers)
 USE_WINOGRAD = True          # plain 3x3 layers: Winograd F(2x2,3x3) MFMA kernel when the shape allows it
 WINOGRAD_MIN_BLOCKS = 256    # below this many (64 cout x 64 tile) blocks the direct kernel's smaller tiles win
-# Arithmetic of the 3x3 modulated convs on the no-grad (inference) path:
+# Arithmetic of the 3x3 modulated convs (inference path, autograd forward, and dL/dx of the plain convs; the strided dL/dx of
+# the transposed convs and the weight gradients always use the fp32 MFMA kernels):
 #   'fp16x3' (default)  fp32 operands split into fp16 hi + lo (11+11 mantissa bits; range-shifted by exact powers of two,
 #                       |x*s| saturates at 1.04e6), hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulation
 #                       (csrc/split.hip).  fp32-grade: measured 7.7e-6 max-abs vs an fp64 evaluation on 256x256 images
 #                       (fp32 MFMA kernels: 9.5e-6) and held to the same per-layer bound by tests/test_gpu_split.py.
-#   'fp32'              fp32 MFMA kernels (direct + Winograd): what the autograd path always uses.
+#   'fp32'              fp32 MFMA kernels (direct + Winograd) everywhere.
 #   'bf16x3'            as fp16x3 with bf16 terms: full fp32 range, 8+8 bits (~1e-4 on images; contract 1e-3).
 PRECISION = os.environ.get('SGDFR_PRECISION', 'fp16x3')
 _zeros = {}
@@ -242,16 +243,16 @@ def modconv_wino(x, u, s, d, cout, noise=None, noise_weight=None, bias=None, act
 _SPLIT_ARITH = {'bf16x3': N.SPLIT_BF16, 'fp16x3': N.SPLIT_FP16}
 
 
-def prepack_split(weight, arith=None):
+def prepack_split(weight, arith=None, adjoint=False):
     """weight [1,Cout,Cin,3,3] -> uint16 buffer of 16-bit hi/lo terms of weight/sqrt(9 Cin) in split.hip's LDS order
-    (arith: 'bf16x3' or 'fp16x3', default = the current PRECISION)."""
+    (arith: 'bf16x3' or 'fp16x3', default = the current PRECISION; adjoint: the pack of dL/dx of the plain conv)."""
     arith = _SPLIT_ARITH[arith or PRECISION]
     N.require_device(weight)
     w = N.f32c(weight)
     _, cout, cin, k, _ = w.shape
     n = N.load().sgdfr_modconv_prepack_split_elems(cout, cin)
     wsp = torch.empty(n, device=w.device, dtype=torch.int16)
-    N.call('sgdfr_modconv_prepack_split_f32', N.ptr(w), N.ptr(wsp), cout, cin, arith, N.stream())
+    N.call('sgdfr_modconv_prepack_split_f32', N.ptr(w), N.ptr(wsp), cout, cin, arith, int(bool(adjoint)), N.stream())
     return wsp
 
 

@@ -181,14 +181,19 @@ class ModulatedConv2d(nn.Module):
                 cache[1 + int(adjoint)] = F_.prepack_wino(self.weight.detach(), adjoint=adjoint)
         return cache[1 + int(adjoint)]
 
-    def packed_split(self):
-        """16-bit hi/lo weight pack of the split precision modes (functional.PRECISION), cached per weight version and mode."""
-        key = self._key() + (F_.PRECISION,)
+    def packed_split(self, adjoint=False, arith=None):
+        """16-bit hi/lo weight pack of the split precision modes (default arith = functional.PRECISION), cached per weight
+        version (adjoint=True: the pack of the plain conv's dL/dx conv)."""
+        arith = arith or F_.PRECISION
+        key = self._key()
         cache = getattr(self, '_pack_s', None)
         if cache is None or cache[0] != key:
+            cache = self._pack_s = [key, {}]
+        slot = (arith, bool(adjoint))
+        if slot not in cache[1]:
             with torch.no_grad():
-                cache = self._pack_s = (key, F_.prepack_split(self.weight.detach()))
-        return cache[1]
+                cache[1][slot] = F_.prepack_split(self.weight.detach(), arith=arith, adjoint=adjoint)
+        return cache[1][slot]
 
     def style_spec(self, latent_index):
         """(latent row, modulation weight, bias, Q or None, Cout) for functional.styles_batched."""

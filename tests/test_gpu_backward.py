@@ -5,6 +5,16 @@ import torch
 
 from util import O, S, SEED, golden, hip_generator, maxabs, synthetic_state, t
 
+@pytest.fixture(autouse=True, params=['fp16x3', 'fp32'])
+def _both_arithmetics(request):
+    """Gradients are checked with the split-fp16 conv kernels (forward + plain-conv dL/dx) and with the fp32 MFMA kernels."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    default = F_.PRECISION
+    F_.set_precision(request.param)
+    yield
+    F_.set_precision(default)
+
+
 pytestmark = pytest.mark.gpu
 
 
