@@ -184,7 +184,12 @@ int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, cons
  *                                      [B,Cout,4,H+1,W+1] exactly as sgdfr_modconv2d_fwd_f32(mode UP3) writes them;
  *                                      ksplit > 1 (see ..._ksplit_hint; layers too small to fill the chip) slices the
  *                                      channel blocks over extra thread blocks into `partials` [ksplit][numel(y)] and
- *                                      reduces them in fixed order (deterministic) */
+ *                                      reduces them in fixed order (deterministic).
+ *                                      rgb_part != NULL (PLAIN3, ksplit == 1) also fuses the 1x1 ToRGB conv that follows
+ *                                      the layer (ToRGB.forward model.py:350-359): rgb_w [3][Cout], rgb_s [B][Cout] (its
+ *                                      modulation), rgb_part [B][T*3][H*W] with T = ..._split_cout_tiles(); channel t*3+j
+ *                                      holds the sum over cout tile t, so sgdfr_torgb_fwd_f32 over those T*3 channels with
+ *                                      indicator weights finishes it (+ bias + upsampled skip) without re-reading x */
 #define SGDFR_SPLIT_BF16 0   /* bf16 hi+lo: 16 mantissa bits, fp32 range   (~1e-4 on the 256x256 generator) */
 #define SGDFR_SPLIT_FP16 1   /* fp16 hi+lo: 22 mantissa bits = fp32-grade; operands range-shifted by exact powers of two,
                                 |x*s| saturates at 1.04e6 */
@@ -194,9 +199,16 @@ int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, in
 int sgdfr_modconv2d_split_supported(int B, int Cin, int Cout, int H, int W, int mode);
 int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned short* wsp, const float* s, const float* d,
                               const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
-                              const float* zeros, float* y, float* partials, int ksplit, int B, int Cin, int Cout, int H,
-                              int W, int mode, int arith, int act, float slope, float gain, void* stream);
+                              const float* zeros, float* y, float* partials, int ksplit, const float* rgb_w,
+                              const float* rgb_s, float* rgb_part, int B, int Cin, int Cout, int H, int W, int mode, int arith,
+                              int act, float slope, float gain, void* stream);
+int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H, int W, int mode);
 int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, int mode);
+
+/* The rest of ToRGB.forward (model.py:350-359) when its 1x1 conv was accumulated by sgdfr_modconv2d_split_f32(rgb_part):
+ *   y[b,j,p] = sum_{t<T} part[b, t*3+j, p] + bias[j] + (skip ? upfirdn2d(skip[b,j], fir[4,4], up=2, pad=(2,1))[p] : 0) */
+int sgdfr_torgb_finish_f32(const float* part, int T, const float* bias, const float* skip, const float* fir, float* y, int B,
+                           int H, int W, void* stream);
 
 /* x [B,3,H,W] fp32 -> y [B,H,W,3] uint8:  trunc( (clamp(x,-1,1) + 1) / (2 + 1e-5) * 255 )
  * (libs/utilities/image_utils.py:87-110 tensor_to_image / torch_range_1_to_255, then the writers' uint8 cast) */

@@ -42,8 +42,11 @@ SIGNATURES = {
     'sgdfr_modconv_prepack_split_f32': [_c_f32p, ctypes.c_void_p, _i, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_modconv2d_split_supported': [_i, _i, _i, _i, _i, _i],
     'sgdfr_modconv2d_split_f32': [_c_f32p, _i64, ctypes.c_void_p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
-                                  _c_f32p, _c_f32p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, ctypes.c_void_p],
+                                  _c_f32p, _c_f32p, _i, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f,
+                                  ctypes.c_void_p],
+    'sgdfr_modconv2d_split_cout_tiles': [_i, _i, _i, _i, _i, _i],
     'sgdfr_modconv2d_split_ksplit_hint': [_i, _i, _i, _i, _i, _i],
+    'sgdfr_torgb_finish_f32': [_c_f32p, _i, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_image_to_u8_f32': [_c_f32p, ctypes.c_void_p, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_grid_to_u8_f32': [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), _i, ctypes.c_void_p, _i, _i, _i,
                              _i, ctypes.c_void_p],

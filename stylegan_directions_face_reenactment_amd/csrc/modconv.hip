@@ -695,6 +695,74 @@ extern "C" int sgdfr_modconv2d_fwd_f32(const float* x, int64_t x_bstride, const 
     }
 }
 
+// ToRGB finish: the 1x1 conv was accumulated per cout tile in the feeding conv's epilogue (split.hip); what is left is
+// y[b,j,p] = sum_t part[b, t*3+j, p] + bias[j] + upfirdn2d(skip[b,j], fir, up=2, pad=(2,1))[p].  One thread = 4 pixels of
+// a row x 3 channels; the polyphase upsample reads a 2x3 skip window per channel.
+__global__ __launch_bounds__(256) void torgb_finish_kernel(const float* __restrict__ part, int T, const float* __restrict__ bias,
+                                                          const float* __restrict__ skip, const float* __restrict__ fir,
+                                                          float* __restrict__ y, int B, int H, int W) {
+    __shared__ float kf[16];
+    if (threadIdx.x < 16) kf[threadIdx.x] = fir ? fir[15 - threadIdx.x] : 0.f;  // flipped taps
+    __syncthreads();
+    const int HW = H * W, W4 = W >> 2;
+    const int64_t n = (int64_t)B * H * W4;
+    const int Hs = H >> 1, Ws = W >> 1;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int xq = (int)(idx % W4);
+        const int oy = (int)((idx / W4) % H);
+        const int b = (int)(idx / ((int64_t)W4 * H));
+        const int ox = xq * 4;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float bj = bias ? bias[j] : 0.f;
+            float4 acc = make_float4(bj, bj, bj, bj);
+            for (int t = 0; t < T; ++t) {
+                const float4 v = *reinterpret_cast<const float4*>(part + ((int64_t)b * T * 3 + t * 3 + j) * HW + (int64_t)oy * W + ox);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            if (skip) {
+                // upfirdn2d(up=2, pad=(2,1)): skip sample (m,n) sits at padded (2m+2, 2n+2); output (oy,ox) sums taps (ky,kx) with
+                // oy+ky-2 = 2m, ox+kx-2 = 2n  ->  ky of parity oy&1, kx of parity ox&1: 2x2 taps per output
+                const float* sp = skip + ((int64_t)b * 3 + j) * Hs * Ws;
+                float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int ky = (oy & 1) + 2 * a;
+                    const int m = (oy + ky - 2) >> 1;
+                    if (oy + ky - 2 < 0 || m >= Hs) continue;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int xx = ox + v;
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const int kx = (xx & 1) + 2 * c;
+                            const int nn = (xx + kx - 2) >> 1;
+                            if (xx + kx - 2 < 0 || nn >= Ws) continue;
+                            o[v] = fmaf(sp[m * Ws + nn], kf[ky * 4 + kx], o[v]);
+                        }
+                    }
+                }
+                acc.x += o[0]; acc.y += o[1]; acc.z += o[2]; acc.w += o[3];
+            }
+            *reinterpret_cast<float4*>(y + ((int64_t)b * 3 + j) * HW + (int64_t)oy * W + ox) = acc;
+        }
+    }
+}
+
+extern "C" int sgdfr_torgb_finish_f32(const float* part, int T, const float* bias, const float* skip, const float* fir, float* y,
+                                      int B, int H, int W, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && T > 0 && H > 0 && W > 0 && W % 4 == 0, "torgb_finish: bad shape B=%d T=%d H=%d W=%d (W %% 4 == 0)", B, T,
+                  H, W);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(part && y, "torgb_finish: null pointer");
+    SGDFR_REQUIRE(!skip || (fir && H % 2 == 0), "torgb_finish: skip needs fir taps and even H");
+    SGDFR_REQUIRE(((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "torgb_finish: 16-byte alignment");
+    int64_t g = ((int64_t)B * H * (W / 4) + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    hipLaunchKernelGGL(torgb_finish_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), part, T, bias, skip, fir, y, B, H, W);
+    return check_launch("torgb_finish");
+}
+
 extern "C" int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, const float* bias,
                                    const float* skip, const float* fir, float* y, int B, int Cin, int H, int W,
                                    void* stream) {

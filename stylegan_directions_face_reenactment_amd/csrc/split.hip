@@ -58,6 +58,9 @@ struct SplitParams {
     const float* bias;
     const float* zeros;          // >= 8 zero floats
     float* y;
+    const float* rgb_w;          // fused ToRGB (PLAIN3, ksplit == 1): [3][Cout] 1x1 weights, [B][Cout] styles,
+    const float* rgb_s;          //   partial sums out [B][n_cout_tiles*3][H*W] (bias / skip are added by the finish launch)
+    float* rgb_part;
     int B, Cin, Cout, H, W;
     int P, R;                    // padded pitch / rows per image of the flat space (W+1, H+1)
     int n_pix_tiles, n_cout_tiles;
@@ -471,13 +474,30 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 #pragma unroll
         for (int n = 0; n < NI; ++n) nz[n] = (!UP && whole && p.noise && ybase[n] >= 0) ? nw * p.noise[nzoff[n]] : 0.f;
     }
+    // fused ToRGB: rgb[j] = sum_co y[co] * w_rgb[j][co] * s_rgb[b][co] / sqrt(Cout) over this block's couts
+    const bool fuse_rgb = !UP && whole && p.rgb_part != nullptr;
+    float* const cw = bl + NT;                                  // [simgs][NT][4]
+    float* const red = cw + p.simgs * NT * 4;                   // [WM][PT][3]
+    if (fuse_rgb) {
+        const float rs = rsqrtf((float)p.Cout);
+        for (int e = tid; e < p.simgs * NT; e += NTHR) {
+            const int m = e / NT, c = e - m * NT;
+            const float sv = (img0 + m < p.B) ? p.rgb_s[(int64_t)(img0 + m) * p.Cout + n0 + c] * rs : 0.f;
+            float4 q = make_float4(p.rgb_w[n0 + c] * sv, p.rgb_w[p.Cout + n0 + c] * sv, p.rgb_w[2 * p.Cout + n0 + c] * sv, 0.f);
+            *reinterpret_cast<float4*>(cw + 4 * e) = q;
+        }
+    }
     __syncthreads();
     float* const yout = p.y + (int64_t)ks * p.split_stride;
+    float rgb[NI][3];
+#pragma unroll
+    for (int n = 0; n < NI; ++n) rgb[n][0] = rgb[n][1] = rgb[n][2] = 0.f;
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
         if (ybase[n] < 0) continue;
         const float* dln = dl + (dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi;
         const float* bln = bl + wm * (MI * 32) + 4 * hi;
+        const float* cwn = cw + ((dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi) * 4;
 #pragma unroll
         for (int m = 0; m < MI; ++m) {
 #pragma unroll
@@ -493,6 +513,37 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                     float v = acc[0][m][n][r] * dv + nz[n] + bln[cl];
                     if (whole && p.act) v = lrelu_gain(v, p.slope, p.gain);
                     yout[ybase[n] + (int64_t)co * HW] = v;
+                    if (fuse_rgb) {
+                        const float4 q = *reinterpret_cast<const float4*>(cwn + 4 * cl);
+                        rgb[n][0] = fmaf(v, q.x, rgb[n][0]);
+                        rgb[n][1] = fmaf(v, q.y, rgb[n][1]);
+                        rgb[n][2] = fmaf(v, q.z, rgb[n][2]);
+                    }
+                }
+            }
+        }
+    }
+    if (fuse_rgb) {      // block-uniform
+        // the two lane halves hold different couts of the same pixels; the WM cout-waves of a pixel column meet in LDS
+#pragma unroll
+        for (int n = 0; n < NI; ++n)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                rgb[n][j] += __shfl_xor(rgb[n][j], 32, 64);
+                if (hi == 0) red[(wm * PT + (wn * NI + n) * 32 + l31) * 3 + j] = rgb[n][j];
+            }
+        __syncthreads();
+        if (wm == 0 && hi == 0) {
+#pragma unroll
+            for (int n = 0; n < NI; ++n) {
+                if (ybase[n] < 0) continue;
+                const int rem = (int)(ybase[n] - (int64_t)dimg[n] * p.Cout * HW);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w2 = 0; w2 < WM; ++w2) t += red[(w2 * PT + (wn * NI + n) * 32 + l31) * 3 + j];
+                    p.rgb_part[(((int64_t)dimg[n] * p.n_cout_tiles + ct) * 3 + j) * HW + rem] = t;
                 }
             }
         }
@@ -612,7 +663,9 @@ static const SplitPlan* split_plan(int B, int Cin, int Cout, int H, int W, int m
 }
 
 static size_t split_lds_bytes(const SplitParams& p, int NT, int nss) {
-    return 2 * (size_t)64 * p.xs + 2 * (size_t)NT * 192 * (3 / nss) + (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float);
+    const size_t loop = 2 * (size_t)64 * p.xs + 2 * (size_t)NT * 192 * (3 / nss) + (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float);
+    const size_t epi = ((size_t)p.simgs * NT * 5 + NT + 2 * 512 * 3) * sizeof(float);   // d, bias, ToRGB coefficient and reduce tables
+    return loop > epi ? loop : epi;
 }
 
 extern "C" int sgdfr_modconv2d_split_supported(int B, int Cin, int Cout, int H, int W, int mode) {
@@ -630,6 +683,11 @@ extern "C" int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H
     if (s > max_by_k) s = max_by_k;
     if (s > 16) s = 16;
     return s < 2 ? 1 : s;
+}
+
+extern "C" int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H, int W, int mode) {
+    SplitParams p;
+    return split_plan(B, Cin, Cout, H, W, mode, &p) ? p.n_cout_tiles : 0;
 }
 
 extern "C" int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin) { return (int64_t)Cout * Cin * 9 * 2; }
@@ -680,8 +738,8 @@ static int launch_plan(int cfg, const SplitParams& p, hipStream_t st) {
 extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned short* wsp, const float* s,
                                          const float* d, const float* noise, int64_t noise_bstride, const float* noise_w,
                                          const float* bias, const float* zeros, float* y, float* partials, int ksplit,
-                                         int B, int Cin, int Cout, int H, int W, int mode, int arith, int act, float slope,
-                                         float gain, void* stream) {
+                                         const float* rgb_w, const float* rgb_s, float* rgb_part, int B, int Cin, int Cout,
+                                         int H, int W, int mode, int arith, int act, float slope, float gain, void* stream) {
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "modconv_split: arith must be SGDFR_SPLIT_BF16/FP16");
     SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "modconv_split: bad shape B=%d Cin=%d Cout=%d H=%d W=%d",
                   B, Cin, Cout, H, W);
@@ -701,6 +759,9 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
     p.noise_w = noise_w; p.bias = bias; p.zeros = zeros; p.y = y;
     p.act = act; p.slope = slope; p.gain = gain;
     if (ksplit < 1) ksplit = 1;
+    SGDFR_REQUIRE(!rgb_part || (rgb_w && rgb_s && mode == SGDFR_MODE_PLAIN3 && ksplit == 1),
+                  "modconv_split: the fused ToRGB needs rgb_w, rgb_s, mode PLAIN3 and ksplit == 1");
+    p.rgb_w = rgb_w; p.rgb_s = rgb_s; p.rgb_part = rgb_part;
     SGDFR_REQUIRE(ksplit == 1 || (partials && ksplit <= Cin / SPLIT_CB), "modconv_split: ksplit %d needs a partials buffer "
                   "and at most %d slices", ksplit, Cin / SPLIT_CB);
     const int64_t n_out = (mode == SGDFR_MODE_UP3) ? (int64_t)B * Cout * 4 * p.R * p.P : (int64_t)B * Cout * H * W;

@@ -174,6 +174,7 @@ def _noise_args(noise, B, H, W):
     raise RuntimeError('noise of shape %s does not broadcast to [%d,1,%d,%d]' % (tuple(noise.shape), B, H, W))
 
 
+USE_RGB_FUSION = True        # ToRGB partial sums in the epilogue of the split conv that feeds it (no-grad path)
 USE_SPLITK = True            # K-sliced launches for convs that cannot fill the chip (small batch / 4x4, 8x8 layers)
 USE_WINOGRAD = True          # plain 3x3 layers: Winograd F(2x2,3x3) MFMA kernel when the shape allows it
 WINOGRAD_MIN_BLOCKS = 256    # below this many (64 cout x 64 tile) blocks the direct kernel's smaller tiles win
@@ -261,9 +262,10 @@ def split_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
 
 
 def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2,
-                  batch=None, desc=None, mode=N.MODE_PLAIN3, arith=None):
+                  batch=None, desc=None, mode=N.MODE_PLAIN3, arith=None, rgb=None):
     """3x3 modulated conv in a split arithmetic (same contract as modconv_raw, modes PLAIN3 and UP3); `wsp` must have
-    been packed for the same `arith`."""
+    been packed for the same `arith`.  rgb = (w_rgb [3,Cout], s_rgb [B,Cout]) also returns the per-cout-tile partial sums
+    [B, T*3, H, W] of the ToRGB 1x1 conv that follows the layer (see rgb_fusable / torgb_finish)."""
     arith = _SPLIT_ARITH[arith or PRECISION]
     N.require_device(x, s, d, bias, noise_weight)
     if not wsp.is_cuda or wsp.dtype != torch.int16:
@@ -281,11 +283,41 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
     st = N.stream()
     ks = N.load().sgdfr_modconv2d_split_ksplit_hint(B, cin, cout, H, W, mode) if USE_SPLITK else 1
     partials = torch.empty((ks,) + tuple(y.shape), device=x.device, dtype=torch.float32) if ks > 1 else None
+    rgb_w = rgb_s = part = None
+    if rgb is not None:
+        if ks > 1 or mode != N.MODE_PLAIN3:
+            raise RuntimeError('modconv_split: this launch cannot fuse ToRGB (check rgb_fusable first)')
+        rgb_w, rgb_s = N.f32c(rgb[0]), N.f32c(rgb[1])
+        N.require_device(rgb_w, rgb_s)
+        tiles = N.load().sgdfr_modconv2d_split_cout_tiles(B, cin, cout, H, W, mode)
+        part = torch.empty(B, tiles * 3, H, W, device=x.device, dtype=torch.float32)
     _timed_conv(desc or ('split mode%d %d->%d @%dx%d%s' % (mode, cin, cout, H, W, ' K/%d' % ks if ks > 1 else '')),
                 B * conv_flops(cin, cout, H, W), lambda: N.call(
         'sgdfr_modconv2d_split_f32', N.ptr(x), xb, N.ptr(wsp), N.ptr(s), N.ptr(d), N.ptr(nz), nzb,
         N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(_zero_words(x.device)), N.ptr(y),
-        N.ptr(partials), ks, B, cin, cout, H, W, mode, arith, int(activate), float(slope), float(gain), st))
+        N.ptr(partials), ks, N.ptr(rgb_w), N.ptr(rgb_s), N.ptr(part), B, cin, cout, H, W, mode, arith, int(activate),
+        float(slope), float(gain), st))
+    return y if rgb is None else (y, part)
+
+
+def rgb_fusable(B, cin, cout, H, W):
+    """True when the plain 3x3 conv of this shape runs on the split kernel in one pass, so the ToRGB that follows it can be
+    accumulated in its epilogue instead of re-reading the activation."""
+    return USE_RGB_FUSION and split_ok(B, cin, cout, H, W) and \
+        (not USE_SPLITK or N.load().sgdfr_modconv2d_split_ksplit_hint(B, cin, cout, H, W, N.MODE_PLAIN3) == 1)
+
+
+def torgb_finish(part, bias=None, skip=None, fir=None):
+    """part [B, T*3, H, W] (from modconv_split(rgb=...)) -> rgb [B,3,H,W] = sum over the T cout tiles + bias + upsampled
+    skip (one small launch; the activation is not read again)."""
+    N.require_device(part, bias, skip, fir)
+    B, c3, H, W = part.shape
+    if skip is not None and tuple(skip.shape) != (B, 3, H // 2, W // 2):
+        raise RuntimeError('skip shape %s does not match output [%d,3,%d,%d]/2' % (tuple(skip.shape), B, H, W))
+    y = torch.empty(B, 3, H, W, device=part.device, dtype=torch.float32)
+    N.call('sgdfr_torgb_finish_f32', N.ptr(part), c3 // 3, N.ptr(N.f32c(bias)) if bias is not None else None,
+           N.ptr(N.f32c(skip)) if skip is not None else None, N.ptr(N.f32c(fir)) if fir is not None else None, N.ptr(y), B, H, W,
+           N.stream())
     return y
 
 
@@ -335,7 +367,7 @@ def blur_bias_act(planes, fir, H, W, noise=None, noise_weight=None, bias=None, a
 
 
 def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_weight=None, bias=None,
-               activate=False, slope=0.2, gain=SQRT2, batch=None, return_planes=False, wino=None, split=None):
+               activate=False, slope=0.2, gain=SQRT2, batch=None, return_planes=False, wino=None, split=None, rgb=None):
     """Shared-weight modulated 3x3 conv (model.py:232-273) with the StyledConv tail fused in
     (noise model.py:287, bias + leaky-ReLU op/fused_act.py:81-86).
 
@@ -347,7 +379,9 @@ def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_we
         B = s.shape[0] if batch is None else batch
         if split is not None and split_ok(B, cin, cout, H, W):
             return modconv_split(x, split() if callable(split) else split, s, d, cout, noise, noise_weight, bias,
-                                 activate, slope, gain, batch)
+                                 activate, slope, gain, batch, rgb=rgb)
+        if rgb is not None:
+            raise RuntimeError('modconv3x3: ToRGB fusion needs the split kernel (check rgb_fusable first)')
         if wino is not None and wino_ok(B, cin, cout, H, W):
             return modconv_wino(x, wino() if callable(wino) else wino, s, d, cout, noise, noise_weight, bias, activate,
                                 slope, gain, batch)

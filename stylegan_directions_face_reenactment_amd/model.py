@@ -211,7 +211,7 @@ class ModulatedConv2d(nn.Module):
             return out if q is not None else (out, None)
         return F_.style_demod(style, mod.weight, mod.bias, q, self.out_channel)
 
-    def fused(self, input, style, noise=None, noise_weight=None, bias=None, activate=False, batch=None, sd=None):
+    def fused(self, input, style, noise=None, noise_weight=None, bias=None, activate=False, batch=None, sd=None, rgb=None):
         """conv (+ noise + bias + leaky-ReLU) in one pass; what StyledConv.forward calls.
         `sd` = precomputed (s, d), e.g. from the generator's batched style launch."""
         if self.kernel_size != 3:
@@ -223,7 +223,7 @@ class ModulatedConv2d(nn.Module):
                              fir=self.blur.kernel if self.upsample else None, noise=noise,
                              noise_weight=noise_weight, bias=bias, activate=activate, batch=batch,
                              wino=None if self.upsample else self.packed_wino,
-                             split=self.packed_split)
+                             split=self.packed_split, rgb=rgb)
 
     def forward(self, input, style):
         if self.kernel_size == 1:
@@ -272,13 +272,14 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, noise=None, batch=None, sd=None):
+    def forward(self, input, style, noise=None, batch=None, sd=None, rgb=None):
+        """rgb = (w_rgb [3,C], s_rgb [B,C]) (no-grad path): also returns the ToRGB partial sums, see functional.rgb_fusable."""
         if noise is None:   # fresh per-sample noise, model.py:283-285
             B = style.shape[0] if sd is None else sd[0].shape[0]
             r = input.shape[-1] * (2 if self.conv.upsample else 1)
             noise = torch.empty(B, 1, r, r, device=input.device, dtype=torch.float32).normal_()
         return self.conv.fused(input, style, noise=noise, noise_weight=self.noise.weight, bias=self.activate.bias,
-                               activate=True, batch=batch, sd=sd)
+                               activate=True, batch=batch, sd=sd, rgb=rgb)
 
 
 class ToRGB(nn.Module):
@@ -303,6 +304,17 @@ class ToRGB(nn.Module):
         if _needs_grad(input, s, skip, conv.weight, self.bias):
             return AG.ToRGBFn.apply(input, s, conv.weight, self.bias, skip, fir)
         return F_.torgb(input, conv.weight.view(3, conv.in_channel), s, bias=self.bias.view(3), skip=skip, fir=fir)
+
+    def finish(self, part, skip=None):
+        """The rest of forward() when the 1x1 conv was accumulated in the feeding conv's epilogue (no-grad path):
+        sum of the per-cout-tile partials + bias + upsampled skip."""
+        fir = None
+        if skip is not None:
+            up = getattr(self, 'upsample', None)
+            if up is None or tuple(up.kernel.shape) != (4, 4) or up.pad != (2, 1):
+                raise NotImplementedError('ToRGB skip path is built for the 4-tap 2x Upsample')
+            fir = up.kernel
+        return F_.torgb_finish(part, bias=self.bias.view(3), skip=skip, fir=fir)
 
 
 class Generator(nn.Module):
@@ -394,28 +406,49 @@ class Generator(nn.Module):
         else:      # every layer's s = A_l(w_l) and demodulation d_l in two launches (instead of 33)
             sd = iter(F_.styles_batched(latent, [m.style_spec(li) for m, li in order]))
 
+        def conv_rgb(layer, to_rgb, x, nz, sd_conv, sd_rgb, batch_arg=None):
+            """plain StyledConv + the 1x1 conv of the ToRGB behind it; fused into one launch when the shape allows
+            (no-grad path).  Returns (activation, None) or (activation, ToRGB partial sums)."""
+            c = layer.conv
+            if not grad and F_.rgb_fusable(batch, c.in_channel, c.out_channel, x.shape[2], x.shape[3]):
+                return layer(x, None, noise=nz, batch=batch_arg, sd=sd_conv,
+                             rgb=(to_rgb.conv.weight.view(3, c.out_channel), sd_rgb[0]))
+            return layer(x, None, noise=nz, batch=batch_arg, sd=sd_conv), None
+
         # ConstantInput is broadcast inside the kernel (batch stride 0) instead of repeated
-        out = self.conv1(self.input.input, None, noise=noise[0], batch=batch, sd=next(sd))
+        sd_c, sd_r = next(sd), next(sd)
+        out, part = conv_rgb(self.conv1, self.to_rgb1, self.input.input, noise[0], sd_c, sd_r, batch)
         # The RGB branch (HBM-bound ToRGB kernels, a chain over `skip`) runs on a side HIP stream next to the
         # MFMA-bound conv chain of the main stream; it joins before the image is returned.  No-grad path only.
         side = _side_stream(out.device) if (self.overlap_rgb and not grad) else None
         main = torch.cuda.current_stream() if side is not None else None
 
-        def rgb(layer, x, skip_in, sdl):
+        on_side = [False]                          # is the latest `skip` being produced on the side stream?
+
+        def rgb(layer, x, part_in, skip_in, sdl):
+            if part_in is not None:                # the 1x1 conv is done: a small finish launch, kept on the main stream
+                if on_side[0]:
+                    main.wait_stream(side)
+                    skip_in.record_stream(main)
+                    on_side[0] = False
+                return layer.finish(part_in, skip_in)
+            run = lambda: layer(x, None, skip_in, sd=sdl)
             if side is None:
-                return layer(x, None, skip_in, sd=sdl)
+                return run()
+            on_side[0] = True
             side.wait_stream(main)                 # x (and this forward's styles) are ready
             x.record_stream(side)
             with torch.cuda.stream(side):
-                return layer(x, None, skip_in, sd=sdl)
+                return run()
 
-        skip = rgb(self.to_rgb1, out, None, next(sd))
+        skip = rgb(self.to_rgb1, out, part, None, sd_r)
         for conv1, conv2, noise1, noise2, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2],
                                                         noise[2::2], self.to_rgbs):
             out = conv1(out, None, noise=noise1, sd=next(sd))
-            out = conv2(out, None, noise=noise2, sd=next(sd))
-            skip = rgb(to_rgb, out, skip, next(sd))
-        if side is not None:
+            sd_c, sd_r = next(sd), next(sd)
+            out, part = conv_rgb(conv2, to_rgb, out, noise2, sd_c, sd_r)
+            skip = rgb(to_rgb, out, part, skip, sd_r)
+        if side is not None and on_side[0]:
             main.wait_stream(side)
             skip.record_stream(main)
         image = skip

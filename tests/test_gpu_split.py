@@ -109,6 +109,38 @@ def test_split_generator_within_contract():
         assert not torch.equal(outs['fp16x3'], exact) and not torch.equal(outs['bf16x3'], exact)   # split kernels really ran
 
 
+@pytest.mark.parametrize('cin,cout,H,B', [(64, 64, 128, 6), (32, 256, 32, 50), (48, 128, 128, 3)])      # >= 192 blocks: no K slices
+def test_fused_torgb_partials(cin, cout, H, B):
+    """ToRGB accumulated in the conv epilogue (per-cout-tile partial sums, finished by the ToRGB kernel over the partial
+    channels) == the separate ToRGB launch on the conv output (model.py:350-359), incl. bias and FIR-upsampled skip."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    key = 'rgbfuse.%d.%d.%d.%d' % (cin, cout, H, B)
+    w = S.counter_tensor(5, key + '.w', (1, cout, cin, 3, 3)).cuda()
+    x = S.counter_tensor(5, key + '.x', (B, cin, H, H)).cuda()
+    s = S.counter_tensor(5, key + '.s', (B, cin), 1.0, 0.3).cuda()
+    d = S.counter_tensor(5, key + '.d', (B, cout), 1.0, 0.2).cuda()
+    noise = S.counter_tensor(5, key + '.n', (1, 1, H, H)).cuda()
+    nw = torch.full((1,), 0.1).cuda()
+    bias = S.counter_tensor(5, key + '.b', (cout,), 0.0, 0.1).cuda()
+    w_rgb = S.counter_tensor(5, key + '.wr', (3, cout)).cuda()
+    s_rgb = S.counter_tensor(5, key + '.sr', (B, cout), 1.0, 0.3).cuda()
+    b_rgb = S.counter_tensor(5, key + '.br', (3,), 0.0, 0.1).cuda()
+    skip = S.counter_tensor(5, key + '.sk', (B, 3, H // 2, H // 2)).cuda()
+    fir = torch.tensor(O.make_fir([1, 3, 3, 1], gain=4.0).numpy()).cuda()
+    assert F_.rgb_fusable(B, cin, cout, H, H)
+    wsp = F_.prepack_split(w, 'fp16x3')
+    y, part = F_.modconv_split(x, wsp, s, d, cout, noise, nw, bias, True, arith='fp16x3', rgb=(w_rgb, s_rgb))
+    y_plain = F_.modconv_split(x, wsp, s, d, cout, noise, nw, bias, True, arith='fp16x3')
+    assert torch.equal(y, y_plain)                                   # the activation itself is untouched
+    fused = F_.torgb_finish(part, bias=b_rgb, skip=skip, fir=fir)
+    separate = F_.torgb(y, w_rgb, s_rgb, bias=b_rgb, skip=skip, fir=fir)
+    ref = (y.double().cpu() * s_rgb.double().cpu()[:, :, None, None])
+    ref = torch.einsum('bchw,jc->bjhw', ref, w_rgb.double().cpu()) / cout ** 0.5 + b_rgb.double().cpu().view(1, 3, 1, 1)
+    ref = ref + O.upfirdn2d(skip.double().cpu(), O.make_fir([1, 3, 3, 1], gain=4.0, dtype=torch.float64), up=2, pad=(2, 1))
+    scale = float(ref.abs().max())
+    assert maxabs(separate, ref) <= 1e-5 * scale and maxabs(fused, ref) <= 1e-5 * scale
+
+
 def test_fp16_split_saturates_instead_of_overflowing():
     """|x*s| beyond the fp16-split range (1.04e6) clamps; nothing becomes inf/nan."""
     from stylegan_directions_face_reenactment_amd import functional as F_
