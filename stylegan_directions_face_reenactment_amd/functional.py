@@ -262,7 +262,7 @@ def split_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
 
 
 def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2,
-                  batch=None, desc=None, mode=N.MODE_PLAIN3, arith=None, rgb=None):
+                  batch=None, desc=None, mode=N.MODE_PLAIN3, arith=None, rgb=None, out=None):
     """3x3 modulated conv in a split arithmetic (same contract as modconv_raw, modes PLAIN3 and UP3); `wsp` must have
     been packed for the same `arith`.  rgb = (w_rgb [3,Cout], s_rgb [B,Cout]) also returns the per-cout-tile partial sums
     [B, T*3, H, W] of the ToRGB 1x1 conv that follows the layer (see rgb_fusable / torgb_finish)."""
@@ -276,7 +276,9 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
     xb = 0 if (x.shape[0] == 1 and B != 1) else cin * H * W
     if mode == N.MODE_UP3:
         nz, nzb = None, 0
-        y = torch.empty(B, cout, 4, H + 1, W + 1, device=x.device, dtype=torch.float32)
+        y = out if out is not None else torch.empty(B, cout, 4, H + 1, W + 1, device=x.device, dtype=torch.float32)
+        if tuple(y.shape) != (B, cout, 4, H + 1, W + 1) or not y.is_contiguous():
+            raise RuntimeError('modconv_split: out must be a contiguous [B,Cout,4,H+1,W+1] tensor')
     else:
         nz, nzb = _noise_args(noise, B, H, W)
         y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
@@ -354,12 +356,14 @@ def modconv_raw(x, wp, s, d, cout, mode, H, W, noise=None, noise_weight=None, bi
     return y
 
 
-def blur_bias_act(planes, fir, H, W, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2):
+def blur_bias_act(planes, fir, H, W, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2, out=None):
     """planes [B,C,4,H+1,W+1] -> [B,C,2H,2W]: 4x4 FIR (pad 1,1) + noise + bias + leaky-ReLU."""
     N.require_device(planes, fir, bias, noise_weight)
     B, C = planes.shape[0], planes.shape[1]
     nz, nzb = _noise_args(noise, B, 2 * H, 2 * W)
-    y = torch.empty(B, C, 2 * H, 2 * W, device=planes.device, dtype=torch.float32)
+    y = out if out is not None else torch.empty(B, C, 2 * H, 2 * W, device=planes.device, dtype=torch.float32)
+    if tuple(y.shape) != (B, C, 2 * H, 2 * W) or not y.is_contiguous():
+        raise RuntimeError('blur_bias_act: out must be a contiguous [B,C,2H,2W] tensor')
     N.call('sgdfr_blur_bias_act_f32', N.ptr(planes), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
            N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(y), B, C, H, W, int(activate),
            float(slope), float(gain), N.stream())
@@ -390,7 +394,8 @@ def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_we
     if fir is None:
         raise RuntimeError('upsample modconv needs the blur FIR taps')
     Bu = s.shape[0] if batch is None else batch
-    if split is not None and split_ok(Bu, cin, cout, H, W, N.MODE_UP3):
+    use_split = split is not None and split_ok(Bu, cin, cout, H, W, N.MODE_UP3)
+    if use_split:
         planes = modconv_split(x, split() if callable(split) else split, s, d, cout, batch=batch, mode=N.MODE_UP3)
     else:
         planes = modconv_raw(x, wp, s, d, cout, N.MODE_UP3, H, W, batch=batch, desc='up3 %d->%d @%dx%d' % (cin, cout, H, W))
