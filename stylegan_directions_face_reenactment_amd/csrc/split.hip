@@ -73,6 +73,7 @@ struct SplitParams {
     float slope, gain;
     int ksplit;                  // K (channel-block) slices; > 1: slice ks writes d * partial sums to y + ks*split_stride
     int64_t split_stride;
+    int desync;                  // first-round start spread: 4096-clock units per channel block (0 = off)
     int stagger;                 // which waves run MFMAs before staging inside a sub-stage (0 none, 1 waves 4-7, 2 odd waves)
 };
 
@@ -142,6 +143,15 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7;
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    // First-round desynchronisation (transposed conv): equal blocks started together reach their plane-store phase together
+    // and share the HBM write bandwidth; spreading the first round over about one block time lets later rounds store while
+    // other CUs compute (measured +5 % on the 32x32..128x128 transposed layers; nothing on the plain ones, which stay off).
+    if (UP && p.desync > 0 && blockIdx.x < 256 && gridDim.x > 512) {
+        const int slot = (int)((blockIdx.x * 2654435761u) >> 24);          // 0..255, scrambled
+        const int units = (p.Cin / SPLIT_CB) * p.desync;                     // s_sleep(64) units of 4096 clocks
+        const int n_sleep = (slot * units) >> 8;
+        for (int i = 0; i < n_sleep; ++i) __builtin_amdgcn_s_sleep(64);
     }
     const int tiles_per_slice = p.n_pix_tiles * p.n_cout_tiles;
     const int ks = lid / tiles_per_slice;                 // K slice of this block (0 when ksplit == 1)
@@ -770,6 +780,8 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
     if (ksplit > 1) p.y = partials;
     static const int stagger = getenv("SGDFR_SPLIT_STAGGER") ? atoi(getenv("SGDFR_SPLIT_STAGGER")) : 1;
     p.stagger = stagger;
+    static const int desync = getenv("SGDFR_SPLIT_DESYNC") ? atoi(getenv("SGDFR_SPLIT_DESYNC")) : 1;
+    p.desync = desync;
     hipStream_t st = as_stream(stream);
     const int rc = arith == SGDFR_SPLIT_FP16 ? launch_plan<SGDFR_SPLIT_FP16>(plan->cfg, p, st)
                                              : launch_plan<SGDFR_SPLIT_BF16>(plan->cfg, p, st);
