@@ -113,6 +113,14 @@ __global__ __launch_bounds__(256) void blur_bias_act_kernel(const float* __restr
             if (m >= H) break;
             load_row(2 * m + 2, win[3]);
             load_row(2 * m + 3, win[4]);
+            float nzq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+            if (noise) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(noise + (int64_t)b * noise_bstride + (int64_t)(2 * m + rr) * OW + 2 * n);
+                    nzq[rr][0] = t2.x; nzq[rr][1] = t2.y;
+                }
+            }
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 float o0 = 0.f, o1 = 0.f;
@@ -125,11 +133,8 @@ __global__ __launch_bounds__(256) void blur_bias_act_kernel(const float* __restr
                     }
                 const int oy = 2 * m + rr;
                 float v0 = o0 + bv, v1 = o1 + bv;
-                if (noise) {
-                    const float* np = noise + (int64_t)b * noise_bstride + (int64_t)oy * OW + 2 * n;
-                    v0 = fmaf(nw, np[0], v0);
-                    v1 = fmaf(nw, np[1], v1);
-                }
+                v0 = fmaf(nw, nzq[rr][0], v0);
+                v1 = fmaf(nw, nzq[rr][1], v1);
                 if (act) {
                     v0 = lrelu_gain(v0, slope, gain);
                     v1 = lrelu_gain(v1, slope, gain);
