@@ -13,8 +13,9 @@ specific to this build:
     projection, stem) is folded into one conv with bias, activations are kept channels-last for MIOpen's NHWC
     kernels, and the plan is cached until a parameter changes;
   * the 14 style heads are evaluated as 3 groups (coarse / middle / fine share their input feature map): the
-    first conv of a group is one conv with the heads' filters concatenated, the following stride-2 convs are one
-    grouped conv per depth, and the 14 `EqualLinear`s run on the HIP linear kernel (`sgdfr_linear_f32`);
+    first conv of a group is one conv with the heads' filters concatenated, the following stride-2 convs (per-head
+    filters on 8x8 ... 1x1 maps) are an unfold + one batched GEMM per depth, and the 14 `EqualLinear`s run on the HIP
+    linear kernel (`sgdfr_linear_f32`);
   * like the reference (psp_encoders.py:185-199) no `latent_avg` is added; the generator applies truncation.
 """
 import math
@@ -168,12 +169,17 @@ class Encoder4Editing(nn.Module):
                 plan['heads'].append(None)
                 continue
             depth = len(heads[0].convs) // 2
-            convs = []
-            for k in range(depth):
-                w = torch.cat([h.convs[2 * k].weight for h in heads], 0).contiguous(memory_format=cl)
-                b = torch.cat([h.convs[2 * k].bias for h in heads], 0)
-                convs.append((w, b, 1 if k == 0 else len(heads)))
-            plan['heads'].append((convs, heads))
+            # first conv of the group: one conv with the heads' filters concatenated (they share the input map)
+            w0 = torch.cat([h.convs[0].weight for h in heads], 0).contiguous(memory_format=cl)
+            b0 = torch.cat([h.convs[0].bias for h in heads], 0)
+            # deeper stride-2 convs: per-head filters on tiny maps (8x8 ... 1x1) -> unfold + ONE batched GEMM per depth
+            # (MIOpen only has its naive kernel for grouped fp32 NHWC convs: measured 100x slower than this)
+            deeper = []
+            for k in range(1, depth):
+                wk = torch.stack([h.convs[2 * k].weight.reshape(h.out_c, -1).t() for h in heads], 0).contiguous()   # [G, Cin*9, Cout]
+                bk = torch.stack([h.convs[2 * k].bias for h in heads], 0).unsqueeze(1)                              # [G, 1, Cout]
+                deeper.append((wk, bk))
+            plan['heads'].append(((w0, b0), deeper, heads))
         return plan
 
     @torch.no_grad()
@@ -204,13 +210,19 @@ class Encoder4Editing(nn.Module):
         for f, grp in zip((c3, p2, p1), plan['heads']):
             if grp is None:
                 continue
-            convs, heads = grp
-            h = f
-            for w, b, groups in convs:
-                h = F.leaky_relu(F.conv2d(h, w, b, 2, 1, 1, groups), 0.01)
-            h = h.reshape(h.shape[0], len(heads), -1)                      # [B, heads, 512] (spatial is 1x1 here)
-            if h.shape[2] != heads[0].out_c:
+            (w0, b0), deeper, heads = grp
+            G, C, B = len(heads), heads[0].out_c, f.shape[0]
+            h = F.leaky_relu(F.conv2d(f, w0, b0, 2, 1), 0.01)                                  # [B, G*C, H, W]
+            for wk, bk in deeper:
+                Hc, Wc = h.shape[2], h.shape[3]
+                Ho, Wo = (Hc + 1) // 2, (Wc + 1) // 2
+                cols = F.unfold(h.reshape(B * G, C, Hc, Wc), 3, padding=1, stride=2)           # [B*G, C*9, Ho*Wo]
+                cols = cols.view(B, G, C * 9, Ho * Wo).permute(1, 0, 3, 2).reshape(G, B * Ho * Wo, C * 9)
+                h = F.leaky_relu(torch.baddbmm(bk, cols, wk), 0.01)                            # [G, B*Ho*Wo, C]
+                h = h.view(G, B, Ho, Wo, C).permute(1, 0, 4, 2, 3).reshape(B, G * C, Ho, Wo)
+            if h.shape[2] != 1 or h.shape[3] != 1:
                 raise RuntimeError('style heads expect a %dx%d feature map' % (heads[0].spatial, heads[0].spatial))
+            h = h.reshape(B, G, C)                                                             # spatial is 1x1 here
             rows += [head.linear(h[:, j].contiguous()) for j, head in enumerate(heads)]
         w0 = rows[0]
         return torch.stack([w0] + [w0 + d for d in rows[1:]], dim=1)
