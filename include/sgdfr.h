@@ -189,7 +189,9 @@ int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, cons
  *                                      the layer (ToRGB.forward model.py:350-359): rgb_w [3][Cout], rgb_s [B][Cout] (its
  *                                      modulation), rgb_part [B][T*3][H*W] with T = ..._split_cout_tiles(); channel t*3+j
  *                                      holds the sum over cout tile t, so sgdfr_torgb_fwd_f32 over those T*3 channels with
- *                                      indicator weights finishes it (+ bias + upsampled skip) without re-reading x */
+ *                                      indicator weights finishes it (+ bias + upsampled skip) without re-reading x;
+ *                                      with rgb_part, y may be NULL: the activation is then not stored at all (last layer of
+ *                                      the generator: only its ToRGB consumes it) */
 #define SGDFR_SPLIT_BF16 0   /* bf16 hi+lo: 16 mantissa bits, fp32 range   (~1e-4 on the 256x256 generator) */
 #define SGDFR_SPLIT_FP16 1   /* fp16 hi+lo: 22 mantissa bits = fp32-grade; operands range-shifted by exact powers of two,
                                 |x*s| saturates at 1.04e6 */

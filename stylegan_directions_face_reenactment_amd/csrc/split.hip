@@ -300,11 +300,48 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         }
     };
 
+    // ---- epilogue coefficient tables.  Loads and stores share the in-order vmcnt counter: a per-output `d` / bias load
+    // between two stores would make the wave wait for the previous store's HBM round trip, so every coefficient goes
+    // through LDS (lgkmcnt) and the noise values into registers.  Tiles inside <= 2 images fill their tables HERE, in a
+    // dedicated LDS region beside the style table (no barrier pair and no exposed global-load latency between the K loop
+    // and the stores); tiles spanning many small images (4x4, 8x8) fill them after the loop in the dead staging buffers.
+    const bool whole = p.ksplit == 1;     // K slices only scale by d; noise / bias / activation follow the reduction
+    const bool fuse_rgb = !UP && whole && p.rgb_part != nullptr;      // fused ToRGB partial sums (PLAIN3)
+    const bool early = p.simgs <= 2;
+    float* const dl = early ? ls + ((p.simgs * p.Cin + 3) & ~3) : reinterpret_cast<float*>(smem);   // [simgs][NT]  d * output scale
+    float* const bl = dl + p.simgs * NT;                        // [NT]            bias
+    float* const cw = bl + NT;                                  // [simgs][NT][4]  ToRGB coefficients
+    float* const red = cw + p.simgs * NT * 4;                   // [WM][PT][3]     ToRGB cross-wave reduce
+    auto fill_tables = [&]() {
+        const float oscale = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_OUT : 1.f;
+        for (int e = tid; e < p.simgs * NT; e += NTHR) {
+            const int m = e / NT, c = e - m * NT;
+            dl[e] = (p.d && img0 + m < p.B) ? p.d[(int64_t)(img0 + m) * p.Cout + n0 + c] * oscale : oscale;
+        }
+        for (int e = tid; e < NT; e += NTHR) bl[e] = (whole && p.bias) ? p.bias[n0 + e] : 0.f;
+        if (fuse_rgb) {      // rgb[j] = sum_co y[co] * w_rgb[j][co] * s_rgb[b][co] / sqrt(Cout) over this block's couts
+            const float rs = rsqrtf((float)p.Cout);
+            for (int e = tid; e < p.simgs * NT; e += NTHR) {
+                const int m = e / NT, c = e - m * NT;
+                const float sv = (img0 + m < p.B) ? p.rgb_s[(int64_t)(img0 + m) * p.Cout + n0 + c] * rs : 0.f;
+                float4 q = make_float4(p.rgb_w[n0 + c] * sv, p.rgb_w[p.Cout + n0 + c] * sv, p.rgb_w[2 * p.Cout + n0 + c] * sv, 0.f);
+                *reinterpret_cast<float4*>(cw + 4 * e) = q;
+            }
+        }
+    };
+    float nz[NI];
+    {
+        const float nw = (whole && p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
+#pragma unroll
+        for (int n = 0; n < NI; ++n) nz[n] = (!UP && whole && p.noise && ybase[n] >= 0) ? nw * p.noise[nzoff[n]] : 0.f;
+    }
+
     // ---- prologue: style table, channel block 0 staged, block 1 in registers, weight row 0 in flight
     for (int e = tid; e < p.simgs * p.Cin; e += NTHR) {
         const int m = e / p.Cin;
         ls[e] = (img0 + m < p.B) ? p.s[(int64_t)(img0 + m) * p.Cin + (e - m * p.Cin)] * (ET == SGDFR_SPLIT_FP16 ? SPLIT_F16_XSCALE : 1.f) : 0.f;
     }
+    if (early) fill_tables();
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < NEX; ++e) load_x(e, cb0);
@@ -461,39 +498,11 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     }
 
     // ---- epilogue.  C/D layout of 32x32: column (pixel) = lane&31, row (cout) = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // Loads and stores share the in-order vmcnt counter: a per-output `d` / bias load between two stores makes the
-    // wave wait for the previous store's HBM round trip.  So every coefficient the stores need is first brought into
-    // LDS (whose reads count on lgkmcnt) and the noise values into registers; after that the wave only issues stores.
-    const bool whole = p.ksplit == 1;     // K slices only scale by d; noise / bias / activation follow the reduction
-    __syncthreads();                      // every wave is done with the staging buffers
-    float* const dl = reinterpret_cast<float*>(smem);          // [simgs][NT]  d * output scale
-    float* const bl = dl + p.simgs * NT;                        // [NT]         bias
-    const float oscale = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_OUT : 1.f;
-    for (int e = tid; e < p.simgs * NT; e += NTHR) {
-        const int m = e / NT, c = e - m * NT;
-        dl[e] = (p.d && img0 + m < p.B) ? p.d[(int64_t)(img0 + m) * p.Cout + n0 + c] * oscale : oscale;
+    if (!early) {
+        __syncthreads();                  // every wave is done with the staging buffers the tables are about to overwrite
+        fill_tables();
+        __syncthreads();
     }
-    for (int e = tid; e < NT; e += NTHR) bl[e] = (whole && p.bias) ? p.bias[n0 + e] : 0.f;
-    float nz[NI];
-    {
-        const float nw = (whole && p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
-#pragma unroll
-        for (int n = 0; n < NI; ++n) nz[n] = (!UP && whole && p.noise && ybase[n] >= 0) ? nw * p.noise[nzoff[n]] : 0.f;
-    }
-    // fused ToRGB: rgb[j] = sum_co y[co] * w_rgb[j][co] * s_rgb[b][co] / sqrt(Cout) over this block's couts
-    const bool fuse_rgb = !UP && whole && p.rgb_part != nullptr;
-    float* const cw = bl + NT;                                  // [simgs][NT][4]
-    float* const red = cw + p.simgs * NT * 4;                   // [WM][PT][3]
-    if (fuse_rgb) {
-        const float rs = rsqrtf((float)p.Cout);
-        for (int e = tid; e < p.simgs * NT; e += NTHR) {
-            const int m = e / NT, c = e - m * NT;
-            const float sv = (img0 + m < p.B) ? p.rgb_s[(int64_t)(img0 + m) * p.Cout + n0 + c] * rs : 0.f;
-            float4 q = make_float4(p.rgb_w[n0 + c] * sv, p.rgb_w[p.Cout + n0 + c] * sv, p.rgb_w[2 * p.Cout + n0 + c] * sv, 0.f);
-            *reinterpret_cast<float4*>(cw + 4 * e) = q;
-        }
-    }
-    __syncthreads();
     float* const yout = p.y + (int64_t)ks * p.split_stride;
     float rgb[NI][3];
 #pragma unroll
@@ -518,7 +527,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                 } else {
                     float v = acc[0][m][n][r] * dv + nz[n] + bln[cl];
                     if (whole && p.act) v = lrelu_gain(v, p.slope, p.gain);
-                    yout[ybase[n] + (int64_t)co * HW] = v;
+                    if (p.y) yout[ybase[n] + (int64_t)co * HW] = v;      // (NULL: only the fused ToRGB consumes this layer)
                     if (fuse_rgb) {
                         const float4 q = *reinterpret_cast<const float4*>(cwn + 4 * cl);
                         rgb[n][0] = fmaf(v, q.x, rgb[n][0]);
@@ -598,6 +607,13 @@ static const SplitPlan kPlanUpWide = {2, 128, 128, 3, 8};       // transposed: 1
 static const SplitPlan kPlanUpNarrow = {3, 64, 256, 3, 8};      // transposed, Cout % 128 != 0 (or as a fallback): 64 x 256
 static const SplitPlan kPlanUpDeep = {4, 64, 256, 1, 8};        // transposed: 64 x 256, all 9 taps between barriers
 
+static size_t split_lds_bytes(const SplitParams& p, int NT, int nss) {
+    const size_t loop = 2 * (size_t)64 * p.xs + 2 * (size_t)NT * 192 * (3 / nss) + (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float);
+    const size_t epi = ((size_t)p.simgs * NT * 5 + NT + 2 * 512 * 3) * sizeof(float);   // d, bias, ToRGB coefficient and reduce tables
+    if (p.simgs <= 2) return loop + epi;      // tables live beside the style table for the whole kernel
+    return loop > epi ? loop : epi;           // tables overwrite the dead staging buffers after the K loop
+}
+
 // geometry of the pixel tiling for one plan; returns 0 when the shape cannot use it
 static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, const SplitPlan& plan, SplitParams* out) {
     if (Cin % SPLIT_CB != 0 || Cout % plan.nt != 0 || B < 1) return 0;
@@ -668,11 +684,6 @@ static const SplitPlan* split_plan(int B, int Cin, int Cout, int H, int W, int m
     return nullptr;
 }
 
-static size_t split_lds_bytes(const SplitParams& p, int NT, int nss) {
-    const size_t loop = 2 * (size_t)64 * p.xs + 2 * (size_t)NT * 192 * (3 / nss) + (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float);
-    const size_t epi = ((size_t)p.simgs * NT * 5 + NT + 2 * 512 * 3) * sizeof(float);   // d, bias, ToRGB coefficient and reduce tables
-    return loop > epi ? loop : epi;
-}
 
 extern "C" int sgdfr_modconv2d_split_supported(int B, int Cin, int Cout, int H, int W, int mode) {
     SplitParams p;
@@ -758,7 +769,7 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
                   Cin, Cout, H, W, mode);
     SGDFR_REQUIRE(mode == SGDFR_MODE_PLAIN3 || (!noise && !bias && !act), "modconv_split: UP3 writes raw parity planes "
                   "(noise / bias / activation belong to sgdfr_blur_bias_act_f32)");
-    SGDFR_REQUIRE(x && wsp && s && y && zeros, "modconv_split: null pointer");
+    SGDFR_REQUIRE(x && wsp && s && zeros && (y || rgb_part), "modconv_split: null pointer");
     SGDFR_REQUIRE(!noise || noise_w, "modconv_split: noise without noise_w");
     SGDFR_REQUIRE(((reinterpret_cast<uintptr_t>(wsp) | reinterpret_cast<uintptr_t>(s)) & 15) == 0,
                   "modconv_split: wsp and s must be 16-byte aligned");

@@ -262,7 +262,7 @@ def split_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
 
 
 def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2,
-                  batch=None, desc=None, mode=N.MODE_PLAIN3, arith=None, rgb=None, out=None):
+                  batch=None, desc=None, mode=N.MODE_PLAIN3, arith=None, rgb=None, out=None, want_y=True):
     """3x3 modulated conv in a split arithmetic (same contract as modconv_raw, modes PLAIN3 and UP3); `wsp` must have
     been packed for the same `arith`.  rgb = (w_rgb [3,Cout], s_rgb [B,Cout]) also returns the per-cout-tile partial sums
     [B, T*3, H, W] of the ToRGB 1x1 conv that follows the layer (see rgb_fusable / torgb_finish)."""
@@ -281,9 +281,13 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
             raise RuntimeError('modconv_split: out must be a contiguous [B,Cout,4,H+1,W+1] tensor')
     else:
         nz, nzb = _noise_args(noise, B, H, W)
-        y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+        if not want_y and rgb is None:
+            raise RuntimeError('modconv_split: want_y=False only makes sense with the fused ToRGB (rgb=...)')
+        y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32) if want_y else None
     st = N.stream()
     ks = N.load().sgdfr_modconv2d_split_ksplit_hint(B, cin, cout, H, W, mode) if USE_SPLITK else 1
+    if ks > 1 and y is None:
+        raise RuntimeError('modconv_split: this launch is K-sliced and cannot fuse ToRGB (check rgb_fusable first)')
     partials = torch.empty((ks,) + tuple(y.shape), device=x.device, dtype=torch.float32) if ks > 1 else None
     rgb_w = rgb_s = part = None
     if rgb is not None:
@@ -371,7 +375,8 @@ def blur_bias_act(planes, fir, H, W, noise=None, noise_weight=None, bias=None, a
 
 
 def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_weight=None, bias=None,
-               activate=False, slope=0.2, gain=SQRT2, batch=None, return_planes=False, wino=None, split=None, rgb=None):
+               activate=False, slope=0.2, gain=SQRT2, batch=None, return_planes=False, wino=None, split=None, rgb=None,
+               want_y=True):
     """Shared-weight modulated 3x3 conv (model.py:232-273) with the StyledConv tail fused in
     (noise model.py:287, bias + leaky-ReLU op/fused_act.py:81-86).
 
@@ -383,7 +388,7 @@ def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_we
         B = s.shape[0] if batch is None else batch
         if split is not None and split_ok(B, cin, cout, H, W):
             return modconv_split(x, split() if callable(split) else split, s, d, cout, noise, noise_weight, bias,
-                                 activate, slope, gain, batch, rgb=rgb)
+                                 activate, slope, gain, batch, rgb=rgb, want_y=want_y)
         if rgb is not None:
             raise RuntimeError('modconv3x3: ToRGB fusion needs the split kernel (check rgb_fusable first)')
         if wino is not None and wino_ok(B, cin, cout, H, W):

@@ -211,7 +211,8 @@ class ModulatedConv2d(nn.Module):
             return out if q is not None else (out, None)
         return F_.style_demod(style, mod.weight, mod.bias, q, self.out_channel)
 
-    def fused(self, input, style, noise=None, noise_weight=None, bias=None, activate=False, batch=None, sd=None, rgb=None):
+    def fused(self, input, style, noise=None, noise_weight=None, bias=None, activate=False, batch=None, sd=None, rgb=None,
+              want_y=True):
         """conv (+ noise + bias + leaky-ReLU) in one pass; what StyledConv.forward calls.
         `sd` = precomputed (s, d), e.g. from the generator's batched style launch."""
         if self.kernel_size != 3:
@@ -223,7 +224,7 @@ class ModulatedConv2d(nn.Module):
                              fir=self.blur.kernel if self.upsample else None, noise=noise,
                              noise_weight=noise_weight, bias=bias, activate=activate, batch=batch,
                              wino=None if self.upsample else self.packed_wino,
-                             split=self.packed_split, rgb=rgb)
+                             split=self.packed_split, rgb=rgb, want_y=want_y)
 
     def forward(self, input, style):
         if self.kernel_size == 1:
@@ -272,14 +273,15 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, noise=None, batch=None, sd=None, rgb=None):
-        """rgb = (w_rgb [3,C], s_rgb [B,C]) (no-grad path): also returns the ToRGB partial sums, see functional.rgb_fusable."""
+    def forward(self, input, style, noise=None, batch=None, sd=None, rgb=None, want_y=True):
+        """rgb = (w_rgb [3,C], s_rgb [B,C]) (no-grad path): also returns the ToRGB partial sums, see functional.rgb_fusable;
+        want_y=False then skips storing the activation itself (last layer: nothing else reads it)."""
         if noise is None:   # fresh per-sample noise, model.py:283-285
             B = style.shape[0] if sd is None else sd[0].shape[0]
             r = input.shape[-1] * (2 if self.conv.upsample else 1)
             noise = torch.empty(B, 1, r, r, device=input.device, dtype=torch.float32).normal_()
         return self.conv.fused(input, style, noise=noise, noise_weight=self.noise.weight, bias=self.activate.bias,
-                               activate=True, batch=batch, sd=sd, rgb=rgb)
+                               activate=True, batch=batch, sd=sd, rgb=rgb, want_y=want_y)
 
 
 class ToRGB(nn.Module):
@@ -406,13 +408,13 @@ class Generator(nn.Module):
         else:      # every layer's s = A_l(w_l) and demodulation d_l in two launches (instead of 33)
             sd = iter(F_.styles_batched(latent, [m.style_spec(li) for m, li in order]))
 
-        def conv_rgb(layer, to_rgb, x, nz, sd_conv, sd_rgb, batch_arg=None):
+        def conv_rgb(layer, to_rgb, x, nz, sd_conv, sd_rgb, batch_arg=None, last=False):
             """plain StyledConv + the 1x1 conv of the ToRGB behind it; fused into one launch when the shape allows
             (no-grad path).  Returns (activation, None) or (activation, ToRGB partial sums)."""
             c = layer.conv
             if not grad and F_.rgb_fusable(batch, c.in_channel, c.out_channel, x.shape[2], x.shape[3]):
                 return layer(x, None, noise=nz, batch=batch_arg, sd=sd_conv,
-                             rgb=(to_rgb.conv.weight.view(3, c.out_channel), sd_rgb[0]))
+                             rgb=(to_rgb.conv.weight.view(3, c.out_channel), sd_rgb[0]), want_y=not last)
             return layer(x, None, noise=nz, batch=batch_arg, sd=sd_conv), None
 
         # ConstantInput is broadcast inside the kernel (batch stride 0) instead of repeated
@@ -442,11 +444,12 @@ class Generator(nn.Module):
                 return run()
 
         skip = rgb(self.to_rgb1, out, part, None, sd_r)
-        for conv1, conv2, noise1, noise2, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2],
-                                                        noise[2::2], self.to_rgbs):
+        n_pairs = len(self.to_rgbs)
+        for k, (conv1, conv2, noise1, noise2, to_rgb) in enumerate(zip(self.convs[::2], self.convs[1::2], noise[1::2],
+                                                                       noise[2::2], self.to_rgbs)):
             out = conv1(out, None, noise=noise1, sd=next(sd))
             sd_c, sd_r = next(sd), next(sd)
-            out, part = conv_rgb(conv2, to_rgb, out, noise2, sd_c, sd_r)
+            out, part = conv_rgb(conv2, to_rgb, out, noise2, sd_c, sd_r, last=(k == n_pairs - 1))
             skip = rgb(to_rgb, out, part, skip, sd_r)
         if side is not None and on_side[0]:
             main.wait_stream(side)
