@@ -202,8 +202,14 @@ int sgdfr_modconv2d_split_supported(int B, int Cin, int Cout, int H, int W, int 
 int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned short* wsp, const float* s, const float* d,
                               const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
                               const float* zeros, float* y, float* partials, int ksplit, const float* rgb_w,
-                              const float* rgb_s, float* rgb_part, int B, int Cin, int Cout, int H, int W, int mode, int arith,
-                              int act, float slope, float gain, void* stream);
+                              const float* rgb_s, float* rgb_part, int x_is_split, unsigned short* xs_out, const float* s_next,
+                              int B, int Cin, int Cout, int H, int W, int mode, int arith, int act, float slope, float gain,
+                              void* stream);
+/* x [B,Cin,H,W], s [B,Cin] -> xs [B][Cin/8][2][H*W][8] 16-bit: x*s already split (and range-shifted) the way the kernel
+ * stages it; sgdfr_modconv2d_split_f32(x = xs, s = NULL, x_is_split = 1) then fills LDS by DMA only.  Producers can emit
+ * that form directly: sgdfr_modconv2d_split_f32(xs_out, s_next = the NEXT layer's modulation [B,Cout]) (y may then be NULL)
+ * and sgdfr_blur_bias_act_f32's split variant, so activations between layers never exist as fp32 in HBM. */
+int sgdfr_to_split_f32(const float* x, const float* s, unsigned short* xs, int B, int Cin, int H, int W, int arith, void* stream);
 int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H, int W, int mode);
 int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, int mode);
 

@@ -42,8 +42,9 @@ SIGNATURES = {
     'sgdfr_modconv_prepack_split_f32': [_c_f32p, ctypes.c_void_p, _i, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_modconv2d_split_supported': [_i, _i, _i, _i, _i, _i],
     'sgdfr_modconv2d_split_f32': [_c_f32p, _i64, ctypes.c_void_p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
-                                  _c_f32p, _c_f32p, _i, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f,
-                                  ctypes.c_void_p],
+                                  _c_f32p, _c_f32p, _i, _c_f32p, _c_f32p, _c_f32p, _i, ctypes.c_void_p, _c_f32p, _i, _i, _i, _i,
+                                  _i, _i, _i, _i, _f, _f, ctypes.c_void_p],
+    'sgdfr_to_split_f32': [_c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_modconv2d_split_cout_tiles': [_i, _i, _i, _i, _i, _i],
     'sgdfr_modconv2d_split_ksplit_hint': [_i, _i, _i, _i, _i, _i],
     'sgdfr_torgb_finish_f32': [_c_f32p, _i, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],

@@ -61,6 +61,8 @@ struct SplitParams {
     const float* rgb_w;          // fused ToRGB (PLAIN3, ksplit == 1): [3][Cout] 1x1 weights, [B][Cout] styles,
     const float* rgb_s;          //   partial sums out [B][n_cout_tiles*3][H*W] (bias / skip are added by the finish launch)
     float* rgb_part;
+    unsigned char* xs_out;       // PLAIN3, ksplit == 1: the activation in the NEXT layer's split input form (x * s_next, see XIN)
+    const float* s_next;         //   [B][Cout] modulation of the next layer
     int B, Cin, Cout, H, W;
     int P, R;                    // padded pitch / rows per image of the flat space (W+1, H+1)
     int n_pix_tiles, n_cout_tiles;
@@ -112,7 +114,9 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
 // output-parity planes T[B,Cout,4,H+1,W+1] (same contract as modconv.hip): one "pixel" is a super-pixel of the padded
 // flat space, each of the 9 taps feeds the accumulator set of its parity phase.
 // NSS: barrier-delimited sub-stages per 16-channel block: 3 = one kernel row (3 taps) each, 1 = all 9 taps.
-template <int MODE, int ET, int WM, int WN, int MI, int NI, int NEX, int NSS>
+// XIN: the input is already in the kernel's own split form ("XS": x * s * range shift as 16-bit hi/lo pairs,
+// [B][Cin/8][hi,lo][H*W][8]), written by the producer; staging is then a pure global->LDS DMA (no registers, no VALU).
+template <int MODE, int ET, int WM, int WN, int MI, int NI, int NEX, int NSS, bool XIN = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma_kernel(SplitParams p) {
     constexpr int NW = WM * WN;            // 8 waves, one block per CU (4-wave blocks, two per CU, measured slower: more
                                            // halo staging and 1.0 ds_read per MFMA)
@@ -223,6 +227,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 
     // ---- staging descriptors: item = (position j, k-half h) -> 8 channels -> one 16-byte hi and one 16-byte lo chunk
     const float* xsrc[NEX];
+    int64_t xs16[NEX];    // XIN only
     int soff[NEX];        // float offset into the LDS style table, -1: nothing to write (beyond the range)
     int ldst[NEX];        // byte offset inside an x buffer
 #pragma unroll
@@ -250,6 +255,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         xsrc[e] = ok ? p.x + (int64_t)img * p.x_bstride + (int64_t)(8 * h) * HW + pix : nullptr;
         soff[e] = !(h < 2 && j < p.xs) ? -1 : ok ? (img - img0) * p.Cin + 8 * h : 0;
         ldst[e] = (h * p.xs + j) * 16;
+        if (XIN) {      // byte address of the hi chunk of channel group (cb = 0, h); -1: zero page; -2: no item (skip the DMA)
+            xs16[e] = !(h < 2 && j < p.xs) ? -2 : ok ? ((((int64_t)img * (p.Cin / 8) + h) * 2) * HW + pix) * 16 : -1;
+        }
     }
 
     f32x16 acc[PH][MI][NI];
@@ -300,6 +308,20 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         }
     };
 
+    // XIN staging: both parts of slot e of channel block cb -> x buffer xb, 16 bytes per lane, LDS image = lane order
+    auto issue_x = [&](int e, int cb, unsigned char* xb) {
+        const int i0 = __builtin_amdgcn_readfirstlane(tid - lane + e * NTHR);     // first item of this wave's slot
+        if (i0 >= 2 * p.xs) return;                                                // wave-uniform (xs % 64 == 0)
+        const int h0 = i0 / p.xs, j0 = i0 - h0 * p.xs;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(p.x);
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const unsigned char* src = xs16[e] >= 0 ? base + xs16[e] + ((int64_t)cb * 4 + part) * HW * 16
+                                                    : reinterpret_cast<const unsigned char*>(p.zeros);
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(xb + part * 32 * p.xs + (h0 * p.xs + j0) * 16), 16, 0, 0);
+        }
+    };
+
     // ---- epilogue coefficient tables.  Loads and stores share the in-order vmcnt counter: a per-output `d` / bias load
     // between two stores would make the wave wait for the previous store's HBM round trip, so every coefficient goes
     // through LDS (lgkmcnt) and the noise values into registers.  Tiles inside <= 2 images fill their tables HERE, in a
@@ -312,6 +334,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     float* const bl = dl + p.simgs * NT;                        // [NT]            bias
     float* const cw = bl + NT;                                  // [simgs][NT][4]  ToRGB coefficients
     float* const red = cw + p.simgs * NT * 4;                   // [WM][PT][3]     ToRGB cross-wave reduce
+    float* const sn = red + 2 * 512 * 3;                        // [simgs][NT]     next layer's style * range shift (xs_out)
+    const bool emit_xs = !UP && whole && p.xs_out != nullptr;
     auto fill_tables = [&]() {
         const float oscale = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_OUT : 1.f;
         for (int e = tid; e < p.simgs * NT; e += NTHR) {
@@ -319,6 +343,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             dl[e] = (p.d && img0 + m < p.B) ? p.d[(int64_t)(img0 + m) * p.Cout + n0 + c] * oscale : oscale;
         }
         for (int e = tid; e < NT; e += NTHR) bl[e] = (whole && p.bias) ? p.bias[n0 + e] : 0.f;
+        if (emit_xs) {
+            const float xsc = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_XSCALE : 1.f;
+            for (int e = tid; e < p.simgs * NT; e += NTHR) {
+                const int m = e / NT, c = e - m * NT;
+                sn[e] = (img0 + m < p.B) ? p.s_next[(int64_t)(img0 + m) * p.Cout + n0 + c] * xsc : 0.f;
+            }
+        }
         if (fuse_rgb) {      // rgb[j] = sum_co y[co] * w_rgb[j][co] * s_rgb[b][co] / sqrt(Cout) over this block's couts
             const float rs = rsqrtf((float)p.Cout);
             for (int e = tid; e < p.simgs * NT; e += NTHR) {
@@ -339,21 +370,28 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     // ---- prologue: style table, channel block 0 staged, block 1 in registers, weight row 0 in flight
     for (int e = tid; e < p.simgs * p.Cin; e += NTHR) {
         const int m = e / p.Cin;
-        ls[e] = (img0 + m < p.B) ? p.s[(int64_t)(img0 + m) * p.Cin + (e - m * p.Cin)] * (ET == SGDFR_SPLIT_FP16 ? SPLIT_F16_XSCALE : 1.f) : 0.f;
+        ls[e] = (!XIN && img0 + m < p.B) ? p.s[(int64_t)(img0 + m) * p.Cin + (e - m * p.Cin)] * (ET == SGDFR_SPLIT_FP16 ? SPLIT_F16_XSCALE : 1.f) : 0.f;
     }
     if (early) fill_tables();
     __syncthreads();
+    if (XIN) {
 #pragma unroll
-    for (int e = 0; e < NEX; ++e) load_x(e, cb0);
-#pragma unroll
-    for (int e = 0; e < NEX; ++e) convert_store(e, cb0, xb0 + (cb0 & 1) * xbuf_bytes);
-    issue_w(cb0 * NSS);
-    if (ncb > cb0 + 1) {
-#pragma unroll
-        for (int e = 0; e < NEX; ++e) load_x(e, cb0 + 1);
-        split_wait_vmcnt<NEX * 8>();
-    } else {
+        for (int e = 0; e < NEX; ++e) issue_x(e, cb0, xb0 + (cb0 & 1) * xbuf_bytes);
+        issue_w(cb0 * NSS);
         split_wait_vmcnt<0>();
+    } else {
+#pragma unroll
+        for (int e = 0; e < NEX; ++e) load_x(e, cb0);
+#pragma unroll
+        for (int e = 0; e < NEX; ++e) convert_store(e, cb0, xb0 + (cb0 & 1) * xbuf_bytes);
+        issue_w(cb0 * NSS);
+        if (ncb > cb0 + 1) {
+#pragma unroll
+            for (int e = 0; e < NEX; ++e) load_x(e, cb0 + 1);
+            split_wait_vmcnt<NEX * 8>();
+        } else {
+            split_wait_vmcnt<0>();
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -365,7 +403,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         const int col = wm * (MI * 32) + m * 32;
         aoff[m] = (col / 64) * (RPS * WROW64) + (hi * 64 + (col % 64) + l31) * 16;
     }
-    const bool stagger = NW == 8 && ((p.stagger & 3) == 1 ? (wave >= 4) : (p.stagger & 3) == 2 ? (wave & 1) : false);
+    const bool stagger = !XIN && NW == 8 && ((p.stagger & 3) == 1 ? (wave >= 4) : (p.stagger & 3) == 2 ? (wave & 1) : false);
     for (int cb = cb0; cb < ncb; ++cb) {
         const unsigned char* xcur = xb0 + (cb & 1) * xbuf_bytes;
         unsigned char* xnext = xb0 + ((cb + 1) & 1) * xbuf_bytes;
@@ -382,8 +420,12 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                 if (conv_next) {
 #pragma unroll
                     for (int e = ss; e < NEX; e += NSS) {
-                        convert_store(e, cb + 1, xnext);
-                        if (load_next) load_x(e, cb + 2);
+                        if (XIN) {
+                            issue_x(e, cb + 1, xnext);
+                        } else {
+                            convert_store(e, cb + 1, xnext);
+                            if (load_next) load_x(e, cb + 2);
+                        }
                     }
                 }
             };
@@ -484,7 +526,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             __builtin_amdgcn_sched_barrier(0);
             if (stagger) stage_part();
             if (more_w) {
-                if (conv_next && load_next) {
+                if (XIN) {
+                    split_wait_vmcnt<0>();
+                } else if (conv_next && load_next) {
                     if (ss == 0) split_wait_vmcnt<8 * kSlots[0]>();
                     else if (ss == 1) split_wait_vmcnt<8 * kSlots[1]>();
                     else split_wait_vmcnt<8 * kSlots[2]>();
@@ -513,6 +557,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         const float* dln = dl + (dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi;
         const float* bln = bl + wm * (MI * 32) + 4 * hi;
         const float* cwn = cw + ((dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi) * 4;
+        const float* snn = sn + (dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi;
+        float xsv[4];
 #pragma unroll
         for (int m = 0; m < MI; ++m) {
 #pragma unroll
@@ -527,7 +573,20 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                 } else {
                     float v = acc[0][m][n][r] * dv + nz[n] + bln[cl];
                     if (whole && p.act) v = lrelu_gain(v, p.slope, p.gain);
-                    if (p.y) yout[ybase[n] + (int64_t)co * HW] = v;      // (NULL: only the fused ToRGB consumes this layer)
+                    if (p.y) yout[ybase[n] + (int64_t)co * HW] = v;      // (NULL: only the fused ToRGB / xs_out consume this layer)
+                    if (emit_xs) {        // rows r = 4g..4g+3 are 4 consecutive couts: half of one 8-channel chunk of this pixel
+                        xsv[r & 3] = v * snn[cl];
+                        if ((r & 3) == 3) {
+                            unsigned h01, l01, h23, l23;
+                            split_pair<ET>(xsv[0], xsv[1], h01, l01);
+                            split_pair<ET>(xsv[2], xsv[3], h23, l23);
+                            const int cg = (n0 + wm * (MI * 32) + m * 32) / 8 + (r >> 2);
+                            const int rem = (int)(ybase[n] - (int64_t)dimg[n] * p.Cout * HW);
+                            unsigned char* dst = p.xs_out + ((((int64_t)dimg[n] * (p.Cout / 8) + cg) * 2) * HW + rem) * 16 + 8 * hi;
+                            *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+                            *reinterpret_cast<uint2*>(dst + (int64_t)HW * 16) = make_uint2(l01, l23);
+                        }
+                    }
                     if (fuse_rgb) {
                         const float4 q = *reinterpret_cast<const float4*>(cwn + 4 * cl);
                         rgb[n][0] = fmaf(v, q.x, rgb[n][0]);
@@ -562,6 +621,33 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                 }
             }
         }
+    }
+}
+
+// x [B,Cin,HW] fp32 (NCHW) and s [B,Cin] -> XS [B][Cin/8][hi,lo][HW][8]: the split form of x*s (with the fp16 range shift)
+// that split_mfma_kernel<..., XIN> stages by DMA.  One thread = one pixel of one 8-channel group.
+template <int ET>
+__global__ __launch_bounds__(256) void to_split_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                      unsigned char* __restrict__ xs, int B, int Cin, int HW) {
+    const int G = Cin / 8;
+    const int64_t n = (int64_t)B * G * HW;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int pix = (int)(idx % HW);
+        const int64_t bg = idx / HW;
+        const int g = (int)(bg % G);
+        const int b = (int)(bg / G);
+        const float* xp = x + ((int64_t)b * Cin + g * 8) * HW + pix;
+        const float* sp = s + (int64_t)b * Cin + g * 8;
+        uint4 vh, vl;
+        unsigned* ph = reinterpret_cast<unsigned*>(&vh);
+        unsigned* pl = reinterpret_cast<unsigned*>(&vl);
+        const float sc = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_XSCALE : 1.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            split_pair<ET>(xp[(int64_t)(2 * c) * HW] * (sp[2 * c] * sc), xp[(int64_t)(2 * c + 1) * HW] * (sp[2 * c + 1] * sc), ph[c], pl[c]);
+        unsigned char* dst = xs + ((bg * 2) * HW + pix) * 16;
+        *reinterpret_cast<uint4*>(dst) = vh;
+        *reinterpret_cast<uint4*>(dst + (int64_t)HW * 16) = vl;
     }
 }
 
@@ -609,7 +695,7 @@ static const SplitPlan kPlanUpDeep = {4, 64, 256, 1, 8};        // transposed: 6
 
 static size_t split_lds_bytes(const SplitParams& p, int NT, int nss) {
     const size_t loop = 2 * (size_t)64 * p.xs + 2 * (size_t)NT * 192 * (3 / nss) + (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float);
-    const size_t epi = ((size_t)p.simgs * NT * 5 + NT + 2 * 512 * 3) * sizeof(float);   // d, bias, ToRGB coefficient and reduce tables
+    const size_t epi = ((size_t)p.simgs * NT * 6 + NT + 2 * 512 * 3) * sizeof(float);   // d, bias, ToRGB coefficient / reduce, next-style tables
     if (p.simgs <= 2) return loop + epi;      // tables live beside the style table for the whole kernel
     return loop > epi ? loop : epi;           // tables overwrite the dead staging buffers after the K loop
 }
@@ -705,6 +791,23 @@ extern "C" int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H
     return s < 2 ? 1 : s;
 }
 
+extern "C" int sgdfr_to_split_f32(const float* x, const float* s, unsigned short* xs, int B, int Cin, int H, int W, int arith,
+                                  void* stream) {
+    SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cin % 8 == 0 && H > 0 && W > 0, "to_split: bad shape B=%d Cin=%d H=%d W=%d (Cin %% 8)", B, Cin, H, W);
+    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "to_split: arith must be SGDFR_SPLIT_BF16/FP16");
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(x && s && xs && (reinterpret_cast<uintptr_t>(xs) & 15) == 0, "to_split: null or misaligned pointer");
+    int64_t g = ((int64_t)B * (Cin / 8) * H * W + 255) / 256;
+    if (g > 256 * 32) g = 256 * 32;
+    if (arith == SGDFR_SPLIT_FP16)
+        hipLaunchKernelGGL(to_split_kernel<SGDFR_SPLIT_FP16>, dim3((int)g), dim3(256), 0, as_stream(stream), x, s,
+                           reinterpret_cast<unsigned char*>(xs), B, Cin, H * W);
+    else
+        hipLaunchKernelGGL(to_split_kernel<SGDFR_SPLIT_BF16>, dim3((int)g), dim3(256), 0, as_stream(stream), x, s,
+                           reinterpret_cast<unsigned char*>(xs), B, Cin, H * W);
+    return check_launch("to_split");
+}
+
 extern "C" int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H, int W, int mode) {
     SplitParams p;
     return split_plan(B, Cin, Cout, H, W, mode, &p) ? p.n_cout_tiles : 0;
@@ -727,15 +830,15 @@ extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned sho
     return check_launch("modconv_prepack_split");
 }
 
-template <int MODE, int ET, int WM, int WN, int MI, int NI, int NSS = 3>
+template <int MODE, int ET, int WM, int WN, int MI, int NI, int NSS = 3, bool XIN = false>
 static int launch_split(const SplitParams& p, hipStream_t st) {
     constexpr int NTHR = WM * WN * 64;
     const int nex = (2 * p.xs + NTHR - 1) / NTHR;
     constexpr int NEX_MAX = (MODE == SGDFR_MODE_UP3) ? 3 : 4;   // UP3 stages at most PT + P + 2 positions
     SGDFR_REQUIRE(nex <= NEX_MAX, "modconv_split: staged range %d too long for mode %d", p.xlen, MODE);
-    void (*kern)(SplitParams) = nex <= 2   ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 2, NSS>
-                                : nex == 3 ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 3, NSS>
-                                           : split_mfma_kernel<MODE, ET, WM, WN, MI, NI, NEX_MAX, NSS>;
+    void (*kern)(SplitParams) = nex <= 2   ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 2, NSS, XIN>
+                                : nex == 3 ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 3, NSS, XIN>
+                                           : split_mfma_kernel<MODE, ET, WM, WN, MI, NI, NEX_MAX, NSS, XIN>;
     const size_t lds = split_lds_bytes(p, WM * MI * 32, NSS);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess)
@@ -745,7 +848,15 @@ static int launch_split(const SplitParams& p, hipStream_t st) {
 }
 
 template <int ET>
-static int launch_plan(int cfg, const SplitParams& p, hipStream_t st) {
+static int launch_plan(int cfg, const SplitParams& p, hipStream_t st, bool xin) {
+    if (xin) {
+        switch (cfg) {
+            case 0: return launch_split<SGDFR_MODE_PLAIN3, ET, 2, 4, 2, 2, 3, true>(p, st);
+            case 1: return launch_split<SGDFR_MODE_PLAIN3, ET, 1, 8, 2, 2, 3, true>(p, st);
+            case 4: return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 1, true>(p, st);
+            default: set_error("modconv_split: pre-split input is not built for tiling plan %d", cfg); return 1;
+        }
+    }
     switch (cfg) {
         case 0: return launch_split<SGDFR_MODE_PLAIN3, ET, 2, 4, 2, 2, 3>(p, st);
         case 1: return launch_split<SGDFR_MODE_PLAIN3, ET, 1, 8, 2, 2, 3>(p, st);
@@ -758,8 +869,9 @@ static int launch_plan(int cfg, const SplitParams& p, hipStream_t st) {
 extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned short* wsp, const float* s,
                                          const float* d, const float* noise, int64_t noise_bstride, const float* noise_w,
                                          const float* bias, const float* zeros, float* y, float* partials, int ksplit,
-                                         const float* rgb_w, const float* rgb_s, float* rgb_part, int B, int Cin, int Cout,
-                                         int H, int W, int mode, int arith, int act, float slope, float gain, void* stream) {
+                                         const float* rgb_w, const float* rgb_s, float* rgb_part, int x_is_split,
+                                         unsigned short* xs_out, const float* s_next, int B, int Cin, int Cout, int H, int W,
+                                         int mode, int arith, int act, float slope, float gain, void* stream) {
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "modconv_split: arith must be SGDFR_SPLIT_BF16/FP16");
     SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "modconv_split: bad shape B=%d Cin=%d Cout=%d H=%d W=%d",
                   B, Cin, Cout, H, W);
@@ -769,7 +881,12 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
                   Cin, Cout, H, W, mode);
     SGDFR_REQUIRE(mode == SGDFR_MODE_PLAIN3 || (!noise && !bias && !act), "modconv_split: UP3 writes raw parity planes "
                   "(noise / bias / activation belong to sgdfr_blur_bias_act_f32)");
-    SGDFR_REQUIRE(x && wsp && s && zeros && (y || rgb_part), "modconv_split: null pointer");
+    SGDFR_REQUIRE(x && wsp && zeros && (y || rgb_part || xs_out) && (s || x_is_split), "modconv_split: null pointer");
+    SGDFR_REQUIRE(!xs_out || (s_next && mode == SGDFR_MODE_PLAIN3 && ksplit <= 1 && Cout % 8 == 0 &&
+                              (reinterpret_cast<uintptr_t>(xs_out) & 15) == 0),
+                  "modconv_split: xs_out needs s_next, mode PLAIN3, ksplit == 1 and a 16-byte aligned buffer");
+    SGDFR_REQUIRE(!x_is_split || (x_bstride != 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0),
+                  "modconv_split: a pre-split input is per image and 16-byte aligned");
     SGDFR_REQUIRE(!noise || noise_w, "modconv_split: noise without noise_w");
     SGDFR_REQUIRE(((reinterpret_cast<uintptr_t>(wsp) | reinterpret_cast<uintptr_t>(s)) & 15) == 0,
                   "modconv_split: wsp and s must be 16-byte aligned");
@@ -782,6 +899,7 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
     SGDFR_REQUIRE(!rgb_part || (rgb_w && rgb_s && mode == SGDFR_MODE_PLAIN3 && ksplit == 1),
                   "modconv_split: the fused ToRGB needs rgb_w, rgb_s, mode PLAIN3 and ksplit == 1");
     p.rgb_w = rgb_w; p.rgb_s = rgb_s; p.rgb_part = rgb_part;
+    p.xs_out = reinterpret_cast<unsigned char*>(xs_out); p.s_next = s_next;
     SGDFR_REQUIRE(ksplit == 1 || (partials && ksplit <= Cin / SPLIT_CB), "modconv_split: ksplit %d needs a partials buffer "
                   "and at most %d slices", ksplit, Cin / SPLIT_CB);
     const int64_t n_out = (mode == SGDFR_MODE_UP3) ? (int64_t)B * Cout * 4 * p.R * p.P : (int64_t)B * Cout * H * W;
@@ -802,8 +920,8 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
         p.desync = (up && pct > 0 && blocks >= 1024) ? (int)((mfma_clk + store_clk) * pct / 100 / 4096) : 0;   // >= 4 rounds
     }
     hipStream_t st = as_stream(stream);
-    const int rc = arith == SGDFR_SPLIT_FP16 ? launch_plan<SGDFR_SPLIT_FP16>(plan->cfg, p, st)
-                                             : launch_plan<SGDFR_SPLIT_BF16>(plan->cfg, p, st);
+    const int rc = arith == SGDFR_SPLIT_FP16 ? launch_plan<SGDFR_SPLIT_FP16>(plan->cfg, p, st, x_is_split != 0)
+                                             : launch_plan<SGDFR_SPLIT_BF16>(plan->cfg, p, st, x_is_split != 0);
     if (rc || ksplit == 1) return rc;
     const bool plain = mode == SGDFR_MODE_PLAIN3;
     return launch_splitk_reduce(partials, ksplit, n_out, plain ? noise : nullptr, noise_bstride, noise_w, plain ? bias : nullptr, y,

@@ -262,18 +262,25 @@ def split_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
 
 
 def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2,
-                  batch=None, desc=None, mode=N.MODE_PLAIN3, arith=None, rgb=None, out=None, want_y=True):
+                  batch=None, desc=None, mode=N.MODE_PLAIN3, arith=None, rgb=None, out=None, want_y=True, x_split=None, s_next=None):
     """3x3 modulated conv in a split arithmetic (same contract as modconv_raw, modes PLAIN3 and UP3); `wsp` must have
     been packed for the same `arith`.  rgb = (w_rgb [3,Cout], s_rgb [B,Cout]) also returns the per-cout-tile partial sums
     [B, T*3, H, W] of the ToRGB 1x1 conv that follows the layer (see rgb_fusable / torgb_finish)."""
     arith = _SPLIT_ARITH[arith or PRECISION]
-    N.require_device(x, s, d, bias, noise_weight)
+    N.require_device(s, d, bias, noise_weight)
     if not wsp.is_cuda or wsp.dtype != torch.int16:
         raise RuntimeError('modconv_split: wsp must be the int16 device buffer made by prepack_split')
-    x = N.f32c(x)
-    B = s.shape[0] if batch is None else batch
-    _, cin, H, W = x.shape
-    xb = 0 if (x.shape[0] == 1 and B != 1) else cin * H * W
+    if x_split is not None:         # (B, Cin, H, W) of the pre-split int16 input made by to_split(): x*s is already applied
+        if not x.is_cuda or x.dtype != torch.int16:
+            raise RuntimeError('modconv_split: a pre-split input is the int16 buffer made by to_split')
+        B, cin, H, W = x_split
+        xb = cin * H * W
+    else:
+        N.require_device(x)
+        x = N.f32c(x)
+        B = s.shape[0] if batch is None else batch
+        _, cin, H, W = x.shape
+        xb = 0 if (x.shape[0] == 1 and B != 1) else cin * H * W
     if mode == N.MODE_UP3:
         nz, nzb = None, 0
         y = out if out is not None else torch.empty(B, cout, 4, H + 1, W + 1, device=x.device, dtype=torch.float32)
@@ -281,15 +288,21 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
             raise RuntimeError('modconv_split: out must be a contiguous [B,Cout,4,H+1,W+1] tensor')
     else:
         nz, nzb = _noise_args(noise, B, H, W)
-        if not want_y and rgb is None:
-            raise RuntimeError('modconv_split: want_y=False only makes sense with the fused ToRGB (rgb=...)')
+        if not want_y and rgb is None and s_next is None:
+            raise RuntimeError('modconv_split: want_y=False only makes sense with the fused ToRGB (rgb=...) or s_next')
         y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32) if want_y else None
     st = N.stream()
     ks = N.load().sgdfr_modconv2d_split_ksplit_hint(B, cin, cout, H, W, mode) if USE_SPLITK else 1
     if ks > 1 and y is None:
         raise RuntimeError('modconv_split: this launch is K-sliced and cannot fuse ToRGB (check rgb_fusable first)')
     partials = torch.empty((ks,) + tuple(y.shape), device=x.device, dtype=torch.float32) if ks > 1 else None
-    rgb_w = rgb_s = part = None
+    rgb_w = rgb_s = part = xs_out = None
+    if s_next is not None:
+        if ks > 1 or mode != N.MODE_PLAIN3:
+            raise RuntimeError('modconv_split: this launch cannot emit the split activation (K-sliced or not PLAIN3)')
+        N.require_device(s_next)
+        s_next = N.f32c(s_next)
+        xs_out = torch.empty(B, cout // 8, 2, H * W, 8, device=s_next.device, dtype=torch.int16)
     if rgb is not None:
         if ks > 1 or mode != N.MODE_PLAIN3:
             raise RuntimeError('modconv_split: this launch cannot fuse ToRGB (check rgb_fusable first)')
@@ -301,9 +314,24 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
                 B * conv_flops(cin, cout, H, W), lambda: N.call(
         'sgdfr_modconv2d_split_f32', N.ptr(x), xb, N.ptr(wsp), N.ptr(s), N.ptr(d), N.ptr(nz), nzb,
         N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(_zero_words(x.device)), N.ptr(y),
-        N.ptr(partials), ks, N.ptr(rgb_w), N.ptr(rgb_s), N.ptr(part), B, cin, cout, H, W, mode, arith, int(activate),
+        N.ptr(partials), ks, N.ptr(rgb_w), N.ptr(rgb_s), N.ptr(part), int(x_split is not None), N.ptr(xs_out),
+        N.ptr(s_next) if s_next is not None else None, B, cin, cout, H, W, mode, arith, int(activate),
         float(slope), float(gain), st))
+    if s_next is not None:      # (activation or None, ToRGB partials or None, the activation in the next layer's split form)
+        return y, part, xs_out
     return y if rgb is None else (y, part)
+
+
+def to_split(x, s, arith=None):
+    """x [B,Cin,H,W], s [B,Cin] -> int16 buffer [B, Cin/8, 2, H*W, 8]: x*s in the split form the kernels stage
+    (modconv_split(x=that, s=None, x_split=(B,Cin,H,W)) then fills LDS by DMA)."""
+    arith = _SPLIT_ARITH[arith or PRECISION]
+    N.require_device(x, s)
+    x, s = N.f32c(x), N.f32c(s)
+    B, cin, H, W = x.shape
+    xs = torch.empty(B, cin // 8, 2, H * W, 8, device=x.device, dtype=torch.int16)
+    N.call('sgdfr_to_split_f32', N.ptr(x), N.ptr(s), N.ptr(xs), B, cin, H, W, arith, N.stream())
+    return xs
 
 
 def rgb_fusable(B, cin, cout, H, W):
