@@ -165,6 +165,12 @@ int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const float* noise
                             const float* noise_w, const float* bias, float* y, int B, int C, int H, int W, int act,
                             float slope, float gain, void* stream);
 
+/* sgdfr_blur_bias_act_f32 with the result multiplied by the NEXT layer's modulation s_next [B,C] and written in that layer's
+ * split input form xs [B][C/8][2][2H*2W][8] (see sgdfr_to_split_f32) instead of fp32 NCHW. */
+int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, const float* noise, int64_t noise_bstride,
+                                  const float* noise_w, const float* bias, const float* s_next, unsigned short* xs, int B, int C,
+                                  int H, int W, int arith, int act, float slope, float gain, void* stream);
+
 /* y[b,j,p] = sum_i w_rgb[j*Cin+i]/sqrt(Cin) * s[b,i] * x[b,i,p] + bias[j]
  *          + (skip ? upfirdn2d(skip[b,j] (H/2 x W/2), fir[4,4], up=2, pad=(2,1))[p] : 0),  j<3 */
 int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, const float* bias, const float* skip,
@@ -209,6 +215,7 @@ int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned 
  * stages it; sgdfr_modconv2d_split_f32(x = xs, s = NULL, x_is_split = 1) then fills LDS by DMA only.  Producers can emit
  * that form directly: sgdfr_modconv2d_split_f32(xs_out, s_next = the NEXT layer's modulation [B,Cout]) (y may then be NULL)
  * and sgdfr_blur_bias_act_f32's split variant, so activations between layers never exist as fp32 in HBM. */
+int sgdfr_modconv2d_split_xin_supported(int B, int Cin, int Cout, int H, int W, int mode);   /* x_is_split allowed for this shape */
 int sgdfr_to_split_f32(const float* x, const float* s, unsigned short* xs, int B, int Cin, int H, int W, int arith, void* stream);
 int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H, int W, int mode);
 int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, int mode);

@@ -38,3 +38,17 @@ for cin, cout, h in [(64, 128, 64), (128, 64, 128), (32, 256, 32)]:
     y2, _, xs2 = F_.modconv_split(x, wsp, s, d, cout, nz, nw, bias, True, arith='fp16x3', s_next=sn, want_y=False)
     print('producer %d->%d @%d: xs_out == to_split(y, s_next): %s ; without y: %s (y is None: %s)' %
           (cin, cout, h, bool(torch.equal(xs_out, ref)), bool(torch.equal(xs2, ref)), y2 is None))
+
+# producer side 2: blur writing the split form
+fir = torch.tensor([[1., 3, 3, 1]], device='cuda'); fir = (fir.t() @ fir); fir = fir / fir.sum() * 4
+for C, h in [(512, 8), (256, 32), (128, 64), (64, 128)]:
+    Bp = 64
+    planes = torch.randn(Bp, C, 4, h + 1, h + 1, device='cuda')
+    nz = torch.randn(1, 1, 2 * h, 2 * h, device='cuda'); nw = torch.full((1,), 0.1, device='cuda'); bias = torch.randn(C, device='cuda')
+    sn = torch.randn(Bp, C, device='cuda')
+    y = F_.blur_bias_act(planes, fir, h, h, nz, nw, bias, True)
+    ref = F_.to_split(y, sn, 'fp16x3')
+    xs = F_.blur_bias_act_split(planes, fir, h, h, sn, nz, nw, bias, True, arith='fp16x3')
+    t0 = bench(lambda: F_.blur_bias_act(planes, fir, h, h, nz, nw, bias, True))
+    t1 = bench(lambda: F_.blur_bias_act_split(planes, fir, h, h, sn, nz, nw, bias, True, arith='fp16x3'))
+    print('blur C=%d %d->%d: fp32 out %.0f us | split out %.0f us | identical %s' % (C, h, 2 * h, t0, t1, bool(torch.equal(xs, ref))))

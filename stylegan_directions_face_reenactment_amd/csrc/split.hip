@@ -744,8 +744,7 @@ static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, cons
     p.n_cout_tiles = Cout / plan.nt;
     const int nthr = plan.nw * 64;
     if ((2 * p.xs + nthr - 1) / nthr > (mode == SGDFR_MODE_UP3 ? 3 : 4)) return 0;                 // staging slots
-    const size_t lds = 2 * (size_t)64 * p.xs + 2 * (size_t)plan.nt * 192 * (3 / plan.nss) +
-                       (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float);
+    const size_t lds = split_lds_bytes(p, plan.nt, plan.nss);
     if (lds > (plan.nw == 8 ? 160 : 80) * 1024) return 0;
     if (out) *out = p;
     return 1;
@@ -808,6 +807,12 @@ extern "C" int sgdfr_to_split_f32(const float* x, const float* s, unsigned short
     return check_launch("to_split");
 }
 
+extern "C" int sgdfr_modconv2d_split_xin_supported(int B, int Cin, int Cout, int H, int W, int mode) {
+    SplitParams p;
+    const SplitPlan* plan = split_plan(B, Cin, Cout, H, W, mode, &p);
+    return (plan && (plan->cfg == 0 || plan->cfg == 1 || plan->cfg == 4)) ? 1 : 0;     // the instantiations of launch_plan(xin)
+}
+
 extern "C" int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H, int W, int mode) {
     SplitParams p;
     return split_plan(B, Cin, Cout, H, W, mode, &p) ? p.n_cout_tiles : 0;
@@ -841,8 +846,12 @@ static int launch_split(const SplitParams& p, hipStream_t st) {
                                            : split_mfma_kernel<MODE, ET, WM, WN, MI, NI, NEX_MAX, NSS, XIN>;
     const size_t lds = split_lds_bytes(p, WM * MI * 32, NSS);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
-        return check_launch("modconv_split(lds attribute)");
+        hipSuccess) {
+        (void)hipGetLastError();
+        set_error("modconv_split: LDS request %zu B refused (B=%d Cin=%d Cout=%d H=%d W=%d xs=%d simgs=%d)", lds, p.B, p.Cin, p.Cout,
+                  p.H, p.W, p.xs, p.simgs);
+        return 2;
+    }
     hipLaunchKernelGGL(kern, dim3(p.n_pix_tiles * p.n_cout_tiles * p.ksplit), dim3(NTHR), lds, st, p);
     return check_launch("modconv2d_split");
 }

@@ -149,6 +149,139 @@ __global__ __launch_bounds__(256) void blur_bias_act_kernel(const float* __restr
     }
 }
 
+
+// The same blur + noise + bias + leaky-ReLU, but the result is multiplied by the NEXT layer's modulation and written in
+// that layer's split input form ("XS": [B][C/8][hi,lo][2H*2W][8] 16-bit pairs, see split.hip) instead of fp32 NCHW.
+// A block = one 8-channel group x 8 output rows x 64 output columns: thread (channel, quad column) slides the same
+// 5x5 window down 4 quads, the 16-bit halves meet in LDS as [part][row][px][8 channels], and every thread then writes
+// whole 16-byte pixel chunks (1 KB runs per row and part).
+typedef _Float16 bl_f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bl_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float bl_f32x2 __attribute__((ext_vector_type(2)));
+
+template <int ET>
+__device__ __forceinline__ void blur_split1(float v, unsigned short& hi, unsigned short& lo) {
+    if (ET == SGDFR_SPLIT_FP16) {
+        v = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+        const _Float16 h = (_Float16)v;
+        hi = __builtin_bit_cast(unsigned short, h);
+        lo = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h));
+    } else {
+        const bl_bf16x2 h = __builtin_convertvector((bl_f32x2){v, 0.f}, bl_bf16x2);
+        const unsigned hb = __builtin_bit_cast(unsigned, h) & 0xffffu;
+        hi = (unsigned short)hb;
+        const bl_bf16x2 l = __builtin_convertvector((bl_f32x2){v - __builtin_bit_cast(float, hb << 16), 0.f}, bl_bf16x2);
+        lo = (unsigned short)(__builtin_bit_cast(unsigned, l) & 0xffffu);
+    }
+}
+
+template <int ET>
+__global__ __launch_bounds__(256) void blur_split_kernel(const float* __restrict__ t, const float* __restrict__ fir,
+                                                        const float* __restrict__ noise, int64_t noise_bstride,
+                                                        const float* __restrict__ noise_w, const float* __restrict__ bias,
+                                                        const float* __restrict__ s_next, unsigned char* __restrict__ xs,
+                                                        int B, int C, int H, int W, int act, float slope, float gain) {
+    __shared__ __attribute__((aligned(16))) unsigned short tile[2][8][64][8];   // [part][row][px][channel]: 16 KB
+    float kf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kf[i] = fir[15 - i];
+    const int GW = W + 1, GH = H + 1;
+    const int64_t plane_t = (int64_t)4 * GH * GW;
+    const int G = C / 8, OW = 2 * W, OHW = 4 * H * W;
+    const int col_tiles = (W + 31) / 32, row_tiles = (H + BLUR_QV - 1) / BLUR_QV;
+    const int64_t n_tiles = (int64_t)B * G * row_tiles * col_tiles;
+    const float nw = (noise && noise_w) ? noise_w[0] : 0.f;
+    const float xsc = (ET == SGDFR_SPLIT_FP16) ? 0.0625f : 1.f;
+    const int c8 = threadIdx.x >> 5, nx = threadIdx.x & 31;
+    for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+        const int ct = (int)(tile_id % col_tiles);
+        int64_t r = tile_id / col_tiles;
+        const int rt = (int)(r % row_tiles);
+        r /= row_tiles;
+        const int g = (int)(r % G);
+        const int b = (int)(r / G);
+        const int c = g * 8 + c8;
+        const int n = ct * 32 + nx;            // quad column
+        const int ms = rt * BLUR_QV;           // first quad row
+        if (n < W) {
+            const float* tp = t + ((int64_t)b * C + c) * plane_t;
+            const float bv = bias ? bias[c] : 0.f;
+            const float sv = s_next[(int64_t)b * C + c] * xsc;
+            int coff[5];
+            bool cok[5];
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                const int tc = 2 * n - 1 + v;
+                cok[v] = tc >= 0;
+                coff[v] = (tc & 1) * GH * GW + (tc >> 1);
+            }
+            float win[5][5];
+            auto load_row = [&](int tr, float (&dst)[5]) {
+                const bool rok = tr >= 0;
+                const int roff = (tr & 1) * 2 * GH * GW + (tr >> 1) * GW;
+#pragma unroll
+                for (int v = 0; v < 5; ++v) dst[v] = (rok && cok[v]) ? tp[roff + coff[v]] : 0.f;
+            };
+#pragma unroll
+            for (int u = 0; u < 3; ++u) load_row(2 * ms - 1 + u, win[u]);
+#pragma unroll
+            for (int qv = 0; qv < BLUR_QV; ++qv) {
+                const int m = ms + qv;
+                if (m >= H) break;
+                load_row(2 * m + 2, win[3]);
+                load_row(2 * m + 3, win[4]);
+                float nzq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+                if (noise) {
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const float2 t2 = *reinterpret_cast<const float2*>(noise + (int64_t)b * noise_bstride + (int64_t)(2 * m + rr) * OW + 2 * n);
+                        nzq[rr][0] = t2.x; nzq[rr][1] = t2.y;
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+                    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 4; ++kx) {
+                            o0 = fmaf(win[rr + ky][kx], kf[ky * 4 + kx], o0);
+                            o1 = fmaf(win[rr + ky][1 + kx], kf[ky * 4 + kx], o1);
+                        }
+                    float v0 = fmaf(nw, nzq[rr][0], o0 + bv), v1 = fmaf(nw, nzq[rr][1], o1 + bv);
+                    if (act) {
+                        v0 = lrelu_gain(v0, slope, gain);
+                        v1 = lrelu_gain(v1, slope, gain);
+                    }
+                    unsigned short h0, l0, h1, l1;
+                    blur_split1<ET>(v0 * sv, h0, l0);
+                    blur_split1<ET>(v1 * sv, h1, l1);
+                    const int row = 2 * qv + rr, px = 2 * nx;
+                    tile[0][row][px][c8] = h0; tile[1][row][px][c8] = l0;
+                    tile[0][row][px + 1][c8] = h1; tile[1][row][px + 1][c8] = l1;
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+#pragma unroll
+                    for (int v = 0; v < 5; ++v) win[u][v] = win[u + 2][v];
+            }
+        }
+        __syncthreads();
+        // 2 parts x 8 rows x 64 px chunks of 16 bytes
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int item = threadIdx.x + 256 * k;
+            const int px = item & 63, row = (item >> 6) & 7, part = item >> 9;
+            const int oy = 2 * ms + row, ox = ct * 64 + px;
+            if (oy < 2 * H && ox < OW) {
+                const uint4 q = *reinterpret_cast<const uint4*>(&tile[part][row][px][0]);
+                *reinterpret_cast<uint4*>(xs + ((((int64_t)b * G + g) * 2 + part) * OHW + (int64_t)oy * OW + ox) * 16) = q;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace sgdfr
 
 using namespace sgdfr;
@@ -187,4 +320,26 @@ extern "C" int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const f
     hipLaunchKernelGGL(blur_bias_act_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), t, fir, noise,
                        noise_bstride, noise_w, bias, y, B, C, H, W, act, slope, gain);
     return check_launch("blur_bias_act");
+}
+
+extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, const float* noise, int64_t noise_bstride,
+                                             const float* noise_w, const float* bias, const float* s_next, unsigned short* xs,
+                                             int B, int C, int H, int W, int arith, int act, float slope, float gain,
+                                             void* stream) {
+    SGDFR_REQUIRE(B >= 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "blur_bias_act_split: bad shape %d %d %d %d (C %% 8)", B, C, H, W);
+    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "blur_bias_act_split: arith must be SGDFR_SPLIT_BF16/FP16");
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(t && fir && s_next && xs && (reinterpret_cast<uintptr_t>(xs) & 15) == 0, "blur_bias_act_split: null / misaligned pointer");
+    SGDFR_REQUIRE(!noise || noise_w, "blur_bias_act_split: noise without noise_w");
+    const int64_t tiles = (int64_t)B * (C / 8) * ((H + BLUR_QV - 1) / BLUR_QV) * ((W + 31) / 32);
+    int64_t g = tiles;
+    if (g > 256 * 32) g = 256 * 32;
+    unsigned char* out = reinterpret_cast<unsigned char*>(xs);
+    if (arith == SGDFR_SPLIT_FP16)
+        hipLaunchKernelGGL(blur_split_kernel<SGDFR_SPLIT_FP16>, dim3((int)g), dim3(256), 0, as_stream(stream), t, fir, noise,
+                           noise_bstride, noise_w, bias, s_next, out, B, C, H, W, act, slope, gain);
+    else
+        hipLaunchKernelGGL(blur_split_kernel<SGDFR_SPLIT_BF16>, dim3((int)g), dim3(256), 0, as_stream(stream), t, fir, noise,
+                           noise_bstride, noise_w, bias, s_next, out, B, C, H, W, act, slope, gain);
+    return check_launch("blur_bias_act_split");
 }

@@ -174,6 +174,7 @@ def _noise_args(noise, B, H, W):
     raise RuntimeError('noise of shape %s does not broadcast to [%d,1,%d,%d]' % (tuple(noise.shape), B, H, W))
 
 
+USE_SPLIT_CHAIN = os.environ.get('SGDFR_SPLIT_CHAIN', '1') != '0'   # activations between split convs only in split form
 USE_RGB_FUSION = True        # ToRGB partial sums in the epilogue of the split conv that feeds it (no-grad path)
 USE_SPLITK = True            # K-sliced launches for convs that cannot fill the chip (small batch / 4x4, 8x8 layers)
 USE_WINOGRAD = True          # plain 3x3 layers: Winograd F(2x2,3x3) MFMA kernel when the shape allows it
@@ -334,6 +335,48 @@ def to_split(x, s, arith=None):
     return xs
 
 
+class SplitAct:
+    """An activation that only exists in the NEXT conv's split input form (x * s_next as 16-bit hi/lo pairs,
+    [B, C/8, 2, H*W, 8] int16): written by the producing kernel's epilogue, staged by DMA in the consumer."""
+    __slots__ = ('xs', 'shape')
+
+    def __init__(self, xs, shape):
+        self.xs, self.shape = xs, tuple(shape)
+
+
+def xin_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
+    """Can the split conv of this shape take its input as a SplitAct?"""
+    return USE_SPLIT_CHAIN and split_ok(B, cin, cout, H, W, mode) and \
+        bool(N.load().sgdfr_modconv2d_split_xin_supported(B, cin, cout, H, W, mode))
+
+
+def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, noise_weight=None, bias=None, batch=None,
+                      s_next=None, rgb=None, want_y=True):
+    """One StyledConv on the split kernels with the inference-only dataflow options: x may be a SplitAct (then `s` is
+    already applied), s_next asks for the output as a SplitAct for the next conv, rgb for the fused ToRGB partial sums.
+    Returns (activation: fp32 tensor | SplitAct | None, ToRGB partials | None)."""
+    if isinstance(x, SplitAct):
+        B, cin, H, W = x.shape
+        xin, x_split, s_arg = x.xs, x.shape, None
+        batch = B
+    else:
+        xin, x_split, s_arg = x, None, s
+        B = s.shape[0] if batch is None else batch
+        H, W = x.shape[2], x.shape[3]
+    if not upsample:
+        res = modconv_split(xin, wsp, s_arg, d, cout, noise, noise_weight, bias, True, batch=batch, rgb=rgb,
+                            want_y=want_y and s_next is None, x_split=x_split, s_next=s_next)
+        if s_next is not None:          # the activation leaves only as the next conv's split input
+            _, part, xs = res
+            return SplitAct(xs, (B, cout, H, W)), part
+        return res if rgb is not None else (res, None)
+    planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split)
+    if s_next is not None:
+        xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True)
+        return SplitAct(xs, (B, cout, 2 * H, 2 * W)), None
+    return blur_bias_act(planes, fir, H, W, noise, noise_weight, bias, True), None
+
+
 def rgb_fusable(B, cin, cout, H, W):
     """True when the plain 3x3 conv of this shape runs on the split kernel in one pass, so the ToRGB that follows it can be
     accumulated in its epilogue instead of re-reading the activation."""
@@ -400,6 +443,21 @@ def blur_bias_act(planes, fir, H, W, noise=None, noise_weight=None, bias=None, a
            N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(y), B, C, H, W, int(activate),
            float(slope), float(gain), N.stream())
     return y
+
+
+def blur_bias_act_split(planes, fir, H, W, s_next, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2,
+                        gain=SQRT2, arith=None):
+    """blur_bias_act whose result goes out as the next layer's split input (x * s_next as 16-bit hi/lo pairs,
+    [B, C/8, 2, 2H*2W, 8] int16) instead of fp32 NCHW."""
+    arith = _SPLIT_ARITH[arith or PRECISION]
+    N.require_device(planes, fir, bias, noise_weight, s_next)
+    B, C = planes.shape[0], planes.shape[1]
+    nz, nzb = _noise_args(noise, B, 2 * H, 2 * W)
+    xs = torch.empty(B, C // 8, 2, 4 * H * W, 8, device=planes.device, dtype=torch.int16)
+    N.call('sgdfr_blur_bias_act_split_f32', N.ptr(planes), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
+           N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(N.f32c(s_next)), N.ptr(xs), B, C, H, W, arith,
+           int(activate), float(slope), float(gain), N.stream())
+    return xs
 
 
 def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_weight=None, bias=None,

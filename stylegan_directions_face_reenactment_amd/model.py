@@ -408,27 +408,24 @@ class Generator(nn.Module):
         else:      # every layer's s = A_l(w_l) and demodulation d_l in two launches (instead of 33)
             sd = iter(F_.styles_batched(latent, [m.style_spec(li) for m, li in order]))
 
-        def conv_rgb(layer, to_rgb, x, nz, sd_conv, sd_rgb, batch_arg=None, last=False):
-            """plain StyledConv + the 1x1 conv of the ToRGB behind it; fused into one launch when the shape allows
-            (no-grad path).  Returns (activation, None) or (activation, ToRGB partial sums)."""
-            c = layer.conv
-            if not grad and F_.rgb_fusable(batch, c.in_channel, c.out_channel, x.shape[2], x.shape[3]):
-                return layer(x, None, noise=nz, batch=batch_arg, sd=sd_conv,
-                             rgb=(to_rgb.conv.weight.view(3, c.out_channel), sd_rgb[0]), want_y=not last)
-            return layer(x, None, noise=nz, batch=batch_arg, sd=sd_conv), None
+        sd = list(sd)              # (s, d) per entry of `order`: conv1, to_rgb1, then (up, plain, to_rgb) per resolution
+        layers = [self.conv1] + list(self.convs)           # StyledConvs in execution order: plain, (up, plain) x n
+        to_rgbs = [self.to_rgb1] + list(self.to_rgbs)      # to_rgbs[k] follows layers[2k]
+        sd_of_layer = [0] + [2 + 3 * (i // 2) + (i % 2) for i in range(len(self.convs))]
+        sd_of_rgb = [1] + [4 + 3 * k for k in range(len(self.to_rgbs))]
+        # inference on the split kernels: layers are launched through functional.styled_conv_split, not through their
+        # modules -- unless somebody hooked a layer's forward (per-layer probes), then every module really runs
+        hooked = any(m._forward_hooks or m._forward_pre_hooks for m in layers + to_rgbs)
+        chain = (not grad) and (not hooked) and F_.PRECISION in ('fp16x3', 'bf16x3')
 
-        # ConstantInput is broadcast inside the kernel (batch stride 0) instead of repeated
-        sd_c, sd_r = next(sd), next(sd)
-        out, part = conv_rgb(self.conv1, self.to_rgb1, self.input.input, noise[0], sd_c, sd_r, batch)
-        # The RGB branch (HBM-bound ToRGB kernels, a chain over `skip`) runs on a side HIP stream next to the
-        # MFMA-bound conv chain of the main stream; it joins before the image is returned.  No-grad path only.
-        side = _side_stream(out.device) if (self.overlap_rgb and not grad) else None
+        # The RGB branch: a fused ToRGB (partial sums from the conv epilogue) is finished by a small launch on the main
+        # stream; an unfused one (HBM-bound kernel re-reading the activation) runs on a side HIP stream next to the conv chain.
+        side = _side_stream(latent.device) if (self.overlap_rgb and not grad) else None
         main = torch.cuda.current_stream() if side is not None else None
-
         on_side = [False]                          # is the latest `skip` being produced on the side stream?
 
         def rgb(layer, x, part_in, skip_in, sdl):
-            if part_in is not None:                # the 1x1 conv is done: a small finish launch, kept on the main stream
+            if part_in is not None:
                 if on_side[0]:
                     main.wait_stream(side)
                     skip_in.record_stream(main)
@@ -443,14 +440,42 @@ class Generator(nn.Module):
             with torch.cuda.stream(side):
                 return run()
 
-        skip = rgb(self.to_rgb1, out, part, None, sd_r)
-        n_pairs = len(self.to_rgbs)
-        for k, (conv1, conv2, noise1, noise2, to_rgb) in enumerate(zip(self.convs[::2], self.convs[1::2], noise[1::2],
-                                                                       noise[2::2], self.to_rgbs)):
-            out = conv1(out, None, noise=noise1, sd=next(sd))
-            sd_c, sd_r = next(sd), next(sd)
-            out, part = conv_rgb(conv2, to_rgb, out, noise2, sd_c, sd_r, last=(k == n_pairs - 1))
-            skip = rgb(to_rgb, out, part, skip, sd_r)
+        # ConstantInput is broadcast inside the kernel (batch stride 0) instead of repeated
+        x, skip, res = self.input.input, None, self.input.input.shape[2]
+        for li, layer in enumerate(layers):
+            c = layer.conv
+            up = c.upsample
+            sdl = sd[sd_of_layer[li]]
+            nz = noise[li]
+            first = li == 0
+            res_out = 2 * res if up else res
+            nxt = layers[li + 1].conv if li + 1 < len(layers) else None
+            mode = F_.N.MODE_UP3 if up else F_.N.MODE_PLAIN3
+            use_chain = chain and nz is not None and F_.split_ok(batch, c.in_channel, c.out_channel, res, res, mode)
+            if not use_chain:
+                if isinstance(x, F_.SplitAct):
+                    raise RuntimeError('internal: a split activation reached a layer that cannot take it')
+                out, part = layer(x, None, noise=nz, batch=batch if first else None, sd=sdl), None
+            else:
+                fuse = (not up) and F_.rgb_fusable(batch, c.in_channel, c.out_channel, res, res)
+                k = li // 2
+                rgb_arg = (to_rgbs[k].conv.weight.view(3, c.out_channel), sd[sd_of_rgb[k]][0]) if fuse else None
+                # hand the activation to the next conv in its own split input form when it can stage that by DMA (and,
+                # for a plain conv, when nothing else needs the fp32 tensor: its ToRGB is fused into this launch)
+                s_next = None
+                if nxt is not None and (up or fuse) and nxt.kernel_size == 3 and \
+                        F_.xin_ok(batch, nxt.in_channel, nxt.out_channel, res_out, res_out,
+                                  F_.N.MODE_UP3 if nxt.upsample else F_.N.MODE_PLAIN3) and noise[li + 1] is not None:
+                    s_next = sd[sd_of_layer[li + 1]][0]
+                want_y = not (fuse and (nxt is None or s_next is not None))
+                out, part = F_.styled_conv_split(
+                    x, c.packed_split(), sdl[0], sdl[1], c.out_channel, upsample=up, fir=c.blur.kernel if up else None,
+                    noise=nz, noise_weight=layer.noise.weight, bias=layer.activate.bias, batch=batch if first else None,
+                    s_next=s_next, rgb=rgb_arg, want_y=want_y)
+            if not up:
+                k = li // 2
+                skip = rgb(to_rgbs[k], out, part, skip, sd[sd_of_rgb[k]])
+            x, res = out, res_out
         if side is not None and on_side[0]:
             main.wait_stream(side)
             skip.record_stream(main)

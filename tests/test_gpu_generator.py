@@ -199,6 +199,26 @@ def test_batched_reenactment_equals_per_frame_loop():
         images_to_uint8(torch.full((1, 3, 2, 2), -5.0).cuda()).max() == 0
 
 
+def test_split_chain_is_bit_identical_to_layer_by_layer():
+    """Inference dataflow of the split kernels (activations handed over only in the next conv's split form, ToRGB fused,
+    last activation never stored) == the same kernels run layer by layer through fp32 activations, bit for bit."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    if F_.PRECISION == 'fp32':
+        pytest.skip('the chain exists only for the split arithmetics')
+    for size, B in ((64, 5), (256, 9)):
+        G = hip_generator(size, 1)
+        w = S.synthetic_latents(SEED, B, n_latent=G.n_latent, key='chain.w').cuda()
+        tr = S.counter_tensor(SEED, 'chain.t', (1, 512)).cuda()
+        with torch.no_grad():
+            a, _ = G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr)
+            F_.USE_SPLIT_CHAIN = False
+            try:
+                b, _ = G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr)
+            finally:
+                F_.USE_SPLIT_CHAIN = True
+        assert torch.equal(a, b)
+
+
 def test_graphed_reenactment_session_is_bit_identical():
     """hipGraph replay of the per-batch step (small-batch latency path) == eager launches, incl. a ragged tail."""
     from stylegan_directions_face_reenactment_amd.direction_matrix import DirectionMatrix
