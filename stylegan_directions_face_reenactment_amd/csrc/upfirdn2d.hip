@@ -152,47 +152,53 @@ __global__ __launch_bounds__(256) void blur_bias_act_kernel(const float* __restr
 
 // The same blur + noise + bias + leaky-ReLU, but the result is multiplied by the NEXT layer's modulation and written in
 // that layer's split input form ("XS": [B][C/8][hi,lo][2H*2W][8] 16-bit pairs, see split.hip) instead of fp32 NCHW.
-// A block = one 8-channel group x 8 output rows x 64 output columns: thread (channel, quad column) slides the same
-// 5x5 window down 4 quads, the 16-bit halves meet in LDS as [part][row][px][8 channels], and every thread then writes
-// whole 16-byte pixel chunks (1 KB runs per row and part).
+// A block = one 8-channel group x 8 output rows x 128 output columns: thread (channel, quad column) slides the same
+// 5x5 window down 4 quads, the fp32 results meet in LDS as [row][px][8 channels], and every thread then scales, splits and
+// writes whole 16-byte pixel chunks (2 KB runs per row and part).
 typedef _Float16 bl_f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bl_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float bl_f32x2 __attribute__((ext_vector_type(2)));
 
 template <int ET>
-__device__ __forceinline__ void blur_split1(float v, unsigned short& hi, unsigned short& lo) {
+__device__ __forceinline__ void blur_split2(float a, float b, unsigned& hi, unsigned& lo) {     // as split.hip's split_pair
     if (ET == SGDFR_SPLIT_FP16) {
-        v = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
-        const _Float16 h = (_Float16)v;
-        hi = __builtin_bit_cast(unsigned short, h);
-        lo = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)h));
+        a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
+        b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
+        const bl_f16x2 h = __builtin_convertvector((bl_f32x2){a, b}, bl_f16x2);
+        hi = __builtin_bit_cast(unsigned, h);
+        const bl_f32x2 hf = __builtin_convertvector(h, bl_f32x2);
+        lo = __builtin_bit_cast(unsigned, __builtin_convertvector((bl_f32x2){a - hf[0], b - hf[1]}, bl_f16x2));
     } else {
-        const bl_bf16x2 h = __builtin_convertvector((bl_f32x2){v, 0.f}, bl_bf16x2);
-        const unsigned hb = __builtin_bit_cast(unsigned, h) & 0xffffu;
-        hi = (unsigned short)hb;
-        const bl_bf16x2 l = __builtin_convertvector((bl_f32x2){v - __builtin_bit_cast(float, hb << 16), 0.f}, bl_bf16x2);
-        lo = (unsigned short)(__builtin_bit_cast(unsigned, l) & 0xffffu);
+        hi = __builtin_bit_cast(unsigned, __builtin_convertvector((bl_f32x2){a, b}, bl_bf16x2));
+        const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+        lo = __builtin_bit_cast(unsigned, __builtin_convertvector((bl_f32x2){a - ha, b - hb}, bl_bf16x2));
     }
 }
 
-template <int ET>
-__global__ __launch_bounds__(256) void blur_split_kernel(const float* __restrict__ t, const float* __restrict__ fir,
+// QC: quad columns per channel wave-group (64: a full wave per channel, for W >= 64; 32: two channels per wave, less idle
+// lanes on the narrow layers); block = 8 * QC threads.
+template <int ET, int QC>
+__global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restrict__ t, const float* __restrict__ fir,
                                                         const float* __restrict__ noise, int64_t noise_bstride,
                                                         const float* __restrict__ noise_w, const float* __restrict__ bias,
                                                         const float* __restrict__ s_next, unsigned char* __restrict__ xs,
                                                         int B, int C, int H, int W, int act, float slope, float gain) {
-    __shared__ __attribute__((aligned(16))) unsigned short tile[2][8][64][8];   // [part][row][px][channel]: 16 KB
+    // fp32 results of the block's tile as [row 8][px 128][channel 8 (+1 pad: the lanes of a wave write px 2 apart ->
+    // 18-dword stride, conflict-free)]; the hand-over to 16-byte chunks happens when the tile is read back.
+    // 8 waves = 8 channels, a wave = 64 quad columns (256-byte coalesced plane reads, as the fp32 kernel).
+    __shared__ float tile[8][2 * QC][9];
+    __shared__ float sv[8];
     float kf[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) kf[i] = fir[15 - i];
     const int GW = W + 1, GH = H + 1;
     const int64_t plane_t = (int64_t)4 * GH * GW;
     const int G = C / 8, OW = 2 * W, OHW = 4 * H * W;
-    const int col_tiles = (W + 31) / 32, row_tiles = (H + BLUR_QV - 1) / BLUR_QV;
+    const int col_tiles = (W + QC - 1) / QC, row_tiles = (H + BLUR_QV - 1) / BLUR_QV;
     const int64_t n_tiles = (int64_t)B * G * row_tiles * col_tiles;
     const float nw = (noise && noise_w) ? noise_w[0] : 0.f;
     const float xsc = (ET == SGDFR_SPLIT_FP16) ? 0.0625f : 1.f;
-    const int c8 = threadIdx.x >> 5, nx = threadIdx.x & 31;
+    const int c8 = threadIdx.x / QC, nx = threadIdx.x % QC;
     for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
         const int ct = (int)(tile_id % col_tiles);
         int64_t r = tile_id / col_tiles;
@@ -201,12 +207,12 @@ __global__ __launch_bounds__(256) void blur_split_kernel(const float* __restrict
         const int g = (int)(r % G);
         const int b = (int)(r / G);
         const int c = g * 8 + c8;
-        const int n = ct * 32 + nx;            // quad column
+        const int n = ct * QC + nx;            // quad column
         const int ms = rt * BLUR_QV;           // first quad row
+        if (threadIdx.x < 8) sv[threadIdx.x] = s_next[(int64_t)b * C + g * 8 + threadIdx.x] * xsc;
         if (n < W) {
             const float* tp = t + ((int64_t)b * C + c) * plane_t;
             const float bv = bias ? bias[c] : 0.f;
-            const float sv = s_next[(int64_t)b * C + c] * xsc;
             int coff[5];
             bool cok[5];
 #pragma unroll
@@ -253,12 +259,8 @@ __global__ __launch_bounds__(256) void blur_split_kernel(const float* __restrict
                         v0 = lrelu_gain(v0, slope, gain);
                         v1 = lrelu_gain(v1, slope, gain);
                     }
-                    unsigned short h0, l0, h1, l1;
-                    blur_split1<ET>(v0 * sv, h0, l0);
-                    blur_split1<ET>(v1 * sv, h1, l1);
-                    const int row = 2 * qv + rr, px = 2 * nx;
-                    tile[0][row][px][c8] = h0; tile[1][row][px][c8] = l0;
-                    tile[0][row][px + 1][c8] = h1; tile[1][row][px + 1][c8] = l1;
+                    tile[2 * qv + rr][2 * nx][c8] = v0;
+                    tile[2 * qv + rr][2 * nx + 1][c8] = v1;
                 }
 #pragma unroll
                 for (int u = 0; u < 3; ++u)
@@ -267,15 +269,22 @@ __global__ __launch_bounds__(256) void blur_split_kernel(const float* __restrict
             }
         }
         __syncthreads();
-        // 2 parts x 8 rows x 64 px chunks of 16 bytes
+        // 8 rows x 64 px pixels -> 8 channels each: multiply by the next layer's style, split, two 16-byte chunks
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int item = threadIdx.x + 256 * k;
-            const int px = item & 63, row = (item >> 6) & 7, part = item >> 9;
-            const int oy = 2 * ms + row, ox = ct * 64 + px;
+        for (int k = 0; k < 2; ++k) {
+            const int item = threadIdx.x + 8 * QC * k;
+            const int px = item % (2 * QC), row = item / (2 * QC);
+            const int oy = 2 * ms + row, ox = ct * 2 * QC + px;
             if (oy < 2 * H && ox < OW) {
-                const uint4 q = *reinterpret_cast<const uint4*>(&tile[part][row][px][0]);
-                *reinterpret_cast<uint4*>(xs + ((((int64_t)b * G + g) * 2 + part) * OHW + (int64_t)oy * OW + ox) * 16) = q;
+                uint4 vh, vl;
+                unsigned* ph = reinterpret_cast<unsigned*>(&vh);
+                unsigned* pl = reinterpret_cast<unsigned*>(&vl);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+                    blur_split2<ET>(tile[row][px][2 * cc] * sv[2 * cc], tile[row][px][2 * cc + 1] * sv[2 * cc + 1], ph[cc], pl[cc]);
+                unsigned char* dst = xs + ((((int64_t)b * G + g) * 2) * OHW + (int64_t)oy * OW + ox) * 16;
+                *reinterpret_cast<uint4*>(dst) = vh;
+                *reinterpret_cast<uint4*>(dst + (int64_t)OHW * 16) = vl;
             }
         }
         __syncthreads();
@@ -331,15 +340,16 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
     if (B == 0) return 0;
     SGDFR_REQUIRE(t && fir && s_next && xs && (reinterpret_cast<uintptr_t>(xs) & 15) == 0, "blur_bias_act_split: null / misaligned pointer");
     SGDFR_REQUIRE(!noise || noise_w, "blur_bias_act_split: noise without noise_w");
-    const int64_t tiles = (int64_t)B * (C / 8) * ((H + BLUR_QV - 1) / BLUR_QV) * ((W + 31) / 32);
+    const int QC = W >= 64 ? 64 : 32;
+    const int64_t tiles = (int64_t)B * (C / 8) * ((H + BLUR_QV - 1) / BLUR_QV) * ((W + QC - 1) / QC);
     int64_t g = tiles;
     if (g > 256 * 32) g = 256 * 32;
     unsigned char* out = reinterpret_cast<unsigned char*>(xs);
-    if (arith == SGDFR_SPLIT_FP16)
-        hipLaunchKernelGGL(blur_split_kernel<SGDFR_SPLIT_FP16>, dim3((int)g), dim3(256), 0, as_stream(stream), t, fir, noise,
-                           noise_bstride, noise_w, bias, s_next, out, B, C, H, W, act, slope, gain);
-    else
-        hipLaunchKernelGGL(blur_split_kernel<SGDFR_SPLIT_BF16>, dim3((int)g), dim3(256), 0, as_stream(stream), t, fir, noise,
-                           noise_bstride, noise_w, bias, s_next, out, B, C, H, W, act, slope, gain);
+    void (*kern)(const float*, const float*, const float*, int64_t, const float*, const float*, const float*, unsigned char*, int,
+                 int, int, int, int, float, float);
+    if (arith == SGDFR_SPLIT_FP16) kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_FP16, 64> : blur_split_kernel<SGDFR_SPLIT_FP16, 32>;
+    else kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_BF16, 64> : blur_split_kernel<SGDFR_SPLIT_BF16, 32>;
+    hipLaunchKernelGGL(kern, dim3((int)g), dim3(8 * QC), 0, as_stream(stream), t, fir, noise, noise_bstride, noise_w, bias, s_next,
+                       out, B, C, H, W, act, slope, gain);
     return check_launch("blur_bias_act_split");
 }
