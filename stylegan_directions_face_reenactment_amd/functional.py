@@ -4,6 +4,7 @@ Each function is one (or a fixed short sequence of) native launch(es) on torch's
 nothing here computes with torch ops.  Reference lines each function stands for are cited inline
 (paths relative to the reference's libs/gan/StyleGAN2/).
 """
+import functools
 import math
 import os
 
@@ -258,8 +259,14 @@ def prepack_split(weight, arith=None, adjoint=False):
     return wsp
 
 
+@functools.lru_cache(maxsize=None)
+def _shape_query(name, *shape):
+    """Pure shape -> int queries of the library (tiling plans), memoised: the launch-bound small batches feel every call."""
+    return getattr(N.load(), name)(*shape)
+
+
 def split_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
-    return PRECISION in _SPLIT_ARITH and bool(N.load().sgdfr_modconv2d_split_supported(B, cin, cout, H, W, mode))
+    return PRECISION in _SPLIT_ARITH and bool(_shape_query('sgdfr_modconv2d_split_supported', B, cin, cout, H, W, mode))
 
 
 def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2,
@@ -293,7 +300,7 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
             raise RuntimeError('modconv_split: want_y=False only makes sense with the fused ToRGB (rgb=...) or s_next')
         y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32) if want_y else None
     st = N.stream()
-    ks = N.load().sgdfr_modconv2d_split_ksplit_hint(B, cin, cout, H, W, mode) if USE_SPLITK else 1
+    ks = _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cin, cout, H, W, mode) if USE_SPLITK else 1
     if ks > 1 and y is None:
         raise RuntimeError('modconv_split: this launch is K-sliced and cannot fuse ToRGB (check rgb_fusable first)')
     partials = torch.empty((ks,) + tuple(y.shape), device=x.device, dtype=torch.float32) if ks > 1 else None
@@ -309,7 +316,7 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
             raise RuntimeError('modconv_split: this launch cannot fuse ToRGB (check rgb_fusable first)')
         rgb_w, rgb_s = N.f32c(rgb[0]), N.f32c(rgb[1])
         N.require_device(rgb_w, rgb_s)
-        tiles = N.load().sgdfr_modconv2d_split_cout_tiles(B, cin, cout, H, W, mode)
+        tiles = _shape_query('sgdfr_modconv2d_split_cout_tiles', B, cin, cout, H, W, mode)
         part = torch.empty(B, tiles * 3, H, W, device=x.device, dtype=torch.float32)
     _timed_conv(desc or ('split mode%d %d->%d @%dx%d%s' % (mode, cin, cout, H, W, ' K/%d' % ks if ks > 1 else '')),
                 B * conv_flops(cin, cout, H, W), lambda: N.call(
@@ -347,7 +354,7 @@ class SplitAct:
 def xin_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
     """Can the split conv of this shape take its input as a SplitAct?"""
     return USE_SPLIT_CHAIN and split_ok(B, cin, cout, H, W, mode) and \
-        bool(N.load().sgdfr_modconv2d_split_xin_supported(B, cin, cout, H, W, mode))
+        bool(_shape_query('sgdfr_modconv2d_split_xin_supported', B, cin, cout, H, W, mode))
 
 
 def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, noise_weight=None, bias=None, batch=None,
@@ -381,7 +388,7 @@ def rgb_fusable(B, cin, cout, H, W):
     """True when the plain 3x3 conv of this shape runs on the split kernel in one pass, so the ToRGB that follows it can be
     accumulated in its epilogue instead of re-reading the activation."""
     return USE_RGB_FUSION and split_ok(B, cin, cout, H, W) and \
-        (not USE_SPLITK or N.load().sgdfr_modconv2d_split_ksplit_hint(B, cin, cout, H, W, N.MODE_PLAIN3) == 1)
+        (not USE_SPLITK or _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cin, cout, H, W, N.MODE_PLAIN3) == 1)
 
 
 def torgb_finish(part, bias=None, skip=None, fir=None):

@@ -440,42 +440,56 @@ class Generator(nn.Module):
             with torch.cuda.stream(side):
                 return run()
 
+        # Per-layer launch decisions depend only on (batch, arithmetic, which noises are given): cached, so a forward does
+        # not query the library 40 times (it matters for the launch-bound small batches).
+        key = (batch, chain, F_.PRECISION, F_.USE_SPLIT_CHAIN, F_.USE_RGB_FUSION, F_.USE_SPLITK, tuple(n is None for n in noise))
+        plan = self._chain_plans.get(key) if hasattr(self, '_chain_plans') else None
+        if plan is None:
+            plan, res = [], self.input.input.shape[2]
+            for li, layer in enumerate(layers):
+                c = layer.conv
+                up = c.upsample
+                res_out = 2 * res if up else res
+                nxt = layers[li + 1].conv if li + 1 < len(layers) else None
+                mode = F_.N.MODE_UP3 if up else F_.N.MODE_PLAIN3
+                use_chain = chain and noise[li] is not None and F_.split_ok(batch, c.in_channel, c.out_channel, res, res, mode)
+                fuse = use_chain and (not up) and F_.rgb_fusable(batch, c.in_channel, c.out_channel, res, res)
+                # hand the activation to the next conv in its own split input form when it can stage that by DMA (and,
+                # for a plain conv, when nothing else needs the fp32 tensor: its ToRGB is fused into this launch)
+                to_next = use_chain and nxt is not None and (up or fuse) and nxt.kernel_size == 3 and \
+                    noise[li + 1] is not None and \
+                    F_.xin_ok(batch, nxt.in_channel, nxt.out_channel, res_out, res_out,
+                              F_.N.MODE_UP3 if nxt.upsample else F_.N.MODE_PLAIN3)
+                want_y = not (fuse and (nxt is None or to_next))
+                plan.append((use_chain, fuse, to_next, want_y))
+                res = res_out
+            if not hasattr(self, '_chain_plans'):
+                self._chain_plans = {}
+            self._chain_plans[key] = plan
+
         # ConstantInput is broadcast inside the kernel (batch stride 0) instead of repeated
-        x, skip, res = self.input.input, None, self.input.input.shape[2]
+        x, skip = self.input.input, None
         for li, layer in enumerate(layers):
             c = layer.conv
             up = c.upsample
             sdl = sd[sd_of_layer[li]]
             nz = noise[li]
             first = li == 0
-            res_out = 2 * res if up else res
-            nxt = layers[li + 1].conv if li + 1 < len(layers) else None
-            mode = F_.N.MODE_UP3 if up else F_.N.MODE_PLAIN3
-            use_chain = chain and nz is not None and F_.split_ok(batch, c.in_channel, c.out_channel, res, res, mode)
+            use_chain, fuse, to_next, want_y = plan[li]
+            k = li // 2
             if not use_chain:
                 if isinstance(x, F_.SplitAct):
                     raise RuntimeError('internal: a split activation reached a layer that cannot take it')
                 out, part = layer(x, None, noise=nz, batch=batch if first else None, sd=sdl), None
             else:
-                fuse = (not up) and F_.rgb_fusable(batch, c.in_channel, c.out_channel, res, res)
-                k = li // 2
                 rgb_arg = (to_rgbs[k].conv.weight.view(3, c.out_channel), sd[sd_of_rgb[k]][0]) if fuse else None
-                # hand the activation to the next conv in its own split input form when it can stage that by DMA (and,
-                # for a plain conv, when nothing else needs the fp32 tensor: its ToRGB is fused into this launch)
-                s_next = None
-                if nxt is not None and (up or fuse) and nxt.kernel_size == 3 and \
-                        F_.xin_ok(batch, nxt.in_channel, nxt.out_channel, res_out, res_out,
-                                  F_.N.MODE_UP3 if nxt.upsample else F_.N.MODE_PLAIN3) and noise[li + 1] is not None:
-                    s_next = sd[sd_of_layer[li + 1]][0]
-                want_y = not (fuse and (nxt is None or s_next is not None))
                 out, part = F_.styled_conv_split(
                     x, c.packed_split(), sdl[0], sdl[1], c.out_channel, upsample=up, fir=c.blur.kernel if up else None,
                     noise=nz, noise_weight=layer.noise.weight, bias=layer.activate.bias, batch=batch if first else None,
-                    s_next=s_next, rgb=rgb_arg, want_y=want_y)
+                    s_next=sd[sd_of_layer[li + 1]][0] if to_next else None, rgb=rgb_arg, want_y=want_y)
             if not up:
-                k = li // 2
                 skip = rgb(to_rgbs[k], out, part, skip, sd[sd_of_rgb[k]])
-            x, res = out, res_out
+            x = out
         if side is not None and on_side[0]:
             main.wait_stream(side)
             skip.record_stream(main)
