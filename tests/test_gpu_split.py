@@ -141,6 +141,59 @@ def test_fused_torgb_partials(cin, cout, H, B):
     assert maxabs(separate, ref) <= 1e-5 * scale and maxabs(fused, ref) <= 1e-5 * scale
 
 
+def _decode_split(xs, shape, arith):
+    """XS [B, C/8, 2, HW, 8] int16 -> fp64 [B,C,H,W] = hi + lo (the value the consumer's MFMAs see, before the range shift)."""
+    B, C, H, W = shape
+    dt = torch.float16 if arith == 'fp16x3' else torch.bfloat16
+    v = xs.view(dt).double()                                   # [B, C/8, 2, HW, 8]
+    v = v[:, :, 0] + v[:, :, 1]                                # [B, C/8, HW, 8]
+    v = v.permute(0, 1, 3, 2).reshape(B, C, H, W)
+    return v * (16.0 if arith == 'fp16x3' else 1.0)
+
+
+@pytest.mark.parametrize('arith', ['fp16x3', 'bf16x3'])
+def test_split_form_handover_pieces(arith):
+    """The inference dataflow's pieces one by one: to_split() keeps 22 (16) mantissa bits of x*s; a conv fed with that form
+    (DMA staging) is bit-identical to the conv fed with fp32 x; the plain conv's epilogue and the blur kernel emit exactly
+    to_split(their fp32 output, s_next)."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    N = F_.N
+    B, cin, cout, h = 40, 64, 128, 64
+    w = S.counter_tensor(6, 'xs.w', (1, cout, cin, 3, 3)).cuda()
+    x = S.counter_tensor(6, 'xs.x', (B, cin, h, h)).cuda()
+    s = S.counter_tensor(6, 'xs.s', (B, cin), 1.0, 0.3).cuda()
+    d = S.counter_tensor(6, 'xs.d', (B, cout), 1.0, 0.2).cuda()
+    sn = S.counter_tensor(6, 'xs.sn', (B, cout), 1.0, 0.3).cuda()
+    noise = S.counter_tensor(6, 'xs.n', (1, 1, h, h)).cuda()
+    nw = torch.full((1,), 0.1).cuda()
+    bias = S.counter_tensor(6, 'xs.b', (cout,), 0.0, 0.1).cuda()
+    xs = F_.to_split(x, s, arith)
+    want = (x.double() * s.double()[:, :, None, None]).cpu()
+    # fp16 terms: 22 bits, except that lo goes subnormal for |x*s| < 1 (absolute step 16 * 2^-24); bf16 terms: 16 bits
+    rel, floor = (2.0 ** -21, 16 * 2.0 ** -24) if arith == 'fp16x3' else (2.0 ** -15, 0.0)
+    err = (_decode_split(xs, x.shape, arith).cpu() - want).abs()
+    assert bool((err <= rel * want.abs() + floor).all())
+    wsp = F_.prepack_split(w, arith)
+    for mode in (N.MODE_PLAIN3, N.MODE_UP3):
+        assert F_.xin_ok(B, cin, cout, h, h, mode)
+        a = F_.modconv_split(x, wsp, s, d, cout, arith=arith, mode=mode)
+        b = F_.modconv_split(xs, wsp, None, d, cout, arith=arith, mode=mode, x_split=tuple(x.shape), batch=B)
+        assert torch.equal(a, b)
+    y, _, xs_out = F_.modconv_split(x, wsp, s, d, cout, noise, nw, bias, True, arith=arith, s_next=sn)
+    assert torch.equal(xs_out, F_.to_split(y, sn, arith))
+    none_y, _, xs_only = F_.modconv_split(x, wsp, s, d, cout, noise, nw, bias, True, arith=arith, s_next=sn, want_y=False)
+    assert none_y is None and torch.equal(xs_only, xs_out)
+    planes = F_.modconv_split(x, wsp, s, d, cout, arith=arith, mode=N.MODE_UP3)
+    fir = torch.tensor(O.make_fir([1, 3, 3, 1], gain=4.0).numpy()).cuda()
+    noise2 = S.counter_tensor(6, 'xs.n2', (1, 1, 2 * h, 2 * h)).cuda()
+    yb = F_.blur_bias_act(planes, fir, h, h, noise2, nw, bias, True)
+    assert torch.equal(F_.blur_bias_act_split(planes, fir, h, h, sn, noise2, nw, bias, True, arith=arith), F_.to_split(yb, sn, arith))
+    planes_s = F_.modconv_split(x[:3, :, :16, :16].contiguous(), wsp, s[:3], d[:3], cout, arith=arith, mode=N.MODE_UP3)   # narrow image
+    nz3 = noise2[:, :, :32, :32].contiguous()
+    yb3 = F_.blur_bias_act(planes_s, fir, 16, 16, nz3, nw, bias, True)
+    assert torch.equal(F_.blur_bias_act_split(planes_s, fir, 16, 16, sn[:3], nz3, nw, bias, True, arith=arith), F_.to_split(yb3, sn[:3], arith))
+
+
 def test_fp16_split_saturates_instead_of_overflowing():
     """|x*s| beyond the fp16-split range (1.04e6) clamps; nothing becomes inf/nan."""
     from stylegan_directions_face_reenactment_amd import functional as F_
