@@ -1,26 +1,34 @@
-// 3x3 modulated convolution on the bf16 matrix cores with fp32 operands split in two bf16 terms ("bf16x3"):
+// 3x3 modulated convolution on the 16-bit matrix cores with every fp32 operand split in two 16-bit terms:
 //
-//     a = a_hi + a_lo,  b = b_hi + b_lo   (hi = bf16(v), lo = bf16(v - hi): 16 mantissa bits kept)
-//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi      accumulated in fp32 by v_mfma_f32_32x32x16_bf16
+//     a = a_hi + a_lo,  b = b_hi + b_lo   (hi = round16(v), lo = round16(v - hi); v - hi is exact in fp32)
+//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi      accumulated in fp32 by v_mfma_f32_32x32x16_{f16,bf16}
 //
-// Three bf16 MFMAs replace eight fp32 ones (v_mfma_f32_32x32x2_f32 covers K=2 in 64 cycles, the bf16 form K=16 in
-// 32), so the contraction runs ~5x above the fp32-MFMA roof; the kernel is then bound by staging and LDS/L2
-// bandwidth.  Per-product error is ~2^-17 relative (the dropped lo*lo term and the 16-bit split), measured end to end
-// on the 256x256 generator: 1.1e-4 max-abs against the fp64 oracle (fp32 path: 1e-5; contract: 1e-3).  This is an
-// OPT-IN precision mode (functional.PRECISION / SGDFR_PRECISION=bf16x3); the default path stays exact fp32.
+// Three 16-bit MFMAs replace eight fp32 ones (v_mfma_f32_32x32x2_f32 covers K=2 in 64 cycles, the 16-bit form K=16 in
+// 32), so the contraction runs ~5x above the fp32-MFMA roof and the kernel is bound by LDS reads + MFMA issue, stores
+// and staging instead.
+//   ET = SGDFR_SPLIT_FP16 (default arithmetic of the inference path): 11+11 mantissa bits = fp32-grade products; operands
+//        are range-shifted by exact powers of two (x*2^-4, W*2^6, result*2^-2) and |x*s| saturates at 1.04e6.  Measured on
+//        the 256x256 generator: 7.7e-6 max-abs vs the fp64 oracle (fp32 MFMA kernels: 9.5e-6).
+//   ET = SGDFR_SPLIT_BF16: 8+8 bits, full fp32 range (1.2e-4 on images; contract 1e-3).  Used for dL/dx (gradients have no
+//        natural scale).
 //
 // Same algebra as modconv.hip (y = d * conv(x*s, Wc), batch folded into the pixel dimension), different data path:
 //   * GEMM view M = cout, N = pixels, K = (tap, cin); one MFMA = 16 input channels of one tap.  A lane holds 8
-//     consecutive channels (16 B): LDS keeps activations as [part hi/lo][k-half][position][8 x bf16] and weights as
-//     [tap][part][k-half][cout][8 x bf16], so every fragment is one conflict-free ds_read_b128.
-//   * block = 8 waves: NT = 64*WM couts x PT = 64*WN pixels, wave tile 64 x 64 (2x2 MFMA tiles x 3 products).
-//   * K loop over 16-channel blocks, each split in 3 sub-stages (one kernel row = 3 taps).  The weight row slab
-//     (NT*192 B, prepacked in LDS order) is DMA'd global->LDS one sub-stage ahead into a 2-slot ring; the activation
-//     tile of the NEXT channel block is converted (x*s -> hi/lo) from registers and written to the other x buffer
-//     one third per sub-stage, while its global loads were issued a full channel block earlier.  One barrier per
-//     sub-stage (36 MFMAs per wave).
+//     consecutive channels (16 B): LDS keeps activations as [part hi/lo][k-half][position][8 x 16 bit] and weights as
+//     [cout tile of 64][row][tap][part][k-half][cout][8 x 16 bit], so every fragment is one conflict-free ds_read_b128.
+//   * block = 8 waves, one block per CU: NT couts x PT pixels from a tiling plan (plain 128x256 / 64x512, wave tile 64x64 =
+//     2x2 MFMA tiles x 3 products; transposed conv: 4 parity-phase accumulator sets, wave tile 32x64, 64x256 or 128x128).
+//   * K loop over 16-channel blocks in NSS barrier-delimited sub-stages (3 = one kernel row each, 1 = all 9 taps).  The
+//     weight slab of a sub-stage (prepacked in LDS order) is DMA'd global->LDS one sub-stage ahead into a 2-slot ring.
+//     Activations of the NEXT channel block go to the other x buffer either (fp32 input) converted x*s -> hi/lo from
+//     registers loaded a whole channel block earlier, the two waves of a SIMD running {convert, MFMA} in opposite order,
+//     or (XIN: the producer already wrote the split form, see to_split_kernel / xs_out / upfirdn2d.hip's blur) by DMA.
+//     Fragments of tap k+1 are requested while the MFMAs of tap k run.
 //   * pixel tiles: contiguous runs of the padded flat space for W <= 64 (a tile may span images), TR x 128 patches
-//     for wider images.
+//     for wider images; layers with too few tiles slice the channel blocks over more blocks (deterministic reduce).
+//   * epilogue: coefficients (d, bias, next layer's style, ToRGB weights) come from LDS tables so the wave issues its
+//     stores back to back; optional outputs: fp32 activation, the activation in the next conv's split input form, and the
+//     partial sums of the 1x1 ToRGB conv that follows the layer.
 #include <stdlib.h>
 
 #include "common.h"
