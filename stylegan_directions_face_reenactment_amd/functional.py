@@ -5,7 +5,6 @@ nothing here computes with torch ops.  Reference lines each function stands for 
 (paths relative to the reference's libs/gan/StyleGAN2/).
 """
 import functools
-import math
 import os
 
 import torch
