@@ -218,6 +218,9 @@ def main():
                      'conv_ms_per_step': round(conv_s / args.steps * 1e3, 3),
                      'alg_gflop_per_frame': round(conv_flops / (B * args.steps) / 1e9, 3)},
     }
+    if args.precision == 'fp16x3':
+        # operand pairs the fp16-split kernels had to clamp (|x*s| > 1.04e6) during this whole run: 0 = the fp32-grade claim holds
+        out['fp16_saturated_pairs'] = F_.split_saturation_count(reset=False)
     if alt is not None:
         out['alt_arithmetic'] = alt
     if args.precision != 'fp32':

@@ -215,6 +215,9 @@ int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned 
  * stages it; sgdfr_modconv2d_split_f32(x = xs, s = NULL, x_is_split = 1) then fills LDS by DMA only.  Producers can emit
  * that form directly: sgdfr_modconv2d_split_f32(xs_out, s_next = the NEXT layer's modulation [B,Cout]) (y may then be NULL)
  * and sgdfr_blur_bias_act_f32's split variant, so activations between layers never exist as fp32 in HBM. */
+/* fp16-split operand pairs clamped to +-65504 (|x*s| > 1.04e6) by any split kernel on the current device since the last
+ * reset -- the fp16x3 arithmetic never saturates silently.  Synchronises the device; < 0 on a HIP error. */
+long long sgdfr_split_saturation_count(int reset);
 int sgdfr_modconv2d_split_xin_supported(int B, int Cin, int Cout, int H, int W, int mode);   /* x_is_split allowed for this shape */
 int sgdfr_to_split_f32(const float* x, const float* s, unsigned short* xs, int B, int Cin, int H, int W, int arith, void* stream);
 int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H, int W, int mode);

@@ -99,6 +99,8 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.sgdfr_abi_version.restype = ctypes.c_int
     lib.sgdfr_last_error.restype = ctypes.c_char_p
+    lib.sgdfr_split_saturation_count.argtypes = [ctypes.c_int]
+    lib.sgdfr_split_saturation_count.restype = ctypes.c_longlong
     lib.sgdfr_modconv_prepack_split_elems.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.sgdfr_modconv_prepack_split_elems.restype = ctypes.c_int64
     if lib.sgdfr_abi_version() != ABI_VERSION:

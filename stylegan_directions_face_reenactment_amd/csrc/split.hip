@@ -52,6 +52,8 @@ __device__ __forceinline__ f32x16 split_mfma(frag128 a, frag128 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+__device__ unsigned int g_split_saturated = 0;   // operand pairs clamped to the fp16 range by this translation unit's kernels
+
 constexpr float SPLIT_F16_XSCALE = 0.0625f, SPLIT_F16_WSCALE = 64.f, SPLIT_F16_OUT = 0.25f, SPLIT_F16_MAX = 65504.f;
 
 struct SplitParams {
@@ -98,6 +100,8 @@ __device__ __forceinline__ void split_wait_vmcnt() {
 template <int ET>
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
     if (ET == SGDFR_SPLIT_FP16) {
+        // saturation is never silent: every clamped pair bumps a device counter (sgdfr_split_saturation_count)
+        if (__builtin_expect(fmaxf(fabsf(a), fabsf(b)) > SPLIT_F16_MAX, 0)) atomicAdd(&g_split_saturated, 1u);
         a = __builtin_amdgcn_fmed3f(a, -SPLIT_F16_MAX, SPLIT_F16_MAX);
         b = __builtin_amdgcn_fmed3f(b, -SPLIT_F16_MAX, SPLIT_F16_MAX);
         f32x2 v = {a, b};
@@ -813,6 +817,20 @@ extern "C" int sgdfr_to_split_f32(const float* x, const float* s, unsigned short
         hipLaunchKernelGGL(to_split_kernel<SGDFR_SPLIT_BF16>, dim3((int)g), dim3(256), 0, as_stream(stream), x, s,
                            reinterpret_cast<unsigned char*>(xs), B, Cin, H * W);
     return check_launch("to_split");
+}
+
+unsigned int blur_split_saturation_count(int reset);     // upfirdn2d.hip's counter
+
+// Number of fp16-split operand pairs that hit the +-65504 clamp (|x*s| > 1.04e6) since the last reset, over all split
+// kernels on the current device; synchronises the device.  Negative: HIP error.
+extern "C" long long sgdfr_split_saturation_count(int reset) {
+    unsigned int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_split_saturated), sizeof(v)) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned int z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_split_saturated), &z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return (long long)v + (long long)blur_split_saturation_count(reset);
 }
 
 extern "C" int sgdfr_modconv2d_split_xin_supported(int B, int Cin, int Cout, int H, int W, int mode) {

@@ -159,9 +159,12 @@ typedef _Float16 bl_f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bl_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float bl_f32x2 __attribute__((ext_vector_type(2)));
 
+__device__ unsigned int g_blur_saturated = 0;    // operand pairs clamped to the fp16 range (see sgdfr_split_saturation_count)
+
 template <int ET>
 __device__ __forceinline__ void blur_split2(float a, float b, unsigned& hi, unsigned& lo) {     // as split.hip's split_pair
     if (ET == SGDFR_SPLIT_FP16) {
+        if (__builtin_expect(fmaxf(fabsf(a), fabsf(b)) > 65504.f, 0)) atomicAdd(&g_blur_saturated, 1u);
         a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
         b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
         const bl_f16x2 h = __builtin_convertvector((bl_f32x2){a, b}, bl_f16x2);
@@ -294,6 +297,16 @@ __global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restr
 }  // namespace sgdfr
 
 using namespace sgdfr;
+
+unsigned int blur_split_saturation_count(int reset) {
+    unsigned int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_blur_saturated), sizeof(v)) != hipSuccess) return 0;
+    if (reset) {
+        const unsigned int z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blur_saturated), &z, sizeof(z));
+    }
+    return v;
+}
 
 extern "C" int sgdfr_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int in_h, int in_w, int minor,
                                    int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,

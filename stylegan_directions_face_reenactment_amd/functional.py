@@ -191,6 +191,15 @@ PRECISION = os.environ.get('SGDFR_PRECISION', 'fp16x3')
 _zeros = {}
 
 
+def split_saturation_count(reset=True):
+    """How many operand pairs the fp16x3 kernels had to clamp to the fp16 range (|x*s| > 1.04e6) on this device since the last
+    reset: 0 means the fp32-grade accuracy claim held for everything computed so far; otherwise use 'bf16x3' or 'fp32'."""
+    n = N.load().sgdfr_split_saturation_count(int(bool(reset)))
+    if n < 0:
+        raise RuntimeError('sgdfr_split_saturation_count failed')
+    return int(n)
+
+
 def set_precision(mode):
     global PRECISION
     if mode not in ('fp32', 'fp16x3', 'bf16x3'):

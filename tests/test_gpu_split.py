@@ -201,8 +201,14 @@ def test_fp16_split_saturates_instead_of_overflowing():
     x = S.counter_tensor(9, 'sat.x', (2, 32, 8, 8)).cuda() * 1e7
     s = torch.ones(2, 32).cuda()
     d = torch.ones(2, 64).cuda()
+    F_.split_saturation_count(reset=True)
     y = F_.modconv_split(x, F_.prepack_split(w, 'fp16x3'), s, d, 64, arith='fp16x3')
     assert bool(torch.isfinite(y).all())
+    assert F_.split_saturation_count(reset=True) > 0            # ... and it is counted, never silent
     small = F_.modconv_split(x * 1e-7 * 5e4, F_.prepack_split(w, 'fp16x3'), s, d, 64, arith='fp16x3')     # 5e4..2e5: in range
     ref = torch.nn.functional.conv2d((x * 1e-7 * 5e4).double().cpu(), w[0].double().cpu() / (32 * 9) ** 0.5, padding=1)
     assert maxabs(small, ref) <= 2e-5 * float(ref.abs().max())
+    assert F_.split_saturation_count() == 0                      # in range: nothing clamped
+    # the producers of the split hand-over count too
+    F_.to_split(x, s, 'fp16x3')
+    assert F_.split_saturation_count() > 0
