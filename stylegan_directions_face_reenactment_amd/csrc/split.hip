@@ -31,6 +31,8 @@
 //     partial sums of the 1x1 ToRGB conv that follows the layer.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace sgdfr {
@@ -87,6 +89,8 @@ struct SplitParams {
     int64_t split_stride;
     int desync;                  // first-round start spread: estimated block time in 4096-clock units (0 = off)
     int stagger;                 // which waves run MFMAs before staging inside a sub-stage (0 none, 1 waves 4-7, 2 odd waves)
+    int dbg;
+    int total_blocks;            // tiles x cout tiles x K slices; the grid may be smaller (persistent blocks)
 };
 
 constexpr int SPLIT_CB = 16;     // input channels per K block (one MFMA K)
@@ -97,11 +101,13 @@ __device__ __forceinline__ void split_wait_vmcnt() {
 }
 
 // two floats -> packed hi pair and packed lo pair (lo = round(v - float(hi)), the subtraction is exact)
+// `sat` counts the pairs this thread clamped; the caller adds it to g_split_saturated once (split_flush_saturation): a
+// branch per pair would fence the scheduler around every conversion.
 template <int ET>
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo, unsigned& sat) {
     if (ET == SGDFR_SPLIT_FP16) {
-        // saturation is never silent: every clamped pair bumps a device counter (sgdfr_split_saturation_count)
-        if (__builtin_expect(fmaxf(fabsf(a), fabsf(b)) > SPLIT_F16_MAX, 0)) atomicAdd(&g_split_saturated, 1u);
+        // saturation is never silent: every clamped pair ends up in a device counter (sgdfr_split_saturation_count)
+        sat += (fmaxf(fabsf(a), fabsf(b)) > SPLIT_F16_MAX) ? 1u : 0u;
         a = __builtin_amdgcn_fmed3f(a, -SPLIT_F16_MAX, SPLIT_F16_MAX);
         b = __builtin_amdgcn_fmed3f(b, -SPLIT_F16_MAX, SPLIT_F16_MAX);
         f32x2 v = {a, b};
@@ -120,6 +126,10 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
         bf16x2 l = __builtin_convertvector(r, bf16x2);
         lo = __builtin_bit_cast(unsigned, l);
     }
+}
+
+__device__ __forceinline__ void split_flush_saturation(unsigned sat) {
+    if (__builtin_expect(sat != 0, 0)) atomicAdd(&g_split_saturated, sat);
 }
 
 // MODE PLAIN3: y = conv3x3(x*s) * d (+ noise, bias, activation).  MODE UP3: stride-2 transposed conv into the four
@@ -154,45 +164,90 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     const int l31 = lane & 31, hi = lane >> 5;
     const int HW = p.H * p.W;
 
-    int lid;
-    {
-        const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7;
+    // Persistent blocks: the grid is one block per CU (or fewer); block b works on tiles base + map(b) of every round of
+    // gridDim.x tiles.  map() keeps the tiles of one XCD (blockIdx & 7) contiguous, so neighbours share halos and weights in L2.
+    constexpr bool PERSIST = XIN;       // (the fp32-input variants have no registers to spare for the loop)
+    auto lid_of = [&](int base) -> int {        // tile of this block in the round starting at `base`, -1: none
+        if (base >= p.total_blocks) return -1;
+        const int nblk = PERSIST ? min((int)gridDim.x, p.total_blocks - base) : (int)gridDim.x, q8 = nblk >> 3, r8 = nblk & 7;
+        if ((int)blockIdx.x >= nblk) return -1;
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    }
+        return base + (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    };
+    struct TileOrg { int ks, ct, pt, q0, img0, row0, col0; };
+    auto tile_org = [&](int lid) -> TileOrg {
+        TileOrg t;
+        const int tiles_per_slice = p.n_pix_tiles * p.n_cout_tiles;
+        t.ks = lid / tiles_per_slice;                 // K slice of this block (0 when ksplit == 1)
+        const int lt = lid - t.ks * tiles_per_slice;
+        t.ct = lt / p.n_pix_tiles;
+        t.pt = lt - t.ct * p.n_pix_tiles;
+        t.q0 = 0; t.row0 = 0; t.col0 = 0;
+        if (p.patch) {
+            const int per_img = p.tiles_x * p.tiles_y;
+            t.img0 = t.pt / per_img;
+            const int rem = t.pt - t.img0 * per_img;
+            const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+            t.row0 = ty * p.TR;
+            t.col0 = tx * p.TC;
+        } else if (UP) {
+            t.q0 = t.pt * PT;                       // super-pixels ARE positions of the padded flat space
+            t.img0 = t.q0 / (p.R * p.P);
+        } else {
+            const int p0 = t.pt * PT;
+            t.img0 = p0 / HW;
+            const int rem = p0 - t.img0 * HW;
+            const int a = rem / p.W, b = rem - a * p.W;
+            t.q0 = (t.img0 * p.R + a + 1) * p.P + b + 1 - p.P - 1;
+        }
+        return t;
+    };
+    // XIN staging item e of this thread for a tile: byte address of the hi chunk of channel group (cb = 0, h);
+    // -1: zero page; -2: no item (skip the DMA)
+    auto xin_addr = [&](const TileOrg& t, int e) -> int64_t {
+        const int i = tid + e * NTHR;
+        const int h = i / p.xs;
+        const int j = i - h * p.xs;
+        if (!(h < 2 && j < p.xs)) return -2;
+        bool ok = j < p.xlen;
+        int img, pix;
+        if (p.patch) {
+            const int sg = j / p.seglen, cc = j - sg * p.seglen;
+            const int row = t.row0 - 1 + sg, col = t.col0 - 1 + cc;
+            img = t.img0;
+            ok = ok && row >= 0 && row < p.H && col >= 0 && col < p.W && img < p.B;
+            pix = row * p.W + col;
+        } else {
+            const int q = t.q0 + j;
+            const int pir = q / p.P, pc = q - pir * p.P;
+            img = pir / p.R;
+            const int pr = pir - img * p.R;
+            ok = ok && pc >= 1 && pr >= 1 && img < p.B && q >= 0;
+            pix = (pr - 1) * p.W + (pc - 1);
+        }
+        return ok ? ((((int64_t)img * (p.Cin / 8) + h) * 2) * HW + pix) * 16 : -1;
+    };
+    unsigned sat = 0;              // fp16 operand pairs this thread clamped
+    int base = 0;
+    int xsel = 0, wsel = 0;        // x buffer of the current channel block / weight slot of the current sub-stage
+    bool prefetched = false;       // this tile's first channel block and weight slab were staged by the previous tile
+    do {
+    const int lid = lid_of(base);
+    if (lid < 0) break;
+    const int lid_n = PERSIST ? lid_of(base + gridDim.x) : -1;
+    // (tiles over many small images put their epilogue tables into the dead staging buffers: nothing may be staged ahead)
+    const bool has_next = lid_n >= 0 && p.simgs <= 2;
     // First-round desynchronisation: equal blocks started together reach their store phase together and share the HBM
     // write bandwidth (one block per CU: nothing else hides it).  Spreading the starts of the first round over about one
     // block time lets every later round store while other CUs compute.  p.desync = block-time estimate in 4096-clock units.
-    if (p.desync > 0 && blockIdx.x < 256) {
+    if (p.desync > 0 && blockIdx.x < 256 && base == 0) {
         const int slot = (int)((blockIdx.x * 2654435761u) >> 24);          // 0..255, scrambled
         const int n_sleep = (slot * p.desync) >> 8;
         for (int i = 0; i < n_sleep; ++i) __builtin_amdgcn_s_sleep(64);
     }
-    const int tiles_per_slice = p.n_pix_tiles * p.n_cout_tiles;
-    const int ks = lid / tiles_per_slice;                 // K slice of this block (0 when ksplit == 1)
-    const int lt = lid - ks * tiles_per_slice;
-    const int ct = lt / p.n_pix_tiles, pt = lt - ct * p.n_pix_tiles;
+    const TileOrg T = tile_org(lid), Tn = has_next ? tile_org(lid_n) : T;
+    const int ks = T.ks, ct = T.ct, pt = T.pt, q0 = T.q0, img0 = T.img0, row0 = T.row0, col0 = T.col0;
     const int n0 = ct * NT;
-
-    // ---- tile origin
-    int q0 = 0, img0, row0 = 0, col0 = 0;
-    if (p.patch) {
-        const int per_img = p.tiles_x * p.tiles_y;
-        img0 = pt / per_img;
-        const int rem = pt - img0 * per_img;
-        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-        row0 = ty * p.TR;
-        col0 = tx * p.TC;
-    } else if (UP) {
-        q0 = pt * PT;                       // super-pixels ARE positions of the padded flat space
-        img0 = q0 / (p.R * p.P);
-    } else {
-        const int p0 = pt * PT;
-        img0 = p0 / HW;
-        const int rem = p0 - img0 * HW;
-        const int a = rem / p.W, b = rem - a * p.W;
-        q0 = (img0 * p.R + a + 1) * p.P + b + 1 - p.P - 1;
-    }
 
     // ---- this lane's two output pixels: position inside the staged range, and where they are stored
     int boff[NI];
@@ -244,6 +299,11 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     int ldst[NEX];        // byte offset inside an x buffer
 #pragma unroll
     for (int e = 0; e < NEX; ++e) {
+        if (XIN) {
+            xs16[e] = xin_addr(T, e);
+            xsrc[e] = nullptr; soff[e] = -1; ldst[e] = 0;
+            continue;
+        }
         const int i = tid + e * NTHR;
         const int h = i / p.xs;
         const int j = i - h * p.xs;
@@ -267,9 +327,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         xsrc[e] = ok ? p.x + (int64_t)img * p.x_bstride + (int64_t)(8 * h) * HW + pix : nullptr;
         soff[e] = !(h < 2 && j < p.xs) ? -1 : ok ? (img - img0) * p.Cin + 8 * h : 0;
         ldst[e] = (h * p.xs + j) * 16;
-        if (XIN) {      // byte address of the hi chunk of channel group (cb = 0, h); -1: zero page; -2: no item (skip the DMA)
-            xs16[e] = !(h < 2 && j < p.xs) ? -2 : ok ? ((((int64_t)img * (p.Cin / 8) + h) * 2) * HW + pix) * 16 : -1;
-        }
+        xs16[e] = -2;
     }
 
     f32x16 acc[PH][MI][NI];
@@ -301,16 +359,23 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         unsigned* ph = reinterpret_cast<unsigned*>(&vh);
         unsigned* pl = reinterpret_cast<unsigned*>(&vl);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split_pair<ET>(xr[e][2 * c] * sv[2 * c], xr[e][2 * c + 1] * sv[2 * c + 1], ph[c], pl[c]);
+        for (int c = 0; c < 4; ++c) split_pair<ET>(xr[e][2 * c] * sv[2 * c], xr[e][2 * c + 1] * sv[2 * c + 1], ph[c], pl[c], sat);
         *reinterpret_cast<uint4*>(xb + ldst[e]) = vh;
         *reinterpret_cast<uint4*>(xb + 32 * p.xs + ldst[e]) = vl;
     };
     const int ncb_all = p.Cin / SPLIT_CB;
+#ifdef SGDFR_SPLIT_PROBE      // scripts/tile_probe.py: 1 = one channel block only, 4 = no K loop, 2 = no epilogue
+    const int cb0 = (int)((int64_t)ncb_all * ks / p.ksplit);
+    const int ncb = (p.dbg & 4) ? cb0 : (p.dbg & 1) ? cb0 + 1 : (int)((int64_t)ncb_all * (ks + 1) / p.ksplit);
+#else
     const int cb0 = (int)((int64_t)ncb_all * ks / p.ksplit), ncb = (int)((int64_t)ncb_all * (ks + 1) / p.ksplit);
+#endif
     const unsigned char* const wglb = reinterpret_cast<const unsigned char*>(p.wsp) + (int64_t)ct * WT * ncb_all * 3 * WROW64;
+    const unsigned char* const wglb_n = reinterpret_cast<const unsigned char*>(p.wsp) + (int64_t)Tn.ct * WT * ncb_all * 3 * WROW64;
+    const int cb0_n = (int)((int64_t)ncb_all * Tn.ks / p.ksplit);
     constexpr int WV = (WCHUNKS + NW - 1) / NW; // DMA pieces per wave and sub-stage (every wave issues exactly WV)
-    auto issue_w = [&](int u) {      // sub-stage u = cb*NSS + ss -> ring slot u & 1
-        unsigned char* dst = wb0 + (u & 1) * WROW_BYTES;
+    auto issue_w = [&](const unsigned char* wglb, int u, int slot) {      // sub-stage u = cb*NSS + ss of a cout tile -> ring slot
+        unsigned char* dst = wb0 + slot * WROW_BYTES;
 #pragma unroll
         for (int v = 0; v < WV; ++v) {
             const int chunk = (wave + v * NW) % WCHUNKS;          // wrap: a duplicate piece rewrites identical bytes
@@ -321,14 +386,14 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     };
 
     // XIN staging: both parts of slot e of channel block cb -> x buffer xb, 16 bytes per lane, LDS image = lane order
-    auto issue_x = [&](int e, int cb, unsigned char* xb) {
+    auto issue_x = [&](int64_t addr, int e, int cb, unsigned char* xb) {
         const int i0 = __builtin_amdgcn_readfirstlane(tid - lane + e * NTHR);     // first item of this wave's slot
         if (i0 >= 2 * p.xs) return;                                                // wave-uniform (xs % 64 == 0)
         const int h0 = i0 / p.xs, j0 = i0 - h0 * p.xs;
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(p.x);
+        const unsigned char* xbase = reinterpret_cast<const unsigned char*>(p.x);
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
-            const unsigned char* src = xs16[e] >= 0 ? base + xs16[e] + ((int64_t)cb * 4 + part) * HW * 16
+            const unsigned char* src = addr >= 0 ? xbase + addr + ((int64_t)cb * 4 + part) * HW * 16
                                                     : reinterpret_cast<const unsigned char*>(p.zeros);
             __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(xb + part * 32 * p.xs + (h0 * p.xs + j0) * 16), 16, 0, 0);
         }
@@ -349,27 +414,25 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     float* const sn = red + 2 * 512 * 3;                        // [simgs][NT]     next layer's style * range shift (xs_out)
     const bool emit_xs = !UP && whole && p.xs_out != nullptr;
     auto fill_tables = [&]() {
+        // one pass, every global load of an entry issued before the first LDS write (one exposed latency, not four)
         const float oscale = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_OUT : 1.f;
+        const float xsc = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_XSCALE : 1.f;
+        const float rs = rsqrtf((float)p.Cout);
         for (int e = tid; e < p.simgs * NT; e += NTHR) {
             const int m = e / NT, c = e - m * NT;
-            dl[e] = (p.d && img0 + m < p.B) ? p.d[(int64_t)(img0 + m) * p.Cout + n0 + c] * oscale : oscale;
-        }
-        for (int e = tid; e < NT; e += NTHR) bl[e] = (whole && p.bias) ? p.bias[n0 + e] : 0.f;
-        if (emit_xs) {
-            const float xsc = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_XSCALE : 1.f;
-            for (int e = tid; e < p.simgs * NT; e += NTHR) {
-                const int m = e / NT, c = e - m * NT;
-                sn[e] = (img0 + m < p.B) ? p.s_next[(int64_t)(img0 + m) * p.Cout + n0 + c] * xsc : 0.f;
-            }
-        }
-        if (fuse_rgb) {      // rgb[j] = sum_co y[co] * w_rgb[j][co] * s_rgb[b][co] / sqrt(Cout) over this block's couts
-            const float rs = rsqrtf((float)p.Cout);
-            for (int e = tid; e < p.simgs * NT; e += NTHR) {
-                const int m = e / NT, c = e - m * NT;
-                const float sv = (img0 + m < p.B) ? p.rgb_s[(int64_t)(img0 + m) * p.Cout + n0 + c] * rs : 0.f;
-                float4 q = make_float4(p.rgb_w[n0 + c] * sv, p.rgb_w[p.Cout + n0 + c] * sv, p.rgb_w[2 * p.Cout + n0 + c] * sv, 0.f);
-                *reinterpret_cast<float4*>(cw + 4 * e) = q;
-            }
+            const bool in = img0 + m < p.B;
+            const int64_t bc = (int64_t)(img0 + m) * p.Cout + n0 + c;
+            const float dv = (p.d && in) ? p.d[bc] : 1.f;
+            const float bv = (whole && p.bias) ? p.bias[n0 + c] : 0.f;
+            const float sv = (emit_xs && in) ? p.s_next[bc] : 0.f;
+            // rgb[j] = sum_co y[co] * w_rgb[j][co] * s_rgb[b][co] / sqrt(Cout) over this block's couts
+            const float rv = (fuse_rgb && in) ? p.rgb_s[bc] : 0.f;
+            const float w0 = fuse_rgb ? p.rgb_w[n0 + c] : 0.f, w1 = fuse_rgb ? p.rgb_w[p.Cout + n0 + c] : 0.f,
+                        w2 = fuse_rgb ? p.rgb_w[2 * p.Cout + n0 + c] : 0.f;
+            dl[e] = dv * oscale;
+            if (m == 0) bl[c] = bv;
+            if (emit_xs) sn[e] = sv * xsc;
+            if (fuse_rgb) *reinterpret_cast<float4*>(cw + 4 * e) = make_float4(w0 * (rv * rs), w1 * (rv * rs), w2 * (rv * rs), 0.f);
         }
     };
     float nz[NI];
@@ -380,23 +443,27 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     }
 
     // ---- prologue: style table, channel block 0 staged, block 1 in registers, weight row 0 in flight
-    for (int e = tid; e < p.simgs * p.Cin; e += NTHR) {
-        const int m = e / p.Cin;
-        ls[e] = (!XIN && img0 + m < p.B) ? p.s[(int64_t)(img0 + m) * p.Cin + (e - m * p.Cin)] * (ET == SGDFR_SPLIT_FP16 ? SPLIT_F16_XSCALE : 1.f) : 0.f;
-    }
-    if (early) fill_tables();
-    __syncthreads();
     if (XIN) {
+        // (a persistent block passed the barrier that ends the previous tile: buffers and tables are free)
+        if (!prefetched) {
 #pragma unroll
-        for (int e = 0; e < NEX; ++e) issue_x(e, cb0, xb0 + (cb0 & 1) * xbuf_bytes);
-        issue_w(cb0 * NSS);
+            for (int e = 0; e < NEX; ++e) issue_x(xs16[e], e, cb0, xb0 + xsel * xbuf_bytes);
+            issue_w(wglb, cb0 * NSS, wsel);
+        }
+        if (early) fill_tables();      // while the DMA is in flight
         split_wait_vmcnt<0>();
     } else {
+        for (int e = tid; e < p.simgs * p.Cin; e += NTHR) {
+            const int m = e / p.Cin;
+            ls[e] = (img0 + m < p.B) ? p.s[(int64_t)(img0 + m) * p.Cin + (e - m * p.Cin)] * (ET == SGDFR_SPLIT_FP16 ? SPLIT_F16_XSCALE : 1.f) : 0.f;
+        }
+        if (early) fill_tables();
+        __syncthreads();
 #pragma unroll
         for (int e = 0; e < NEX; ++e) load_x(e, cb0);
 #pragma unroll
-        for (int e = 0; e < NEX; ++e) convert_store(e, cb0, xb0 + (cb0 & 1) * xbuf_bytes);
-        issue_w(cb0 * NSS);
+        for (int e = 0; e < NEX; ++e) convert_store(e, cb0, xb0 + xsel * xbuf_bytes);
+        issue_w(wglb, cb0 * NSS, wsel);
         if (ncb > cb0 + 1) {
 #pragma unroll
             for (int e = 0; e < NEX; ++e) load_x(e, cb0 + 1);
@@ -417,14 +484,17 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     }
     const bool stagger = !XIN && NW == 8 && ((p.stagger & 3) == 1 ? (wave >= 4) : (p.stagger & 3) == 2 ? (wave & 1) : false);
     for (int cb = cb0; cb < ncb; ++cb) {
-        const unsigned char* xcur = xb0 + (cb & 1) * xbuf_bytes;
-        unsigned char* xnext = xb0 + ((cb + 1) & 1) * xbuf_bytes;
+        const unsigned char* xcur = xb0 + xsel * xbuf_bytes;
+        unsigned char* xnext = xb0 + (xsel ^ 1) * xbuf_bytes;
         const bool conv_next = cb + 1 < ncb, load_next = cb + 2 < ncb;
+        // the last channel block of a persistent block's tile stages the first block (and weight slab) of its next tile
+        const bool pre_next = XIN && !conv_next && has_next;
 #pragma unroll
         for (int ss = 0; ss < NSS; ++ss) {
             const int u = cb * NSS + ss;
             const bool more_w = u + 1 < ncb * NSS;
-            if (more_w) issue_w(u + 1);
+            if (more_w) issue_w(wglb, u + 1, wsel ^ 1);
+            else if (XIN && has_next) issue_w(wglb_n, cb0_n * NSS, wsel ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             constexpr int kSlots[3] = {(NEX + NSS - 1) / NSS, NSS == 3 ? (NEX + 1) / 3 : 0, NSS == 3 ? NEX / 3 : 0};
             // 1/NSS of the next channel block's activations: registers -> hi/lo -> LDS, then refill the registers
@@ -433,15 +503,18 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 #pragma unroll
                     for (int e = ss; e < NEX; e += NSS) {
                         if (XIN) {
-                            issue_x(e, cb + 1, xnext);
+                            issue_x(xs16[e], e, cb + 1, xnext);
                         } else {
                             convert_store(e, cb + 1, xnext);
                             if (load_next) load_x(e, cb + 2);
                         }
                     }
+                } else if (pre_next) {
+#pragma unroll
+                    for (int e = ss; e < NEX; e += NSS) issue_x(xin_addr(Tn, e), e, cb0_n, xnext);
                 }
             };
-            const unsigned char* wslot = wb0 + (u & 1) * WROW_BYTES;
+            const unsigned char* wslot = wb0 + wsel * WROW_BYTES;
             auto mfma_row = [&](int ky) {
                 const unsigned char* wcur = wslot + (ky - ss * RPS) * WROW64;
                 if (UP) {
@@ -549,10 +622,18 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+            } else if (XIN && has_next) {
+                split_wait_vmcnt<0>();      // the next tile's first stage has landed before this tile's stores join the queue
             }
+            wsel ^= 1;
         }
+        xsel ^= 1;
     }
+    prefetched = XIN && has_next && ncb > cb0;
 
+#ifdef SGDFR_SPLIT_PROBE
+    if (p.dbg & 2) { if (PERSIST) __syncthreads(); continue; }
+#endif
     // ---- epilogue.  C/D layout of 32x32: column (pixel) = lane&31, row (cout) = (r&3) + 8*(r>>2) + 4*(lane>>5).
     if (!early) {
         __syncthreads();                  // every wave is done with the staging buffers the tables are about to overwrite
@@ -563,49 +644,73 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     float rgb[NI][3];
 #pragma unroll
     for (int n = 0; n < NI; ++n) rgb[n][0] = rgb[n][1] = rgb[n][2] = 0.f;
+    // no activation = slope 1, gain 1 (exact), so the element loop has no runtime switch at all: which outputs exist is a
+    // compile-time property of the variant dispatched below (a uniform branch per element would fence every LDS read,
+    // conversion and store of the 64 elements a lane owns)
+    const float e_slope = (whole && p.act) ? p.slope : 1.f, e_gain = (whole && p.act) ? p.gain : 1.f;
+    auto epilogue = [&](auto has_y_t, auto emit_xs_t, auto fuse_rgb_t) {
+        constexpr bool HAS_Y = decltype(has_y_t)::value, EMIT_XS = decltype(emit_xs_t)::value, FUSE_RGB = decltype(fuse_rgb_t)::value;
 #pragma unroll
-    for (int n = 0; n < NI; ++n) {
-        if (ybase[n] < 0) continue;
-        const float* dln = dl + (dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi;
-        const float* bln = bl + wm * (MI * 32) + 4 * hi;
-        const float* cwn = cw + ((dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi) * 4;
-        const float* snn = sn + (dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi;
-        float xsv[4];
+        for (int n = 0; n < NI; ++n) {
+            if (ybase[n] < 0) continue;
+            const float* dln = dl + (dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi;
+            const float* bln = bl + wm * (MI * 32) + 4 * hi;
+            const float* cwn = cw + ((dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi) * 4;
+            const float* snn = sn + (dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi;
+            const int rem = UP ? 0 : (int)(ybase[n] - (int64_t)dimg[n] * p.Cout * HW);
+            float xsv[4];
 #pragma unroll
-        for (int m = 0; m < MI; ++m) {
+            for (int m = 0; m < MI; ++m) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cl = m * 32 + (r & 3) + 8 * (r >> 2);          // cout inside the wave's rows (without 4*hi)
-                const int co = n0 + wm * (MI * 32) + cl + 4 * hi;
-                const float dv = dln[cl];
-                if (UP) {
-                    float* dst = yout + ybase[n] + (int64_t)co * 4 * RP;
+                for (int r = 0; r < 16; ++r) {
+                    const int cl = m * 32 + (r & 3) + 8 * (r >> 2);          // cout inside the wave's rows (without 4*hi)
+                    const int co = n0 + wm * (MI * 32) + cl + 4 * hi;
+                    const float dv = dln[cl];
+                    if (UP) {
+                        float* dst = yout + ybase[n] + (int64_t)co * 4 * RP;
 #pragma unroll
-                    for (int ph = 0; ph < PH; ++ph) dst[(int64_t)ph * RP] = acc[ph][m][n][r] * dv;
-                } else {
-                    float v = acc[0][m][n][r] * dv + nz[n] + bln[cl];
-                    if (whole && p.act) v = lrelu_gain(v, p.slope, p.gain);
-                    if (p.y) yout[ybase[n] + (int64_t)co * HW] = v;      // (NULL: only the fused ToRGB / xs_out consume this layer)
-                    if (emit_xs) {        // rows r = 4g..4g+3 are 4 consecutive couts: half of one 8-channel chunk of this pixel
-                        xsv[r & 3] = v * snn[cl];
-                        if ((r & 3) == 3) {
-                            unsigned h01, l01, h23, l23;
-                            split_pair<ET>(xsv[0], xsv[1], h01, l01);
-                            split_pair<ET>(xsv[2], xsv[3], h23, l23);
-                            const int cg = (n0 + wm * (MI * 32) + m * 32) / 8 + (r >> 2);
-                            const int rem = (int)(ybase[n] - (int64_t)dimg[n] * p.Cout * HW);
-                            unsigned char* dst = p.xs_out + ((((int64_t)dimg[n] * (p.Cout / 8) + cg) * 2) * HW + rem) * 16 + 8 * hi;
-                            *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
-                            *reinterpret_cast<uint2*>(dst + (int64_t)HW * 16) = make_uint2(l01, l23);
+                        for (int ph = 0; ph < PH; ++ph) dst[(int64_t)ph * RP] = acc[ph][m][n][r] * dv;
+                    } else {
+                        const float v = lrelu_gain(acc[0][m][n][r] * dv + nz[n] + bln[cl], e_slope, e_gain);
+                        if (HAS_Y) yout[ybase[n] + (int64_t)co * HW] = v;      // (no y: only the fused ToRGB / xs_out consume this layer)
+                        if (EMIT_XS) {        // rows r = 4g..4g+3 are 4 consecutive couts: half of one 8-channel chunk of this pixel
+                            xsv[r & 3] = v * snn[cl];
+                            if ((r & 3) == 3) {
+                                unsigned h01, l01, h23, l23;
+                                split_pair<ET>(xsv[0], xsv[1], h01, l01, sat);
+                                split_pair<ET>(xsv[2], xsv[3], h23, l23, sat);
+                                const int cg = (n0 + wm * (MI * 32) + m * 32) / 8 + (r >> 2);
+                                unsigned char* dst = p.xs_out + ((((int64_t)dimg[n] * (p.Cout / 8) + cg) * 2) * HW + rem) * 16 + 8 * hi;
+                                *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+                                *reinterpret_cast<uint2*>(dst + (int64_t)HW * 16) = make_uint2(l01, l23);
+                            }
+                        }
+                        if (FUSE_RGB) {
+                            const float4 q = *reinterpret_cast<const float4*>(cwn + 4 * cl);
+                            rgb[n][0] = fmaf(v, q.x, rgb[n][0]);
+                            rgb[n][1] = fmaf(v, q.y, rgb[n][1]);
+                            rgb[n][2] = fmaf(v, q.z, rgb[n][2]);
                         }
                     }
-                    if (fuse_rgb) {
-                        const float4 q = *reinterpret_cast<const float4*>(cwn + 4 * cl);
-                        rgb[n][0] = fmaf(v, q.x, rgb[n][0]);
-                        rgb[n][1] = fmaf(v, q.y, rgb[n][1]);
-                        rgb[n][2] = fmaf(v, q.z, rgb[n][2]);
-                    }
                 }
+            }
+        }
+    };
+    {
+        using yes = std::true_type;
+        using no = std::false_type;
+        if (UP) {
+            epilogue(yes{}, no{}, no{});
+        } else {
+            switch ((p.y ? 1 : 0) | (emit_xs ? 2 : 0) | (fuse_rgb ? 4 : 0)) {       // block-uniform
+                case 1: epilogue(yes{}, no{}, no{}); break;
+                case 2: epilogue(no{}, yes{}, no{}); break;
+                case 3: epilogue(yes{}, yes{}, no{}); break;
+                case 4: epilogue(no{}, no{}, yes{}); break;
+                case 5: epilogue(yes{}, no{}, yes{}); break;
+                case 6: epilogue(no{}, yes{}, yes{}); break;
+                case 7: epilogue(yes{}, yes{}, yes{}); break;
+                default: break;
             }
         }
     }
@@ -634,6 +739,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             }
         }
     }
+    if (PERSIST) __syncthreads();      // the next tile refills the tables and the staging buffers
+    } while (PERSIST && (base += gridDim.x) < p.total_blocks);
+    if (ET == SGDFR_SPLIT_FP16) split_flush_saturation(sat);
 }
 
 // x [B,Cin,HW] fp32 (NCHW) and s [B,Cin] -> XS [B][Cin/8][hi,lo][HW][8]: the split form of x*s (with the fp16 range shift)
@@ -643,6 +751,7 @@ __global__ __launch_bounds__(256) void to_split_kernel(const float* __restrict__
                                                       unsigned char* __restrict__ xs, int B, int Cin, int HW) {
     const int G = Cin / 8;
     const int64_t n = (int64_t)B * G * HW;
+    unsigned sat = 0;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
         const int pix = (int)(idx % HW);
         const int64_t bg = idx / HW;
@@ -656,11 +765,12 @@ __global__ __launch_bounds__(256) void to_split_kernel(const float* __restrict__
         const float sc = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_XSCALE : 1.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            split_pair<ET>(xp[(int64_t)(2 * c) * HW] * (sp[2 * c] * sc), xp[(int64_t)(2 * c + 1) * HW] * (sp[2 * c + 1] * sc), ph[c], pl[c]);
+            split_pair<ET>(xp[(int64_t)(2 * c) * HW] * (sp[2 * c] * sc), xp[(int64_t)(2 * c + 1) * HW] * (sp[2 * c + 1] * sc), ph[c], pl[c], sat);
         unsigned char* dst = xs + ((bg * 2) * HW + pix) * 16;
         *reinterpret_cast<uint4*>(dst) = vh;
         *reinterpret_cast<uint4*>(dst + (int64_t)HW * 16) = vl;
     }
+    if (ET == SGDFR_SPLIT_FP16) split_flush_saturation(sat);
 }
 
 // weight [Cout,Cin,3,3] fp32 -> bf16 hi/lo of Wc = weight/sqrt(9 Cin) in the kernel's LDS order:
@@ -677,9 +787,10 @@ __global__ __launch_bounds__(256) void prepack_split_kernel(const float* __restr
         const int ci = (int)((idx / 9) % n_in);
         const int co = (int)(idx / (9 * (int64_t)n_in));
         const float v = (transpose_flip ? w[((int64_t)ci * Cin + co) * 9 + (8 - tap)] : w[idx]) * scale;   // fp16: scale carries 2^6
-        unsigned hp, lp;
-        if (et == SGDFR_SPLIT_FP16) split_pair<SGDFR_SPLIT_FP16>(v, 0.f, hp, lp);
-        else split_pair<SGDFR_SPLIT_BF16>(v, 0.f, hp, lp);
+        unsigned hp, lp, sat = 0;
+        if (et == SGDFR_SPLIT_FP16) split_pair<SGDFR_SPLIT_FP16>(v, 0.f, hp, lp, sat);
+        else split_pair<SGDFR_SPLIT_BF16>(v, 0.f, hp, lp, sat);
+        split_flush_saturation(sat);
         const unsigned hbits = hp & 0xffffu, lbits = lp & 0xffffu;
         const int ctile = co / NT, col = co - ctile * NT, cb = ci / SPLIT_CB, h = (ci % SPLIT_CB) / 8, c8 = ci % 8;
         const int ky = tap / 3, kx = tap - ky * 3;
@@ -878,7 +989,11 @@ static int launch_split(const SplitParams& p, hipStream_t st) {
                   p.H, p.W, p.xs, p.simgs);
         return 2;
     }
-    hipLaunchKernelGGL(kern, dim3(p.n_pix_tiles * p.n_cout_tiles * p.ksplit), dim3(NTHR), lds, st, p);
+    SplitParams q = p;
+    q.total_blocks = p.n_pix_tiles * p.n_cout_tiles * p.ksplit;
+    static const int persist = getenv("SGDFR_SPLIT_PERSIST") ? atoi(getenv("SGDFR_SPLIT_PERSIST")) : 256;
+    const int grid = (XIN && persist > 0 && q.total_blocks > persist) ? persist : q.total_blocks;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, st, q);
     return check_launch("modconv2d_split");
 }
 
@@ -943,6 +1058,7 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
     if (ksplit > 1) p.y = partials;
     static const int stagger = getenv("SGDFR_SPLIT_STAGGER") ? atoi(getenv("SGDFR_SPLIT_STAGGER")) : 1;
     p.stagger = stagger;
+    p.dbg = getenv("SGDFR_SPLIT_DBG") ? atoi(getenv("SGDFR_SPLIT_DBG")) : 0;
     {
         // block time ~ K loop (MFMAs of the two waves of a SIMD, ~55 % busy) + epilogue stores at the per-CU HBM share
         // Measured: +4..6 % on the 32x32..128x128 transposed layers at 50-100 % of the estimate, nothing (or a loss) on the
