@@ -991,8 +991,14 @@ static int launch_split(const SplitParams& p, hipStream_t st) {
     }
     SplitParams q = p;
     q.total_blocks = p.n_pix_tiles * p.n_cout_tiles * p.ksplit;
+    // Persistent blocks (one per CU, each walking its share of the tiles and staging the next tile's first channel block
+    // while the current one finishes) pay off where a tile is short and stores little: measured at B=64, 64->64 @256x256
+    // (32 tiles per CU, ToRGB sums only) -6 %, 128->128 @128x128 -2.7 %.  A persistent block's first wait of the next tile
+    // also drains its own stores (loads and stores share the in-order vmcnt), which a fresh block never waits for: the
+    // transposed conv (262 KB of stores per tile) loses 2-7 %, the 8-tiles-per-CU layers gain nothing -> one block per tile.
     static const int persist = getenv("SGDFR_SPLIT_PERSIST") ? atoi(getenv("SGDFR_SPLIT_PERSIST")) : 256;
-    const int grid = (XIN && persist > 0 && q.total_blocks > persist) ? persist : q.total_blocks;
+    const bool persistent = XIN && MODE == SGDFR_MODE_PLAIN3 && persist > 0 && q.total_blocks >= 12 * persist;
+    const int grid = persistent ? persist : q.total_blocks;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, st, q);
     return check_launch("modconv2d_split");
 }

@@ -162,9 +162,9 @@ typedef float bl_f32x2 __attribute__((ext_vector_type(2)));
 __device__ unsigned int g_blur_saturated = 0;    // operand pairs clamped to the fp16 range (see sgdfr_split_saturation_count)
 
 template <int ET>
-__device__ __forceinline__ void blur_split2(float a, float b, unsigned& hi, unsigned& lo) {     // as split.hip's split_pair
+__device__ __forceinline__ void blur_split2(float a, float b, unsigned& hi, unsigned& lo, unsigned& sat) {     // as split.hip's split_pair
     if (ET == SGDFR_SPLIT_FP16) {
-        if (__builtin_expect(fmaxf(fabsf(a), fabsf(b)) > 65504.f, 0)) atomicAdd(&g_blur_saturated, 1u);
+        sat += (fmaxf(fabsf(a), fabsf(b)) > 65504.f) ? 1u : 0u;      // flushed once per thread: no branch per pair
         a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
         b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
         const bl_f16x2 h = __builtin_convertvector((bl_f32x2){a, b}, bl_f16x2);
@@ -202,6 +202,7 @@ __global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restr
     const float nw = (noise && noise_w) ? noise_w[0] : 0.f;
     const float xsc = (ET == SGDFR_SPLIT_FP16) ? 0.0625f : 1.f;
     const int c8 = threadIdx.x / QC, nx = threadIdx.x % QC;
+    unsigned sat = 0;
     for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
         const int ct = (int)(tile_id % col_tiles);
         int64_t r = tile_id / col_tiles;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restr
                 unsigned* pl = reinterpret_cast<unsigned*>(&vl);
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc)
-                    blur_split2<ET>(tile[row][px][2 * cc] * sv[2 * cc], tile[row][px][2 * cc + 1] * sv[2 * cc + 1], ph[cc], pl[cc]);
+                    blur_split2<ET>(tile[row][px][2 * cc] * sv[2 * cc], tile[row][px][2 * cc + 1] * sv[2 * cc + 1], ph[cc], pl[cc], sat);
                 unsigned char* dst = xs + ((((int64_t)b * G + g) * 2) * OHW + (int64_t)oy * OW + ox) * 16;
                 *reinterpret_cast<uint4*>(dst) = vh;
                 *reinterpret_cast<uint4*>(dst + (int64_t)OHW * 16) = vl;
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restr
         }
         __syncthreads();
     }
+    if (ET == SGDFR_SPLIT_FP16 && sat != 0) atomicAdd(&g_blur_saturated, sat);
 }
 
 }  // namespace sgdfr
