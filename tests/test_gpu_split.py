@@ -194,6 +194,36 @@ def test_split_form_handover_pieces(arith):
     assert torch.equal(F_.blur_bias_act_split(planes_s, fir, 16, 16, sn[:3], nz3, nw, bias, True, arith=arith), F_.to_split(yb3, sn[:3], arith))
 
 
+@pytest.mark.parametrize('cin,cout,H,B', [(16, 64, 256, 25), (48, 64, 256, 27), (32, 128, 128, 50)])
+def test_persistent_blocks_match_one_block_per_tile(cin, cout, H, B):
+    """Layers with >= 12 tiles per CU and a pre-split input run as persistent blocks (one per CU, each staging its next
+    tile's first channel block while the current tile finishes).  Same bits as the one-block-per-tile launch of the fp32
+    input, on every output the epilogue has, with a ragged last round and (cin = 16) a K loop of a single channel block."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    x = S.counter_tensor(7, 'pb.x', (B, cin, H, H)).cuda()
+    w = S.counter_tensor(7, 'pb.w', (1, cout, cin, 3, 3)).cuda()
+    s = S.counter_tensor(7, 'pb.s', (B, cin), 1.0, 0.3).cuda()
+    d = S.counter_tensor(7, 'pb.d', (B, cout), 1.0, 0.2).cuda()
+    sn = S.counter_tensor(7, 'pb.sn', (B, cout), 1.0, 0.3).cuda()
+    rw = S.counter_tensor(7, 'pb.rw', (3, cout)).cuda()
+    rs = S.counter_tensor(7, 'pb.rs', (B, cout), 1.0, 0.3).cuda()
+    noise = S.counter_tensor(7, 'pb.n', (1, 1, H, H)).cuda()
+    nw = torch.full((1,), 0.1).cuda()
+    bias = S.counter_tensor(7, 'pb.b', (cout,), 0.0, 0.1).cuda()
+    wsp = F_.prepack_split(w, 'fp16x3')
+    xs = F_.to_split(x, s, 'fp16x3')
+    assert F_.xin_ok(B, cin, cout, H, H) and F_.rgb_fusable(B, cin, cout, H, H)
+    ya, pa, xa = F_.modconv_split(x, wsp, s, d, cout, noise, nw, bias, True, arith='fp16x3', rgb=(rw, rs), s_next=sn)
+    yb, pb, xb = F_.modconv_split(xs, wsp, None, d, cout, noise, nw, bias, True, arith='fp16x3', rgb=(rw, rs), s_next=sn,
+                                  x_split=tuple(x.shape), batch=B)
+    assert torch.equal(ya, yb) and torch.equal(pa, pb) and torch.equal(xa, xb)
+    yc, pc = F_.modconv_split(xs, wsp, None, d, cout, noise, nw, bias, True, arith='fp16x3', rgb=(rw, rs), want_y=False,
+                              x_split=tuple(x.shape), batch=B)                    # the last layer's form: ToRGB sums only
+    assert yc is None and torch.equal(pc, pa)
+    yd = F_.modconv_split(xs, wsp, None, d, cout, arith='fp16x3', x_split=tuple(x.shape), batch=B)      # bare conv
+    assert torch.equal(yd, F_.modconv_split(x, wsp, s, d, cout, arith='fp16x3'))
+
+
 def test_fp16_split_saturates_instead_of_overflowing():
     """|x*s| beyond the fp16-split range (1.04e6) clamps; nothing becomes inf/nan."""
     from stylegan_directions_face_reenactment_amd import functional as F_
