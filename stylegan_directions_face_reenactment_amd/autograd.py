@@ -143,6 +143,47 @@ class StyleFn(Function):
         return gstyle, gw, gb, None, None, None
 
 
+class StylesBatchedFn(Function):
+    """Every layer's s_l = modulation_l(w_l) and d_l of one forward in two launches (functional.styles_batched), for the
+    frozen-generator case (the direction trainer optimises A alone, trainer.py:106-111,188): differentiable w.r.t. the
+    W+ latent only.  Outputs: s of every entry of `order`, followed by its d when the layer demodulates."""
+
+    @staticmethod
+    def forward(ctx, latent, order):
+        out = F_.styles_batched(latent, [m.style_spec(li) for m, li in order])
+        flat = []
+        for s, d in out:
+            flat.append(s)
+            if d is not None:
+                flat.append(d)
+        ctx.order = order
+        ctx.has_d = [d is not None for _, d in out]
+        ctx.lat_shape = latent.shape
+        ctx.save_for_backward(*flat)
+        return tuple(flat)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        flat = ctx.saved_tensors
+        glat = torch.zeros(ctx.lat_shape, device=flat[0].device, dtype=torch.float32)
+        i = 0
+        for (m, li), has_d in zip(ctx.order, ctx.has_d):
+            s, gs = flat[i], grads[i]
+            i += 1
+            d = gd = None
+            if has_d:
+                d, gd = flat[i], grads[i]
+                i += 1
+            if gs is None and gd is None:
+                continue
+            if gs is None:
+                gs = torch.zeros_like(s)
+            ds = F_.demod_grad(gd, d, m.packed()[2], s, gs) if gd is not None else N.f32c(gs)
+            mod_w = m.modulation.weight
+            glat[:, li] += F_.linear(ds, _t(mod_w), wscale=1.0 / math.sqrt(mod_w.shape[1]))
+        return glat, None
+
+
 # ------------------------------------------------------------------ modulated convs
 
 class StyledConvFn(Function):

@@ -403,7 +403,11 @@ class Generator(nn.Module):
         for conv1, conv2, to_rgb in zip(self.convs[::2], self.convs[1::2], self.to_rgbs):
             order += [(conv1.conv, i), (conv2.conv, i + 1), (to_rgb.conv, i + 2)]
             i += 2
-        if grad:   # differentiable per-layer modulation (autograd routes dL/ds back into the latent rows)
+        if grad and not any(p.requires_grad for p in self.parameters()):
+            # frozen generator (the direction trainer): the two batched launches, differentiable w.r.t. the latent only
+            flat = iter(AG.StylesBatchedFn.apply(latent, order))
+            sd = iter([(next(flat), next(flat) if (m.kernel_size == 3 and m.demodulate) else None) for m, _ in order])
+        elif grad:   # differentiable per-layer modulation (autograd routes dL/ds back into the latent rows and the weights)
             sd = iter([m.styles(latent[:, li]) for m, li in order])
         else:      # every layer's s = A_l(w_l) and demodulation d_l in two launches (instead of 33)
             sd = iter(F_.styles_batched(latent, [m.style_spec(li) for m, li in order]))
