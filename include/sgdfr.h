@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 3
+#define SGDFR_ABI_VERSION 4
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -182,7 +182,8 @@ int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, cons
  * whole 256x256 generator stays within 1.1e-4 max-abs of the fp64 oracle, contract 1e-3).  Never selected implicitly.
  *   sgdfr_modconv_prepack_split_elems: uint16 elements of the packed weight buffer (= 2*9*Cout*Cin)
  *   sgdfr_modconv_prepack_split_f32:   weight [Cout,Cin,3,3] -> 16-bit hi/lo of weight/sqrt(9 Cin) in kernel order;
- *                                      transpose_flip != 0 packs the adjoint conv (Cin outputs, Cout inputs, taps rotated):
+ *                                      transpose_flip = 1 packs the adjoint conv (Cin outputs, Cout inputs, taps rotated),
+ *                                      2 the adjoint of the transposed conv (channels swapped, taps stored phase by phase):
  *                                      dL/dx of the plain conv is then the same PLAIN3 kernel
  *   sgdfr_modconv2d_split_supported:   1 when the shape can use it (Cin % 16 == 0, Cout % 64 == 0, tileable H x W)
  *   sgdfr_modconv2d_split_f32:         arguments as sgdfr_modconv2d_wino_f32 with wsp in place of u, plus mode:
@@ -220,6 +221,15 @@ int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned 
 long long sgdfr_split_saturation_count(int reset);
 int sgdfr_modconv2d_split_xin_supported(int B, int Cin, int Cout, int H, int W, int mode);   /* x_is_split allowed for this shape */
 int sgdfr_to_split_f32(const float* x, const float* s, unsigned short* xs, int B, int Cin, int H, int W, int arith, void* stream);
+/* Backward of the transposed conv on the split kernels (autograd of ModulatedConv2d.forward model.py:246-256; consumers
+ * trainer.py:188, optimization.py:67): dL/d(x*s) = the stride-2 3x3 conv of the gradient's parity planes with the transposed
+ * kernel = sgdfr_modconv2d_split_f32(mode = SGDFR_MODE_DOWN3, x_is_split = 1, Cin = plane channels C, Cout = channels of
+ * dL/dx, H x W = size of x, weights packed with transpose_flip = 2).  Its input is written by
+ *   sgdfr_planes_to_split_f32: gt [B,C,4,H+1,W+1] fp32 (gradient of the parity planes), d [B,C] or NULL (the per-plane
+ *                              scale: the layer's demodulation) -> xs [B][(ph*C + c)/8][2][(H+1)*(W+1)][8] 16-bit, the
+ *                              phase-major split form of gt*d (16-byte aligned, 4 bytes per element). */
+int sgdfr_planes_to_split_f32(const float* gt, const float* d, unsigned short* xs, int B, int C, int H, int W, int arith,
+                              void* stream);
 int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H, int W, int mode);
 int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, int mode);
 

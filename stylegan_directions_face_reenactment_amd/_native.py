@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libsgdfr_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -45,6 +45,7 @@ SIGNATURES = {
                                   _c_f32p, _c_f32p, _i, _c_f32p, _c_f32p, _c_f32p, _i, ctypes.c_void_p, _c_f32p, _i, _i, _i, _i,
                                   _i, _i, _i, _i, _f, _f, ctypes.c_void_p],
     'sgdfr_to_split_f32': [_c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i, ctypes.c_void_p],
+    'sgdfr_planes_to_split_f32': [_c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_modconv2d_split_cout_tiles': [_i, _i, _i, _i, _i, _i],
     'sgdfr_modconv2d_split_xin_supported': [_i, _i, _i, _i, _i, _i],
     'sgdfr_modconv2d_split_ksplit_hint': [_i, _i, _i, _i, _i, _i],

@@ -218,8 +218,15 @@ class StyledConvFn(Function):
         ones_d = d if d is not None else torch.ones(B, cout, device=out.device, dtype=torch.float32)
         if up:
             gT, A = F_.blur_adjoint(g_pre, mod.blur.kernel, planes if d is not None else None)
-            gu = F_.modconv_raw(gT, mod.packed_t(), ones_d, None, cin, N.MODE_DOWN3, H, W,
-                                desc='bwd down3 %d->%d @%dx%d' % (cout, cin, H, W))
+            if F_.PRECISION != 'fp32' and F_.split_ok(B, cout, cin, H, W, N.MODE_DOWN3):
+                # dL/d(x*s) of the transposed conv on the split kernels too (bf16 terms: gradients have no natural scale):
+                # the planes times d go through the phase-major split form, the conv walks (channel block, phase) pairs
+                gu = F_.modconv_split(F_.planes_to_split(gT, d, 'bf16x3'), mod.packed_split(adjoint='down', arith='bf16x3'),
+                                      None, None, cin, mode=N.MODE_DOWN3, arith='bf16x3', x_split=(B, cout, H, W), batch=B,
+                                      desc='bwd split down3 %d->%d @%dx%d' % (cout, cin, H, W))
+            else:
+                gu = F_.modconv_raw(gT, mod.packed_t(), ones_d, None, cin, N.MODE_DOWN3, H, W,
+                                    desc='bwd down3 %d->%d @%dx%d' % (cout, cin, H, W))
         else:
             A = sums[:, :, 2] if d is not None else None
             if F_.split_ok(B, cout, cin, H, W):    # dL/dx of a plain conv is a plain conv: same kernels, adjoint packs.

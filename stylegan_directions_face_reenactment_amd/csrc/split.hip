@@ -135,6 +135,11 @@ __device__ __forceinline__ void split_flush_saturation(unsigned sat) {
 // MODE PLAIN3: y = conv3x3(x*s) * d (+ noise, bias, activation).  MODE UP3: stride-2 transposed conv into the four
 // output-parity planes T[B,Cout,4,H+1,W+1] (same contract as modconv.hip): one "pixel" is a super-pixel of the padded
 // flat space, each of the 9 taps feeds the accumulator set of its parity phase.
+// MODE DOWN3 (XIN only): the adjoint of UP3 = dL/d(x*s) of the transposed conv, a stride-2 3x3 conv over the gradient's
+// four parity planes: gx[a,b] = sum_taps W[ky,kx]^T gT[phase(ky,kx)][a + (ky==2), b + (kx==2)].  Output "pixels" are
+// positions of the same padded flat space as UP3 (row H / column W are dead outputs).  The K loop walks (16-channel block,
+// phase) pairs: each pair stages its own plane slice (the input is the phase-major split form written by
+// planes_to_split_kernel) and runs only the taps of that phase (4, 2, 2, 1 of the 9).
 // NSS: barrier-delimited sub-stages per 16-channel block: 3 = one kernel row (3 taps) each, 1 = all 9 taps.
 // XIN: the input is already in the kernel's own split form ("XS": x * s * range shift as 16-bit hi/lo pairs,
 // [B][Cin/8][hi,lo][H*W][8]), written by the producer; staging is then a pure global->LDS DMA (no registers, no VALU).
@@ -144,14 +149,18 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                                            // halo staging and 1.0 ds_read per MFMA)
     constexpr int NTHR = NW * 64;
     constexpr int NT = WM * MI * 32, PT = WN * NI * 32;
-    constexpr bool UP = (MODE == SGDFR_MODE_UP3);
+    constexpr bool UP = (MODE == SGDFR_MODE_UP3), DOWN = (MODE == SGDFR_MODE_DOWN3);
     constexpr int PH = UP ? 4 : 1;
+    static_assert(!DOWN || (XIN && NSS == 1), "DOWN3 stages pre-split planes, one (channel block, phase) pair per stage");
     static_assert(NW == 8 || NW == 4, "4 or 8 waves per block");
     static_assert(NT % 64 == 0 && (NSS == 1 || NSS == 3), "cout tiles are packed 64 wide");
     constexpr int RPS = 3 / NSS;                          // kernel rows per sub-stage
     constexpr int WT = NT / 64;                           // 64-cout pack tiles per block
     constexpr int WROW64 = 64 * 192;                      // one kernel row of one pack tile: [3 kx][2 part][2 k-half][64][8] x 16 bit
-    constexpr int WROW_BYTES = WT * RPS * WROW64;         // weight bytes of one sub-stage: [pack tile][row][kx][part][k-half][64][8]
+    constexpr int WTAP = 4096;                            // one tap of one pack tile: [2 part][2 k-half][64][8] x 16 bit
+    constexpr int WSLOT_TAPS = DOWN ? 4 : RPS * 3;        // taps a ring slot holds (DOWN3: the largest phase)
+    constexpr int WTILE_BYTES = WSLOT_TAPS * WTAP;
+    constexpr int WROW_BYTES = WT * WTILE_BYTES;          // weight bytes of one sub-stage: [pack tile][tap][part][k-half][64][8]
     constexpr int WCHUNKS = WROW_BYTES / 1024;            // 64-lane x 16-byte DMA pieces
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int xbuf_bytes = 64 * p.xs;                    // [2 part][2 k-half][xs][8] bf16
@@ -163,6 +172,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hi = lane >> 5;
     const int HW = p.H * p.W;
+    const int HWin = DOWN ? p.R * p.P : HW;       // positions per channel of the staged tensor
 
     // Persistent blocks: the grid is one block per CU (or fewer); block b works on tiles base + map(b) of every round of
     // gridDim.x tiles.  map() keeps the tiles of one XCD (blockIdx & 7) contiguous, so neighbours share halos and weights in L2.
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
             t.row0 = ty * p.TR;
             t.col0 = tx * p.TC;
-        } else if (UP) {
+        } else if (UP || DOWN) {
             t.q0 = t.pt * PT;                       // super-pixels ARE positions of the padded flat space
             t.img0 = t.q0 / (p.R * p.P);
         } else {
@@ -217,6 +227,11 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             img = t.img0;
             ok = ok && row >= 0 && row < p.H && col >= 0 && col < p.W && img < p.B;
             pix = row * p.W + col;
+        } else if (DOWN) {        // the planes ARE the flat space
+            const int q = t.q0 + j;
+            img = q / HWin;
+            pix = q - img * HWin;
+            ok = ok && img < p.B;
         } else {
             const int q = t.q0 + j;
             const int pir = q / p.P, pc = q - pir * p.P;
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             ok = ok && pc >= 1 && pr >= 1 && img < p.B && q >= 0;
             pix = (pr - 1) * p.W + (pc - 1);
         }
-        return ok ? ((((int64_t)img * (p.Cin / 8) + h) * 2) * HW + pix) * 16 : -1;
+        return ok ? ((((int64_t)img * (p.Cin / 8) + h) * 2) * HWin + pix) * 16 : -1;
     };
     unsigned sat = 0;              // fp16 operand pairs this thread clamped
     int base = 0;
@@ -267,6 +282,18 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             const int rem = (int)(pix - (int64_t)img * RP);
             boff[n] = l;
             ybase[n] = ok ? (int64_t)img * p.Cout * 4 * RP + rem : -1;
+            nzoff[n] = 0;
+            dimg[n] = img;
+        } else if (DOWN) {        // position (a, b) of the (H+1) x (W+1) grid -> output pixel (a, b) when a < H and b < W
+            int64_t pix = (int64_t)pt * PT + l;
+            bool ok = pix < p.total_pix;
+            if (!ok) pix = p.total_pix - 1;
+            const int img = (int)(pix / RP);
+            const int rem = (int)(pix - (int64_t)img * RP);
+            const int a = rem / p.P, b = rem - a * p.P;
+            ok = ok && a < p.H && b < p.W;
+            boff[n] = l;
+            ybase[n] = ok ? (int64_t)img * p.Cout * HW + a * p.W + b : -1;
             nzoff[n] = 0;
             dimg[n] = img;
         } else if (p.patch) {
@@ -370,8 +397,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 #else
     const int cb0 = (int)((int64_t)ncb_all * ks / p.ksplit), ncb = (int)((int64_t)ncb_all * (ks + 1) / p.ksplit);
 #endif
-    const unsigned char* const wglb = reinterpret_cast<const unsigned char*>(p.wsp) + (int64_t)ct * WT * ncb_all * 3 * WROW64;
-    const unsigned char* const wglb_n = reinterpret_cast<const unsigned char*>(p.wsp) + (int64_t)Tn.ct * WT * ncb_all * 3 * WROW64;
+    // channel blocks of the weight pack per 64-cout tile (DOWN3: the loop index is (block, phase); the pack holds 9 taps per block)
+    const int wcb = DOWN ? ncb_all / 4 : ncb_all;
+    const unsigned char* const wglb = reinterpret_cast<const unsigned char*>(p.wsp) + (int64_t)ct * WT * wcb * 9 * WTAP;
+    const unsigned char* const wglb_n = reinterpret_cast<const unsigned char*>(p.wsp) + (int64_t)Tn.ct * WT * wcb * 9 * WTAP;
+    // DOWN3 stage u = (channel block u >> 2, phase u & 3): plane slice ph * C/16 + block of the phase-major input, taps
+    // [first, first + count) of the block's 9 (pack order: phase 0's four taps, 1's two, 2's two, 3's one)
+    auto chan_block = [&](int u) { return DOWN ? (u & 3) * wcb + (u >> 2) : u; };
     const int cb0_n = (int)((int64_t)ncb_all * Tn.ks / p.ksplit);
     constexpr int WV = (WCHUNKS + NW - 1) / NW; // DMA pieces per wave and sub-stage (every wave issues exactly WV)
     auto issue_w = [&](const unsigned char* wglb, int u, int slot) {      // sub-stage u = cb*NSS + ss of a cout tile -> ring slot
@@ -379,8 +411,16 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 #pragma unroll
         for (int v = 0; v < WV; ++v) {
             const int chunk = (wave + v * NW) % WCHUNKS;          // wrap: a duplicate piece rewrites identical bytes
-            const int tile = chunk / (RPS * 12), within = chunk - tile * (RPS * 12);
-            const unsigned char* src = wglb + ((int64_t)tile * ncb_all * 3 + (int64_t)u * RPS) * WROW64 + within * 1024;
+            const int tile = chunk / (WSLOT_TAPS * 4), within = chunk - tile * (WSLOT_TAPS * 4);
+            const unsigned char* src;
+            if (DOWN) {
+                const int ph = u & 3;
+                const int first = ph == 0 ? 0 : ph == 1 ? 4 : ph == 2 ? 6 : 8, count = ph == 0 ? 4 : ph == 3 ? 1 : 2;
+                if (within >= count * 4) continue;                 // wave-uniform: this phase has fewer taps than the slot
+                src = wglb + ((int64_t)tile * wcb * 9 + (int64_t)(u >> 2) * 9 + first) * WTAP + within * 1024;
+            } else {
+                src = wglb + ((int64_t)tile * wcb * 9 + (int64_t)u * (RPS * 3)) * WTAP + within * 1024;
+            }
             __builtin_amdgcn_global_load_lds((glb_void*)(src + lane * 16), (lds_void*)(dst + chunk * 1024), 16, 0, 0);
         }
     };
@@ -393,7 +433,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         const unsigned char* xbase = reinterpret_cast<const unsigned char*>(p.x);
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
-            const unsigned char* src = addr >= 0 ? xbase + addr + ((int64_t)cb * 4 + part) * HW * 16
+            const unsigned char* src = addr >= 0 ? xbase + addr + ((int64_t)chan_block(cb) * 4 + part) * HWin * 16
                                                     : reinterpret_cast<const unsigned char*>(p.zeros);
             __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(xb + part * 32 * p.xs + (h0 * p.xs + j0) * 16), 16, 0, 0);
         }
@@ -405,14 +445,14 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     // dedicated LDS region beside the style table (no barrier pair and no exposed global-load latency between the K loop
     // and the stores); tiles spanning many small images (4x4, 8x8) fill them after the loop in the dead staging buffers.
     const bool whole = p.ksplit == 1;     // K slices only scale by d; noise / bias / activation follow the reduction
-    const bool fuse_rgb = !UP && whole && p.rgb_part != nullptr;      // fused ToRGB partial sums (PLAIN3)
+    const bool fuse_rgb = !UP && !DOWN && whole && p.rgb_part != nullptr;      // fused ToRGB partial sums (PLAIN3)
     const bool early = p.simgs <= 2;
     float* const dl = early ? ls + ((p.simgs * p.Cin + 3) & ~3) : reinterpret_cast<float*>(smem);   // [simgs][NT]  d * output scale
     float* const bl = dl + p.simgs * NT;                        // [NT]            bias
     float* const cw = bl + NT;                                  // [simgs][NT][4]  ToRGB coefficients
     float* const red = cw + p.simgs * NT * 4;                   // [WM][PT][3]     ToRGB cross-wave reduce
     float* const sn = red + 2 * 512 * 3;                        // [simgs][NT]     next layer's style * range shift (xs_out)
-    const bool emit_xs = !UP && whole && p.xs_out != nullptr;
+    const bool emit_xs = !UP && !DOWN && whole && p.xs_out != nullptr;
     auto fill_tables = [&]() {
         // one pass, every global load of an entry issued before the first LDS write (one exposed latency, not four)
         const float oscale = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_OUT : 1.f;
@@ -480,7 +520,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 #pragma unroll
     for (int m = 0; m < MI; ++m) {
         const int col = wm * (MI * 32) + m * 32;
-        aoff[m] = (col / 64) * (RPS * WROW64) + (hi * 64 + (col % 64) + l31) * 16;
+        aoff[m] = (col / 64) * WTILE_BYTES + (hi * 64 + (col % 64) + l31) * 16;
     }
     const bool stagger = !XIN && NW == 8 && ((p.stagger & 3) == 1 ? (wave >= 4) : (p.stagger & 3) == 2 ? (wave & 1) : false);
     for (int cb = cb0; cb < ncb; ++cb) {
@@ -599,7 +639,55 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                     }
                 }
             };
+            // DOWN3: the taps of one phase, gx[q] += W[tap]^T plane[q + off]; same tap software pipeline as the plain conv
+            auto mfma_down = [&](auto ntaps_t, int o0, int o1, int o2, int o3) {
+                constexpr int NTAPS = decltype(ntaps_t)::value;
+                const int off[4] = {o0, o1, o2, o3};
+                frag128 a[2][2][MI], b[2][2][NI];     // [set][part][tile]
+                auto fetch = [&](int set, int t) {
+#pragma unroll
+                    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+                        for (int m = 0; m < MI; ++m)
+                            a[set][part][m] = *reinterpret_cast<const frag128*>(wslot + aoff[m] + t * WTAP + part * 2048);
+#pragma unroll
+                        for (int n = 0; n < NI; ++n)
+                            b[set][part][n] =
+                                *reinterpret_cast<const frag128*>(xcur + part * 32 * p.xs + (boff[n] + off[t]) * 16);
+                    }
+                };
+                fetch(0, 0);
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t) {
+                    const int cur = t & 1;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < MI; ++m)
+#pragma unroll
+                        for (int n = 0; n < NI; ++n) acc[0][m][n] = split_mfma<ET>(a[cur][0][m], b[cur][0][n], acc[0][m][n]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 1 < NTAPS) fetch(cur ^ 1, t + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int tt = 1; tt < 3; ++tt)
+#pragma unroll
+                        for (int m = 0; m < MI; ++m)
+#pragma unroll
+                            for (int n = 0; n < NI; ++n)
+                                acc[0][m][n] = split_mfma<ET>(a[cur][tt == 2][m], b[cur][tt == 1][n], acc[0][m][n]);
+                }
+            };
             auto mfma_part = [&]() {
+                if (DOWN) {       // taps (ky,kx) of phase 2*(ky&1) + (kx&1) read the plane at q + (ky==2)*P + (kx==2)
+                    using std::integral_constant;
+                    switch (u & 3) {          // block-uniform
+                        case 0: mfma_down(integral_constant<int, 4>{}, 0, 1, p.P, p.P + 1); break;   // (0,0) (0,2) (2,0) (2,2)
+                        case 1: mfma_down(integral_constant<int, 2>{}, 0, p.P, 0, 0); break;         // (0,1) (2,1)
+                        case 2: mfma_down(integral_constant<int, 2>{}, 0, 1, 0, 0); break;           // (1,0) (1,2)
+                        default: mfma_down(integral_constant<int, 1>{}, 0, 0, 0, 0); break;          // (1,1)
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int r = 0; r < RPS; ++r) mfma_row(ss * RPS + r);
             };
@@ -699,7 +787,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     {
         using yes = std::true_type;
         using no = std::false_type;
-        if (UP) {
+        if (UP || DOWN) {
             epilogue(yes{}, no{}, no{});
         } else {
             switch ((p.y ? 1 : 0) | (emit_xs ? 2 : 0) | (fuse_rgb ? 4 : 0)) {       // block-uniform
@@ -773,12 +861,46 @@ __global__ __launch_bounds__(256) void to_split_kernel(const float* __restrict__
     if (ET == SGDFR_SPLIT_FP16) split_flush_saturation(sat);
 }
 
+// gT [B,C,4,RP] fp32 parity planes and d [B,C] (or null) -> the phase-major split form of gT*d that the DOWN3 kernel stages:
+// [B][(ph*C + c)/8][hi,lo][RP][8].  One thread = one position of one 8-channel group of one phase.
+template <int ET>
+__global__ __launch_bounds__(256) void planes_to_split_kernel(const float* __restrict__ gt, const float* __restrict__ d,
+                                                             unsigned char* __restrict__ xs, int B, int C, int RP) {
+    const int G = C / 8;
+    const int64_t n = (int64_t)B * 4 * G * RP;
+    unsigned sat = 0;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int pos = (int)(idx % RP);
+        int64_t r = idx / RP;
+        const int g = (int)(r % G);
+        r /= G;
+        const int ph = (int)(r % 4);
+        const int b = (int)(r / 4);
+        const float* xp = gt + (((int64_t)b * C + g * 8) * 4 + ph) * RP + pos;
+        const float sc = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_XSCALE : 1.f;
+        float sv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) sv[c] = (d ? d[(int64_t)b * C + g * 8 + c] : 1.f) * sc;
+        uint4 vh, vl;
+        unsigned* ph_ = reinterpret_cast<unsigned*>(&vh);
+        unsigned* pl_ = reinterpret_cast<unsigned*>(&vl);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            split_pair<ET>(xp[(int64_t)(2 * c) * 4 * RP] * sv[2 * c], xp[(int64_t)(2 * c + 1) * 4 * RP] * sv[2 * c + 1], ph_[c], pl_[c], sat);
+        unsigned char* dst = xs + ((((int64_t)b * 4 * G + ph * G + g) * 2) * RP + pos) * 16;
+        *reinterpret_cast<uint4*>(dst) = vh;
+        *reinterpret_cast<uint4*>(dst + (int64_t)RP * 16) = vl;
+    }
+    if (ET == SGDFR_SPLIT_FP16) split_flush_saturation(sat);
+}
+
 // weight [Cout,Cin,3,3] fp32 -> bf16 hi/lo of Wc = weight/sqrt(9 Cin) in the kernel's LDS order:
 //   [cout tile][cin block][ky][kx][part][k-half][cout in tile (NT)][8 cin]
 __global__ __launch_bounds__(256) void prepack_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
                                                            int Cout, int Cin, int NT, float scale, int et, int transpose_flip) {
-    // packed conv: n_out x n_in channels.  transpose_flip: the adjoint conv (dL/dx of the plain conv): channels swapped, taps
-    // rotated by 180 degrees; weight stays indexed [Cout][Cin][3][3]
+    // packed conv: n_out x n_in channels.  transpose_flip 1: the adjoint conv (dL/dx of the plain conv): channels swapped, taps
+    // rotated by 180 degrees; 2: the adjoint of the transposed conv (DOWN3): channels swapped, taps as they are but stored
+    // phase by phase ((0,0) (0,2) (2,0) (2,2) | (0,1) (2,1) | (1,0) (1,2) | (1,1)); weight stays indexed [Cout][Cin][3][3]
     const int n_out = transpose_flip ? Cin : Cout, n_in = transpose_flip ? Cout : Cin;
     const int64_t n = (int64_t)n_out * n_in * 9;
     const int ncb = n_in / SPLIT_CB;
@@ -786,15 +908,17 @@ __global__ __launch_bounds__(256) void prepack_split_kernel(const float* __restr
         const int tap = (int)(idx % 9);
         const int ci = (int)((idx / 9) % n_in);
         const int co = (int)(idx / (9 * (int64_t)n_in));
-        const float v = (transpose_flip ? w[((int64_t)ci * Cin + co) * 9 + (8 - tap)] : w[idx]) * scale;   // fp16: scale carries 2^6
+        const float v = (transpose_flip == 1 ? w[((int64_t)ci * Cin + co) * 9 + (8 - tap)]
+                         : transpose_flip == 2 ? w[((int64_t)ci * Cin + co) * 9 + tap] : w[idx]) * scale;   // fp16: scale carries 2^6
         unsigned hp, lp, sat = 0;
         if (et == SGDFR_SPLIT_FP16) split_pair<SGDFR_SPLIT_FP16>(v, 0.f, hp, lp, sat);
         else split_pair<SGDFR_SPLIT_BF16>(v, 0.f, hp, lp, sat);
         split_flush_saturation(sat);
         const unsigned hbits = hp & 0xffffu, lbits = lp & 0xffffu;
         const int ctile = co / NT, col = co - ctile * NT, cb = ci / SPLIT_CB, h = (ci % SPLIT_CB) / 8, c8 = ci % 8;
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int64_t base = ((((int64_t)ctile * ncb + cb) * 3 + ky) * 3 + kx) * 2;   // -> [part]
+        const int down_pos[9] = {0, 4, 1, 6, 8, 7, 2, 5, 3};      // tap ky*3+kx -> slot in the phase-by-phase order
+        const int slot = transpose_flip == 2 ? down_pos[tap] : tap;
+        const int64_t base = (((int64_t)ctile * ncb + cb) * 9 + slot) * 2;   // -> [part]
         out[(((base + 0) * 2 + h) * NT + col) * 8 + c8] = (unsigned short)hbits;
         out[(((base + 1) * 2 + h) * NT + col) * 8 + c8] = (unsigned short)lbits;
     }
@@ -815,9 +939,11 @@ static const SplitPlan kPlanPlainNarrow = {1, 64, 512, 3, 8};   // plain, Cout %
 static const SplitPlan kPlanUpWide = {2, 128, 128, 3, 8};       // transposed: 128 couts x 128 super-pixels, row sub-stages
 static const SplitPlan kPlanUpNarrow = {3, 64, 256, 3, 8};      // transposed, Cout % 128 != 0 (or as a fallback): 64 x 256
 static const SplitPlan kPlanUpDeep = {4, 64, 256, 1, 8};        // transposed: 64 x 256, all 9 taps between barriers
+static const SplitPlan kPlanDown = {5, 128, 256, 1, 8};         // adjoint of the transposed conv: 128 x 256 positions, (block, phase) stages
 
-static size_t split_lds_bytes(const SplitParams& p, int NT, int nss) {
-    const size_t loop = 2 * (size_t)64 * p.xs + 2 * (size_t)NT * 192 * (3 / nss) + (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float);
+static size_t split_lds_bytes(const SplitParams& p, int NT, int nss, bool down = false) {
+    const size_t wslot = down ? (size_t)NT * 256 : (size_t)NT * 192 * (3 / nss);       // DOWN3: 4 taps x 64 bytes per cout
+    const size_t loop = 2 * (size_t)64 * p.xs + 2 * wslot + (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float);
     const size_t epi = ((size_t)p.simgs * NT * 6 + NT + 2 * 512 * 3) * sizeof(float);   // d, bias, ToRGB coefficient / reduce, next-style tables
     if (p.simgs <= 2) return loop + epi;      // tables live beside the style table for the whole kernel
     return loop > epi ? loop : epi;           // tables overwrite the dead staging buffers after the K loop
@@ -826,13 +952,15 @@ static size_t split_lds_bytes(const SplitParams& p, int NT, int nss) {
 // geometry of the pixel tiling for one plan; returns 0 when the shape cannot use it
 static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, const SplitPlan& plan, SplitParams* out) {
     if (Cin % SPLIT_CB != 0 || Cout % plan.nt != 0 || B < 1) return 0;
+    const bool down = mode == SGDFR_MODE_DOWN3;
+    if (down) Cin *= 4;          // K channels = (plane channel, phase)
     SplitParams p{};
     const int PT = plan.pt;
     const int HW = H * W;
     p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.P = W + 1; p.R = H + 1;
     p.total_pix = (int64_t)B * HW;
     if ((int64_t)B * p.R * p.P + 4ll * p.P + 8 >= (1ll << 31) || p.total_pix >= (1ll << 31)) return 0;
-    if (mode == SGDFR_MODE_UP3) {
+    if (mode == SGDFR_MODE_UP3 || down) {
         p.patch = 0;
         p.total_pix = (int64_t)B * p.R * p.P;            // super-pixels
         p.xlen = PT + p.P + 2;
@@ -866,8 +994,8 @@ static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, cons
     p.xs = plan.nw == 8 ? (p.xlen + 63) & ~63 : (p.xlen + 7) & ~7;
     p.n_cout_tiles = Cout / plan.nt;
     const int nthr = plan.nw * 64;
-    if ((2 * p.xs + nthr - 1) / nthr > (mode == SGDFR_MODE_UP3 ? 3 : 4)) return 0;                 // staging slots
-    const size_t lds = split_lds_bytes(p, plan.nt, plan.nss);
+    if ((2 * p.xs + nthr - 1) / nthr > (mode == SGDFR_MODE_PLAIN3 ? 4 : 3)) return 0;                 // staging slots
+    const size_t lds = split_lds_bytes(p, plan.nt, plan.nss, down);
     if (lds > (plan.nw == 8 ? 160 : 80) * 1024) return 0;
     if (out) *out = p;
     return 1;
@@ -886,6 +1014,8 @@ static const SplitPlan* split_plan(int B, int Cin, int Cout, int H, int W, int m
     } else if (mode == SGDFR_MODE_PLAIN3) {
         if (Cout % 128 == 0) order[n++] = &kPlanPlainWide;
         order[n++] = &kPlanPlainNarrow;
+    } else if (mode == SGDFR_MODE_DOWN3) {
+        order[n++] = &kPlanDown;
     }
     for (int i = 0; i < n; ++i)
         if (split_geometry(B, Cin, Cout, H, W, mode, *order[i], out)) return order[i];
@@ -930,6 +1060,24 @@ extern "C" int sgdfr_to_split_f32(const float* x, const float* s, unsigned short
     return check_launch("to_split");
 }
 
+extern "C" int sgdfr_planes_to_split_f32(const float* gt, const float* d, unsigned short* xs, int B, int C, int H, int W,
+                                        int arith, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "planes_to_split: bad shape B=%d C=%d H=%d W=%d (C %% 8)", B, C, H, W);
+    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "planes_to_split: arith must be SGDFR_SPLIT_BF16/FP16");
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(gt && xs && (reinterpret_cast<uintptr_t>(xs) & 15) == 0, "planes_to_split: null or misaligned pointer");
+    const int RP = (H + 1) * (W + 1);
+    int64_t g = ((int64_t)B * 4 * (C / 8) * RP + 255) / 256;
+    if (g > 256 * 32) g = 256 * 32;
+    if (arith == SGDFR_SPLIT_FP16)
+        hipLaunchKernelGGL(planes_to_split_kernel<SGDFR_SPLIT_FP16>, dim3((int)g), dim3(256), 0, as_stream(stream), gt, d,
+                           reinterpret_cast<unsigned char*>(xs), B, C, RP);
+    else
+        hipLaunchKernelGGL(planes_to_split_kernel<SGDFR_SPLIT_BF16>, dim3((int)g), dim3(256), 0, as_stream(stream), gt, d,
+                           reinterpret_cast<unsigned char*>(xs), B, C, RP);
+    return check_launch("planes_to_split");
+}
+
 unsigned int blur_split_saturation_count(int reset);     // upfirdn2d.hip's counter
 
 // Number of fp16-split operand pairs that hit the +-65504 clamp (|x*s| > 1.04e6) since the last reset, over all split
@@ -947,7 +1095,7 @@ extern "C" long long sgdfr_split_saturation_count(int reset) {
 extern "C" int sgdfr_modconv2d_split_xin_supported(int B, int Cin, int Cout, int H, int W, int mode) {
     SplitParams p;
     const SplitPlan* plan = split_plan(B, Cin, Cout, H, W, mode, &p);
-    return (plan && (plan->cfg == 0 || plan->cfg == 1 || plan->cfg == 4)) ? 1 : 0;     // the instantiations of launch_plan(xin)
+    return (plan && (plan->cfg == 0 || plan->cfg == 1 || plan->cfg == 4 || plan->cfg == 5)) ? 1 : 0;     // the instantiations of launch_plan(xin)
 }
 
 extern "C" int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H, int W, int mode) {
@@ -960,6 +1108,8 @@ extern "C" int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin) { return
 extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int arith,
                                                int transpose_flip, void* stream) {
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "prepack_split: arith must be SGDFR_SPLIT_BF16/FP16");
+    SGDFR_REQUIRE(transpose_flip >= 0 && transpose_flip <= 2, "prepack_split: transpose_flip is 0 (forward), 1 (adjoint of "
+                  "the plain conv) or 2 (adjoint of the transposed conv)");
     const int n_out = transpose_flip ? Cin : Cout, n_in = transpose_flip ? Cout : Cin;
     SGDFR_REQUIRE(Cout > 0 && Cin > 0 && n_in % SPLIT_CB == 0 && n_out % 64 == 0,
                   "prepack_split: needs in-channels %% 16 == 0 and out-channels %% 64 == 0, got in=%d out=%d", n_in, n_out);
@@ -976,12 +1126,12 @@ template <int MODE, int ET, int WM, int WN, int MI, int NI, int NSS = 3, bool XI
 static int launch_split(const SplitParams& p, hipStream_t st) {
     constexpr int NTHR = WM * WN * 64;
     const int nex = (2 * p.xs + NTHR - 1) / NTHR;
-    constexpr int NEX_MAX = (MODE == SGDFR_MODE_UP3) ? 3 : 4;   // UP3 stages at most PT + P + 2 positions
+    constexpr int NEX_MAX = (MODE == SGDFR_MODE_PLAIN3) ? 4 : 3;   // UP3 / DOWN3 stage at most PT + P + 2 positions
     SGDFR_REQUIRE(nex <= NEX_MAX, "modconv_split: staged range %d too long for mode %d", p.xlen, MODE);
     void (*kern)(SplitParams) = nex <= 2   ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 2, NSS, XIN>
                                 : nex == 3 ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 3, NSS, XIN>
                                            : split_mfma_kernel<MODE, ET, WM, WN, MI, NI, NEX_MAX, NSS, XIN>;
-    const size_t lds = split_lds_bytes(p, WM * MI * 32, NSS);
+    const size_t lds = split_lds_bytes(p, WM * MI * 32, NSS, MODE == SGDFR_MODE_DOWN3);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess) {
         (void)hipGetLastError();
@@ -1010,8 +1160,13 @@ static int launch_plan(int cfg, const SplitParams& p, hipStream_t st, bool xin) 
             case 0: return launch_split<SGDFR_MODE_PLAIN3, ET, 2, 4, 2, 2, 3, true>(p, st);
             case 1: return launch_split<SGDFR_MODE_PLAIN3, ET, 1, 8, 2, 2, 3, true>(p, st);
             case 4: return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 1, true>(p, st);
+            case 5: return launch_split<SGDFR_MODE_DOWN3, ET, 2, 4, 2, 2, 1, true>(p, st);
             default: set_error("modconv_split: pre-split input is not built for tiling plan %d", cfg); return 1;
         }
+    }
+    if (cfg == 5) {
+        set_error("modconv_split: DOWN3 reads the phase-major split planes of sgdfr_planes_to_split_f32 (x_is_split = 1)");
+        return 1;
     }
     switch (cfg) {
         case 0: return launch_split<SGDFR_MODE_PLAIN3, ET, 2, 4, 2, 2, 3>(p, st);
@@ -1036,7 +1191,9 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
                   "modconv_split: shape B=%d Cin=%d Cout=%d H=%d W=%d mode=%d not supported; use sgdfr_modconv2d_fwd_f32", B,
                   Cin, Cout, H, W, mode);
     SGDFR_REQUIRE(mode == SGDFR_MODE_PLAIN3 || (!noise && !bias && !act), "modconv_split: UP3 writes raw parity planes "
-                  "(noise / bias / activation belong to sgdfr_blur_bias_act_f32)");
+                  "(noise / bias / activation belong to sgdfr_blur_bias_act_f32), DOWN3 a raw gradient");
+    SGDFR_REQUIRE(mode != SGDFR_MODE_DOWN3 || (x_is_split && y && !rgb_part && !xs_out), "modconv_split: DOWN3 takes "
+                  "pre-split planes and writes y only");
     SGDFR_REQUIRE(x && wsp && zeros && (y || rgb_part || xs_out) && (s || x_is_split), "modconv_split: null pointer");
     SGDFR_REQUIRE(!xs_out || (s_next && mode == SGDFR_MODE_PLAIN3 && ksplit <= 1 && Cout % 8 == 0 &&
                               (reinterpret_cast<uintptr_t>(xs_out) & 15) == 0),

@@ -256,14 +256,16 @@ _SPLIT_ARITH = {'bf16x3': N.SPLIT_BF16, 'fp16x3': N.SPLIT_FP16}
 
 def prepack_split(weight, arith=None, adjoint=False):
     """weight [1,Cout,Cin,3,3] -> uint16 buffer of 16-bit hi/lo terms of weight/sqrt(9 Cin) in split.hip's LDS order
-    (arith: 'bf16x3' or 'fp16x3', default = the current PRECISION; adjoint: the pack of dL/dx of the plain conv)."""
+    (arith: 'bf16x3' or 'fp16x3', default = the current PRECISION; adjoint: True = the pack of dL/dx of the plain conv,
+    'down' = of dL/dx of the transposed conv, mode DOWN3)."""
     arith = _SPLIT_ARITH[arith or PRECISION]
     N.require_device(weight)
     w = N.f32c(weight)
     _, cout, cin, k, _ = w.shape
     n = N.load().sgdfr_modconv_prepack_split_elems(cout, cin)
     wsp = torch.empty(n, device=w.device, dtype=torch.int16)
-    N.call('sgdfr_modconv_prepack_split_f32', N.ptr(w), N.ptr(wsp), cout, cin, arith, int(bool(adjoint)), N.stream())
+    N.call('sgdfr_modconv_prepack_split_f32', N.ptr(w), N.ptr(wsp), cout, cin, arith, 2 if adjoint == 'down' else int(bool(adjoint)),
+           N.stream())
     return wsp
 
 
@@ -291,13 +293,20 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
             raise RuntimeError('modconv_split: a pre-split input is the int16 buffer made by to_split')
         B, cin, H, W = x_split
         xb = cin * H * W
+        if mode == N.MODE_DOWN3:        # (B, plane channels, H, W of dL/dx): the planes are (H+1) x (W+1), 4 per channel
+            xb = cin * 4 * (H + 1) * (W + 1)
     else:
         N.require_device(x)
         x = N.f32c(x)
         B = s.shape[0] if batch is None else batch
         _, cin, H, W = x.shape
         xb = 0 if (x.shape[0] == 1 and B != 1) else cin * H * W
-    if mode == N.MODE_UP3:
+    if mode == N.MODE_DOWN3:
+        if x_split is None:
+            raise RuntimeError('modconv_split: DOWN3 reads the buffer made by planes_to_split (x_split=(B, C, H, W))')
+        nz, nzb = None, 0
+        y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+    elif mode == N.MODE_UP3:
         nz, nzb = None, 0
         y = out if out is not None else torch.empty(B, cout, 4, H + 1, W + 1, device=x.device, dtype=torch.float32)
         if tuple(y.shape) != (B, cout, 4, H + 1, W + 1) or not y.is_contiguous():
@@ -336,6 +345,19 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
     if s_next is not None:      # (activation or None, ToRGB partials or None, the activation in the next layer's split form)
         return y, part, xs_out
     return y if rgb is None else (y, part)
+
+
+def planes_to_split(gt, d, arith=None):
+    """gt [B,C,4,H+1,W+1] (gradient of the transposed conv's parity planes), d [B,C] or None -> int16 buffer
+    [B, 4*C/8, 2, (H+1)*(W+1), 8]: gt*d in the phase-major split form that modconv_split(mode=DOWN3) stages."""
+    arith = _SPLIT_ARITH[arith or PRECISION]
+    N.require_device(gt, d)
+    gt = N.f32c(gt)
+    B, C, _, R, P = gt.shape
+    xs = torch.empty(B, 4 * C // 8, 2, R * P, 8, device=gt.device, dtype=torch.int16)
+    N.call('sgdfr_planes_to_split_f32', N.ptr(gt), N.ptr(N.f32c(d)) if d is not None else None, N.ptr(xs), B, C, R - 1, P - 1, arith,
+           N.stream())
+    return xs
 
 
 def to_split(x, s, arith=None):

@@ -183,13 +183,13 @@ class ModulatedConv2d(nn.Module):
 
     def packed_split(self, adjoint=False, arith=None):
         """16-bit hi/lo weight pack of the split precision modes (default arith = functional.PRECISION), cached per weight
-        version (adjoint=True: the pack of the plain conv's dL/dx conv)."""
+        version (adjoint=True: the pack of the plain conv's dL/dx conv; 'down': of the transposed conv's, mode DOWN3)."""
         arith = arith or F_.PRECISION
         key = self._key()
         cache = getattr(self, '_pack_s', None)
         if cache is None or cache[0] != key:
             cache = self._pack_s = [key, {}]
-        slot = (arith, bool(adjoint))
+        slot = (arith, adjoint if adjoint == 'down' else bool(adjoint))
         if slot not in cache[1]:
             with torch.no_grad():
                 cache[1][slot] = F_.prepack_split(self.weight.detach(), arith=arith, adjoint=adjoint)

@@ -224,6 +224,35 @@ def test_persistent_blocks_match_one_block_per_tile(cin, cout, H, B):
     assert torch.equal(yd, F_.modconv_split(x, wsp, s, d, cout, arith='fp16x3'))
 
 
+@pytest.mark.parametrize('C,cin,H,B', [(64, 128, 32, 6), (32, 128, 64, 3), (128, 256, 8, 40), (16, 128, 16, 5), (64, 128, 128, 2)])
+def test_split_down3_matches_fp32_kernel_and_oracle(C, cin, H, B):
+    """dL/d(x*s) of the transposed conv (mode DOWN3: stride-2 conv over the gradient's parity planes) on the split kernels
+    (bf16 terms) vs the fp32 MFMA kernel of the same mode and vs torch's fp64 conv_transpose2d autograd."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    N = F_.N
+    w = S.counter_tensor(8, 'dn.w', (1, C, cin, 3, 3)).cuda()              # forward layer: cin -> C channels, H x H -> planes
+    gT = S.counter_tensor(8, 'dn.g', (B, C, 4, H + 1, H + 1)).cuda()
+    gT[:, :, 1, :, H] = 0; gT[:, :, 3, :, H] = 0; gT[:, :, 2, H, :] = 0; gT[:, :, 3, H, :] = 0   # the planes' padding row / column
+    d = S.counter_tensor(8, 'dn.d', (B, C), 1.0, 0.2).cuda()
+    assert F_.split_ok(B, C, cin, H, H, N.MODE_DOWN3)
+    ref = F_.modconv_raw(gT, F_.prepack_t(w, flip=False), d, None, cin, N.MODE_DOWN3, H, H)
+    xs = F_.planes_to_split(gT, d, 'bf16x3')
+    got = F_.modconv_split(xs, F_.prepack_split(w, 'bf16x3', adjoint='down'), None, None, cin, mode=N.MODE_DOWN3, arith='bf16x3',
+                           x_split=(B, C, H, H), batch=B)
+    assert got.shape == ref.shape == (B, cin, H, H)
+    # fp64: planes -> full-resolution gradient of conv_transpose2d(u, Wc^T, stride 2) -> its input gradient
+    full = torch.zeros(B, C, 2 * H + 2, 2 * H + 2, dtype=torch.float64)
+    g64 = (gT.double() * d.double()[:, :, None, None, None]).cpu()
+    for ph in range(4):
+        full[:, :, (ph >> 1)::2, (ph & 1)::2] = g64[:, :, ph]
+    full = full[:, :, :2 * H + 1, :2 * H + 1]
+    wc = (w[0].double().cpu() / (cin * 9) ** 0.5)                         # [C, cin, 3, 3]
+    want = torch.nn.functional.conv2d(full, wc.transpose(0, 1).contiguous(), stride=2)       # [B, cin, H, H]
+    scale = want.abs().max().item()
+    assert (ref.double().cpu() - want).abs().max().item() <= 2e-5 * scale       # the fp32 kernel pins the restatement
+    assert (got.double().cpu() - want).abs().max().item() <= 3e-4 * scale       # bf16 hi+lo terms: 2^-16 per operand
+
+
 def test_fp16_split_saturates_instead_of_overflowing():
     """|x*s| beyond the fp16-split range (1.04e6) clamps; nothing becomes inf/nan."""
     from stylegan_directions_face_reenactment_amd import functional as F_
