@@ -230,6 +230,11 @@ int sgdfr_to_split_f32(const float* x, const float* s, unsigned short* xs, int B
  *                              phase-major split form of gt*d (16-byte aligned, 4 bytes per element). */
 int sgdfr_planes_to_split_f32(const float* gt, const float* d, unsigned short* xs, int B, int C, int H, int W, int arith,
                               void* stream);
+/* sgdfr_blur_adjoint_f32 followed by sgdfr_planes_to_split_f32 in one pass (frozen generator: nothing else reads the fp32
+ * plane gradient): g [B,C,2H,2W] -> xs as above (times d [B,C] or 1), asum[b,c] = sum gT*t when the forward planes
+ * t [B,C,4,H+1,W+1] are given (the demodulation gradient; asum is zeroed first). */
+int sgdfr_blur_adjoint_split_f32(const float* g, const float* fir, const float* t, const float* d, unsigned short* xs,
+                                 float* asum, int B, int C, int H, int W, int arith, void* stream);
 int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H, int W, int mode);
 int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, int mode);
 

@@ -217,12 +217,20 @@ class StyledConvFn(Function):
                                          slope=slope, gain=gain)
         ones_d = d if d is not None else torch.ones(B, cout, device=out.device, dtype=torch.float32)
         if up:
-            gT, A = F_.blur_adjoint(g_pre, mod.blur.kernel, planes if d is not None else None)
-            if F_.PRECISION != 'fp32' and F_.split_ok(B, cout, cin, H, W, N.MODE_DOWN3):
+            split_down = F_.PRECISION != 'fp32' and F_.split_ok(B, cout, cin, H, W, N.MODE_DOWN3)
+            gT = None
+            if split_down and not ctx.needs_input_grad[3]:
+                # frozen weights: only the conv below reads the plane gradient -> the blur adjoint writes it directly in the
+                # conv's split input form (no fp32 planes, no conversion pass)
+                gxs, A = F_.blur_adjoint_split(g_pre, mod.blur.kernel, planes if d is not None else None, d, 'bf16x3')
+            else:
+                gT, A = F_.blur_adjoint(g_pre, mod.blur.kernel, planes if d is not None else None)
+                gxs = F_.planes_to_split(gT, d, 'bf16x3') if split_down else None
+            if split_down:
                 # dL/d(x*s) of the transposed conv on the split kernels too (bf16 terms: gradients have no natural scale):
-                # the planes times d go through the phase-major split form, the conv walks (channel block, phase) pairs
-                gu = F_.modconv_split(F_.planes_to_split(gT, d, 'bf16x3'), mod.packed_split(adjoint='down', arith='bf16x3'),
-                                      None, None, cin, mode=N.MODE_DOWN3, arith='bf16x3', x_split=(B, cout, H, W), batch=B,
+                # the planes times d come in the phase-major split form, the conv walks (channel block, phase) pairs
+                gu = F_.modconv_split(gxs, mod.packed_split(adjoint='down', arith='bf16x3'), None, None, cin, mode=N.MODE_DOWN3,
+                                      arith='bf16x3', x_split=(B, cout, H, W), batch=B,
                                       desc='bwd split down3 %d->%d @%dx%d' % (cout, cin, H, W))
             else:
                 gu = F_.modconv_raw(gT, mod.packed_t(), ones_d, None, cin, N.MODE_DOWN3, H, W,

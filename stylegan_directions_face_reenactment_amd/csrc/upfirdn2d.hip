@@ -296,6 +296,130 @@ __global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restr
     if (ET == SGDFR_SPLIT_FP16 && sat != 0) atomicAdd(&g_blur_saturated, sat);
 }
 
+
+// Adjoint of the blur feeding the split-kernel backward of the transposed conv (autograd of Blur, model.py:72-88, consumers
+// trainer.py:188): g [B,C,2H,2W] = dL/d(blur output) -> the gradient of the four parity planes gT[2a+py, 2b+px] =
+// sum_{dy,dx} g[2a+py+1-dy, 2b+px+1-dx] K[3-dy][3-dx], written ONLY in the phase-major split form of gT*d that
+// split_mfma_kernel<DOWN3> stages ([B][(ph*C+c)/8][hi,lo][(H+1)(W+1)][8]); asum[b,c] += sum gT*T (the demodulation
+// gradient) when the forward planes t are given.  Block = 8 channels x QC super-pixel columns x BLUR_QV rows, same
+// sliding 5x5 window as backward.hip's blur_adjoint_kernel; the fp32 results meet in LDS as [phase][row][column][8
+// channels] and leave as whole 16-byte chunks.  When W is a multiple of QC, the planes' extra column W (only its even
+// phases are real) is computed by the thread of column W-1 from the same window, so no tile is nearly empty.
+template <int ET, int QC>
+__global__ __launch_bounds__(8 * QC) void blur_adjoint_split_kernel(const float* __restrict__ g, const float* __restrict__ fir,
+                                                                const float* __restrict__ t, const float* __restrict__ d,
+                                                                unsigned char* __restrict__ xs, float* __restrict__ asum,
+                                                                int B, int C, int H, int W) {
+    __shared__ float tile[4][BLUR_QV][QC + 1][9];
+    __shared__ float sv[8];
+    float k[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) k[i] = fir[i];
+    const int GH = H + 1, GW = W + 1, OH = 2 * H, OW = 2 * W, RP = GH * GW;
+    const int G = C / 8;
+    const bool extra = (W % QC) == 0;                                  // column W rides on the thread of column W-1
+    const int col_tiles = extra ? W / QC : (GW + QC - 1) / QC, row_tiles = (GH + BLUR_QV - 1) / BLUR_QV;
+    const int64_t n_tiles = (int64_t)B * G * row_tiles * col_tiles;
+    const float xsc = (ET == SGDFR_SPLIT_FP16) ? 0.0625f : 1.f;
+    const int c8 = threadIdx.x / QC, nx = threadIdx.x % QC;
+    unsigned sat = 0;
+    for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+        const int ct = (int)(tile_id % col_tiles);
+        int64_t r = tile_id / col_tiles;
+        const int rt = (int)(r % row_tiles);
+        r /= row_tiles;
+        const int gi = (int)(r % G);
+        const int b = (int)(r / G);
+        const int c = gi * 8 + c8;
+        const int bb = ct * QC + nx;
+        const int as = rt * BLUR_QV;
+        const int64_t pl = (int64_t)b * C + c;
+        const bool last_ct = ct == col_tiles - 1;
+        const int ncols = min(QC, GW - ct * QC) + ((extra && last_ct) ? 1 : 0);     // columns this tile hands over
+        const bool two = extra && last_ct && nx == QC - 1;                            // this thread also owns column W
+        if (threadIdx.x < 8) sv[threadIdx.x] = (d ? d[(int64_t)b * C + gi * 8 + threadIdx.x] : 1.f) * xsc;
+        float acc_a = 0.f;
+        if (bb < (extra ? W : GW)) {
+            const float* gp = g + pl * (int64_t)OH * OW;
+            const float* tp = t ? t + pl * (int64_t)4 * RP : nullptr;
+            bool cok[5];
+#pragma unroll
+            for (int v = 0; v < 5; ++v) cok[v] = (2 * bb - 2 + v) >= 0 && (2 * bb - 2 + v) < OW;
+            float win[5][5];
+            auto load_row = [&](int gr, float (&dst)[5]) {
+                const bool rok = gr >= 0 && gr < OH;
+                const float* rp = gp + (int64_t)gr * OW + 2 * bb - 2;
+#pragma unroll
+                for (int v = 0; v < 5; ++v) dst[v] = (rok && cok[v]) ? rp[v] : 0.f;
+            };
+#pragma unroll
+            for (int u = 0; u < 3; ++u) load_row(2 * as - 2 + u, win[u]);
+#pragma unroll
+            for (int qv = 0; qv < BLUR_QV; ++qv) {
+                const int a = as + qv;
+                if (a >= GH) break;
+                load_row(2 * a + 1, win[3]);
+                load_row(2 * a + 2, win[4]);
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 4; ++dx) v = fmaf(win[py + 3 - dy][px + 3 - dx], k[(3 - dy) * 4 + (3 - dx)], v);
+                        // rows / cols 2H+1, 2W+1 of the planes are padding (zeros in the forward planes)
+                        if (2 * a + py > 2 * H || 2 * bb + px > 2 * W) v = 0.f;
+                        tile[py * 2 + px][qv][nx][c8] = v;
+                        if (tp) acc_a = fmaf(v, tp[(py * 2 + px) * RP + a * GW + bb], acc_a);
+                    }
+                    if (two) {          // column W: phase px = 0 reads g columns 2W-2, 2W-1 = window columns 2, 3; px = 1 is padding
+                        float v = 0.f;
+#pragma unroll
+                        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+                            for (int dx = 2; dx < 4; ++dx) v = fmaf(win[py + 3 - dy][5 - dx], k[(3 - dy) * 4 + (3 - dx)], v);
+                        if (2 * a + py > 2 * H) v = 0.f;
+                        tile[py * 2][qv][QC][c8] = v;
+                        tile[py * 2 + 1][qv][QC][c8] = 0.f;
+                        if (tp) acc_a = fmaf(v, tp[(py * 2) * RP + a * GW + W], acc_a);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+#pragma unroll
+                    for (int v = 0; v < 5; ++v) win[u][v] = win[u + 2][v];
+            }
+        }
+        if (t) {            // the QC threads of a channel are QC consecutive lanes
+#pragma unroll
+            for (int off = QC / 2; off > 0; off >>= 1) acc_a += __shfl_xor(acc_a, off, 64);
+            if (nx == 0) atomicAdd(&asum[pl], acc_a);
+        }
+        __syncthreads();
+        // (phase, row, column) items -> 8 channels each: times d, split, two 16-byte chunks
+        const int rows = min(BLUR_QV, GH - as);
+        const int n_items = 4 * rows * ncols;
+        for (int item = threadIdx.x; item < n_items; item += 8 * QC) {
+            const int col = item % ncols;
+            const int rq = item / ncols;
+            const int qv = rq % rows, ph = rq / rows;
+            uint4 vh, vl;
+            unsigned* phv = reinterpret_cast<unsigned*>(&vh);
+            unsigned* plv = reinterpret_cast<unsigned*>(&vl);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+                blur_split2<ET>(tile[ph][qv][col][2 * cc] * sv[2 * cc], tile[ph][qv][col][2 * cc + 1] * sv[2 * cc + 1], phv[cc], plv[cc], sat);
+            unsigned char* dst = xs + ((((int64_t)b * 4 * G + ph * G + gi) * 2) * RP + (int64_t)(as + qv) * GW + ct * QC + col) * 16;
+            *reinterpret_cast<uint4*>(dst) = vh;
+            *reinterpret_cast<uint4*>(dst + (int64_t)RP * 16) = vl;
+        }
+        __syncthreads();
+    }
+    if (ET == SGDFR_SPLIT_FP16 && sat != 0) atomicAdd(&g_blur_saturated, sat);
+}
+
 }  // namespace sgdfr
 
 using namespace sgdfr;
@@ -367,4 +491,26 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
     hipLaunchKernelGGL(kern, dim3((int)g), dim3(8 * QC), 0, as_stream(stream), t, fir, noise, noise_bstride, noise_w, bias, s_next,
                        out, B, C, H, W, act, slope, gain);
     return check_launch("blur_bias_act_split");
+}
+
+extern "C" int sgdfr_blur_adjoint_split_f32(const float* g, const float* fir, const float* t, const float* d, unsigned short* xs,
+                                            float* asum, int B, int C, int H, int W, int arith, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "blur_adjoint_split: bad shape %d %d %d %d (C %% 8)", B, C, H, W);
+    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "blur_adjoint_split: arith must be SGDFR_SPLIT_BF16/FP16");
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(g && fir && xs && (reinterpret_cast<uintptr_t>(xs) & 15) == 0, "blur_adjoint_split: null / misaligned pointer");
+    SGDFR_REQUIRE(!t || asum, "blur_adjoint_split: t given without asum");
+    hipStream_t st = as_stream(stream);
+    if (t && hipMemsetAsync(asum, 0, sizeof(float) * (size_t)B * C, st) != hipSuccess) return check_launch("memset");
+    const int QC = W >= 64 ? 64 : 32;
+    const int col_tiles = (W % QC) == 0 ? W / QC : (W + 1 + QC - 1) / QC;
+    const int64_t tiles = (int64_t)B * (C / 8) * ((H + 1 + BLUR_QV - 1) / BLUR_QV) * col_tiles;
+    int64_t grid = tiles;
+    if (grid > 256 * 32) grid = 256 * 32;
+    unsigned char* out = reinterpret_cast<unsigned char*>(xs);
+    void (*kern)(const float*, const float*, const float*, const float*, unsigned char*, float*, int, int, int, int);
+    if (arith == SGDFR_SPLIT_FP16) kern = QC == 64 ? blur_adjoint_split_kernel<SGDFR_SPLIT_FP16, 64> : blur_adjoint_split_kernel<SGDFR_SPLIT_FP16, 32>;
+    else kern = QC == 64 ? blur_adjoint_split_kernel<SGDFR_SPLIT_BF16, 64> : blur_adjoint_split_kernel<SGDFR_SPLIT_BF16, 32>;
+    hipLaunchKernelGGL(kern, dim3((int)grid), dim3(8 * QC), 0, st, g, fir, t, d, out, asum, B, C, H, W);
+    return check_launch("blur_adjoint_split");
 }

@@ -613,6 +613,21 @@ def blur_adjoint(g, fir, planes=None):
     return gt, asum
 
 
+def blur_adjoint_split(g, fir, planes=None, d=None, arith=None):
+    """blur_adjoint + planes_to_split in one pass: g [B,C,2H,2W] -> (the int16 phase-major split form of gT*d that
+    modconv_split(mode=DOWN3) stages, asum [B,C] = sum gT*T when the forward planes are given)."""
+    arith = _SPLIT_ARITH[arith or PRECISION]
+    N.require_device(g, fir, planes, d)
+    g = N.f32c(g)
+    B, C, H2, W2 = g.shape
+    H, W = H2 // 2, W2 // 2
+    xs = torch.empty(B, 4 * C // 8, 2, (H + 1) * (W + 1), 8, device=g.device, dtype=torch.int16)
+    asum = torch.empty(B, C, device=g.device, dtype=torch.float32) if planes is not None else None
+    N.call('sgdfr_blur_adjoint_split_f32', N.ptr(g), N.ptr(N.f32c(fir)), N.ptr(planes), N.ptr(N.f32c(d)) if d is not None else None,
+           N.ptr(xs), N.ptr(asum), B, C, H, W, arith, N.stream())
+    return xs, asum
+
+
 def scale_reduce(gu, x, s):
     """dx = gu * s[b,c] (in place) and r[b,c] = sum_q x*gu; x may be a [1,C,H,W] broadcast constant."""
     N.require_device(gu, x, s)

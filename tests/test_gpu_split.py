@@ -253,6 +253,25 @@ def test_split_down3_matches_fp32_kernel_and_oracle(C, cin, H, B):
     assert (got.double().cpu() - want).abs().max().item() <= 3e-4 * scale       # bf16 hi+lo terms: 2^-16 per operand
 
 
+@pytest.mark.parametrize('C,H,B', [(64, 128, 2), (16, 64, 3), (32, 32, 5), (24, 16, 4), (8, 4, 7), (16, 48, 2)])
+def test_blur_adjoint_split_equals_the_two_pass_form(C, H, B):
+    """The fused blur adjoint (plane gradient written only in the DOWN3 conv's split input form) == sgdfr_blur_adjoint_f32
+    followed by sgdfr_planes_to_split_f32, bit for bit; the demodulation-gradient sums agree to fp32 summation order."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    g = S.counter_tensor(9, 'ba.g', (B, C, 2 * H, 2 * H)).cuda()
+    planes = S.counter_tensor(9, 'ba.t', (B, C, 4, H + 1, H + 1)).cuda()
+    d = S.counter_tensor(9, 'ba.d', (B, C), 1.0, 0.2).cuda()
+    fir = torch.tensor(O.make_fir([1, 3, 3, 1], gain=4.0).numpy()).cuda()
+    for arith in ('bf16x3', 'fp16x3'):
+        gT, A = F_.blur_adjoint(g, fir, planes)
+        want = F_.planes_to_split(gT, d, arith)
+        got, A2 = F_.blur_adjoint_split(g, fir, planes, d, arith)
+        assert torch.equal(got, want)
+        assert torch.allclose(A2, A, rtol=1e-4, atol=1e-3 * A.abs().max().item())
+        got0, none = F_.blur_adjoint_split(g, fir, None, None, arith)
+        assert none is None and torch.equal(got0, F_.planes_to_split(gT, None, arith))
+
+
 def test_fp16_split_saturates_instead_of_overflowing():
     """|x*s| beyond the fp16-split range (1.04e6) clamps; nothing becomes inf/nan."""
     from stylegan_directions_face_reenactment_amd import functional as F_
