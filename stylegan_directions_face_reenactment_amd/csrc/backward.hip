@@ -93,11 +93,15 @@ __global__ __launch_bounds__(256) void blur_adjoint_kernel(const float* __restri
 #pragma unroll
         for (int v = 0; v < 5; ++v) cok[v] = (2 * bb - 2 + v) >= 0 && (2 * bb - 2 + v) < OW;
         float win[5][5];
+        // window columns 2bb-2 .. 2bb+2 as two aligned float2 and one float (each pair is in range or not as a whole)
         auto load_row = [&](int gr, float (&dst)[5]) {
             const bool rok = gr >= 0 && gr < OH;
             const float* rp = gp + (int64_t)gr * OW + 2 * bb - 2;
-#pragma unroll
-            for (int v = 0; v < 5; ++v) dst[v] = (rok && cok[v]) ? rp[v] : 0.f;
+            const float2 z2 = make_float2(0.f, 0.f);
+            const float2 p01 = (rok && cok[0]) ? *reinterpret_cast<const float2*>(rp) : z2;
+            const float2 p23 = (rok && cok[2]) ? *reinterpret_cast<const float2*>(rp + 2) : z2;
+            dst[0] = p01.x; dst[1] = p01.y; dst[2] = p23.x; dst[3] = p23.y;
+            dst[4] = (rok && cok[4]) ? rp[4] : 0.f;
         };
 #pragma unroll
         for (int u = 0; u < 3; ++u) load_row(2 * as - 2 + u, win[u]);
