@@ -176,7 +176,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 
     // Persistent blocks: the grid is one block per CU (or fewer); block b works on tiles base + map(b) of every round of
     // gridDim.x tiles.  map() keeps the tiles of one XCD (blockIdx & 7) contiguous, so neighbours share halos and weights in L2.
-    constexpr bool PERSIST = XIN;       // (the fp32-input variants have no registers to spare for the loop)
+    // (only the plain conv is ever launched persistent, see launch_split; the fp32-input variants have no registers to spare)
+    constexpr bool PERSIST = XIN && MODE == SGDFR_MODE_PLAIN3;
     auto lid_of = [&](int base) -> int {        // tile of this block in the round starting at `base`, -1: none
         if (base >= p.total_blocks) return -1;
         const int nblk = PERSIST ? min((int)gridDim.x, p.total_blocks - base) : (int)gridDim.x, q8 = nblk >> 3, r8 = nblk & 7;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     if (lid < 0) break;
     const int lid_n = PERSIST ? lid_of(base + gridDim.x) : -1;
     // (tiles over many small images put their epilogue tables into the dead staging buffers: nothing may be staged ahead)
-    const bool has_next = lid_n >= 0 && p.simgs <= 2;
+    const bool has_next = PERSIST && lid_n >= 0 && p.simgs <= 2;
     // First-round desynchronisation: equal blocks started together reach their store phase together and share the HBM
     // write bandwidth (one block per CU: nothing else hides it).  Spreading the starts of the first round over about one
     // block time lets every later round store while other CUs compute.  p.desync = block-time estimate in 4096-clock units.
@@ -407,6 +408,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     const int cb0_n = (int)((int64_t)ncb_all * Tn.ks / p.ksplit);
     constexpr int WV = (WCHUNKS + NW - 1) / NW; // DMA pieces per wave and sub-stage (every wave issues exactly WV)
     auto issue_w = [&](const unsigned char* wglb, int u, int slot) {      // sub-stage u = cb*NSS + ss of a cout tile -> ring slot
+#ifdef SGDFR_SPLIT_PROBE
+        if (p.dbg & 16) return;
+#endif
         unsigned char* dst = wb0 + slot * WROW_BYTES;
 #pragma unroll
         for (int v = 0; v < WV; ++v) {
@@ -429,6 +433,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     auto issue_x = [&](int64_t addr, int e, int cb, unsigned char* xb) {
         const int i0 = __builtin_amdgcn_readfirstlane(tid - lane + e * NTHR);     // first item of this wave's slot
         if (i0 >= 2 * p.xs) return;                                                // wave-uniform (xs % 64 == 0)
+#ifdef SGDFR_SPLIT_PROBE
+        if (p.dbg & 8) return;
+#endif
         const int h0 = i0 / p.xs, j0 = i0 - h0 * p.xs;
         const unsigned char* xbase = reinterpret_cast<const unsigned char*>(p.x);
 #pragma unroll
