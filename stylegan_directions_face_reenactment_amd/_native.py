@@ -35,6 +35,8 @@ SIGNATURES = {
     'sgdfr_torgb_bwd_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_modconv_wgrad_f32': [_c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _i, _i, _i, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_modconv_wgrad_finish_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, ctypes.c_void_p],
+    'sgdfr_modconv_wgrad_parts_f32': [_c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _i, _i, _i, _i, _i, _i, ctypes.c_void_p],
+    'sgdfr_modconv_wgrad_finish_parts_f32': [_c_f32p, _i, _c_f32p, _c_f32p, _c_f32p, _i, _i, ctypes.c_void_p],
     'sgdfr_modconv_prepack_wino_f32': [_c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_modconv2d_wino_supported': [_i, _i, _i, _i, _i],
     'sgdfr_modconv2d_wino_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,

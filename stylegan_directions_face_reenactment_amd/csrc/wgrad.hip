@@ -23,6 +23,7 @@ struct WgradParams {
     int64_t x_bstride;
     const float* s;
     float* dwp;
+    float* part;       // != NULL: slice ks stores its sums to part[ks][9][Cout][Cin] (no atomics), reduced by the finish kernel
     int B, Cin, Cout, H, W, P, R;
     int PC, chunks_per_row, total_chunks, chunks_per_block, n_ot, n_it;
 };
@@ -106,14 +107,20 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradParams p) {
             }
         }
     }
-    // ---- split-K combine: dwp[i][tap][o] += acc
+    // ---- split-K combine.  Atomics (dwp[i][tap][o] += acc) cost ~0.35 ms per layer whatever its size: every layer ends up with
+    // ~9.4 M of them (256-way contention per address on the 64x64 layers).  With a partials buffer each slice stores its
+    // sums as [tap][o][i] rows (the 32 lanes of a half-wave = 32 consecutive i = one 128-byte line) and the finish kernel adds
+    // the slices in fixed order (deterministic).
 #pragma unroll
     for (int k = 0; k < 9; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int o = ot * 64 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             const int i = it * 64 + wi * 32 + l31;
-            if (o < p.Cout && i < p.Cin) atomicAdd(&p.dwp[((int64_t)i * 9 + k) * p.Cout + o], acc[k][r]);
+            if (o < p.Cout && i < p.Cin) {
+                if (p.part) p.part[(((int64_t)ks * 9 + k) * p.Cout + o) * p.Cin + i] = acc[k][r];
+                else atomicAdd(&p.dwp[((int64_t)i * 9 + k) * p.Cout + o], acc[k][r]);
+            }
         }
 }
 
@@ -165,6 +172,34 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
     }
 }
 
+// dW[o][i][k] = scale * ( sum_ks part[ks][k][o][i] + 2 * wp[i][k][o] * dq[o][i] )      (i fastest: coalesced partial reads)
+__global__ __launch_bounds__(256) void wgrad_finish_parts_kernel(const float* __restrict__ part, int ksplit,
+                                                                const float* __restrict__ wp, const float* __restrict__ dq,
+                                                                float* __restrict__ dw, int Cout, int Cin, float scale) {
+    const int64_t total = (int64_t)Cout * Cin * 9;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % Cin);
+        const int o = (int)((idx / Cin) % Cout);
+        const int k = (int)(idx / ((int64_t)Cin * Cout));
+        float v = 0.f;
+        for (int ks = 0; ks < ksplit; ++ks) v += part[(int64_t)ks * total + idx];
+        if (dq) v = fmaf(2.f * wp[((int64_t)i * 9 + k) * Cout + o], dq[(int64_t)o * Cin + i], v);
+        dw[((int64_t)o * Cin + i) * 9 + k] = v * scale;
+    }
+}
+
+// K slices of a shape: ~1024 blocks, at least 4 pixel chunks per block
+static int wgrad_ksplit(const WgradParams& p, int* chunks_per_block) {
+    const int ntile = ((p.Cout + 63) / 64) * ((p.Cin + 63) / 64);
+    int ksplit = (1024 + ntile - 1) / ntile;
+    int maxsplit = (p.total_chunks + 3) / 4;
+    if (maxsplit < 1) maxsplit = 1;
+    if (ksplit > maxsplit) ksplit = maxsplit;
+    const int cpb = (p.total_chunks + ksplit - 1) / ksplit;
+    if (chunks_per_block) *chunks_per_block = cpb;
+    return (p.total_chunks + cpb - 1) / cpb;
+}
+
 template <int MODE, int PCMAX>
 static int launch_wgrad(WgradParams& p, hipStream_t st) {
     constexpr int NSEG = (MODE == SGDFR_MODE_UP3) ? 8 : 3;
@@ -172,13 +207,7 @@ static int launch_wgrad(WgradParams& p, hipStream_t st) {
     p.n_ot = (p.Cout + 63) / 64;
     p.n_it = (p.Cin + 63) / 64;
     const int ntile = p.n_ot * p.n_it;
-    // split K so that ~1024 blocks exist, but keep at least 4 chunks per block
-    int ksplit = (1024 + ntile - 1) / ntile;
-    int maxsplit = (p.total_chunks + 3) / 4;
-    if (maxsplit < 1) maxsplit = 1;
-    if (ksplit > maxsplit) ksplit = maxsplit;
-    p.chunks_per_block = (p.total_chunks + ksplit - 1) / ksplit;
-    ksplit = (p.total_chunks + p.chunks_per_block - 1) / p.chunks_per_block;
+    const int ksplit = wgrad_ksplit(p, &p.chunks_per_block);
     const size_t lds = (size_t)(64 * UST + 64 * GST) * sizeof(float);
     auto kern = wgrad_mfma_kernel<MODE, PCMAX>;
     if (lds > 64 * 1024) {
@@ -194,6 +223,51 @@ static int launch_wgrad(WgradParams& p, hipStream_t st) {
 
 using namespace sgdfr;
 
+// pixel chunking of a shape; false: only the direct kernel applies
+static bool wgrad_shape(WgradParams& p, int B, int Cin, int Cout, int H, int W, int mode) {
+    p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.P = W + 1; p.R = H + 1;
+    const int pcmax = (mode == SGDFR_MODE_UP3) ? 32 : 64;
+    const int PC = W < pcmax ? W : pcmax;
+    if (!((W % PC == 0) && (PC % 2 == 0))) return false;
+    p.PC = PC;
+    p.chunks_per_row = W / PC;
+    p.total_chunks = B * H * p.chunks_per_row;
+    return true;
+}
+
+extern "C" int sgdfr_modconv_wgrad_ksplit(int B, int Cin, int Cout, int H, int W, int mode) {
+    WgradParams p{};
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || !wgrad_shape(p, B, Cin, Cout, H, W, mode)) return 0;
+    return wgrad_ksplit(p, nullptr);
+}
+
+extern "C" int sgdfr_modconv_wgrad_parts_f32(const float* g, const float* d, const float* x, int64_t x_bstride, const float* s,
+                                             float* part, int B, int Cin, int Cout, int H, int W, int mode, void* stream) {
+    SGDFR_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "wgrad_parts: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin,
+                  Cout, H, W);
+    SGDFR_REQUIRE(mode == SGDFR_MODE_PLAIN3 || mode == SGDFR_MODE_UP3, "wgrad_parts: mode must be PLAIN3 or UP3, got %d", mode);
+    SGDFR_REQUIRE(g && x && s && part, "wgrad_parts: null pointer");
+    WgradParams p{};
+    p.g = g; p.d = d; p.x = x; p.x_bstride = x_bstride; p.s = s; p.part = part;
+    SGDFR_REQUIRE(wgrad_shape(p, B, Cin, Cout, H, W, mode), "wgrad_parts: shape needs the direct kernel (sgdfr_modconv_wgrad_ksplit "
+                  "returned 0): use sgdfr_modconv_wgrad_f32");
+    hipStream_t st = as_stream(stream);
+    if (mode == SGDFR_MODE_UP3) return launch_wgrad<SGDFR_MODE_UP3, 32>(p, st);
+    return launch_wgrad<SGDFR_MODE_PLAIN3, 64>(p, st);
+}
+
+extern "C" int sgdfr_modconv_wgrad_finish_parts_f32(const float* part, int ksplit, const float* wp, const float* dq,
+                                                    float* dweight, int Cout, int Cin, void* stream) {
+    SGDFR_REQUIRE(Cout > 0 && Cin > 0 && ksplit > 0, "wgrad_finish_parts: bad shape %d %d x%d", Cout, Cin, ksplit);
+    SGDFR_REQUIRE(part && dweight && (wp || !dq), "wgrad_finish_parts: null pointer");
+    const int64_t total = (int64_t)Cout * Cin * 9;
+    int64_t gsz = (total + 255) / 256;
+    if (gsz > 4096) gsz = 4096;
+    hipLaunchKernelGGL(wgrad_finish_parts_kernel, dim3((int)gsz), dim3(256), 0, as_stream(stream), part, ksplit, wp, dq, dweight,
+                       Cout, Cin, 1.0f / sqrtf((float)Cin * 9));
+    return check_launch("modconv_wgrad_finish_parts");
+}
+
 extern "C" int sgdfr_modconv_wgrad_f32(const float* g, const float* d, const float* x, int64_t x_bstride, const float* s,
                                        float* dwp, int B, int Cin, int Cout, int H, int W, int mode, void* stream) {
     SGDFR_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "wgrad: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin,
@@ -203,10 +277,7 @@ extern "C" int sgdfr_modconv_wgrad_f32(const float* g, const float* d, const flo
     hipStream_t st = as_stream(stream);
     WgradParams p{};
     p.g = g; p.d = d; p.x = x; p.x_bstride = x_bstride; p.s = s; p.dwp = dwp;
-    p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.P = W + 1; p.R = H + 1;
-    const int pcmax = (mode == SGDFR_MODE_UP3) ? 32 : 64;
-    const int PC = W < pcmax ? W : pcmax;
-    const bool mfma_ok = (W % PC == 0) && (PC % 2 == 0);
+    const bool mfma_ok = wgrad_shape(p, B, Cin, Cout, H, W, mode);
     if (!mfma_ok) {
         const int64_t total = (int64_t)Cin * 9 * Cout;
         int64_t gsz = (total + 255) / 256;
@@ -215,9 +286,6 @@ extern "C" int sgdfr_modconv_wgrad_f32(const float* g, const float* d, const flo
         return check_launch("modconv_wgrad(direct)");
     }
     if (hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)Cin * 9 * Cout, st) != hipSuccess) return check_launch("memset");
-    p.PC = PC;
-    p.chunks_per_row = W / PC;
-    p.total_chunks = B * H * p.chunks_per_row;
     if (mode == SGDFR_MODE_UP3) return launch_wgrad<SGDFR_MODE_UP3, 32>(p, st);
     return launch_wgrad<SGDFR_MODE_PLAIN3, 64>(p, st);
 }

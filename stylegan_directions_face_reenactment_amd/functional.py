@@ -669,9 +669,16 @@ def wgrad(g, d, x, s, cout, upsample, wp=None, dq=None):
     B = s.shape[0]
     _, cin, H, W = x.shape
     xb = 0 if (x.shape[0] == 1 and B != 1) else cin * H * W
-    dwp = torch.empty(cin, 9, cout, device=x.device, dtype=torch.float32)
-    N.call('sgdfr_modconv_wgrad_f32', N.ptr(g), N.ptr(d), N.ptr(x), xb, N.ptr(s), N.ptr(dwp), B, cin, cout, H, W,
-           N.MODE_UP3 if upsample else N.MODE_PLAIN3, N.stream())
+    mode = N.MODE_UP3 if upsample else N.MODE_PLAIN3
     dw = torch.empty(1, cout, cin, 3, 3, device=x.device, dtype=torch.float32)
+    ks = _shape_query('sgdfr_modconv_wgrad_ksplit', B, cin, cout, H, W, mode)
+    if ks > 0:      # slice sums in a partials buffer, added in fixed order by the finish launch (no atomics)
+        part = torch.empty(ks, 9, cout, cin, device=x.device, dtype=torch.float32)
+        N.call('sgdfr_modconv_wgrad_parts_f32', N.ptr(g), N.ptr(d), N.ptr(x), xb, N.ptr(s), N.ptr(part), B, cin, cout, H, W, mode,
+               N.stream())
+        N.call('sgdfr_modconv_wgrad_finish_parts_f32', N.ptr(part), ks, N.ptr(wp), N.ptr(dq), N.ptr(dw), cout, cin, N.stream())
+        return dw
+    dwp = torch.empty(cin, 9, cout, device=x.device, dtype=torch.float32)
+    N.call('sgdfr_modconv_wgrad_f32', N.ptr(g), N.ptr(d), N.ptr(x), xb, N.ptr(s), N.ptr(dwp), B, cin, cout, H, W, mode, N.stream())
     N.call('sgdfr_modconv_wgrad_finish_f32', N.ptr(dwp), N.ptr(wp), N.ptr(dq), N.ptr(dw), cout, cin, N.stream())
     return dw
