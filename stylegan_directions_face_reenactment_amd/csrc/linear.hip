@@ -2,6 +2,8 @@
 // style modulation, the demodulation coefficients and DirectionMatrix.  M = batch (1..512),
 // N, K <= 4096: a few hundred MFLOP per forward against ~2 TFLOP of convolution, so these are
 // LDS-tiled fp32 VALU kernels (exact fmaf chains) sized for launch latency, not MFMA.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace sgdfr {
@@ -239,8 +241,16 @@ extern "C" int sgdfr_style_demod_f32(const float* style, int64_t ld_style, const
     if (B == 0) return 0;
     SGDFR_REQUIRE(style && mod_w && mod_b && s, "style_demod: null pointer");
     SGDFR_REQUIRE(ld_style >= D, "style_demod: ld_style < D");
-    int rc = launch_linear<0, 0>(style, ld_style, mod_w, mod_b, s, Cin, B, Cin, D, 1.0f / sqrtf((float)D), 1.0f,
-                                     SGDFR_ACT_NONE, 0.f, 1.f, stream);
+    int rc;
+    static const bool skinny_ok = !(getenv("SGDFR_STYLE_SKINNY") && atoi(getenv("SGDFR_STYLE_SKINNY")) == 0);
+    if (skinny_ok && B <= 128 && D <= 512 && Cin >= 64) {      // a few rows through a small layer: the wave-per-column form (see sgdfr_linear_f32)
+        hipLaunchKernelGGL(linear_skinny_kernel, dim3((Cin + 3) / 4), dim3(256), 0, as_stream(stream), style, ld_style, mod_w, mod_b, s,
+                           (int64_t)Cin, B, Cin, D, 1.0f / sqrtf((float)D), 1.0f, SGDFR_ACT_NONE, 0.f, 1.f);
+        rc = check_launch("style_demod(skinny)");
+    } else {
+        rc = launch_linear<0, 0>(style, ld_style, mod_w, mod_b, s, Cin, B, Cin, D, 1.0f / sqrtf((float)D), 1.0f,
+                                 SGDFR_ACT_NONE, 0.f, 1.f, stream);
+    }
     if (rc || !d) return rc;
     SGDFR_REQUIRE(q && Cout > 0, "style_demod: d requested without q/Cout");
     return launch_linear<1, 1>(s, Cin, q, nullptr, d, Cout, B, Cout, Cin, 1e-8f, 0.f, 0, 0.f, 1.f, stream);

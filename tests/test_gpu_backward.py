@@ -161,7 +161,11 @@ def test_conv_weight_gradient(cin, cout, h, up, B):
     nz = S.counter_tensor(25, key + 'n', (1, 1, r, r))
     g = S.counter_tensor(25, key + 'g', (B, cout, r, r))
     P = {'L.' + k: v.double().requires_grad_(k == 'conv.weight') for k, v in sd.items()}
-    (O.styled_conv(P, 'L', x.double(), st.double(), nz.double(), upsample=up) * g.double()).sum().backward()
+    yo = O.styled_conv(P, 'L', x.double(), st.double(), nz.double(), upsample=up)
+    # an output within rounding of 0 takes either slope of the leaky ReLU depending on the last bit of any fp32 kernel (one
+    # such element among 262144 moves dL/dW by 1.7e-3): those elements get no upstream gradient on either side
+    g = g * (yo.detach().abs() > 1e-5).float()
+    (yo * g.double()).sum().backward()
     m = m.cuda()
     (m(x.cuda(), st.cuda(), noise=nz.cuda()) * g.cuda()).sum().backward()
     assert m.conv.weight.grad is not None and m.conv.weight.grad.shape == (1, cout, cin, 3, 3)
