@@ -454,7 +454,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     const bool whole = p.ksplit == 1;     // K slices only scale by d; noise / bias / activation follow the reduction
     const bool fuse_rgb = !UP && !DOWN && whole && p.rgb_part != nullptr;      // fused ToRGB partial sums (PLAIN3)
     const bool early = p.simgs <= 2;
-    float* const dl = early ? ls + ((p.simgs * p.Cin + 3) & ~3) : reinterpret_cast<float*>(smem);   // [simgs][NT]  d * output scale
+    // (DOWN3 has no style table: its input arrives modulated)
+    float* const dl = early ? ls + (DOWN ? 0 : ((p.simgs * p.Cin + 3) & ~3)) : reinterpret_cast<float*>(smem);   // [simgs][NT]  d * output scale
     float* const bl = dl + p.simgs * NT;                        // [NT]            bias
     float* const cw = bl + NT;                                  // [simgs][NT][4]  ToRGB coefficients
     float* const red = cw + p.simgs * NT * 4;                   // [WM][PT][3]     ToRGB cross-wave reduce
@@ -950,7 +951,7 @@ static const SplitPlan kPlanDown = {5, 128, 256, 1, 8};         // adjoint of th
 
 static size_t split_lds_bytes(const SplitParams& p, int NT, int nss, bool down = false) {
     const size_t wslot = down ? (size_t)NT * 256 : (size_t)NT * 192 * (3 / nss);       // DOWN3: 4 taps x 64 bytes per cout
-    const size_t loop = 2 * (size_t)64 * p.xs + 2 * wslot + (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float);
+    const size_t loop = 2 * (size_t)64 * p.xs + 2 * wslot + (down ? 0 : (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float));
     const size_t epi = ((size_t)p.simgs * NT * 6 + NT + 2 * 512 * 3) * sizeof(float);   // d, bias, ToRGB coefficient / reduce, next-style tables
     if (p.simgs <= 2) return loop + epi;      // tables live beside the style table for the whole kernel
     return loop > epi ? loop : epi;           // tables overwrite the dead staging buffers after the K loop

@@ -224,7 +224,8 @@ def test_persistent_blocks_match_one_block_per_tile(cin, cout, H, B):
     assert torch.equal(yd, F_.modconv_split(x, wsp, s, d, cout, arith='fp16x3'))
 
 
-@pytest.mark.parametrize('C,cin,H,B', [(64, 128, 32, 6), (32, 128, 64, 3), (128, 256, 8, 40), (16, 128, 16, 5), (64, 128, 128, 2)])
+@pytest.mark.parametrize('C,cin,H,B', [(64, 128, 32, 6), (32, 128, 64, 3), (128, 256, 8, 40), (16, 128, 16, 5), (64, 128, 128, 2),
+                                       (512, 512, 4, 64), (512, 512, 4, 1)])
 def test_split_down3_matches_fp32_kernel_and_oracle(C, cin, H, B):
     """dL/d(x*s) of the transposed conv (mode DOWN3: stride-2 conv over the gradient's parity planes) on the split kernels
     (bf16 terms) vs the fp32 MFMA kernel of the same mode and vs torch's fp64 conv_transpose2d autograd."""
