@@ -200,3 +200,31 @@ def test_pti_style_step_updates_generator():
     with torch.no_grad():
         img2, _ = G2([w.cuda()], input_is_latent=True)      # repacked weights are picked up
     assert float(((img2 - target.cuda()) ** 2).mean()) < float(loss)
+
+
+def test_pti_driver_graph_replay_matches_eager_steps():
+    """finetune.optimize_g (counterpart of libs/optimization.py:25-72): 12 steps replayed as one captured hipGraph end at the
+    same weights as 12 eager steps, the loss goes down, and only convs[4..11] move."""
+    import copy
+    from stylegan_directions_face_reenactment_amd import finetune
+    G0 = hip_generator(256, 1)
+    w = S.synthetic_latents(SEED, 1, n_latent=G0.n_latent, key='pti.w').cuda()
+    trunc = S.counter_tensor(SEED, 'pti.t', (1, 512)).cuda()
+    with torch.no_grad():
+        base, _ = G0([w], input_is_latent=True, truncation=0.7, truncation_latent=trunc)
+    target = (base + 0.3 * S.counter_tensor(SEED, 'pti.d', tuple(base.shape)).cuda()).clamp(-1, 1)
+    runs = {}
+    for graph in (False, True):
+        G = copy.deepcopy(G0)
+        first = finetune.l2_loss_fn(G([w], input_is_latent=True, truncation=0.7, truncation_latent=trunc)[0], target, 100).item()
+        G, loss = finetune.optimize_g(G, w, target, trunc, opt_steps=12, lr=1e-3, graph=graph)
+        assert loss.item() < first
+        runs[graph] = (G, loss.item())
+    Ge, Gg = runs[False][0], runs[True][0]
+    assert abs(runs[False][1] - runs[True][1]) <= 2e-3 * abs(runs[False][1])
+    for (k, a), (_, b), (_, c) in zip(Ge.state_dict().items(), Gg.state_dict().items(), G0.state_dict().items()):
+        moved = k.startswith('convs.') and 4 <= int(k.split('.')[1]) <= 11 and 'kernel' not in k
+        if moved:
+            assert torch.allclose(a, b, rtol=2e-3, atol=2e-4), k
+        else:
+            assert torch.equal(a, c) and torch.equal(b, c), k
