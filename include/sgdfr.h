@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 4
+#define SGDFR_ABI_VERSION 5
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -166,10 +166,11 @@ int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const float* noise
                             float slope, float gain, void* stream);
 
 /* sgdfr_blur_bias_act_f32 with the result multiplied by the NEXT layer's modulation s_next [B,C] and written in that layer's
- * split input form xs [B][C/8][2][2H*2W][8] (see sgdfr_to_split_f32) instead of fp32 NCHW. */
+ * split input form xs [B][C/8][2][2H*2W][8] (see sgdfr_to_split_f32) instead of fp32 NCHW.  plane_stride: floats between the
+ * parity planes of t (0 = dense (H+1)*(W+1), see sgdfr_modconv2d_split_f32). */
 int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, const float* noise, int64_t noise_bstride,
                                   const float* noise_w, const float* bias, const float* s_next, unsigned short* xs, int B, int C,
-                                  int H, int W, int arith, int act, float slope, float gain, void* stream);
+                                  int H, int W, int64_t plane_stride, int arith, int act, float slope, float gain, void* stream);
 
 /* y[b,j,p] = sum_i w_rgb[j*Cin+i]/sqrt(Cin) * s[b,i] * x[b,i,p] + bias[j]
  *          + (skip ? upfirdn2d(skip[b,j] (H/2 x W/2), fir[4,4], up=2, pad=(2,1))[p] : 0),  j<3 */
@@ -210,8 +211,11 @@ int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned 
                               const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
                               const float* zeros, float* y, float* partials, int ksplit, const float* rgb_w,
                               const float* rgb_s, float* rgb_part, int x_is_split, unsigned short* xs_out, const float* s_next,
-                              int B, int Cin, int Cout, int H, int W, int mode, int arith, int act, float slope, float gain,
-                              void* stream);
+                              int B, int Cin, int Cout, int H, int W, int mode, int64_t plane_stride, int arith, int act,
+                              float slope, float gain, void* stream);
+/* plane_stride (UP3, ksplit <= 1; 0 = dense): floats between the parity planes of y, >= (H+1)*(W+1).  A multiple of 32 makes
+ * every 32-position store run of the kernel one whole 128-byte line (dense planes are odd-sized, their stores run at half the
+ * write bandwidth); sgdfr_blur_bias_act_split_f32 takes the same stride. */
 /* x [B,Cin,H,W], s [B,Cin] -> xs [B][Cin/8][2][H*W][8] 16-bit: x*s already split (and range-shifted) the way the kernel
  * stages it; sgdfr_modconv2d_split_f32(x = xs, s = NULL, x_is_split = 1) then fills LDS by DMA only.  Producers can emit
  * that form directly: sgdfr_modconv2d_split_f32(xs_out, s_next = the NEXT layer's modulation [B,Cout]) (y may then be NULL)

@@ -39,10 +39,11 @@ __global__ __launch_bounds__(512) void probe(float* __restrict__ y, int HW, int 
 }
 
 template <int V>
-void run(const char* name) {
+void run(const char* name, int misalign = 0) {      // misalign: floats added to the base, so every 128-byte run straddles two lines
     const int B = 64, HW = 65536;
-    float* y;
-    hipMalloc(&y, (size_t)B * 64 * HW * 4);
+    float* y0;
+    hipMalloc(&y0, (size_t)B * 64 * HW * 4 + 256);
+    float* y = y0 + misalign;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int tiles = HW / 512;
@@ -55,12 +56,15 @@ void run(const char* name) {
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     printf("%-28s %8.1f us per 1.07 GB  = %6.2f TB/s\n", name, ms / 5 * 1e3, (double)B * 64 * HW * 4 / (ms / 5 * 1e-3) / 1e12);
-    hipFree(y);
+    hipFree(y0);
 }
 
 int main() {
     run<0>("global_store_dword x64");
     run<1>("global_store_dwordx4 x16");
+    run<0>("global_store_dword x64");
+    run<0>("dword x64, runs misaligned", 13);
+    run<1>("dwordx4 x16, misaligned", 13);
     run<0>("global_store_dword x64");
     return 0;
 }

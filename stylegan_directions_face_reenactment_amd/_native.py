@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libsgdfr_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -45,7 +45,7 @@ SIGNATURES = {
     'sgdfr_modconv2d_split_supported': [_i, _i, _i, _i, _i, _i],
     'sgdfr_modconv2d_split_f32': [_c_f32p, _i64, ctypes.c_void_p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
                                   _c_f32p, _c_f32p, _i, _c_f32p, _c_f32p, _c_f32p, _i, ctypes.c_void_p, _c_f32p, _i, _i, _i, _i,
-                                  _i, _i, _i, _i, _f, _f, ctypes.c_void_p],
+                                  _i, _i, _i64, _i, _i, _f, _f, ctypes.c_void_p],
     'sgdfr_to_split_f32': [_c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_planes_to_split_f32': [_c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_blur_adjoint_split_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _c_f32p, _i, _i, _i, _i, _i, ctypes.c_void_p],
@@ -66,8 +66,8 @@ SIGNATURES = {
                                 _i, _i, _i, _i, _i, _i, _i, _f, _f, ctypes.c_void_p],
     'sgdfr_blur_bias_act_f32': [_c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i, _i, _f,
                                 _f, ctypes.c_void_p],
-    'sgdfr_blur_bias_act_split_f32': [_c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i,
-                                      _i, _f, _f, ctypes.c_void_p],
+    'sgdfr_blur_bias_act_split_f32': [_c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i64,
+                                      _i, _i, _f, _f, ctypes.c_void_p],
     'sgdfr_torgb_fwd_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i,
                             ctypes.c_void_p],
 }

@@ -91,6 +91,7 @@ struct SplitParams {
     int stagger;                 // which waves run MFMAs before staging inside a sub-stage (0 none, 1 waves 4-7, 2 odd waves)
     int dbg;
     int total_blocks;            // tiles x cout tiles x K slices; the grid may be smaller (persistent blocks)
+    int rps;                     // UP3: positions per image of the flat space = stride of one parity plane, >= R*P (see plane_stride)
 };
 
 constexpr int SPLIT_CB = 16;     // input channels per K block (one MFMA K)
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             t.col0 = tx * p.TC;
         } else if (UP || DOWN) {
             t.q0 = t.pt * PT;                       // super-pixels ARE positions of the padded flat space
-            t.img0 = t.q0 / (p.R * p.P);
+            t.img0 = t.q0 / (UP ? p.rps : p.R * p.P);
         } else {
             const int p0 = t.pt * PT;
             t.img0 = p0 / HW;
@@ -233,6 +234,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             img = q / HWin;
             pix = q - img * HWin;
             ok = ok && img < p.B;
+        } else if (UP) {          // position r of image img = grid point (r / P, r % P); r >= R*P is the stride padding
+            const int q = t.q0 + j;
+            img = q / p.rps;
+            const int r = q - img * p.rps;
+            const int pr = r / p.P, pc = r - pr * p.P;
+            ok = ok && r < p.R * p.P && pc >= 1 && pr >= 1 && img < p.B;
+            pix = (pr - 1) * p.W + (pc - 1);
         } else {
             const int q = t.q0 + j;
             const int pir = q / p.P, pc = q - pir * p.P;
@@ -279,10 +287,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             int64_t pix = (int64_t)pt * PT + l;
             const bool ok = pix < p.total_pix;
             if (!ok) pix = p.total_pix - 1;
-            const int img = (int)(pix / RP);
-            const int rem = (int)(pix - (int64_t)img * RP);
+            const int img = (int)(pix / p.rps);
+            const int rem = (int)(pix - (int64_t)img * p.rps);
             boff[n] = l;
-            ybase[n] = ok ? (int64_t)img * p.Cout * 4 * RP + rem : -1;
+            ybase[n] = (ok && rem < RP) ? (int64_t)img * p.Cout * 4 * p.rps + rem : -1;      // (rem >= R*P: stride padding)
             nzoff[n] = 0;
             dimg[n] = img;
         } else if (DOWN) {        // position (a, b) of the (H+1) x (W+1) grid -> output pixel (a, b) when a < H and b < W
@@ -344,6 +352,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             img = img0;
             ok = in_range && row >= 0 && row < p.H && col >= 0 && col < p.W && img < p.B;
             pix = row * p.W + col;
+        } else if (UP) {
+            const int q = q0 + j;
+            img = q / p.rps;
+            const int r = q - img * p.rps;
+            const int pr = r / p.P, pc = r - pr * p.P;
+            ok = in_range && r < p.R * p.P && pc >= 1 && pr >= 1 && img < p.B;
+            pix = (pr - 1) * p.W + (pc - 1);
         } else {
             const int q = q0 + j;
             const int pir = q / p.P, pc = q - pir * p.P;
@@ -763,9 +778,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                     const int co = n0 + wm * (MI * 32) + cl + 4 * hi;
                     const float dv = dln[cl];
                     if (UP) {
-                        float* dst = yout + ybase[n] + (int64_t)co * 4 * RP;
+                        float* dst = yout + ybase[n] + (int64_t)co * 4 * p.rps;
 #pragma unroll
-                        for (int ph = 0; ph < PH; ++ph) dst[(int64_t)ph * RP] = acc[ph][m][n][r] * dv;
+                        for (int ph = 0; ph < PH; ++ph) dst[(int64_t)ph * p.rps] = acc[ph][m][n][r] * dv;
                     } else {
                         const float v = lrelu_gain(acc[0][m][n][r] * dv + nz[n] + bln[cl], e_slope, e_gain);
                         if (HAS_Y) yout[ybase[n] + (int64_t)co * HW] = v;      // (no y: only the fused ToRGB / xs_out consume this layer)
@@ -974,6 +989,7 @@ static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, cons
         p.xlen = PT + p.P + 2;
         p.simgs = (p.xlen - 1) / (p.R * p.P) + 2;
         p.n_pix_tiles = (int)((p.total_pix + PT - 1) / PT);
+        p.rps = p.R * p.P;
     } else if (W > 64) {
         p.patch = 1;
         p.TC = 128;
@@ -1190,7 +1206,7 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
                                          const float* bias, const float* zeros, float* y, float* partials, int ksplit,
                                          const float* rgb_w, const float* rgb_s, float* rgb_part, int x_is_split,
                                          unsigned short* xs_out, const float* s_next, int B, int Cin, int Cout, int H, int W,
-                                         int mode, int arith, int act, float slope, float gain, void* stream) {
+                                         int mode, int64_t plane_stride, int arith, int act, float slope, float gain, void* stream) {
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "modconv_split: arith must be SGDFR_SPLIT_BF16/FP16");
     SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "modconv_split: bad shape B=%d Cin=%d Cout=%d H=%d W=%d",
                   B, Cin, Cout, H, W);
@@ -1213,6 +1229,19 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
                   "modconv_split: wsp and s must be 16-byte aligned");
     SplitParams p;
     const SplitPlan* plan = split_plan(B, Cin, Cout, H, W, mode, &p);
+    if (plane_stride != 0) {
+        // UP3 with padded parity planes y [B,Cout,4,plane_stride]: a multiple of 32 floats makes every 32-position store run of
+        // the epilogue one whole 128-byte line (the dense (H+1)(W+1) planes are odd-sized: every run straddles two lines and
+        // plane stores run at 2.4 instead of 4.7 TB/s, scripts/store_probe.hip).  The flat position space gets the same
+        // per-image stride, so tiles stay 256 consecutive positions; the padding positions are computed and dropped.
+        SGDFR_REQUIRE(mode == SGDFR_MODE_UP3 && plane_stride >= (int64_t)p.R * p.P && plane_stride < (1 << 30) && ksplit <= 1,
+                      "modconv_split: plane_stride is for UP3 launches without K slices, >= (H+1)*(W+1)");
+        p.rps = (int)plane_stride;
+        p.total_pix = (int64_t)B * p.rps;
+        SGDFR_REQUIRE(p.total_pix + 4ll * p.P + 8 < (1ll << 31), "modconv_split: padded position space too large");
+        p.n_pix_tiles = (int)((p.total_pix + plan->pt - 1) / plan->pt);
+        p.simgs = (p.xlen - 1) / p.rps + 2;
+    }
     p.x = x; p.x_bstride = x_bstride; p.wsp = wsp; p.s = s; p.d = d; p.noise = noise; p.noise_bstride = noise_bstride;
     p.noise_w = noise_w; p.bias = bias; p.zeros = zeros; p.y = y;
     p.act = act; p.slope = slope; p.gain = gain;
@@ -1223,7 +1252,7 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
     p.xs_out = reinterpret_cast<unsigned char*>(xs_out); p.s_next = s_next;
     SGDFR_REQUIRE(ksplit == 1 || (partials && ksplit <= Cin / SPLIT_CB), "modconv_split: ksplit %d needs a partials buffer "
                   "and at most %d slices", ksplit, Cin / SPLIT_CB);
-    const int64_t n_out = (mode == SGDFR_MODE_UP3) ? (int64_t)B * Cout * 4 * p.R * p.P : (int64_t)B * Cout * H * W;
+    const int64_t n_out = (mode == SGDFR_MODE_UP3) ? (int64_t)B * Cout * 4 * p.rps : (int64_t)B * Cout * H * W;
     p.ksplit = ksplit;
     p.split_stride = n_out;
     if (ksplit > 1) p.y = partials;

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restr
                                                         const float* __restrict__ noise, int64_t noise_bstride,
                                                         const float* __restrict__ noise_w, const float* __restrict__ bias,
                                                         const float* __restrict__ s_next, unsigned char* __restrict__ xs,
-                                                        int B, int C, int H, int W, int act, float slope, float gain) {
+                                                        int B, int C, int H, int W, int pstride, int act, float slope, float gain) {
     // fp32 results of the block's tile as [row 8][px 128][channel 8 (+1 pad: the lanes of a wave write px 2 apart ->
     // 18-dword stride, conflict-free)]; the hand-over to 16-byte chunks happens when the tile is read back.
     // 8 waves = 8 channels, a wave = 64 quad columns (256-byte coalesced plane reads, as the fp32 kernel).
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 16; ++i) kf[i] = fir[15 - i];
     const int GW = W + 1, GH = H + 1;
-    const int64_t plane_t = (int64_t)4 * GH * GW;
+    const int64_t plane_t = (int64_t)4 * pstride;          // pstride = floats between parity planes (>= GH*GW)
     const int G = C / 8, OW = 2 * W, OHW = 4 * H * W;
     const int col_tiles = (W + QC - 1) / QC, row_tiles = (H + BLUR_QV - 1) / BLUR_QV;
     const int64_t n_tiles = (int64_t)B * G * row_tiles * col_tiles;
@@ -223,12 +223,12 @@ __global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restr
             for (int v = 0; v < 5; ++v) {
                 const int tc = 2 * n - 1 + v;
                 cok[v] = tc >= 0;
-                coff[v] = (tc & 1) * GH * GW + (tc >> 1);
+                coff[v] = (tc & 1) * pstride + (tc >> 1);
             }
             float win[5][5];
             auto load_row = [&](int tr, float (&dst)[5]) {
                 const bool rok = tr >= 0;
-                const int roff = (tr & 1) * 2 * GH * GW + (tr >> 1) * GW;
+                const int roff = (tr & 1) * 2 * pstride + (tr >> 1) * GW;
 #pragma unroll
                 for (int v = 0; v < 5; ++v) dst[v] = (rok && cok[v]) ? tp[roff + coff[v]] : 0.f;
             };
@@ -476,24 +476,26 @@ extern "C" int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const f
 
 extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, const float* noise, int64_t noise_bstride,
                                              const float* noise_w, const float* bias, const float* s_next, unsigned short* xs,
-                                             int B, int C, int H, int W, int arith, int act, float slope, float gain,
-                                             void* stream) {
+                                             int B, int C, int H, int W, int64_t plane_stride, int arith, int act, float slope,
+                                             float gain, void* stream) {
     SGDFR_REQUIRE(B >= 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "blur_bias_act_split: bad shape %d %d %d %d (C %% 8)", B, C, H, W);
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "blur_bias_act_split: arith must be SGDFR_SPLIT_BF16/FP16");
     if (B == 0) return 0;
     SGDFR_REQUIRE(t && fir && s_next && xs && (reinterpret_cast<uintptr_t>(xs) & 15) == 0, "blur_bias_act_split: null / misaligned pointer");
     SGDFR_REQUIRE(!noise || noise_w, "blur_bias_act_split: noise without noise_w");
+    if (plane_stride == 0) plane_stride = (int64_t)(H + 1) * (W + 1);
+    SGDFR_REQUIRE(plane_stride >= (int64_t)(H + 1) * (W + 1) && plane_stride < (1 << 30), "blur_bias_act_split: plane_stride < (H+1)*(W+1)");
     const int QC = W >= 64 ? 64 : 32;
     const int64_t tiles = (int64_t)B * (C / 8) * ((H + BLUR_QV - 1) / BLUR_QV) * ((W + QC - 1) / QC);
     int64_t g = tiles;
     if (g > 256 * 32) g = 256 * 32;
     unsigned char* out = reinterpret_cast<unsigned char*>(xs);
     void (*kern)(const float*, const float*, const float*, int64_t, const float*, const float*, const float*, unsigned char*, int,
-                 int, int, int, int, float, float);
+                 int, int, int, int, int, float, float);
     if (arith == SGDFR_SPLIT_FP16) kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_FP16, 64> : blur_split_kernel<SGDFR_SPLIT_FP16, 32>;
     else kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_BF16, 64> : blur_split_kernel<SGDFR_SPLIT_BF16, 32>;
     hipLaunchKernelGGL(kern, dim3((int)g), dim3(8 * QC), 0, as_stream(stream), t, fir, noise, noise_bstride, noise_w, bias, s_next,
-                       out, B, C, H, W, act, slope, gain);
+                       out, B, C, H, W, (int)plane_stride, act, slope, gain);
     return check_launch("blur_bias_act_split");
 }
 

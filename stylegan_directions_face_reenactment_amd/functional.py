@@ -174,6 +174,7 @@ def _noise_args(noise, B, H, W):
     raise RuntimeError('noise of shape %s does not broadcast to [%d,1,%d,%d]' % (tuple(noise.shape), B, H, W))
 
 
+USE_PLANE_PADDING = os.environ.get('SGDFR_PLANE_PADDING', '1') != '0'     # inference chain: parity planes of the transposed conv padded to whole 128-byte lines
 USE_SPLIT_CHAIN = os.environ.get('SGDFR_SPLIT_CHAIN', '1') != '0'   # activations between split convs only in split form
 USE_RGB_FUSION = True        # ToRGB partial sums in the epilogue of the split conv that feeds it (no-grad path)
 USE_SPLITK = True            # K-sliced launches for convs that cannot fill the chip (small batch / 4x4, 8x8 layers)
@@ -280,7 +281,8 @@ def split_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
 
 
 def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2,
-                  batch=None, desc=None, mode=N.MODE_PLAIN3, arith=None, rgb=None, out=None, want_y=True, x_split=None, s_next=None):
+                  batch=None, desc=None, mode=N.MODE_PLAIN3, arith=None, rgb=None, out=None, want_y=True, x_split=None, s_next=None,
+                  plane_stride=0):
     """3x3 modulated conv in a split arithmetic (same contract as modconv_raw, modes PLAIN3 and UP3); `wsp` must have
     been packed for the same `arith`.  rgb = (w_rgb [3,Cout], s_rgb [B,Cout]) also returns the per-cout-tile partial sums
     [B, T*3, H, W] of the ToRGB 1x1 conv that follows the layer (see rgb_fusable / torgb_finish)."""
@@ -308,9 +310,10 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
         y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
     elif mode == N.MODE_UP3:
         nz, nzb = None, 0
-        y = out if out is not None else torch.empty(B, cout, 4, H + 1, W + 1, device=x.device, dtype=torch.float32)
-        if tuple(y.shape) != (B, cout, 4, H + 1, W + 1) or not y.is_contiguous():
-            raise RuntimeError('modconv_split: out must be a contiguous [B,Cout,4,H+1,W+1] tensor')
+        pshape = (B, cout, 4, H + 1, W + 1) if not plane_stride else (B, cout, 4, int(plane_stride))      # padded planes: flat
+        y = out if out is not None else torch.empty(pshape, device=x.device, dtype=torch.float32)
+        if tuple(y.shape) != pshape or not y.is_contiguous():
+            raise RuntimeError('modconv_split: out must be a contiguous %s tensor' % (pshape,))
     else:
         nz, nzb = _noise_args(noise, B, H, W)
         if not want_y and rgb is None and s_next is None:
@@ -340,7 +343,7 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
         'sgdfr_modconv2d_split_f32', N.ptr(x), xb, N.ptr(wsp), N.ptr(s), N.ptr(d), N.ptr(nz), nzb,
         N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(_zero_words(x.device)), N.ptr(y),
         N.ptr(partials), ks, N.ptr(rgb_w), N.ptr(rgb_s), N.ptr(part), int(x_split is not None), N.ptr(xs_out),
-        N.ptr(s_next) if s_next is not None else None, B, cin, cout, H, W, mode, arith, int(activate),
+        N.ptr(s_next) if s_next is not None else None, B, cin, cout, H, W, mode, int(plane_stride), arith, int(activate),
         float(slope), float(gain), st))
     if s_next is not None:      # (activation or None, ToRGB partials or None, the activation in the next layer's split form)
         return y, part, xs_out
@@ -407,6 +410,13 @@ def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, 
             _, part, xs = res
             return SplitAct(xs, (B, cout, H, W)), part
         return res if rgb is not None else (res, None)
+    if s_next is not None and USE_PLANE_PADDING and \
+            _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, x_split[1] if x_split else x.shape[1], cout, H, W, N.MODE_UP3) == 1:
+        # parity planes padded to whole 128-byte lines: the odd-sized dense planes make every store run straddle two lines
+        ps = ((H + 1) * (W + 1) + 31) // 32 * 32
+        planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split, plane_stride=ps)
+        xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, plane_stride=ps)
+        return SplitAct(xs, (B, cout, 2 * H, 2 * W)), None
     planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split)
     if s_next is not None:
         xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True)
@@ -483,17 +493,18 @@ def blur_bias_act(planes, fir, H, W, noise=None, noise_weight=None, bias=None, a
 
 
 def blur_bias_act_split(planes, fir, H, W, s_next, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2,
-                        gain=SQRT2, arith=None):
+                        gain=SQRT2, arith=None, plane_stride=0):
     """blur_bias_act whose result goes out as the next layer's split input (x * s_next as 16-bit hi/lo pairs,
-    [B, C/8, 2, 2H*2W, 8] int16) instead of fp32 NCHW."""
+    [B, C/8, 2, 2H*2W, 8] int16) instead of fp32 NCHW.  plane_stride: floats between the parity planes when `planes` is the
+    padded [B, C, 4, plane_stride] buffer of modconv_split(mode=UP3, plane_stride=...)."""
     arith = _SPLIT_ARITH[arith or PRECISION]
     N.require_device(planes, fir, bias, noise_weight, s_next)
     B, C = planes.shape[0], planes.shape[1]
     nz, nzb = _noise_args(noise, B, 2 * H, 2 * W)
     xs = torch.empty(B, C // 8, 2, 4 * H * W, 8, device=planes.device, dtype=torch.int16)
     N.call('sgdfr_blur_bias_act_split_f32', N.ptr(planes), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
-           N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(N.f32c(s_next)), N.ptr(xs), B, C, H, W, arith,
-           int(activate), float(slope), float(gain), N.stream())
+           N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(N.f32c(s_next)), N.ptr(xs), B, C, H, W,
+           int(plane_stride), arith, int(activate), float(slope), float(gain), N.stream())
     return xs
 
 
