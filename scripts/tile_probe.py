@@ -23,8 +23,10 @@ for cin, cout, h, up, rgb, exs, wy in [(512, 512, 32, 0, 1, 1, 0), (256, 256, 64
     xs = F_.to_split(x, s, 'fp16x3')
     del x
     if up:
-        buf = torch.empty(B, cout, 4, h + 1, h + 1, device='cuda')
-        fn = lambda: F_.modconv_split(xs, wsp, None, d, cout, arith='fp16x3', mode=N.MODE_UP3, x_split=(B, cin, h, h), batch=B, out=buf)
+        ps = ((h + 1) * (h + 1) + 31) // 32 * 32 if os.environ.get('DENSE_PLANES', '0') == '0' else 0      # the chain's padded planes
+        buf = torch.empty((B, cout, 4, ps) if ps else (B, cout, 4, h + 1, h + 1), device='cuda')
+        fn = lambda: F_.modconv_split(xs, wsp, None, d, cout, arith='fp16x3', mode=N.MODE_UP3, x_split=(B, cin, h, h), batch=B, out=buf,
+                                      plane_stride=ps)
     else:
         rw = torch.randn(3, cout, device='cuda'); rs = torch.randn(B, cout, device='cuda'); sn = torch.randn(B, cout, device='cuda')
         fn = lambda: F_.modconv_split(xs, wsp, None, d, cout, nz, nw, bias, True, arith='fp16x3', x_split=(B, cin, h, h), batch=B,
