@@ -28,7 +28,14 @@
 //     for wider images; layers with too few tiles slice the channel blocks over more blocks (deterministic reduce).
 //   * epilogue: coefficients (d, bias, next layer's style, ToRGB weights) come from LDS tables so the wave issues its
 //     stores back to back; optional outputs: fp32 activation, the activation in the next conv's split input form, and the
-//     partial sums of the 1x1 ToRGB conv that follows the layer.
+//     partial sums of the 1x1 ToRGB conv that follows the layer -- which of them exist selects a branch-free instantiation
+//     of the element loop.  Transposed conv: `plane_stride` pads each parity plane (and the flat position space per image)
+//     to whole 128-byte lines, because a store run that straddles two lines costs twice.
+//   * layers of many short tiles (plain conv, pre-split input, >= 12 tiles per CU) run as persistent blocks: one block
+//     per CU walks its tiles and stages the next tile's first channel block and weight slab while the current tile's last
+//     one is in the matrix cores.
+//   * mode DOWN3 (backward of the transposed conv) reuses the transposed conv's position space and gather pattern with
+//     (channel block, phase) stages over phase-major pre-split planes (see the kernel's own comment).
 #include <stdlib.h>
 
 #include <type_traits>
