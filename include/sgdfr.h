@@ -27,6 +27,8 @@
  *                              its boundary is the Python method
  *   sgdfr_blur_bias_act_f32    model.py:257 Blur after the transposed conv (upfirdn2d pad (1,1)) + noise + bias + lrelu
  *   sgdfr_torgb_fwd_f32        model.py:350-359 ToRGB.forward (1x1 modconv, bias, Upsample(skip) :38-46, add)
+ *   sgdfr_make_shift_f32       run_inference.py:201-254 Inference.make_shift, libs/utilities/utils_train.py:127-175 make_shift_vector
+ *   sgdfr_make_shift_random_f32 libs/utilities/utils_train.py:227-286 (single-direction half of make_shift_vector_50)
  */
 #ifndef SGDFR_H
 #define SGDFR_H
@@ -37,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 5
+#define SGDFR_ABI_VERSION 6
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -259,6 +261,46 @@ int sgdfr_image_to_u8_f32(const float* x, unsigned char* y, int B, int H, int W,
 #define SGDFR_MAX_GRID_PANELS 4
 int sgdfr_grid_to_u8_f32(const float* const* panels, const int64_t* bstrides, int K, unsigned char* y, int B, int H,
                          int W, int swap_rb, void* stream);
+
+/* ---- shift-vector construction (the DirectionMatrix input), SURVEY.md §8f-2 ---------------------------------------- */
+
+/* One learned direction: which 3DMM parameter feeds it and how it is placed on the shift axis.
+ *   SGDFR_DIR_ANGLE: position = angle[col] * a / b      (a = shift_scale, b = angle_scales[col]; col 0 yaw, 1 pitch, 2 roll)
+ *   SGDFR_DIR_JAW:   position = a * pose[col] + b       (col = 3 in the reference, params['pose'][:, 3])
+ *   SGDFR_DIR_EXP:   position = a * alpha_exp[col] + b  (a, b from the line through (min,-shift_scale), (max,+shift_scale),
+ *                                                        libs/utilities/generic.py:84-104)
+ *   SGDFR_DIR_ZERO:  the direction is not driven (its entry stays 0) */
+#define SGDFR_DIR_ZERO 0
+#define SGDFR_DIR_ANGLE 1
+#define SGDFR_DIR_JAW 2
+#define SGDFR_DIR_EXP 3
+#define SGDFR_MAX_DIRECTIONS 64
+struct sgdfr_direction {
+    int kind;
+    int col;
+    double a;
+    double b;
+};
+
+/* shift[n,k] = position_k(target n) - position_k(source n) for N frames in one launch: the batched, sync-free counterpart of
+ * run_inference.py:201-254 Inference.make_shift (arith 0: float32 angle scaling, float64 divide / a*x+b / difference, one
+ * final rounding -- the numpy scalar arithmetic of that function) and of libs/utilities/utils_train.py:127-175
+ * make_shift_vector (arith 1: every operation rounded to float32 as torch does on float32 tensors; division is a true
+ * division as in torch's CPU kernel -- the CUDA kernel multiplies by a rounded reciprocal, 1 ulp apart).
+ * Source arrays have batch strides in floats (0 = one source identity for all frames, the run_inference case); target
+ * arrays are contiguous [N,3], [N,pose_dim], [N,exp_dim].  `table` is a HOST array of D entries (passed by value to the
+ * kernel). */
+int sgdfr_make_shift_f32(const float* ang_s, int64_t ang_s_bstride, const float* pose_s, int64_t pose_s_bstride,
+                         const float* exp_s, int64_t exp_s_bstride, const float* ang_t, const float* pose_t,
+                         const float* exp_t, int pose_dim, int exp_dim, const struct sgdfr_direction* table, int D,
+                         float* shift, int N, int arith, void* stream);
+
+/* Second half of make_shift_vector_50 (libs/utilities/utils_train.py:227-286): sample n moves along ONE direction which[n]
+ * (device int32 [N]) by (lo - hi) * u[n] + hi with lo/hi = -/+shift_scale - position(source n), float32 arithmetic; every
+ * other entry of its row is 0.  which / u are drawn by the caller (np.random.choice / torch.rand in the reference). */
+int sgdfr_make_shift_random_f32(const float* ang_s, const float* pose_s, const float* exp_s, int pose_dim, int exp_dim,
+                                const int* which, const float* u, float shift_scale, const struct sgdfr_direction* table,
+                                int D, float* shift, int N, void* stream);
 
 /* ---- backward helpers (autograd of model.py:232-359 as restated in SURVEY.md Appendix C) ------------------------ */
 

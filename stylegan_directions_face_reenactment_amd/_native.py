@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libsgdfr_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -72,6 +72,19 @@ SIGNATURES = {
                             ctypes.c_void_p],
 }
 
+
+
+class Direction(ctypes.Structure):
+    """struct sgdfr_direction (include/sgdfr.h)."""
+    _fields_ = [('kind', ctypes.c_int), ('col', ctypes.c_int), ('a', ctypes.c_double), ('b', ctypes.c_double)]
+
+
+DIR_ZERO, DIR_ANGLE, DIR_JAW, DIR_EXP = 0, 1, 2, 3
+MAX_DIRECTIONS = 64
+SIGNATURES['sgdfr_make_shift_f32'] = [_c_f32p, _i64, _c_f32p, _i64, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i, _i,
+                                      ctypes.POINTER(Direction), _i, _c_f32p, _i, _i, ctypes.c_void_p]
+SIGNATURES['sgdfr_make_shift_random_f32'] = [_c_f32p, _c_f32p, _c_f32p, _i, _i, ctypes.c_void_p, _c_f32p, _f,
+                                             ctypes.POINTER(Direction), _i, _c_f32p, _i, ctypes.c_void_p]
 
 
 class StyleLayer(ctypes.Structure):

@@ -85,8 +85,10 @@ def load_latent_codes(paths, device=None):
 class ReenactmentSession:
     """One source identity, many target poses/expressions."""
 
-    def __init__(self, G, A, source_code, truncation=0.7, trunc=None, batch=32, graph=False):
-        """graph=True captures one `batch`-sized step (DirectionMatrix -> shift -> generator) in a hipGraph the first time a
+    def __init__(self, G, A, source_code, truncation=0.7, trunc=None, batch=32, graph=False, shifts=None):
+        """shifts: a `shift.ShiftVectors` (direction tables of the dataset) -- then `render_targets` / `frames_for_targets`
+        take the 3DMM parameters of source and targets and build the shift vectors on the device too.
+        graph=True captures one `batch`-sized step (DirectionMatrix -> shift -> generator) in a hipGraph the first time a
         full batch is rendered and replays it afterwards: the ~65 launches of a step become one submission, which is what a
         small batch is bound by (B=1: 1.10 -> 0.72 ms per frame).  Weights must not be replaced while the graph is alive
         (call `reset_graph()` after loading new ones); partial last batches run eagerly."""
@@ -100,6 +102,7 @@ class ReenactmentSession:
         self.source = source_code.contiguous()
         self.truncation, self.trunc, self.batch = truncation, trunc, batch
         self.use_graph = bool(graph)
+        self.shifts = shifts
         self._graph = None          # (hipGraph, static shift-vector input, static image output)
 
     def reset_graph(self):
@@ -143,6 +146,21 @@ class ReenactmentSession:
 
     def render(self, shift_vectors, as_uint8=False):
         return torch.cat(list(self.frames(shift_vectors, as_uint8=as_uint8)), 0)
+
+    def shift_vectors_for(self, angles_source, params_source, angles_target, params_target):
+        """[N, learned_directions] for N target frames against the one source identity, in one launch and without a
+        host round trip (the reference: run_inference.py:178 `make_shift`, once per frame, ~10 `.cpu()` syncs each)."""
+        if self.shifts is None:
+            raise RuntimeError('this session was built without direction tables (pass shifts=ShiftVectors(...))')
+        return self.shifts.make_shift(angles_source, angles_target, params_source, params_target)
+
+    def frames_for_targets(self, angles_source, params_source, angles_target, params_target, as_uint8=False):
+        """run_inference.py:170-181 for all target frames: 3DMM parameters in, image batches out."""
+        return self.frames(self.shift_vectors_for(angles_source, params_source, angles_target, params_target), as_uint8=as_uint8)
+
+    def render_targets(self, angles_source, params_source, angles_target, params_target, as_uint8=False):
+        return torch.cat(list(self.frames_for_targets(angles_source, params_source, angles_target, params_target,
+                                                      as_uint8=as_uint8)), 0)
 
     @torch.no_grad()
     def video_frames(self, source_image, target_images, shift_vectors, swap_rb=True):

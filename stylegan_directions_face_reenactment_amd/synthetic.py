@@ -120,6 +120,16 @@ def synthetic_direction_state(seed, input_dim=15, out_dim=512, num_layers=8, w_p
     }
 
 
+def synthetic_shape_params(seed, key, n):
+    """3DMM parameters shaped like the reference's `calculate_shapemodel` output (libs/utilities/generic.py:22-34):
+    (angles [n,3] yaw/pitch/roll in degrees, {'pose': [n,6] (jaw = column 3), 'alpha_exp': [n,50]}) -- the inputs of the
+    shift-vector construction; DECA itself is not available offline."""
+    ang = counter_tensor(seed, key + '.ang', (n, 3), 0.0, 12.0)
+    pose = counter_tensor(seed, key + '.pose', (n, 6), 0.03, 0.08)
+    exp = counter_tensor(seed, key + '.exp', (n, 50), 0.1, 0.7)
+    return ang, {'pose': pose, 'alpha_exp': exp}
+
+
 def synthetic_encoder_state(template, seed=0):
     """Fill an Encoder4Editing-shaped state_dict (psp_encoders.py:122-160 key set) with synthetic values:
     conv filters ~ N(0, gain/fan_in) so activations stay O(1) through the 24 residual units and the style heads, BatchNorm statistics near

@@ -102,3 +102,31 @@ def test_state_layout_matches_reference_keys():
     assert shapes['to_rgbs.5.conv.weight'] == (1, 3, 64, 1, 1)
     assert shapes['noises.noise_12'] == (1, 1, 256, 256)
     assert O.generator_state_shapes(256, 512, 8, 2)['convs.11.conv.weight'] == (1, 128, 128, 3, 3)
+
+
+SHIFT_CASES = (('voxceleb', 15, 6), ('ffhq', 12, 6.0), ('voxceleb', 15, 4.5))
+
+
+def shift_case(g, dataset, D, sc, B=8):
+    """(tag, oracle config, source (angles, params), target (angles, params)) of one kat8 case, regenerated from the seed."""
+    from oracle import shift_oracle as SO
+    tag = '%s_%d_%s' % (dataset, D, str(sc).replace('.', 'p'))
+    cfg = SO.initialize_directions(dataset, D, sc, g['ranges_' + dataset])
+    return tag, cfg, S.synthetic_shape_params(SEED, tag + '.src', B), S.synthetic_shape_params(SEED, tag + '.tgt', B)
+
+
+def test_kat8_shift_vectors_bit_exact():
+    """oracle/shift_oracle.py == the real reference's make_shift / make_shift_vector(_50) (golden), bit for bit."""
+    from oracle import shift_oracle as SO
+    g = golden('kat8_shift.npz')
+    for dataset, D, sc in SHIFT_CASES:
+        tag, cfg, (ang_s, par_s), (ang_t, par_t) = shift_case(g, dataset, D, sc)
+        coef = np.array([[cfg['a_jaw'], cfg['b_jaw']]] + [[d['a'], d['b']] for d in cfg['directions_exp']])
+        assert (coef == g[tag + '.coef']).all()
+        assert (SO.make_shift_vector(cfg, par_s, par_t, ang_s, ang_t).numpy() == g[tag + '.train']).all()
+        sv50 = SO.make_shift_vector_50(cfg, par_s, par_t, ang_s, ang_t, g[tag + '.which'], t(g[tag + '.u']))
+        assert (sv50.numpy() == g[tag + '.train50']).all()
+        if tag + '.infer' in g.files:
+            rows = [SO.make_shift(cfg, ang_s[0:1], ang_t[i:i + 1], {k: v[0:1] for k, v in par_s.items()},
+                                  {k: v[i:i + 1] for k, v in par_t.items()}) for i in range(ang_t.shape[0])]
+            assert (torch.cat(rows, 0).numpy() == g[tag + '.infer']).all()
