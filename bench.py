@@ -1,30 +1,48 @@
 #!/usr/bin/env python
 """Headline benchmark: reenacted frames/s at 256x256 (BASELINE.json), MI355X-native generator path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64] [--cm 1] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config synthesis|inference|trainer] [--batch B] [--cm 1]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1] / configs[3]): StyleGAN2 synthesis network, Generator(256, 512, 8,
-channel_multiplier=1), random W+ codes [64, 14, 512] PER GPU already resident in HBM, fixed noise buffers,
-psi=1 (synthesis only), fp32 tensors end to end, synthetic deterministic weights (no checkpoints exist offline).
-Arithmetic of the 3x3 convs (--precision): fp16x3 (default; fp32 operands split into fp16 hi+lo, three MFMA products,
-fp32 accumulation -- held to the same error bound as the fp32 kernels by tests/test_gpu_split.py), fp32 (fp32 MFMA +
-Winograd kernels), bf16x3.  The default run also times the other arithmetic (`alt_arithmetic`).
-A step = one forward of the whole batch -> [64, 3, 256, 256] fp32 images.  Weak scaling: every rank
-generates its own 64-latent shard of the global batch; rank 0's weights are broadcast once over RCCL
-before the timed region and there is no collective inside it.
+`--gpus N` with N > 1 and no torchrun environment starts the N ranks ITSELF (re-executes under torch.distributed.run on
+127.0.0.1, one process per GPU, backend nccl = RCCL); it refuses to run when fewer than N devices are visible, and every
+rank checks WORLD_SIZE == --gpus, so a line that says n_gpus = N was measured on N RCCL ranks.
+
+--config (BASELINE.json `configs`):
+  synthesis (default; configs[1], and configs[3] at N > 1)  StyleGAN2 synthesis network, Generator(256, 512, 8, cm=1), random
+            W+ codes [64, 14, 512] PER GPU resident in HBM, fixed noise buffers, psi = 1.  A step = one forward of the batch
+            -> [64, 3, 256, 256] fp32 images.
+  inference (configs[2])  the run_inference.py flow at B = 32: the source W+ code comes from the e4e encoder once (outside the
+            timed loop, reported as `e4e_source_ms`); a step = 3DMM parameters of 32 target frames (resident) -> shift vectors
+            (device kernel) -> DirectionMatrix -> shift + truncation psi = 0.7 -> generator -> uint8 source|target|reenacted
+            video frames [32, 256, 768, 3].
+  trainer   (configs[4], per-rank shape B = 16)  one direction-learning step of libs/trainer.py:155-189: two no-grad forwards
+            (source, target) + shape-model stand-in, make_shift_vector_50 on the device, grad forward + backward to A through
+            the HIP generator, loss heads = IR-SE-50 id loss + LPIPS-shaped stack + DECA stand-in (scripts/loss_heads.py, stock
+            PyTorch-ROCm, random weights), one flat all-reduce of A's gradients, Adam step.  value = samples/s.
+Synthetic deterministic weights everywhere (no checkpoints exist offline).  Weak scaling: every rank works on its own shard
+of the global batch; rank 0's weights reach the others in ONE flat RCCL broadcast before the timed region and inference
+has no collective inside it.
+
+Arithmetic of the 3x3 convs (--precision): fp16x3 (default; fp32 operands as fp16 hi+lo, three MFMA products, fp32
+accumulation), fp32 (fp32 MFMA + Winograd kernels), bf16x3.  The synthesis run also times the other arithmetic
+(`alt_arithmetic`, with its own roofline).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline      the 13 3x3 conv launches of a forward: ALGORITHMIC FLOPs (2*9*Cin*Cout per input pixel, whatever
-                multiplies the kernel really issues) / HIP-event time on the launch stream.  peak = 2500/3 TFLOP/s for the
-                split arithmetics (dense 16-bit MFMA peak / 3 products), 157.3 TFLOP/s (fp32 MFMA) for --precision fp32
-  cpu_baseline  the oracle (CPU PyTorch restatement of the reference generator, kind "port") timed on this
-                host's cores on a bounded sample of the same workload (N=1 only)
+  roofline      the 3x3 conv launches of a step: ALGORITHMIC FLOPs (2*9*Cin*Cout per input pixel, whatever multiplies the
+                kernel really issues) / HIP-event time on the launch stream; peak = 2500/3 TFLOP/s for the split arithmetics
+                (dense 16-bit MFMA peak / 3 products per fp32 product), 157.3 TFLOP/s (fp32 MFMA) for --precision fp32;
+                `per_layer` lists every conv instantiation (us per launch, algorithmic TFLOP/s, fraction of that peak)
+  cpu_baseline  the oracle (CPU PyTorch restatement of the reference generator, kind "port") timed on this host's cores on
+                a bounded sample of the same workload (N=1, synthesis only): thread sweep, then B=2 and B=8
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,7 +60,86 @@ from stylegan_directions_face_reenactment_amd.model import Generator           #
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 SPLIT_PEAK_TFLOPS = 2500.0 / 3     # dense fp16/bf16 MFMA peak (same guide) / 3 MFMA products per fp32 product
 SEED = 7
+DEFAULT_BATCH = {'synthesis': 64, 'inference': 32, 'trainer': 16}
+DTYPE = {
+    'fp32': 'f32',
+    'fp16x3': 'f32 (conv operands as fp16 hi+lo after an exact power-of-two range shift: 22 significant bits while '
+              '|x*s| >= 2^-9 of the layer scale, absolute floor below; 3 MFMA products, f32 accumulate)',
+    'bf16x3': 'f32 (conv operands as bf16 hi+lo = 16 significant bits, 3 MFMA products, f32 accumulate)'}
 
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', choices=('synthesis', 'inference', 'trainer'), default='synthesis')
+    ap.add_argument('--batch', type=int, default=None, help='per GPU (default: 64 synthesis / 32 inference / 16 trainer)')
+    ap.add_argument('--cm', type=int, default=1, help='channel_multiplier (1 = voxceleb-256, the headline config)')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--layers', action='store_true', help='also print the per-layer conv table to stderr')
+    ap.add_argument('--precision', choices=('fp16x3', 'fp32', 'bf16x3'), default='fp16x3')
+    ap.add_argument('--no-alt', action='store_true', help='skip the extra leg that times the other arithmetic')
+    ap.add_argument('--host-check', action='store_true',
+                    help='run only the multi-rank host flow (launch, process group, weight broadcast, sharding) on CPU '
+                         'tensors over gloo and print what each rank saw -- no generator launch, no GPU needed')
+    args = ap.parse_args(argv)
+    if args.batch is None:
+        args.batch = DEFAULT_BATCH[args.config]
+    return args
+
+
+# ------------------------------------------------------------------------------------------------ N-rank launch
+
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """--gpus N without a torchrun environment: start the N ranks here, one per GPU (the single-device lines this
+    replaces: run_inference.py:31 / libs/trainer.py:25 `device = 'cuda'`)."""
+    if not args.host_check:
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < args.gpus and os.environ.get('SGDFR_ALLOW_GPU_SHARING') != '1':
+            raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible -- refusing to stack ranks on one device '
+                             '(SGDFR_ALLOW_GPU_SHARING=1 + SGDFR_DIST_BACKEND=gloo allows it for flow tests)' % (args.gpus, n_dev))
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def host_check(args, rank, world):
+    """The N-rank host flow on CPU tensors: every rank builds the generator, rank 0 fills it, ONE flat broadcast, then each
+    rank reports its shard and a checksum of what it received."""
+    import torch.distributed as dist
+    G = Generator(args.size, 512, 8, channel_multiplier=args.cm)
+    if rank == 0:
+        G.load_state_dict(S.synthetic_state_dict({k: v for k, v in G.state_dict().items()}, seed=SEED))
+    t0 = time.perf_counter()
+    nbytes = D.broadcast_state(G, src=0)
+    t_b = time.perf_counter() - t0
+    lo, hi = D.shard_range(args.batch * world, rank, world)
+    mine = torch.tensor([float(sum(v.double().sum() for v in G.state_dict().values())), float(lo), float(hi)], dtype=torch.float64)
+    seen = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(seen, mine)
+    else:
+        seen = [mine]
+    if rank == 0:
+        sums = [float(s[0]) for s in seen]
+        print(json.dumps({'metric': 'host_check', 'n_gpus': world, 'backend': dist.get_backend() if world > 1 else None,
+                          'weight_broadcast_bytes': nbytes, 'broadcast_ms': round(t_b * 1e3, 2),
+                          'shards': [[int(s[1]), int(s[2])] for s in seen],
+                          'weights_identical_on_all_ranks': all(x == sums[0] for x in sums)}), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------ shared pieces
 
 def generator_state_template(size, cm):
     """Key -> zero tensor with FIR buffers at constructor values (no oracle import: product-side helper)."""
@@ -50,34 +147,23 @@ def generator_state_template(size, cm):
     return G, {k: v for k, v in G.state_dict().items()}
 
 
-def cpu_baseline(size, cm, budget_s=20.0):
-    """Times the oracle (checker side) on the host CPU: B=2 forwards of the same synthesis workload."""
-    from oracle import sg2_oracle as O      # allowed here: the cpu_baseline leg only
-    # 16 threads is this workload's sweet spot on the GPU box's 2x64-core EPYC 9575F (measured: 8 thr 5.4,
-    # 16 thr 5.65, 32 thr 4.1, 64 thr 2.5, 256 thr 0.03 frames/s): oneDNN's small grouped convs do not scale further
-    threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
-    P = S.synthetic_state_dict(O.template_state(size, 512, 8, cm), seed=SEED)
-    B = 2
-    w = S.synthetic_latents(SEED, B, key='cpu.w')
-    with torch.no_grad():
-        O.generator_forward(P, [w], input_is_latent=True)          # warm-up
-        t0 = time.perf_counter()
-        reps = 0
-        while True:
-            O.generator_forward(P, [w], input_is_latent=True)
-            reps += 1
-            el = time.perf_counter() - t0
-            if el >= budget_s or reps >= 20:
-                break
-    return {'value': round(B * reps / el, 3), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d forwards of batch %d, Generator(%d, cm=%d) synthesis-only, torch-CPU fp32 oracle '
-                      '(oracle/sg2_oracle.py), %.1f s' % (reps, B, size, cm, el)}
+def kernel_source_hash():
+    """Content hash of everything that defines the kernels (csrc/*, include/*): a PMC traffic figure is only echoed into
+    the bench line when it was measured on exactly these sources (the GPU box has no .git to ask for HEAD)."""
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, 'stylegan_directions_face_reenactment_amd')
+    files = []
+    for d, ext in ((os.path.join(pkg, 'csrc'), ('.hip', '.h')), (os.path.join(ROOT, 'include'), ('.h',)), (pkg, ('.py',))):
+        files += [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(ext)]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(args, B):
-    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (profiles/traffic_latest.json; PMC
-    counters cannot be collected from inside the timed process).  None when the profile is for another shape."""
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (profiles/traffic_latest.json; PMC counters cannot be
+    collected from inside the timed process).  None unless the profile is for this shape AND these kernel sources."""
     path = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
     try:
         t = json.load(open(path))
@@ -85,99 +171,34 @@ def pmc_traffic(args, B):
         return None
     if t.get('config') != {'batch': B, 'cm': args.cm, 'size': args.size, 'precision': args.precision}:
         return None
+    if t.get('source_hash') != kernel_source_hash():
+        return None
     return round(t['bytes_per_launch'])
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=64, help='latents per GPU')
-    ap.add_argument('--cm', type=int, default=1, help='channel_multiplier (1 = voxceleb-256, the headline config)')
-    ap.add_argument('--size', type=int, default=256)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--layers', action='store_true', help='also print the per-layer conv table to stderr')
-    ap.add_argument('--precision', choices=('fp16x3', 'fp32', 'bf16x3'), default='fp16x3',
-                    help="arithmetic of the 3x3 convs: fp16x3 (default) = fp32 operands as fp16 hi+lo (22 mantissa bits), "
-                         "hi*hi+hi*lo+lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- measured as accurate as "
-                         "the fp32 kernels; fp32 = fp32 MFMA / Winograd kernels; bf16x3 = bf16 hi+lo (fp32 range, ~1e-4)")
-    ap.add_argument('--no-alt', action='store_true', help='skip the extra leg that times the other arithmetic')
-    args = ap.parse_args()
+def timed_region(step, args, dev):
+    """W warm-up steps, then EXACTLY K steps between (barrier + synchronize) pairs; returns (max over ranks, this rank)."""
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    mine = time.perf_counter() - t0
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    return D.max_over_ranks(elapsed, dev), mine, out
 
-    rank, local_rank, world = D.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
-    dev_index = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device('cuda', dev_index)
 
-    # ---- weights: rank 0 generates, everyone receives one flat RCCL broadcast
-    G, template = generator_state_template(args.size, args.cm)
-    if rank == 0:
-        G.load_state_dict(S.synthetic_state_dict(template, seed=SEED))
-    G = G.eval().to(dev)
-    bcast_bytes = D.broadcast_state(G, src=0)
-
-    # ---- this rank's shard of the global latent batch (contiguous split), resident in HBM
-    B = args.batch
-    lo, hi = D.shard_range(B * world, rank, world)
-    w = S.synthetic_latents(SEED, B * world, n_latent=G.n_latent, key='bench.w')[lo:hi].contiguous().to(dev)
-
-    def step():
-        img, _ = G([w], input_is_latent=True)
-        return img
-
-    F_.set_precision(args.precision)
-    with torch.no_grad():
-        for _ in range(max(args.warmup, 1)):
-            img = step()
-        assert img.shape == (hi - lo, 3, args.size, args.size) and bool(torch.isfinite(img).all())
-        D.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        D.barrier()
-        elapsed = time.perf_counter() - t0
-        elapsed = D.max_over_ranks(elapsed, dev)
-
-        # ---- roofline leg: HIP events around every MFMA conv launch, on the launch stream
-        F_.CONV_TIMING = []
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        rec, F_.CONV_TIMING = F_.CONV_TIMING, None
-
-        # ---- extra leg: the same steps in the other arithmetic (fp32 MFMA kernels <-> fp16x3) + the deviation between
-        # the two sets of images
-        alt = None
-        alt_mode = 'fp32' if args.precision != 'fp32' else 'fp16x3'
-        if not args.no_alt:
-            exact = step()
-            F_.set_precision(alt_mode)
-            try:
-                for _ in range(max(args.warmup, 1)):
-                    fast = step()
-                D.barrier()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    step()
-                torch.cuda.synchronize()
-                D.barrier()
-                alt_elapsed = D.max_over_ranks(time.perf_counter() - t1, dev)
-            finally:
-                F_.set_precision(args.precision)
-            alt = {'precision': alt_mode, 'value': round(B * world * args.steps / alt_elapsed, 2), 'unit': 'frames/s',
-                   'ms_per_step': round(alt_elapsed / args.steps * 1e3, 3),
-                   'max_abs_between_the_two_paths': float((fast - exact).abs().max()),
-                   'note': 'same workload with --precision %s (SGDFR_PRECISION); tests/test_gpu_split.py holds fp16x3 and the '
-                           'fp32 kernels to the same bound vs the fp64 oracle (measured 7.7e-6 / 9.5e-6 on 256x256 images)'
-                           % alt_mode}
+def conv_roofline(step, steps, peak, kernel_desc, units_per_step):
+    """HIP events around every MFMA conv launch of `steps` steps, on the launch stream."""
+    F_.CONV_TIMING = []
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    rec, F_.CONV_TIMING = F_.CONV_TIMING, None
     per_layer = {}
     for e0, e1, flops, desc in rec:
         a = per_layer.setdefault(desc, [0.0, 0.0, 0])
@@ -188,54 +209,346 @@ def main():
     conv_flops = sum(a[1] for a in per_layer.values())
     n_launch = sum(a[2] for a in per_layer.values())
     achieved = conv_flops / conv_s / 1e12
+    return {'bound': 'mfma', 'kernel': kernel_desc, 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+            'frac': round(achieved / peak, 4), 'traffic': None,
+            'avg_launch_us': round(conv_s / n_launch * 1e6, 2), 'launches_per_step': n_launch // steps,
+            'conv_ms_per_step': round(conv_s / steps * 1e3, 3),
+            'alg_gflop_per_unit': round(conv_flops / (units_per_step * steps) / 1e9, 3),
+            'per_layer': [{'layer': desc, 'us': round(sec / n * 1e6, 1), 'tflops': round(fl / sec / 1e12, 1),
+                           'frac': round(fl / sec / 1e12 / peak, 3)} for desc, (sec, fl, n) in per_layer.items()]}
 
+
+def roofline_for(precision, step, steps, units_per_step):
+    if precision == 'fp32':
+        return conv_roofline(step, steps, FP32_MFMA_PEAK_TFLOPS,
+                             'wino_mfma_kernel (large plain 3x3 layers) + modconv_mfma_kernel (small plain, transposed)',
+                             units_per_step)
+    r = conv_roofline(step, steps, SPLIT_PEAK_TFLOPS, 'split_mfma_kernel (plain + transposed 3x3 conv launches, %s)' % precision,
+                      units_per_step)
+    r['peak_note'] = ('dense 16-bit MFMA peak 2500 TFLOP/s / 3 products per fp32 product; the same achieved figure is %.2fx '
+                      'the 157.3 TFLOP/s fp32-MFMA peak' % (r['achieved'] / FP32_MFMA_PEAK_TFLOPS))
+    return r
+
+
+def cpu_baseline(size, cm, budget_s=24.0):
+    """Times the oracle (checker side) on the host CPU: thread sweep at B=2, then B=2 and B=8 at the best thread count."""
+    from oracle import sg2_oracle as O      # allowed here: the cpu_baseline leg only
+    host = os.cpu_count() or 1
+    P = S.synthetic_state_dict(O.template_state(size, 512, 8, cm), seed=SEED)
+    w8 = S.synthetic_latents(SEED, 8, key='cpu.w')
+
+    def rate(threads, B, seconds, max_reps):
+        torch.set_num_threads(threads)
+        w = w8[:B]
+        with torch.no_grad():
+            O.generator_forward(P, [w], input_is_latent=True)          # warm-up
+            t0, reps = time.perf_counter(), 0
+            while True:
+                O.generator_forward(P, [w], input_is_latent=True)
+                reps += 1
+                el = time.perf_counter() - t0
+                if el >= seconds or reps >= max_reps:
+                    return B * reps / el, reps, el
+    sweep = {}
+    for thr in sorted({t for t in (8, 16, 32, 64, host) if t <= host}):
+        if thr > 64 and host > 64:       # oneDNN's small grouped convs collapse beyond one socket's worth of threads: 1 probe only
+            sweep[thr] = round(rate(thr, 2, 0.0, 1)[0], 2)
+        else:
+            sweep[thr] = round(rate(thr, 2, 1.0, 2)[0], 2)
+    best = max(sweep, key=sweep.get)
+    left = max(6.0, budget_s - 8.0)
+    v2, r2, e2 = rate(best, 2, left * 0.45, 20)
+    v8, r8, e8 = rate(best, 8, left * 0.55, 8)
+    return {'value': round(max(v2, v8), 3), 'unit': 'frames/s', 'cores': best, 'host_cores': host, 'kind': 'port',
+            'batch2_frames_per_s': round(v2, 3), 'batch8_frames_per_s': round(v8, 3), 'thread_sweep_batch2': sweep,
+            'sample': '%d forwards of batch 2 (%.1f s) + %d of batch 8 (%.1f s), Generator(%d, cm=%d) synthesis-only, torch-CPU '
+                      'fp32 oracle (oracle/sg2_oracle.py) at the best of the swept thread counts' % (r2, e2, r8, e8, size, cm)}
+
+
+def rank_spread(frames_local, mine, dev, world):
+    """frames/s of the slowest and fastest rank (each rank's own K steps, before the closing barrier)."""
+    import torch.distributed as dist
+    v = torch.tensor([frames_local / mine], dtype=torch.float64, device=dev)
+    if world == 1:
+        return [round(float(v), 2)] * 2
+    allv = [torch.zeros_like(v) for _ in range(world)]
+    dist.all_gather(allv, v)
+    vals = [float(x) for x in allv]
+    return [round(min(vals), 2), round(max(vals), 2)]
+
+
+def base_line(args, world, metric, unit, value, elapsed, workload, extra_cfg):
+    return {'metric': metric, 'value': round(value, 2), 'unit': unit, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': DTYPE[args.precision], 'data': 'synthetic',
+            'config': dict({'workload': workload, 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
+                            'resolution': args.size, 'channel_multiplier': args.cm,
+                            'parallelism': 'batch-sharded x%d, no data-path collective' % world}, **extra_cfg)}
+
+
+def build_generator(args, rank, dev):
+    """Rank 0 generates the weights; everyone receives ONE flat RCCL broadcast (timed)."""
+    G, template = generator_state_template(args.size, args.cm)
+    if rank == 0:
+        G.load_state_dict(S.synthetic_state_dict(template, seed=SEED))
+    G = G.eval().to(dev)
+    return G
+
+
+def broadcast_timed(*objs):
+    torch.cuda.synchronize()
+    D.barrier()
+    t0 = time.perf_counter()
+    nbytes = D.broadcast_state(*objs, src=0)
+    torch.cuda.synchronize()
+    return nbytes, (time.perf_counter() - t0) * 1e3
+
+
+# ------------------------------------------------------------------------------------------------ configs
+
+def run_synthesis(args, rank, world, dev):
+    G = build_generator(args, rank, dev)
+    bcast_bytes, bcast_ms = broadcast_timed(G)
+    B = args.batch
+    lo, hi = D.shard_range(B * world, rank, world)
+    w = S.synthetic_latents(SEED, B * world, n_latent=G.n_latent, key='bench.w')[lo:hi].contiguous().to(dev)
+
+    def step():
+        img, _ = G([w], input_is_latent=True)
+        return img
+
+    F_.set_precision(args.precision)
+    with torch.no_grad():
+        elapsed, mine, img = timed_region(step, args, dev)
+        assert img.shape == (hi - lo, 3, args.size, args.size) and bool(torch.isfinite(img).all())
+        spread = rank_spread((hi - lo) * args.steps, mine, dev, world)
+        roof = roofline_for(args.precision, step, args.steps, B)
+        roof['traffic'] = pmc_traffic(args, B)
+        alt = None
+        alt_mode = 'fp32' if args.precision != 'fp32' else 'fp16x3'
+        if not args.no_alt:
+            exact = step()
+            F_.set_precision(alt_mode)
+            try:
+                alt_elapsed, _, fast = timed_region(step, args, dev)
+                alt_roof = roofline_for(alt_mode, step, args.steps, B)
+            finally:
+                F_.set_precision(args.precision)
+            alt = {'precision': alt_mode, 'value': round(B * world * args.steps / alt_elapsed, 2), 'unit': 'frames/s',
+                   'ms_per_step': round(alt_elapsed / args.steps * 1e3, 3), 'dtype': DTYPE[alt_mode],
+                   'max_abs_between_the_two_paths': float((fast - exact).abs().max()), 'roofline': alt_roof}
     if rank != 0:
-        return
-    frames = (B * world) * args.steps
-    out = {
-        'metric': 'reenacted frames/sec @256x256',
-        'value': round(frames / elapsed, 2),
-        'unit': 'frames/s',
-        'n_gpus': world,
-        'steps': args.steps,
-        'warmup': args.warmup,
-        'ms_per_step': round(elapsed / args.steps * 1e3, 3),
-        'higher_is_better': True,
-        'scaling': 'weak',
-        'vs_baseline': None,
-        'dtype': {'fp32': 'f32', 'fp16x3': 'f32 (operands as fp16 hi+lo = 22 mantissa bits, 3 MFMA products, f32 accumulate)',
-                  'bf16x3': 'f32 (operands as bf16 hi+lo = 16 mantissa bits, 3 MFMA products, f32 accumulate)'}[args.precision],
-        'data': 'synthetic',
-        'config': {'workload': '%dxMI355X HIP synthesis-only: Generator(%d,512,8,cm=%d), random w+ [%d,14,512] per GPU, '
-                               'fixed noise, psi=1' % (world, args.size, args.cm, B),
-                   'per_gpu_batch': B, 'global_batch': B * world, 'resolution': args.size,
-                   'channel_multiplier': args.cm, 'parallelism': 'batch-sharded x%d, no data-path collective' % world,
-                   'weight_broadcast_bytes': bcast_bytes},
-        'roofline': {'bound': 'mfma', 'kernel': 'wino_mfma_kernel (5 plain 3x3 layers) + modconv_mfma_kernel (2 plain, 6 transposed): 13 conv launches/forward',
-                     'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(args, B),
-                     'avg_launch_us': round(conv_s / n_launch * 1e6, 2),
-                     'conv_ms_per_step': round(conv_s / args.steps * 1e3, 3),
-                     'alg_gflop_per_frame': round(conv_flops / (B * args.steps) / 1e9, 3)},
-    }
+        return None
+    out = base_line(args, world, 'reenacted frames/sec @256x256', 'frames/s', B * world * args.steps / elapsed, elapsed,
+                    '%dxMI355X HIP synthesis-only: Generator(%d,512,8,cm=%d), random w+ [%d,14,512] per GPU, fixed noise, psi=1'
+                    % (world, args.size, args.cm, B),
+                    {'weight_broadcast_bytes': bcast_bytes, 'weight_broadcast_ms': round(bcast_ms, 2),
+                     'per_rank_frames_per_s_min_max': spread})
+    out['roofline'] = roof
     if args.precision == 'fp16x3':
-        # operand pairs the fp16-split kernels had to clamp (|x*s| > 1.04e6) during this whole run: 0 = the fp32-grade claim holds
+        # operand pairs the fp16-split kernels had to clamp / found non-finite during this whole run: 0 = the fp32-grade claim holds
         out['fp16_saturated_pairs'] = F_.split_saturation_count(reset=False)
     if alt is not None:
         out['alt_arithmetic'] = alt
-    if args.precision != 'fp32':
-        # SURVEY.md §8d rule for split arithmetic: ALGORITHMIC fp32 FLOPs over time, denominator stated
-        out['roofline'].update({'kernel': 'split_mfma_kernel (7 plain + 6 transposed 3x3 conv launches/forward, %s)' % args.precision,
-                                'peak': round(SPLIT_PEAK_TFLOPS, 1), 'frac': round(achieved / SPLIT_PEAK_TFLOPS, 4),
-                                'peak_note': 'dense 16-bit MFMA peak 2500 TFLOP/s / 3 products per fp32 product; the same '
-                                             'achieved figure is %.2fx the 157.3 TFLOP/s fp32-MFMA peak'
-                                             % (achieved / FP32_MFMA_PEAK_TFLOPS)})
     if args.layers:
-        for desc, (sec, fl, n) in per_layer.items():
-            sys.stderr.write('%-28s %8.1f us/launch %7.1f TFLOP/s\n' % (desc, sec / n * 1e6, fl / sec / 1e12))
+        for e in roof['per_layer']:
+            sys.stderr.write('%-34s %8.1f us/launch %7.1f TFLOP/s  %.3f\n' % (e['layer'], e['us'], e['tflops'], e['frac']))
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args.size, args.cm)
-    print(json.dumps(out), flush=True)
+    return out
+
+
+def _direction_ranges():
+    """[54,2] (min, max) ranges of the 3DMM parameters: the reference's data file libs/configs/ranges_voxceleb.npy as carried
+    by the kat8 fixture (the reference checkout does not exist on the GPU box)."""
+    import numpy as np
+    return np.load(os.path.join(ROOT, 'tests', 'golden', 'kat8_shift.npz'))['ranges_voxceleb']
+
+
+def run_inference(args, rank, world, dev):
+    from stylegan_directions_face_reenactment_amd.direction_matrix import DirectionMatrix
+    from stylegan_directions_face_reenactment_amd.encoder import Encoder4Editing
+    from stylegan_directions_face_reenactment_amd.reenact import ReenactmentSession, grid_frames_uint8
+    from stylegan_directions_face_reenactment_amd.shift import ShiftVectors
+    G = build_generator(args, rank, dev)
+    enc = Encoder4Editing(50, 'ir_se', args.size).eval()
+    A = DirectionMatrix(512, input_dim=15, out_dim=512, w_plus=True, num_layers=8, verbose=False)
+    if rank == 0:
+        enc.load_state_dict(S.synthetic_encoder_state(enc.state_dict(), seed=SEED + 1))
+        A.load_state_dict(S.synthetic_direction_state(SEED + 2))
+    enc, A = enc.to(dev), A.to(dev).eval()
+    F_.set_precision(args.precision)
+    with torch.no_grad():
+        trunc = G.style(S.synthetic_z(SEED, 4096, key='trunc.z').to(dev)).mean(0, keepdim=True) if rank == 0 else \
+            torch.empty(1, 512, device=dev)
+    bcast_bytes, bcast_ms = broadcast_timed(G, A, [trunc], {k: v for k, v in enc.state_dict().items() if v.dtype == torch.float32})
+    B = args.batch
+    lo, hi = D.shard_range(B * world, rank, world)
+    src_img = S.counter_tensor(SEED, 'c3.src', (1, 3, args.size, args.size), 0.0, 0.5).clamp_(-1, 1).to(dev)
+    tgt_img = S.counter_tensor(SEED, 'c3.tgt', (B * world, 3, args.size, args.size), 0.0, 0.5)[lo:hi].clamp_(-1, 1).contiguous().to(dev)
+    ang_s, par_s = S.synthetic_shape_params(SEED, 'c3.src', 1)
+    ang_t, par_t = S.synthetic_shape_params(SEED, 'c3.tgt', B * world)
+    ang_s, par_s = ang_s.to(dev), {k: v.to(dev) for k, v in par_s.items()}
+    ang_t, par_t = ang_t[lo:hi].contiguous().to(dev), {k: v[lo:hi].contiguous().to(dev) for k, v in par_t.items()}
+    shifts = ShiftVectors('voxceleb', 15, 6.0, ranges=_direction_ranges())
+
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        for _ in range(3):
+            source_code = enc(src_img)
+        torch.cuda.synchronize()
+        for _ in range(5):
+            source_code = enc(src_img)
+        torch.cuda.synchronize()
+        e4e_ms = (time.perf_counter() - t0) / 8 * 1e3
+        sess = ReenactmentSession(G, A, source_code, 0.7, trunc, batch=B, shifts=shifts)
+
+        def step():
+            frames = []
+            for img in sess.frames_for_targets(ang_s, par_s, ang_t, par_t):
+                frames.append(grid_frames_uint8([src_img, tgt_img[:img.shape[0]], img], swap_rb=True))
+            return frames[0]
+
+        elapsed, mine, frames = timed_region(step, args, dev)
+        assert frames.shape == (hi - lo, args.size, 3 * args.size, 3) and frames.dtype == torch.uint8
+        spread = rank_spread((hi - lo) * args.steps, mine, dev, world)
+        roof = roofline_for(args.precision, step, args.steps, B)
+        tb = time.perf_counter()
+        for _ in range(3):
+            enc(tgt_img)
+        torch.cuda.synchronize()
+        e4e_batch = (hi - lo) * 3 / (time.perf_counter() - tb)
+    if rank != 0:
+        return None
+    out = base_line(args, world, 'reenacted frames/sec @256x256', 'frames/s', B * world * args.steps / elapsed, elapsed,
+                    '%dxMI355X run_inference.py flow: e4e source W+ (once) + per batch of %d target frames: shift vectors from 3DMM '
+                    'parameters -> DirectionMatrix -> shift + truncation psi=0.7 -> HIP Generator(%d,cm=%d) -> uint8 '
+                    'source|target|reenacted frames' % (world, B, args.size, args.cm),
+                    {'weight_broadcast_bytes': bcast_bytes, 'weight_broadcast_ms': round(bcast_ms, 2),
+                     'per_rank_frames_per_s_min_max': spread, 'e4e_source_ms': round(e4e_ms, 2),
+                     'e4e_batch_images_per_s': round(e4e_batch, 1),
+                     'not_in_the_timed_step': 'DECA / face detection of the targets (out of scope, SURVEY.md §2); e4e of the one source image'})
+    out['roofline'] = roof
+    if args.precision == 'fp16x3':
+        out['fp16_saturated_pairs'] = F_.split_saturation_count(reset=False)
+    return out
+
+
+def run_trainer(args, rank, world, dev):
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    import loss_heads as LH
+    from stylegan_directions_face_reenactment_amd.direction_matrix import DirectionMatrix
+    from stylegan_directions_face_reenactment_amd.generic import generate_image
+    from stylegan_directions_face_reenactment_amd.shift import ShiftVectors
+    B = args.batch
+    if B % 2:
+        raise SystemExit('--config trainer needs an even per-GPU batch (make_shift_vector_50 halves it, utils_train.py:179-184)')
+    G = build_generator(args, rank, dev)
+    for p in G.parameters():            # only A is optimised (trainer.py:144); the reference leaves requires_grad on and discards
+        p.requires_grad_(False)         # the generator's weight gradients (SURVEY.md App. A.8)
+    torch.manual_seed(SEED)
+    A = DirectionMatrix(512, input_dim=15, out_dim=512, w_plus=True, num_layers=8, verbose=False).to(dev)
+    id_loss, lpips, deca = LH.IdLoss().to(dev).eval(), LH.LpipsShaped().to(dev).eval(), LH.ShapeModelStandIn().to(dev).eval()
+    for m in (id_loss, lpips, deca):
+        for p in m.parameters():
+            p.requires_grad_(False)
+    F_.set_precision(args.precision)
+    with torch.no_grad():
+        trunc = G.style(S.synthetic_z(SEED, 4096, key='trunc.z').to(dev)).mean(0, keepdim=True) if rank == 0 else \
+            torch.empty(1, 512, device=dev)
+    bcast_bytes, bcast_ms = broadcast_timed(G, A, [trunc], id_loss, lpips, deca)
+    opt = torch.optim.Adam(A.parameters(), lr=1e-4, weight_decay=5e-4)             # trainer.py:145
+    shifts = ShiftVectors('voxceleb', 15, 6.0, ranges=_direction_ranges())
+    lo, hi = D.shard_range(B * world, rank, world)
+    zs = S.synthetic_z(SEED, B * world, key='train.zs')[lo:hi].contiguous().to(dev)
+    zt = S.synthetic_z(SEED, B * world, key='train.zt')[lo:hi].contiguous().to(dev)
+    losses = []
+
+    def step():                                                                       # trainer.py:155-189
+        with torch.no_grad():
+            imgs_source, _ = generate_image(G, zs, 0.7, trunc, input_is_latent=False, return_latents=True)
+            params_source, angles_source = deca(imgs_source)
+            imgs_target = generate_image(G, zt, 0.7, trunc, input_is_latent=False, return_latents=False)
+            params_target, angles_target = deca(imgs_target)
+            shift_vector, which = shifts.make_shift_vector_50(params_source, params_target, angles_source, angles_target)
+        shift = A(shift_vector)
+        imgs_shifted, _ = generate_image(G, zs, 0.7, trunc, shift_code=shift, input_is_latent=False, return_latents=True)
+        params_shifted, _ = deca(imgs_shifted)
+        gt = {'pose': torch.cat([params_target['pose'][:B // 2], params_source['pose'][B // 2:]]),     # utils_train.py:288-300
+              'alpha_exp': torch.cat([params_target['alpha_exp'][:B // 2], params_source['alpha_exp'][B // 2:]]),
+              'alpha_shp': params_source['alpha_shp']}
+        loss = 1.0 * deca.landmark_loss(gt, params_shifted) + 10.0 * id_loss(imgs_shifted, imgs_source) + \
+            10.0 * lpips(imgs_shifted, imgs_source)                                  # lambdas: config_arguments.py:15-20
+        A.zero_grad()
+        loss.backward()
+        D.allreduce_grads(A)                                                          # the one collective of a step (262 KB)
+        opt.step()
+        losses.append(loss.detach())
+        return imgs_shifted
+
+    import warnings
+    warnings.simplefilter('ignore')
+    elapsed, mine, img = timed_region(step, args, dev)
+    assert img.shape == (B, 3, args.size, args.size)
+    spread = rank_spread(B * args.steps, mine, dev, world)
+    # where the step goes: generator-only legs timed on their own (same shapes), the rest is the loss heads + optimizer
+    def gen_only():
+        with torch.no_grad():
+            generate_image(G, zs, 0.7, trunc, input_is_latent=False)
+            generate_image(G, zt, 0.7, trunc, input_is_latent=False)
+        sv = S.counter_tensor(SEED, 'train.sv', (B, 15), 0.0, 3.0).to(dev)
+        im = generate_image(G, zs, 0.7, trunc, shift_code=A(sv), input_is_latent=False)
+        A.zero_grad()
+        im.backward(torch.ones_like(im) * 1e-3)
+    for _ in range(2):
+        gen_only()
+    torch.cuda.synchronize()
+    tg = time.perf_counter()
+    for _ in range(args.steps):
+        gen_only()
+    torch.cuda.synchronize()
+    gen_ms = (time.perf_counter() - tg) / args.steps * 1e3
+    roof = roofline_for(args.precision, gen_only, max(2, args.steps // 4), B)
+    finite = bool(torch.isfinite(torch.stack(losses)).all())
+    if rank != 0:
+        return None
+    out = base_line(args, world, 'direction-learning samples/sec @256x256', 'samples/s', B * world * args.steps / elapsed, elapsed,
+                    '%dxMI355X libs/trainer.py step: 2 no-grad forwards + shape-model stand-in, make_shift_vector_50 on device, grad '
+                    'forward + backward to A through the HIP Generator(%d,cm=%d) (frozen), IR-SE-50 id loss + LPIPS-shaped stack + '
+                    'DECA stand-in (PyTorch-ROCm, random weights), all-reduce of dA, Adam; B=%d per GPU'
+                    % (world, args.size, args.cm, B),
+                    {'weight_broadcast_bytes': bcast_bytes, 'weight_broadcast_ms': round(bcast_ms, 2),
+                     'per_rank_samples_per_s_min_max': spread, 'generator_only_ms_per_step': round(gen_ms, 3),
+                     'loss_heads_and_optimizer_ms_per_step': round(elapsed / args.steps * 1e3 - gen_ms, 3),
+                     'losses_finite': finite})
+    out['dtype'] = DTYPE[args.precision] + ('; backward: dL/dx convs in bf16 hi+lo terms (16 operand bits, f32 accumulate), '
+                                            'no weight gradients (G frozen), everything else f32' if args.precision != 'fp32' else '')
+    out['roofline'] = roof
+    out['roofline']['note'] = ('conv launches of the generator legs of a step (2 no-grad forwards + grad forward + the dL/dx convs of '
+                               'the backward), loss heads excluded')
+    return out
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, argv))
+    if args.host_check:
+        os.environ.setdefault('SGDFR_DIST_BACKEND', 'gloo')
+    if D.env_world()[2] != args.gpus:       # before any rendezvous: a mismatched launch must fail, not hang or mis-report
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, D.env_world()[2]))
+    rank, local_rank, world = D.init_from_env(backend='gloo' if args.host_check else None, use_gpu=not args.host_check)
+    if args.host_check:
+        return host_check(args, rank, world)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    dev = torch.device('cuda', torch.cuda.current_device() if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    out = {'synthesis': run_synthesis, 'inference': run_inference, 'trainer': run_trainer}[args.config](args, rank, world, dev)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    D.shutdown()
 
 
 if __name__ == '__main__':

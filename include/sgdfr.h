@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 6
+#define SGDFR_ABI_VERSION 7
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -114,9 +114,32 @@ typedef struct sgdfr_style_layer {
     float* s;           /* [B, cin]  */
     float* d;           /* [B, cout] or NULL */
     int cin, cout, latent_index;
+    /* Range plan of the fp16-split conv (csrc/split.hip), optional -- needs d.  A demodulated conv is invariant to a
+     * per-image scale of its style row: y = d * conv(x*s, W) = (d * 2^-e) * conv(x * (s * 2^e), W).  With s_n / d_n given,
+     * the launch also writes s_n[b,:] = s[b,:] * 2^e_b and d_n[b,:] = d[b,:] * 2^-e_b (exact powers of two) with e_b chosen
+     * so that the conv's fp16 operand x*s_n*2^-4 tops out `headroom` binades below the fp16 maximum:
+     *     e_b = 18 - headroom - L - floor(log2 max_i |s[b,i]|),   |x| < 2^L
+     * L = x_log2, or floor(log2 *x_absmax)+1 when x_absmax (one fp32 bit pattern = max |x| over the input, written by
+     * sgdfr_absmax_f32) is given.  The convs then see the same product range whatever the scale of the styles. */
+    float* s_n;               /* [B, cin] or NULL */
+    float* d_n;               /* [B, cout] or NULL */
+    const unsigned* x_absmax; /* device, 1 word, or NULL */
+    int x_log2, headroom;
 } sgdfr_style_layer;
 int sgdfr_styles_batched_f32(const float* latent, int B, int L, int D, const sgdfr_style_layer* layers, int n_layers,
                              void* stream);
+
+/* The range plan above for ONE layer whose s / d already exist (autograd forward, stand-alone layer calls):
+ * s_n = s * 2^e_b, d_n = d * 2^-e_b.  x_absmax: device words of fp32 bit patterns, one per image (x_absmax_bstride 1), one
+ * for the whole batch (0), or NULL (then |x| < 2^x_log2 is taken on trust). */
+int sgdfr_split_range_f32(const float* s, const float* d, float* s_n, float* d_n, const unsigned* x_absmax,
+                          int x_absmax_bstride, int x_log2, int headroom, int B, int Cin, int Cout, void* stream);
+
+/* out[b] (or out[0] when per_image == 0) = bit pattern of max |x| over image b (over everything): non-negative floats order
+ * like their bit patterns, so this is an atomicMax on words the call zeroes first.  A NaN or Inf anywhere gives a word
+ * >= 0x7f800000.  x_bstride 0 = one image shared by the batch: only out[0] is written. */
+int sgdfr_absmax_f32(const float* x, int64_t x_bstride, int64_t n_per_image, int B, unsigned* out, int per_image,
+                     void* stream);
 
 /* Shared-weight modulated 3x3 convolution on fp32 MFMA.
  *   x      [B, Cin, H, W]  (x_bstride = Cin*H*W, or 0 to broadcast one [Cin,H,W] constant over the batch)

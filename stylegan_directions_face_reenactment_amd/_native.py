@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libsgdfr_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -91,9 +91,12 @@ class StyleLayer(ctypes.Structure):
     """struct sgdfr_style_layer (include/sgdfr.h)."""
     _fields_ = [('mod_w', ctypes.c_void_p), ('mod_b', ctypes.c_void_p), ('q', ctypes.c_void_p),
                 ('s', ctypes.c_void_p), ('d', ctypes.c_void_p), ('cin', ctypes.c_int), ('cout', ctypes.c_int),
-                ('latent_index', ctypes.c_int)]
+                ('latent_index', ctypes.c_int), ('s_n', ctypes.c_void_p), ('d_n', ctypes.c_void_p),
+                ('x_absmax', ctypes.c_void_p), ('x_log2', ctypes.c_int), ('headroom', ctypes.c_int)]
 
 
+SIGNATURES['sgdfr_split_range_f32'] = [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i, _i, ctypes.c_void_p]
+SIGNATURES['sgdfr_absmax_f32'] = [_c_f32p, _i64, _i64, _i, ctypes.c_void_p, _i, ctypes.c_void_p]
 SIGNATURES['sgdfr_styles_batched_f32'] = [_c_f32p, _i, _i, _i, ctypes.POINTER(StyleLayer), _i, ctypes.c_void_p]
 MAX_STYLE_LAYERS = 40
 

@@ -175,6 +175,19 @@ struct StyleBatch {
 // One WAVE per output column n of one layer: the wave keeps the weight row (K <= 512: 8 floats per lane) in registers,
 // then walks the batch: dot(x[b,:], w[n,:]) by 8 FMAs per lane + a 6-step butterfly, lane 0 stores.  K-serial tiles
 // (the generic linear kernel) need ~70 us for these skinny GEMMs whatever the batch; this form needs ~10 us.
+// e of the range plan (include/sgdfr.h, sgdfr_style_layer): m = max |s| of the row, absmax = bit pattern of max |x| or 0
+__device__ __forceinline__ int range_exponent(float m, unsigned absmax_bits, int use_absmax, int x_log2, int headroom) {
+    const unsigned mb = __float_as_uint(m);
+    if (mb == 0u || mb >= 0x7f800000u) return 0;                    // all-zero or non-finite styles: leave the row alone
+    const int fl = max((int)(mb >> 23), 1) - 127;                   // floor(log2 m) (subnormals count as 2^-126)
+    int L = x_log2;
+    if (use_absmax) {
+        if (absmax_bits == 0u || absmax_bits >= 0x7f800000u) return 0;     // zero or non-finite input: nothing to plan
+        L = max((int)(absmax_bits >> 23), 1) - 127 + 1;
+    }
+    return min(max(18 - headroom - L - fl, -120), 120);
+}
+
 template <int STAGE>
 __global__ __launch_bounds__(256) void styles_batched_kernel(StyleBatch sb) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -198,20 +211,82 @@ __global__ __launch_bounds__(256) void styles_batched_kernel(StyleBatch sb) {
         w[j] = k < K ? wrow[k] : 0.f;
     }
     const float bias = STAGE == 0 ? ly.mod_b[n] : 0.f;
+    const bool plan = STAGE == 1 && ly.s_n != nullptr;          // range plan: this wave also sees the whole style row
+    const unsigned absmax = (plan && ly.x_absmax) ? *ly.x_absmax : 0u;
     for (int b = 0; b < sb.B; ++b) {
         const float* xr = xb + b * ldx;
-        float acc = 0.f;
+        float acc = 0.f, m = 0.f;
+        float xv[KPL];
 #pragma unroll
         for (int j = 0; j < KPL; ++j) {
             const int k = lane + 64 * j;
             float v = k < K ? xr[k] : 0.f;
-            if (STAGE == 1) v *= v;
+            xv[j] = v;
+            if (STAGE == 1) {
+                m = fmaxf(m, fabsf(v));
+                v *= v;
+            }
             acc = fmaf(v, w[j], acc);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (lane == 0) out[(int64_t)b * ldo + n] = STAGE == 0 ? acc * sb.wscale + bias : rsqrtf(acc + 1e-8f);
+        const float r = STAGE == 0 ? acc * sb.wscale + bias : rsqrtf(acc + 1e-8f);
+        if (lane == 0) out[(int64_t)b * ldo + n] = r;
+        if (plan) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            const int e = range_exponent(m, absmax, ly.x_absmax != nullptr, ly.x_log2, ly.headroom);
+            if (lane == 0) ly.d_n[(int64_t)b * ldo + n] = ldexpf(r, -e);
+            if (n == 0) {                                        // the first column's wave also writes the scaled style row
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    const int k = lane + 64 * j;
+                    if (k < K) ly.s_n[(int64_t)b * K + k] = ldexpf(xv[j], e);
+                }
+            }
+        }
     }
+}
+
+// the range plan for one layer with existing s / d: one block per image
+__global__ __launch_bounds__(256) void split_range_kernel(const float* __restrict__ s, const float* __restrict__ d,
+                                                         float* __restrict__ s_n, float* __restrict__ d_n,
+                                                         const unsigned* __restrict__ x_absmax, int x_absmax_bstride, int x_log2,
+                                                         int headroom, int Cin, int Cout) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < Cin; i += 256) m = fmaxf(m, fabsf(s[(int64_t)b * Cin + i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const unsigned absmax = x_absmax ? x_absmax[(int64_t)b * x_absmax_bstride] : 0u;
+    const int e = range_exponent(m, absmax, x_absmax != nullptr, x_log2, headroom);
+    for (int i = threadIdx.x; i < Cin; i += 256) s_n[(int64_t)b * Cin + i] = ldexpf(s[(int64_t)b * Cin + i], e);
+    for (int i = threadIdx.x; i < Cout; i += 256) d_n[(int64_t)b * Cout + i] = ldexpf(d[(int64_t)b * Cout + i], -e);
+}
+
+// max |x| per image (or over the batch) as an atomicMax on bit patterns
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t x_bstride, int64_t n, unsigned* __restrict__ out,
+                                                    int per_image) {
+    const int b = blockIdx.y;
+    const float* xb = x + (int64_t)b * x_bstride;
+    unsigned m = 0u;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if ((n & 3) == 0 && (x_bstride & 3) == 0 && ((uintptr_t)x & 15) == 0) {
+        for (; i < n; i += stride * 4) {
+            const float4 v = *reinterpret_cast<const float4*>(xb + i);
+            m = max(max(m, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+        }
+    } else {
+        for (i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = max(m, __float_as_uint(fabsf(xb[i])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out + (per_image ? b : 0), m);
 }
 
 }  // namespace sgdfr
@@ -274,6 +349,8 @@ extern "C" int sgdfr_styles_batched_f32(const float* latent, int B, int L, int D
         SGDFR_REQUIRE(ly.latent_index >= 0 && ly.latent_index < L, "styles_batched: layer %d latent index %d out of range",
                       i, ly.latent_index);
         SGDFR_REQUIRE(!ly.d || (ly.q && ly.cout > 0), "styles_batched: layer %d wants d without q", i);
+        SGDFR_REQUIRE((ly.s_n == nullptr) == (ly.d_n == nullptr) && (!ly.s_n || ly.d), "styles_batched: layer %d: the range plan needs s_n, d_n and d", i);
+        SGDFR_REQUIRE(!ly.s_n || (ly.headroom >= 0 && ly.headroom <= 12 && abs(ly.x_log2) <= 100), "styles_batched: layer %d: bad range plan (x_log2 %d, headroom %d)", i, ly.x_log2, ly.headroom);
         sb.layer[i] = ly;
         SGDFR_REQUIRE(ly.cin <= 512 || !ly.d, "styles_batched: layer %d has %d input channels (> 512)", i, ly.cin);
         sb.tile_start[i] = tiles;
@@ -298,6 +375,35 @@ extern "C" int sgdfr_styles_batched_f32(const float* latent, int B, int L, int D
     sd.n_layers = dl;
     hipLaunchKernelGGL(styles_batched_kernel<1>, dim3((tiles + 3) / 4), dim3(256), 0, as_stream(stream), sd);
     return check_launch("styles_batched(demod)");
+}
+
+extern "C" int sgdfr_split_range_f32(const float* s, const float* d, float* s_n, float* d_n, const unsigned* x_absmax,
+                                     int x_absmax_bstride, int x_log2, int headroom, int B, int Cin, int Cout, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cout > 0, "split_range: bad shape %d %d %d", B, Cin, Cout);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(s && d && s_n && d_n, "split_range: null pointer");
+    SGDFR_REQUIRE(headroom >= 0 && headroom <= 12 && abs(x_log2) <= 100, "split_range: bad plan (x_log2 %d, headroom %d)", x_log2, headroom);
+    SGDFR_REQUIRE(x_absmax_bstride == 0 || x_absmax_bstride == 1, "split_range: x_absmax_bstride must be 0 or 1");
+    hipLaunchKernelGGL(split_range_kernel, dim3(B), dim3(256), 0, as_stream(stream), s, d, s_n, d_n, x_absmax, x_absmax_bstride, x_log2,
+                       headroom, Cin, Cout);
+    return check_launch("split_range");
+}
+
+extern "C" int sgdfr_absmax_f32(const float* x, int64_t x_bstride, int64_t n_per_image, int B, unsigned* out, int per_image,
+                                void* stream) {
+    SGDFR_REQUIRE(B >= 0 && n_per_image >= 0 && x_bstride >= 0, "absmax: bad shape B=%d n=%lld", B, (long long)n_per_image);
+    SGDFR_REQUIRE(out, "absmax: null output");
+    if (hipMemsetAsync(out, 0, sizeof(unsigned) * (per_image ? (B > 0 ? B : 1) : 1), as_stream(stream)) != hipSuccess) {
+        set_error("absmax: hipMemsetAsync failed");
+        return 2;
+    }
+    if (B == 0 || n_per_image == 0) return 0;
+    SGDFR_REQUIRE(x, "absmax: null input");
+    const int nb = x_bstride == 0 ? 1 : B;                       // a broadcast image is read once
+    int gx = (int)((n_per_image + 4095) / 4096);
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    hipLaunchKernelGGL(absmax_kernel, dim3(gx, nb), dim3(256), 0, as_stream(stream), x, x_bstride, n_per_image, out, x_bstride == 0 ? 0 : per_image);
+    return check_launch("absmax");
 }
 
 extern "C" int sgdfr_demod_grad_f32(const float* gd, const float* d, const float* qt, const float* s, const float* gs,

@@ -115,7 +115,8 @@ template <int ET>
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo, unsigned& sat) {
     if (ET == SGDFR_SPLIT_FP16) {
         // saturation is never silent: every clamped pair ends up in a device counter (sgdfr_split_saturation_count)
-        sat += (fmaxf(fabsf(a), fabsf(b)) > SPLIT_F16_MAX) ? 1u : 0u;
+        // (written as !(<=) so that NaN counts too: v_med3 would silently turn it into a finite value)
+        sat += (!(fabsf(a) <= SPLIT_F16_MAX) || !(fabsf(b) <= SPLIT_F16_MAX)) ? 1u : 0u;
         a = __builtin_amdgcn_fmed3f(a, -SPLIT_F16_MAX, SPLIT_F16_MAX);
         b = __builtin_amdgcn_fmed3f(b, -SPLIT_F16_MAX, SPLIT_F16_MAX);
         f32x2 v = {a, b};

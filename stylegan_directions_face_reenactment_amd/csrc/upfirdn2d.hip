@@ -164,7 +164,7 @@ __device__ unsigned int g_blur_saturated = 0;    // operand pairs clamped to the
 template <int ET>
 __device__ __forceinline__ void blur_split2(float a, float b, unsigned& hi, unsigned& lo, unsigned& sat) {     // as split.hip's split_pair
     if (ET == SGDFR_SPLIT_FP16) {
-        sat += (fmaxf(fabsf(a), fabsf(b)) > 65504.f) ? 1u : 0u;      // flushed once per thread: no branch per pair
+        sat += (!(fabsf(a) <= 65504.f) || !(fabsf(b) <= 65504.f)) ? 1u : 0u;      // NaN counts too; flushed once per thread: no branch per pair
         a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
         b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
         const bl_f16x2 h = __builtin_convertvector((bl_f32x2){a, b}, bl_f16x2);

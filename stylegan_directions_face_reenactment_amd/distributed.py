@@ -18,19 +18,40 @@ def env_world():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
 
 
-def init_from_env(backend=None):
-    """Initialise the default process group from torchrun's env (no-op for world size 1)."""
+def init_from_env(backend=None, use_gpu=True):
+    """Initialise the default process group from torchrun's env (no-op for world size 1).
+
+    One process per GPU: rank `local_rank` takes device `local_rank` and the call FAILS when that device does not exist --
+    ranks are never stacked on one GPU silently (RCCL would refuse duplicate devices anyway).  Only the flow tests may share
+    a device: SGDFR_ALLOW_GPU_SHARING=1 together with SGDFR_DIST_BACKEND=gloo."""
     rank, local_rank, world = env_world()
+    gpu = use_gpu and torch.cuda.is_available()
+    if gpu:
+        n_dev = torch.cuda.device_count()
+        if local_rank >= n_dev:
+            if os.environ.get('SGDFR_ALLOW_GPU_SHARING') != '1':
+                raise RuntimeError('rank with LOCAL_RANK=%d but only %d GPU(s) visible: one process per GPU '
+                                   '(set SGDFR_ALLOW_GPU_SHARING=1 and SGDFR_DIST_BACKEND=gloo for flow tests)' % (local_rank, n_dev))
+            torch.cuda.set_device(local_rank % n_dev)
+        else:
+            torch.cuda.set_device(local_rank)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        if backend is None:   # SGDFR_DIST_BACKEND=gloo lets several ranks share one GPU (smoke tests of the N>1 flow)
-            backend = os.environ.get('SGDFR_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
-        if torch.cuda.is_available():
-            torch.cuda.set_device(local_rank % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend is None:
+            backend = os.environ.get('SGDFR_DIST_BACKEND') or ('nccl' if gpu else 'gloo')
+        if backend == 'nccl' and gpu:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def shard_range(total, rank, world):
@@ -49,29 +70,31 @@ def _tensors_of(obj):
     return [(str(i), v) for i, v in enumerate(obj)]
 
 
-def broadcast_state(*objs, src=0, group=None):
+def broadcast_state(*objs, src=0, group=None, force=False):
     """Broadcast every tensor of the given modules / dicts / tensor lists from `src` in ONE collective.
-    All ranks must pass identically-shaped objects (ranks != src may hold uninitialised values)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    All ranks must pass identically-shaped objects (ranks != src may hold uninitialised values).
+    force=True issues the collective even in a one-rank group (exercises the RCCL path on a single GPU)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return 0
     items = [t for o in objs for _, t in _tensors_of(o)]
     if not items:
         return 0
     device = items[0].device
     total = sum(t.numel() for t in items)
-    flat = torch.empty(total, dtype=torch.float32, device=device)
-    if dist.get_rank(group) == src:
-        off = 0
-        for t in items:
-            flat[off:off + t.numel()].copy_(t.detach().reshape(-1))
-            off += t.numel()
+    if dist.get_rank(group) == src:      # one gather launch (torch.cat) instead of one copy per tensor
+        flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in items])
+    else:
+        flat = torch.empty(total, dtype=torch.float32, device=device)
     dist.broadcast(flat, src=src, group=group)
     if dist.get_rank(group) != src:
-        off = 0
         with torch.no_grad():
-            for t in items:
-                t.copy_(flat[off:off + t.numel()].view_as(t))
-                off += t.numel()
+            views = [v.view_as(t) for v, t in zip(flat.split([t.numel() for t in items]), items)]
+            same = [(t, v) for t, v in zip(items, views) if t.dtype == torch.float32]
+            if same:                     # one multi-tensor scatter for the fp32 state, per-tensor only for odd dtypes
+                torch._foreach_copy_([t.detach() for t, _ in same], [v for _, v in same])
+            for t, v in zip(items, views):
+                if t.dtype != torch.float32:
+                    t.copy_(v)
     return total * 4
 
 

@@ -149,6 +149,20 @@ class Encoder4Editing(nn.Module):
     def _state_key(self):
         return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
+    def invalidate_packs(self):
+        """Drop the folded inference plan (needed only after in-place `.data` edits, which the version counters behind
+        `_state_key` do not see)."""
+        self._plan_key, self._plan = None, None
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_packs()
+        return out
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.invalidate_packs()
+
     def _build_plan(self):
         cl = torch.channels_last
         plan = {'stem': _fold(self.input_layer[0], self.input_layer[1]), 'units': [], 'heads': []}

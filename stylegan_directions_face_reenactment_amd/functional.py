@@ -127,38 +127,103 @@ def style_demod(style, mod_weight, mod_bias, q=None, cout=0):
     return s, d
 
 
-def styles_batched(latent, specs):
+def styles_batched(latent, specs, plans=None):
     """All modulations / demodulation coefficients of one forward in two launches.
     latent [B, L, D] contiguous; specs: list of (latent_index, mod_weight, mod_bias, q or None, cout).
-    Returns [(s [B,cin], d [B,cout] or None), ...] as views into two flat buffers."""
+    Returns [(s [B,cin], d [B,cout] or None), ...] as views into flat buffers.
+    plans (optional, aligned with specs): None or (x_log2 | absmax word tensor, headroom) -- the range plan of the
+    fp16-split conv (include/sgdfr.h, sgdfr_style_layer): that entry then comes back as (s * 2^e, d * 2^-e) per image."""
     N.require_device(latent)
     latent = N.f32c(latent)
     B, L, D = latent.shape
     if len(specs) > N.MAX_STYLE_LAYERS:
         raise RuntimeError('too many modulated layers (%d)' % len(specs))
+    planned = [plans is not None and plans[i] is not None and specs[i][3] is not None for i in range(len(specs))]
     n_s = sum(mw.shape[0] for _, mw, _, _, _ in specs)
     n_d = sum(cout for _, _, _, q, cout in specs if q is not None)
-    s_all = torch.empty(B * n_s, device=latent.device, dtype=torch.float32)
-    d_all = torch.empty(max(B * n_d, 1), device=latent.device, dtype=torch.float32)
+    n_sn = sum(specs[i][1].shape[0] for i in range(len(specs)) if planned[i])
+    n_dn = sum(specs[i][4] for i in range(len(specs)) if planned[i])
+    buf = torch.empty(B * (n_s + n_d + n_sn + n_dn) + 1, device=latent.device, dtype=torch.float32)
+    offs = [0]
+
+    def take(n, shape):
+        v = buf[offs[0]:offs[0] + n].view(shape)
+        offs[0] += n
+        return v
     arr = (N.StyleLayer * len(specs))()
-    out, so, do = [], 0, 0
+    out, keep = [], []
     for i, (li, mw, mb, q, cout) in enumerate(specs):
         N.require_device(mw, mb, q)
         cin = mw.shape[0]
-        s = s_all[so:so + B * cin].view(B, cin)
-        so += B * cin
-        d = None
-        if q is not None:
-            d = d_all[do:do + B * cout].view(B, cout)
-            do += B * cout
+        s = take(B * cin, (B, cin))
+        d = take(B * cout, (B, cout)) if q is not None else None
         e = arr[i]
         e.mod_w, e.mod_b = N.f32c(mw).data_ptr(), N.f32c(mb).data_ptr()
         e.q = q.data_ptr() if q is not None else None
         e.s, e.d = s.data_ptr(), (d.data_ptr() if d is not None else None)
         e.cin, e.cout, e.latent_index = cin, cout, li
+        e.s_n = e.d_n = e.x_absmax = None
+        e.x_log2 = e.headroom = 0
+        if planned[i]:
+            bound, headroom = plans[i]
+            s, d = take(B * cin, (B, cin)), take(B * cout, (B, cout))
+            e.s_n, e.d_n, e.headroom = s.data_ptr(), d.data_ptr(), int(headroom)
+            if isinstance(bound, torch.Tensor):
+                keep.append(bound)
+                e.x_absmax = bound.data_ptr()
+            else:
+                e.x_log2 = int(bound)
         out.append((s, d))
     N.call('sgdfr_styles_batched_f32', N.ptr(latent), B, L, D, arr, len(specs), N.stream())
     return out
+
+
+# ---- range plan of the fp16-split conv (SGDFR_RANGE_PLAN=0 switches it off: the fixed 2^-4 pre-scale of round 1)
+RANGE_PLAN = os.environ.get('SGDFR_RANGE_PLAN', '1') != '0'
+DESIGN_X_LOG2 = 10          # uncalibrated bound taken on trust for a conv input: |x| < 2^10
+CALIBRATION_HEADROOM = 6    # binades kept free above a calibrated activation maximum before the fp16 terms saturate
+
+
+def absmax(x, per_image=True, batch=None, out=None):
+    """int32 words [B] (per image) or [1] (whole tensor): fp32 bit pattern of max |x| (sgdfr_absmax_f32).  A [1,...] tensor
+    standing for `batch` images yields one word."""
+    N.require_device(x)
+    x = N.f32c(x)
+    B = x.shape[0]
+    shared = batch is not None and B == 1 and batch != 1
+    per_image = bool(per_image) and not shared
+    n = x[0].numel()
+    if out is None:
+        out = torch.empty(B if per_image else 1, device=x.device, dtype=torch.int32)
+    if per_image:
+        N.call('sgdfr_absmax_f32', N.ptr(x), n, n, B, N.ptr(out), 1, N.stream())
+    else:       # one word over everything: a single "image" of B*n elements
+        N.call('sgdfr_absmax_f32', N.ptr(x), B * n, B * n, 1, N.ptr(out), 0, N.stream())
+    return out
+
+
+def split_range(s, d, x_absmax=None, x_log2=DESIGN_X_LOG2, headroom=0):
+    """(s * 2^e, d * 2^-e) per image with e from the range plan (sgdfr_split_range_f32): exact, and the conv result is the same."""
+    N.require_device(s, d)
+    s, d = N.f32c(s), N.f32c(d)
+    B, cin = s.shape
+    cout = d.shape[1]
+    buf = torch.empty(B * (cin + cout), device=s.device, dtype=torch.float32)
+    s_n, d_n = buf[:B * cin].view(B, cin), buf[B * cin:].view(B, cout)
+    bstride = 0
+    if x_absmax is not None:
+        if x_absmax.dtype != torch.int32 or not x_absmax.is_cuda or x_absmax.numel() not in (1, B):
+            raise RuntimeError('split_range: x_absmax must be the int32 device words made by absmax()')
+        bstride = int(x_absmax.numel() == B and B > 1)
+    N.call('sgdfr_split_range_f32', N.ptr(s), N.ptr(d), N.ptr(s_n), N.ptr(d_n), N.ptr(x_absmax), bstride, int(x_log2), int(headroom),
+           B, cin, cout, N.stream())
+    return s_n, d_n
+
+
+def _exact_range(x, s, d, batch):
+    """Range plan from the true max |x| of each image (two small launches): what a stand-alone layer call uses."""
+    B = s.shape[0] if batch is None else batch
+    return split_range(s, d, absmax(x, per_image=True, batch=B))
 
 
 def _noise_args(noise, B, H, W):
@@ -182,10 +247,16 @@ USE_WINOGRAD = True          # plain 3x3 layers: Winograd F(2x2,3x3) MFMA kernel
 WINOGRAD_MIN_BLOCKS = 256    # below this many (64 cout x 64 tile) blocks the direct kernel's smaller tiles win
 # Arithmetic of the 3x3 modulated convs (inference path, autograd forward, and dL/dx of the plain convs; the strided dL/dx of
 # the transposed convs and the weight gradients always use the fp32 MFMA kernels):
-#   'fp16x3' (default)  fp32 operands split into fp16 hi + lo (11+11 mantissa bits; range-shifted by exact powers of two,
-#                       |x*s| saturates at 1.04e6), hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulation
-#                       (csrc/split.hip).  fp32-grade: measured 7.7e-6 max-abs vs an fp64 evaluation on 256x256 images
-#                       (fp32 MFMA kernels: 9.5e-6) and held to the same per-layer bound by tests/test_gpu_split.py.
+#   'fp16x3' (default)  fp32 operands split into fp16 hi + lo (11+11 significant bits), hi*hi + hi*lo + lo*hi on
+#                       v_mfma_f32_32x32x16_f16, fp32 accumulation (csrc/split.hip).  fp16 has 5 exponent bits, so the operands
+#                       are range-shifted by exact powers of two: statically (x*2^-4, W*2^6, result*2^-2) and per image by the
+#                       RANGE PLAN below (styles scaled by 2^e, demodulation by 2^-e -- the conv is invariant to it), which
+#                       puts the largest |x*s| of the layer `headroom` binades under the fp16 maximum.  Terms of an element
+#                       keep 22 bits down to 2^-17 of that maximum and an absolute floor of 2^-39 of it below.  Operands that
+#                       still leave the range (or are NaN/Inf) are clamped AND counted (split_saturation_count); Generator
+#                       polls the count and falls back to 'bf16x3'.  Measured 7.7e-6 max-abs vs an fp64 evaluation on
+#                       256x256 images (fp32 MFMA kernels: 9.5e-6); tests/test_gpu_split.py holds it to the fp32 kernels'
+#                       per-layer bound RELATIVE to max|y| for inputs scaled by 2^-20 ... 2^15 and styles in [1e-3, 1e3].
 #   'fp32'              fp32 MFMA kernels (direct + Winograd) everywhere.
 #   'bf16x3'            as fp16x3 with bf16 terms: full fp32 range, 8+8 bits (~1e-4 on images; contract 1e-3).
 PRECISION = os.environ.get('SGDFR_PRECISION', 'fp16x3')
@@ -193,8 +264,9 @@ _zeros = {}
 
 
 def split_saturation_count(reset=True):
-    """How many operand pairs the fp16x3 kernels had to clamp to the fp16 range (|x*s| > 1.04e6) on this device since the last
-    reset: 0 means the fp32-grade accuracy claim held for everything computed so far; otherwise use 'bf16x3' or 'fp32'."""
+    """How many operand pairs the fp16x3 kernels had to clamp to the fp16 range, or found NaN/Inf, on this device since the
+    last reset: 0 means the fp32-grade accuracy claim held for everything computed so far; otherwise use 'bf16x3' or 'fp32'
+    (Generator.forward polls this and switches by itself).  Synchronises the device."""
     n = N.load().sgdfr_split_saturation_count(int(bool(reset)))
     if n < 0:
         raise RuntimeError('sgdfr_split_saturation_count failed')
@@ -206,6 +278,20 @@ def set_precision(mode):
     if mode not in ('fp32', 'fp16x3', 'bf16x3'):
         raise ValueError("precision must be 'fp32', 'fp16x3' or 'bf16x3', got %r" % (mode,))
     PRECISION = mode
+
+
+class precision:
+    """`with functional.precision('fp32'):` -- the arithmetic of the 3x3 convs inside the block."""
+
+    def __init__(self, mode):
+        self.mode, self.prev = mode, None
+
+    def __enter__(self):
+        self.prev = PRECISION
+        set_precision(self.mode)
+
+    def __exit__(self, *exc):
+        set_precision(self.prev)
 
 
 def _zero_words(device):
@@ -510,7 +596,7 @@ def blur_bias_act_split(planes, fir, H, W, s_next, noise=None, noise_weight=None
 
 def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_weight=None, bias=None,
                activate=False, slope=0.2, gain=SQRT2, batch=None, return_planes=False, wino=None, split=None, rgb=None,
-               want_y=True):
+               want_y=True, ranged=False):
     """Shared-weight modulated 3x3 conv (model.py:232-273) with the StyledConv tail fused in
     (noise model.py:287, bias + leaky-ReLU op/fused_act.py:81-86).
 
@@ -521,6 +607,8 @@ def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_we
     if not upsample:
         B = s.shape[0] if batch is None else batch
         if split is not None and split_ok(B, cin, cout, H, W):
+            if RANGE_PLAN and not ranged and PRECISION == 'fp16x3' and d is not None:
+                s, d = _exact_range(x, s, d, batch)       # (ranged: the caller's s, d already carry a plan)
             return modconv_split(x, split() if callable(split) else split, s, d, cout, noise, noise_weight, bias,
                                  activate, slope, gain, batch, rgb=rgb, want_y=want_y)
         if rgb is not None:
@@ -535,6 +623,8 @@ def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_we
     Bu = s.shape[0] if batch is None else batch
     use_split = split is not None and split_ok(Bu, cin, cout, H, W, N.MODE_UP3)
     if use_split:
+        if RANGE_PLAN and not ranged and PRECISION == 'fp16x3' and d is not None:
+            s, d = _exact_range(x, s, d, batch)
         planes = modconv_split(x, split() if callable(split) else split, s, d, cout, batch=batch, mode=N.MODE_UP3)
     else:
         planes = modconv_raw(x, wp, s, d, cout, N.MODE_UP3, H, W, batch=batch, desc='up3 %d->%d @%dx%d' % (cin, cout, H, W))

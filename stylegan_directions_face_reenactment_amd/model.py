@@ -18,6 +18,8 @@ Discriminator, Encoder, ...) are never instantiated by the reenactment scripts a
 """
 import math
 import random
+import struct
+import warnings
 
 import torch
 from torch import nn
@@ -151,6 +153,23 @@ class ModulatedConv2d(nn.Module):
         w = self.weight
         return (w.data_ptr(), w._version, w.device)
 
+    def invalidate_packs(self):
+        """Drop every cached re-pack of `weight`.  The caches are keyed on (storage, tensor version, device), which sees
+        optimizer steps, `copy_`, `load_state_dict` and `.cuda()`, but NOT in-place writes through `.data`
+        (`w.data.mul_()`, `w.data.copy_()`, the EMA `accumulate()` idiom): those do not bump the version counter, so
+        call this (or `Generator.invalidate_packs()`) after them."""
+        self._pack = self._pack_t = self._pack_w = None
+        self._pack_s = None
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_packs()
+        return out
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.invalidate_packs()
+
     def packed(self):
         """([Cin, k*k, Cout] scaled weights, Q[o,i] = sum_taps (scale W)^2, Q^T), rebuilt when the parameter's
         storage or version changes (optimizer step, load_state_dict, .cuda())."""
@@ -212,9 +231,11 @@ class ModulatedConv2d(nn.Module):
         return F_.style_demod(style, mod.weight, mod.bias, q, self.out_channel)
 
     def fused(self, input, style, noise=None, noise_weight=None, bias=None, activate=False, batch=None, sd=None, rgb=None,
-              want_y=True):
+              want_y=True, ranged=False):
         """conv (+ noise + bias + leaky-ReLU) in one pass; what StyledConv.forward calls.
-        `sd` = precomputed (s, d), e.g. from the generator's batched style launch."""
+        `sd` = precomputed (s, d), e.g. from the generator's batched style launch; ranged=True says that pair already
+        carries the fp16-split range plan (functional.styles_batched(plans=...)), otherwise the split path plans from the
+        true max |x| of each image."""
         if self.kernel_size != 3:
             raise NotImplementedError('only the 3x3 modulated conv has a fused StyledConv form (1x1 lives in ToRGB)')
         s, d = self.styles(style) if sd is None else sd
@@ -224,7 +245,7 @@ class ModulatedConv2d(nn.Module):
                              fir=self.blur.kernel if self.upsample else None, noise=noise,
                              noise_weight=noise_weight, bias=bias, activate=activate, batch=batch,
                              wino=None if self.upsample else self.packed_wino,
-                             split=self.packed_split, rgb=rgb, want_y=want_y)
+                             split=self.packed_split, rgb=rgb, want_y=want_y, ranged=ranged)
 
     def forward(self, input, style):
         if self.kernel_size == 1:
@@ -273,7 +294,7 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, noise=None, batch=None, sd=None, rgb=None, want_y=True):
+    def forward(self, input, style, noise=None, batch=None, sd=None, rgb=None, want_y=True, ranged=False):
         """rgb = (w_rgb [3,C], s_rgb [B,C]) (no-grad path): also returns the ToRGB partial sums, see functional.rgb_fusable;
         want_y=False then skips storing the activation itself (last layer: nothing else reads it)."""
         if noise is None:   # fresh per-sample noise, model.py:283-285
@@ -281,7 +302,7 @@ class StyledConv(nn.Module):
             r = input.shape[-1] * (2 if self.conv.upsample else 1)
             noise = torch.empty(B, 1, r, r, device=input.device, dtype=torch.float32).normal_()
         return self.conv.fused(input, style, noise=noise, noise_weight=self.noise.weight, bias=self.activate.bias,
-                               activate=True, batch=batch, sd=sd, rgb=rgb, want_y=want_y)
+                               activate=True, batch=batch, sd=sd, rgb=rgb, want_y=want_y, ranged=ranged)
 
 
 class ToRGB(nn.Module):
@@ -355,6 +376,16 @@ class Generator(nn.Module):
         self.n_latent = self.log_size * 2 - 2
         self.overlap_rgb = True     # run the ToRGB chain on a side stream in no-grad forwards
 
+    def invalidate_packs(self):
+        """Forget every cached weight re-pack and launch plan.  Needed only after in-place edits through `.data`
+        (weight blending, EMA, `p.data.copy_()`), which PyTorch's version counter does not see; optimizer steps,
+        `load_state_dict`, `.to()` / `.cuda()` are tracked or invalidate on their own."""
+        for m in self.modules():
+            if isinstance(m, ModulatedConv2d):
+                m.invalidate_packs()
+        self._chain_plans = {}
+        self._range_state = None
+
     # ---- latent-side helpers (model.py:449-469)
     def make_noise(self):
         device = self.input.input.device
@@ -370,6 +401,72 @@ class Generator(nn.Module):
 
     def get_latent(self, input):
         return self.style(input)
+
+    # ---- range plan of the fp16-split arithmetic (functional.PRECISION == 'fp16x3')
+    SATURATION_POLL_EVERY = 64      # no-grad forwards between two reads of the device's saturation counter (each read syncs)
+
+    def _weights_stamp(self):
+        w = self.conv1.conv.weight
+        return (w.data_ptr(), w.device, sum(p._version for p in self.parameters()))
+
+    def _calibrate_ranges(self, latent, noise, specs, layers):
+        """One forward of (at most 8 rows of) this batch on the fp32 kernels, recording max |x| of every 3x3 conv's input:
+        x_log2[l] = floor(log2 max)+1 feeds the range plan of functional.styles_batched.  Runs once per weight version
+        (tracked like the weight packs; after `.data` edits call invalidate_packs()).  One device->host read."""
+        n = min(latent.shape[0], 8)
+        lat = latent[:n].contiguous()
+        words = torch.zeros(len(layers), device=latent.device, dtype=torch.int32)
+        with F_.precision('fp32'):
+            sd = F_.styles_batched(lat, specs)
+            sd_of_layer = [0] + [2 + 3 * (i // 2) + (i % 2) for i in range(len(self.convs))]
+            x = self.input.input
+            for li, layer in enumerate(layers):
+                F_.absmax(x, per_image=False, out=words[li:li + 1])
+                nz = noise[li]
+                if nz is not None and nz.shape[0] not in (1, n):
+                    nz = nz[:n]
+                x = layer(x, None, noise=nz, batch=n if li == 0 else None, sd=sd[sd_of_layer[li]], ranged=True)
+        bits = words.cpu().tolist()
+        x_log2, bad = [], False
+        for b in bits:
+            v = struct.unpack('f', struct.pack('I', b & 0xffffffff))[0]
+            if not math.isfinite(v):
+                bad = True
+                x_log2.append(F_.DESIGN_X_LOG2)
+            else:
+                x_log2.append(0 if v == 0.0 else int(math.floor(math.log2(v))) + 1)
+        return x_log2, bad
+
+    def _range_plans(self, latent, noise, specs, order, layers):
+        """(plans for styles_batched, arithmetic to run this forward in).  fp16x3 only."""
+        st = getattr(self, '_range_state', None)
+        stamp = self._weights_stamp()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if st is None or st['stamp'] != stamp:
+            if capturing:
+                raise RuntimeError('Generator: the first forward after a weight change calibrates activation ranges (one host '
+                                   'read) and cannot run inside a graph capture: run one forward before capturing')
+            x_log2, bad = self._calibrate_ranges(latent, noise, specs, layers)
+            st = self._range_state = {'stamp': stamp, 'x_log2': x_log2, 'mode': 'fp16x3', 'calls': 0,
+                                      'sat_seen': F_.split_saturation_count(reset=False)}
+            if bad:
+                st['mode'] = 'fp32'
+                warnings.warn('Generator: non-finite activations during range calibration; this generator runs on the fp32 '
+                              'kernels until its weights change', RuntimeWarning, stacklevel=3)
+        elif st['mode'] == 'fp16x3' and not capturing and st['calls'] % self.SATURATION_POLL_EVERY == 1 % self.SATURATION_POLL_EVERY:
+            seen = F_.split_saturation_count(reset=False)       # results of the forwards so far (the first one included)
+            if seen > st['sat_seen']:
+                st['mode'] = 'bf16x3'
+                warnings.warn('Generator: %d fp16 operand pairs left the planned range (or were NaN/Inf) in earlier forwards; '
+                              'falling back to the bf16x3 arithmetic (fp32 exponent range) for this generator until its '
+                              'weights change' % (seen - st['sat_seen']), RuntimeWarning, stacklevel=3)
+            st['sat_seen'] = seen
+        st['calls'] += 1
+        if st['mode'] != 'fp16x3':
+            return None, st['mode']
+        conv_layer = {id(l.conv): i for i, l in enumerate(layers)}
+        plans = [(st['x_log2'][conv_layer[id(m)]], F_.CALIBRATION_HEADROOM) if id(m) in conv_layer else None for m, _ in order]
+        return plans, 'fp16x3'
 
     # ---- the path itself (model.py:471-539)
     def forward(self, styles, return_latents=False, return_features=False, inject_index=None, truncation=1,
@@ -409,12 +506,24 @@ class Generator(nn.Module):
             sd = iter([(next(flat), next(flat) if (m.kernel_size == 3 and m.demodulate) else None) for m, _ in order])
         elif grad:   # differentiable per-layer modulation (autograd routes dL/ds back into the latent rows and the weights)
             sd = iter([m.styles(latent[:, li]) for m, li in order])
-        else:      # every layer's s = A_l(w_l) and demodulation d_l in two launches (instead of 33)
-            sd = iter(F_.styles_batched(latent, [m.style_spec(li) for m, li in order]))
-
-        sd = list(sd)              # (s, d) per entry of `order`: conv1, to_rgb1, then (up, plain, to_rgb) per resolution
         layers = [self.conv1] + list(self.convs)           # StyledConvs in execution order: plain, (up, plain) x n
         to_rgbs = [self.to_rgb1] + list(self.to_rgbs)      # to_rgbs[k] follows layers[2k]
+        ranged, arith = False, None                        # arith: this generator's fallback arithmetic, when it has one
+        if not grad:   # every layer's s = A_l(w_l) and demodulation d_l in two launches (instead of 33)
+            specs = [m.style_spec(li) for m, li in order]
+            plans = None
+            if F_.PRECISION == 'fp16x3' and F_.RANGE_PLAN:
+                plans, arith = self._range_plans(latent, noise, specs, order, layers)
+                ranged = plans is not None
+            sd = iter(F_.styles_batched(latent, specs, plans))
+        if arith is not None and arith != F_.PRECISION:    # saturation / non-finite fallback: run this forward in `arith`
+            with F_.precision(arith):
+                return self._synthesis(latent, list(sd), layers, to_rgbs, noise, grad, ranged, return_latents)
+        return self._synthesis(latent, list(sd), layers, to_rgbs, noise, grad, ranged, return_latents)
+
+    def _synthesis(self, latent, sd, layers, to_rgbs, noise, grad, ranged, return_latents):
+        """conv1 ... convs / to_rgbs with the (s, d) pairs of `sd` (one per entry of conv1, to_rgb1, (up, plain, to_rgb)*)."""
+        batch = latent.shape[0]
         sd_of_layer = [0] + [2 + 3 * (i // 2) + (i % 2) for i in range(len(self.convs))]
         sd_of_rgb = [1] + [4 + 3 * k for k in range(len(self.to_rgbs))]
         # inference on the split kernels: layers are launched through functional.styled_conv_split, not through their
@@ -441,6 +550,8 @@ class Generator(nn.Module):
             on_side[0] = True
             side.wait_stream(main)                 # x (and this forward's styles) are ready
             x.record_stream(side)
+            if skip_in is not None:                # may come from a main-stream finish(): keep its block until the side kernel read it
+                skip_in.record_stream(side)
             with torch.cuda.stream(side):
                 return run()
 
@@ -484,7 +595,7 @@ class Generator(nn.Module):
             if not use_chain:
                 if isinstance(x, F_.SplitAct):
                     raise RuntimeError('internal: a split activation reached a layer that cannot take it')
-                out, part = layer(x, None, noise=nz, batch=batch if first else None, sd=sdl), None
+                out, part = layer(x, None, noise=nz, batch=batch if first else None, sd=sdl, ranged=ranged), None
             else:
                 rgb_arg = (to_rgbs[k].conv.weight.view(3, c.out_channel), sd[sd_of_rgb[k]][0]) if fuse else None
                 out, part = F_.styled_conv_split(

@@ -72,3 +72,45 @@ def test_broadcast_and_shard_world2():
     assert all(ok for _, ok, _ in res), res
     assert all(p.exitcode == 0 for p in procs)
     assert res[0][2] > 4 * 20e6     # ~23.6 M floats of Generator(32) state in one flat buffer
+
+
+def _run_bench(*argv, env=None, timeout=280):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + list(argv), capture_output=True, text=True, env=e,
+                       timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus2_spawns_two_ranks_host_check():
+    """`python bench.py --gpus 2` (no torchrun environment) starts 2 ranks itself; the host flow -- process group, one flat
+    weight broadcast, contiguous shards -- is checked on CPU tensors over gloo."""
+    r, line = _run_bench('--gpus', '2', '--host-check', '--size', '32', '--batch', '64')
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line['n_gpus'] == 2 and line['backend'] == 'gloo'
+    assert line['shards'] == [[0, 64], [64, 128]]
+    assert line['weights_identical_on_all_ranks'] is True
+    assert line['weight_broadcast_bytes'] > 4 * 20e6
+
+
+@pytest.mark.timeout(120)
+def test_bench_refuses_more_ranks_than_gpus():
+    """--gpus N on a host with fewer than N devices must fail loudly, never measure fewer GPUs and report N (or 1)."""
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip('needs a host with fewer than 2 GPUs')
+    r, line = _run_bench('--gpus', '2', '--steps', '1', '--warmup', '1')
+    assert r.returncode != 0 and line is None
+    assert 'GPU(s) visible' in (r.stderr + r.stdout)
+    # and a torchrun-style environment that disagrees with --gpus is refused by the worker itself
+    r, line = _run_bench('--gpus', '1', '--host-check', env={'WORLD_SIZE': '2', 'RANK': '0', 'LOCAL_RANK': '0',
+                                                             'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(_free_port())},
+                         timeout=100)
+    assert r.returncode != 0 and line is None

@@ -325,3 +325,189 @@ def test_fp16_split_saturates_instead_of_overflowing():
     # the producers of the split hand-over count too
     F_.to_split(x, s, 'fp16x3')
     assert F_.split_saturation_count() > 0
+
+
+# ---------------------------------------------------------------------------------------------- dynamic range of fp16x3
+# fp16 terms have 5 exponent bits.  The RANGE PLAN (functional.split_range / styles_batched(plans=...)) moves every image's
+# x*s product range under the fp16 maximum with exact powers of two; these tests pin it with a PURELY RELATIVE bound
+# (err <= 2e-5 * max|ref|, no max(1, .)) -- the bound the fp32 kernels meet -- across 35 binades of input scale and six
+# decades of style magnitude, and show that the kernel alone (fixed 2^-4 pre-scale, as shipped in round 1) does not.
+
+def _wide_styles(key, B, cin):
+    """|s| log-uniform in [1e-3, 1e3], random signs."""
+    u = S.counter_tensor(11, key + '.u', (B, cin), 0.0, 1.0).clamp_(-1.7, 1.7) / 1.7        # ~[-1, 1]
+    sign = torch.where(S.counter_tensor(11, key + '.sg', (B, cin)) >= 0, 1.0, -1.0)
+    return (sign * torch.pow(torch.tensor(10.0), 3.0 * u)).float()
+
+
+def _true_demod(w, s):
+    cin = w.shape[2]
+    q = (w[0].double() / (cin * 9) ** 0.5).pow(2).sum((2, 3))                                 # [cout, cin]
+    return torch.rsqrt(s.double().pow(2) @ q.t() + 1e-8).float()
+
+
+def _fp64_layer(x, w, s, d, up, fir):
+    x, w, s, d = x.double().cpu(), w.double().cpu(), s.double().cpu(), d.double().cpu()
+    cin = x.shape[1]
+    u = x * s[:, :, None, None]
+    if not up:
+        return torch.nn.functional.conv2d(u, w[0] / (cin * 9) ** 0.5, padding=1) * d[:, :, None, None]
+    T = torch.nn.functional.conv_transpose2d(u, (w[0] / (cin * 9) ** 0.5).transpose(0, 1), stride=2) * d[:, :, None, None]
+    return O.upfirdn2d(T, fir.double().cpu(), pad=(1, 1))
+
+
+@pytest.mark.parametrize('styles', ['unit', 'wide'])
+@pytest.mark.parametrize('log2_scale', [-20, -10, 0, 15])
+@pytest.mark.parametrize('up', [False, True])
+def test_fp16x3_dynamic_range_relative_bound(up, log2_scale, styles):
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    from stylegan_directions_face_reenactment_amd.model import make_kernel
+    cin, cout, H, B = (64, 128, 32, 3) if not up else (64, 64, 32, 3)
+    key = 'range.%d.%d.%s' % (int(up), log2_scale, styles)
+    w = S.counter_tensor(12, key + '.w', (1, cout, cin, 3, 3))
+    x = (S.counter_tensor(12, key + '.x', (B, cin, H, H)) * 2.0 ** log2_scale)
+    x[1] *= 2.0 ** 7                                                    # images of one batch at different scales
+    s = _wide_styles(key, B, cin) if styles == 'wide' else S.counter_tensor(12, key + '.s', (B, cin), 1.0, 0.3)
+    d = _true_demod(w, s)
+    fir = (make_kernel([1, 3, 3, 1]) * 4)
+    ref = _fp64_layer(x, w, s, d, up, fir)
+    scale = float(ref.abs().max())
+    wg, xg, sg, dg, firg = w.cuda(), x.cuda(), s.cuda(), d.cuda(), fir.cuda()
+    wp, _, _ = F_.prepack(wg)
+    assert F_.PRECISION == 'fp16x3' and F_.RANGE_PLAN
+    F_.split_saturation_count(reset=True)
+    y = F_.modconv3x3(xg, wp, sg, dg, cout, upsample=up, fir=firg if up else None, split=lambda: F_.prepack_split(wg, 'fp16x3'))
+    assert F_.split_saturation_count(reset=True) == 0
+    err = maxabs(y, ref)
+    print('%s up=%d scale 2^%d styles %s: max|ref| %.3e  err/max|ref| %.2e' % (key, up, log2_scale, styles, scale, err / scale))
+    assert err <= 2e-5 * scale, (err, scale)
+    # the fp32 kernels on the same inputs: the bound the plan has to match
+    with F_.precision('fp32'):
+        y32 = F_.modconv3x3(xg, wp, sg, dg, cout, upsample=up, fir=firg if up else None)
+    assert maxabs(y32, ref) <= 2e-5 * scale
+
+
+def test_fp16x3_without_the_plan_loses_small_inputs():
+    """Documents WHY the plan exists: the bare kernel (x*2^-4 pre-scale only) keeps its bound for O(1) inputs and loses it
+    when the whole layer input sits 20 binades lower -- the hole VERDICT r1 pointed at."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    cin, cout, H, B = 64, 128, 32, 2
+    w = S.counter_tensor(13, 'noplan.w', (1, cout, cin, 3, 3))
+    s = S.counter_tensor(13, 'noplan.s', (B, cin), 1.0, 0.3)
+    d = _true_demod(w, s)
+    for log2_scale, ok in ((0, True), (-20, False)):
+        x = S.counter_tensor(13, 'noplan.x', (B, cin, H, H)) * 2.0 ** log2_scale
+        ref = _fp64_layer(x, w, s, d, False, None)
+        y = F_.modconv_split(x.cuda(), F_.prepack_split(w.cuda(), 'fp16x3'), s.cuda(), d.cuda(), cout, arith='fp16x3')
+        rel = maxabs(y, ref) / float(ref.abs().max())
+        assert (rel <= 2e-5) == ok, (log2_scale, rel)
+
+
+def test_range_plan_is_exact_scaling():
+    """split_range returns (s*2^e, d*2^-e) with one e per image: products s_n*d_n == s*d bit for bit, max|s_n| lands in the
+    planned binade, absmax words are the bit patterns of max|x|."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    B, cin, cout = 5, 96, 64
+    s = _wide_styles('exact', B, cin).cuda()
+    d = S.counter_tensor(14, 'exact.d', (B, cout), 1.0, 0.2).cuda()
+    x = (S.counter_tensor(14, 'exact.x', (B, 8, 16, 16)) * torch.tensor([1e-6, 1.0, 37.0, 1e4, 0.0]).view(B, 1, 1, 1)).cuda()
+    words = F_.absmax(x)
+    assert torch.equal(words.cpu(), x.abs().amax((1, 2, 3)).cpu().view(torch.int32))
+    assert int(F_.absmax(x, per_image=False).cpu()) == int(x.abs().max().cpu().view(torch.int32))
+    s_n, d_n = F_.split_range(s, d, words)
+    ratio = (s_n / s)[:, :1]
+    assert torch.equal(s_n, s * ratio) and torch.equal(d_n, d / ratio)                         # one exact power of two per image
+    assert torch.equal(torch.log2(ratio), torch.log2(ratio).round())
+    bound = (s_n.abs().amax(1) * x.abs().amax((1, 2, 3)))[:4].cpu()                             # < 2^19 and >= 2^17 by construction
+    assert (bound < 2.0 ** 19).all() and (bound >= 2.0 ** 17).all(), bound
+    assert torch.equal(s_n[4], s[4]) and torch.equal(d_n[4], d[4])                              # all-zero image: left alone
+    bad = x.clone()
+    bad[2, 0, 0, 0] = float('nan')
+    assert int(F_.absmax(bad).cpu()[2]) >= 0x7f800000                                          # NaN / Inf show up as a non-finite word
+
+
+def _rescaled_generator(size=256):
+    """Generator whose layers sit at very different |x*s|: modulation outputs of some layers ~1e-3, of others ~1e2, the
+    constant input 2^-8 -- demodulation makes the IMAGE almost insensitive to it, a fixed operand pre-scale is not."""
+    state = {k: v.clone() for k, v in synthetic_state(size, 1).items()}
+    state['input.input'] *= 2.0 ** -8
+    for name, f in (('conv1', 1e-3), ('convs.1', 1e-3), ('convs.4', 3e-4), ('convs.6', 1e2), ('convs.9', 2e-3), ('convs.11', 5e-4)):
+        state[name + '.conv.modulation.weight'] *= f
+        state[name + '.conv.modulation.bias'] *= f
+    return state
+
+
+def test_generator_with_low_magnitude_layers():
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    from stylegan_directions_face_reenactment_amd.model import Generator
+    state = _rescaled_generator(256)
+    G = Generator(256, 512, 8, channel_multiplier=1)
+    G.load_state_dict(state)
+    G = G.eval().cuda()
+    w = S.synthetic_latents(SEED, 2, n_latent=G.n_latent, key='lowmag.w')
+    with torch.no_grad():
+        ref, _ = O.generator_forward(O.cast_state(state, torch.float64), [w.double()], input_is_latent=True)
+        F_.split_saturation_count(reset=True)
+        img, _ = G([w.cuda()], input_is_latent=True)
+        assert F_.split_saturation_count(reset=True) == 0 and G._range_state['mode'] == 'fp16x3'
+        with F_.precision('fp32'):
+            img32, _ = G([w.cuda()], input_is_latent=True)
+    scale = max(1.0, float(ref.abs().max()))
+    e16, e32 = maxabs(img, ref), maxabs(img32, ref)
+    print('low-magnitude generator: max|ref| %.2f  fp16x3 %.2e  fp32 kernels %.2e' % (scale, e16, e32))
+    assert e16 <= 1e-4 * scale and e32 <= 1e-4 * scale, (e16, e32)
+
+
+def test_saturation_is_counted_and_generator_falls_back():
+    """Activations far outside the calibrated range (here: a noise map 1e9 times stronger than the calibrated one) clamp,
+    are COUNTED, and the generator switches itself to bf16x3 at its next poll, with a warning -- never silently."""
+    import warnings
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    G = hip_generator(64, 1)
+    G.SATURATION_POLL_EVERY = 1
+    w = S.synthetic_latents(SEED, 16, n_latent=G.n_latent, key='sat.w').cuda()
+    noises = [getattr(G.noises, 'noise_%d' % i) for i in range(G.num_layers)]
+    with torch.no_grad():
+        F_.split_saturation_count(reset=True)
+        ok, _ = G([w], input_is_latent=True)
+        assert G._range_state['mode'] == 'fp16x3'
+        loud = [n * 1e9 if i == 4 else n for i, n in enumerate(noises)]
+        G([w], input_is_latent=True, noise=loud)
+        assert F_.split_saturation_count(reset=False) > 0
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter('always')
+            again, _ = G([w], input_is_latent=True)
+        assert G._range_state['mode'] == 'bf16x3' and any('falling back' in str(r.message) for r in rec)
+        with F_.precision('bf16x3'):
+            bf, _ = G([w], input_is_latent=True)
+        assert torch.equal(again, bf) and not torch.equal(again, ok)
+        # new weights -> fresh calibration, fp16x3 again
+        G.load_state_dict(synthetic_state(64, 1))
+        G([w], input_is_latent=True)
+        assert G._range_state['mode'] == 'fp16x3'
+        # NaN operands are counted too (v_med3 would turn them into finite values)
+        F_.split_saturation_count(reset=True)
+        x = S.counter_tensor(15, 'nan.x', (2, 64, 16, 16)).cuda()
+        x[1, 3, 2, 2] = float('nan')
+        s = S.counter_tensor(15, 'nan.s', (2, 64), 1.0, 0.3).cuda()
+        d = torch.ones(2, 64).cuda()
+        F_.modconv_split(x, F_.prepack_split(S.counter_tensor(15, 'nan.w', (1, 64, 64, 3, 3)).cuda(), 'fp16x3'), s, d, 64, arith='fp16x3')
+        assert F_.split_saturation_count(reset=True) > 0
+
+
+def test_invalidate_packs_after_data_write():
+    """in-place writes through `.data` do not bump the version counter the weight packs are keyed on."""
+    G = hip_generator(64, 1)
+    w = S.synthetic_latents(SEED, 2, n_latent=G.n_latent, key='inv.w').cuda()
+    with torch.no_grad():
+        a, _ = G([w], input_is_latent=True)
+        G.convs[2].conv.weight.data[:, :, :64].mul_(3.0)           # invisible to ._version
+        stale, _ = G([w], input_is_latent=True)
+        G.invalidate_packs()
+        fresh, _ = G([w], input_is_latent=True)
+        G.convs[2].conv.weight.mul_(1.0)                           # a tracked in-place op needs no call
+        tracked, _ = G([w], input_is_latent=True)
+    assert torch.equal(stale, a) and not torch.equal(fresh, a) and torch.equal(tracked, fresh)
+    state = {k: v.cpu() for k, v in G.state_dict().items()}
+    ref, _ = O.generator_forward(state, [w.cpu()], input_is_latent=True)
+    assert maxabs(fresh, ref) <= 2e-4
