@@ -20,17 +20,20 @@ struct DirTable {
     sgdfr_direction d[SGDFR_MAX_DIRECTIONS];
 };
 
+// the three parameter arrays of one face set, indexed by (kind - 1): angles [*,3] (yaw, pitch, roll), pose [*,pose_dim],
+// alpha_exp [*,exp_dim]; bs = batch stride in floats (0 = one source for every frame)
 struct ShiftSrc {
-    const float* ang;     // [*,3] yaw, pitch, roll
-    const float* pose;    // [*,pose_dim]
-    const float* exp;     // [*,exp_dim]
-    int64_t ang_bs, pose_bs, exp_bs;    // batch strides in floats (0 = one source for every frame)
+    const float* base[3];
+    int64_t bs[3];
 };
 
+// (An if-chain over three (pointer, stride) members was miscompiled by hipcc 7.2 for gfx950: the expression branch kept
+// the pose stride -- caught by the golden test.  Both selections are therefore written as explicit, separate selects.)
 __device__ __forceinline__ float pick(const ShiftSrc& p, const sgdfr_direction& e, int n) {
-    if (e.kind == SGDFR_DIR_ANGLE) return p.ang[n * p.ang_bs + e.col];
-    if (e.kind == SGDFR_DIR_JAW) return p.pose[n * p.pose_bs + e.col];
-    return p.exp[n * p.exp_bs + e.col];
+    const int k = e.kind;
+    const float* b = k == SGDFR_DIR_ANGLE ? p.base[0] : (k == SGDFR_DIR_JAW ? p.base[1] : p.base[2]);
+    const int64_t st = k == SGDFR_DIR_ANGLE ? p.bs[0] : (k == SGDFR_DIR_JAW ? p.bs[1] : p.bs[2]);
+    return b[n * st + e.col];
 }
 
 // position of a value on the direction's shift axis, float64 flavour (run_inference.py:217-252)
@@ -99,14 +102,14 @@ extern "C" int sgdfr_make_shift_f32(const float* ang_s, int64_t ang_s_bs, const 
                                     int64_t exp_s_bs, const float* ang_t, const float* pose_t, const float* exp_t, int pose_dim,
                                     int exp_dim, const struct sgdfr_direction* table, int D, float* shift, int N, int arith,
                                     void* stream) {
-    SGDFR_REQUIRE(ang_s && pose_s && exp_s && ang_t && pose_t && exp_t && shift, "make_shift: null pointer");
     SGDFR_REQUIRE(N >= 0 && pose_dim >= 1 && exp_dim >= 1, "make_shift: bad sizes N=%d pose_dim=%d exp_dim=%d", N, pose_dim, exp_dim);
     SGDFR_REQUIRE(arith == 0 || arith == 1, "make_shift: arith must be 0 (float64 scalars) or 1 (float32 tensors), got %d", arith);
     DirTable tab;
     if (int rc = check_table(table, D, pose_dim, exp_dim, &tab)) return rc;
-    if (N == 0) return 0;
-    ShiftSrc src{ang_s, pose_s, exp_s, ang_s_bs, pose_s_bs, exp_s_bs};
-    ShiftSrc tgt{ang_t, pose_t, exp_t, 3, pose_dim, exp_dim};
+    if (N == 0) return 0;                  // empty batch: empty tensors carry null pointers
+    SGDFR_REQUIRE(ang_s && pose_s && exp_s && ang_t && pose_t && exp_t && shift, "make_shift: null pointer");
+    ShiftSrc src{{ang_s, pose_s, exp_s}, {ang_s_bs, pose_s_bs, exp_s_bs}};
+    ShiftSrc tgt{{ang_t, pose_t, exp_t}, {3, pose_dim, exp_dim}};
     const int total = N * D;
     hipLaunchKernelGGL(make_shift_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), src, tgt, tab, D, shift, N, arith);
     return check_launch("make_shift");
@@ -115,13 +118,13 @@ extern "C" int sgdfr_make_shift_f32(const float* ang_s, int64_t ang_s_bs, const 
 extern "C" int sgdfr_make_shift_random_f32(const float* ang_s, const float* pose_s, const float* exp_s, int pose_dim, int exp_dim,
                                            const int* which, const float* u, float shift_scale,
                                            const struct sgdfr_direction* table, int D, float* shift, int N, void* stream) {
-    SGDFR_REQUIRE(ang_s && pose_s && exp_s && which && u && shift, "make_shift_random: null pointer");
     SGDFR_REQUIRE(N >= 0 && pose_dim >= 1 && exp_dim >= 1, "make_shift_random: bad sizes N=%d pose_dim=%d exp_dim=%d", N, pose_dim,
                   exp_dim);
     DirTable tab;
     if (int rc = check_table(table, D, pose_dim, exp_dim, &tab)) return rc;
     if (N == 0) return 0;
-    ShiftSrc src{ang_s, pose_s, exp_s, 3, pose_dim, exp_dim};
+    SGDFR_REQUIRE(ang_s && pose_s && exp_s && which && u && shift, "make_shift_random: null pointer");
+    ShiftSrc src{{ang_s, pose_s, exp_s}, {3, pose_dim, exp_dim}};
     const int total = N * D;
     hipLaunchKernelGGL(make_shift_random_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), src, tab, D, which, u,
                        shift_scale, shift, N);
