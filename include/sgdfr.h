@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 7
+#define SGDFR_ABI_VERSION 8
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -78,6 +78,8 @@ int sgdfr_linear_f32(const float* x, int64_t ldx, const float* w, const float* b
 
 /* y[b,:] = x[b,:] * rsqrt(mean(x[b,:]^2) + eps) */
 int sgdfr_pixelnorm_f32(const float* x, float* y, int B, int D, float eps, void* stream);
+/* its adjoint: dx[b,:] = r*g - x * r^3 * mean(g*x), r = rsqrt(mean(x^2) + eps)   (autograd of model.py:11-16) */
+int sgdfr_pixelnorm_bwd_f32(const float* x, const float* g, float* dx, int B, int D, float eps, void* stream);
 
 /* out[b,l,:] = t + psi * (v - t),   v = w[b,(l),:] + (l < shift_layers ? shift[b,(l),:] : 0)
  *   w:     [B, L, D] if w_is_plus else [B, D] (broadcast over l)
@@ -272,13 +274,22 @@ int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, in
 int sgdfr_torgb_finish_f32(const float* part, int T, const float* bias, const float* skip, const float* fir, float* y, int B,
                            int H, int W, void* stream);
 
+/* sgdfr_torgb_finish_f32 whose result leaves as uint8 HWC instead of fp32 planes -- the output side of the path fused into the
+ * last ToRGB (scaling of libs/utilities/image_utils.py:87-110, identical to sgdfr_image_to_u8_f32 applied to
+ * the fp32 result):  y[b][oy][x_offset + ox][c] = u8(rgb[b, swap_rb ? 2-c : c, oy, ox]),  row_pitch bytes per row, so the
+ * frame can be written as one panel of a wider grid (x_offset, row_pitch multiples of 4). */
+int sgdfr_torgb_finish_u8_f32(const float* part, int T, const float* bias, const float* skip, const float* fir,
+                              unsigned char* y, int64_t row_pitch, int x_offset, int swap_rb, int B, int H, int W,
+                              void* stream);
+
 /* x [B,3,H,W] fp32 -> y [B,H,W,3] uint8:  trunc( (clamp(x,-1,1) + 1) / (2 + 1e-5) * 255 )
  * (libs/utilities/image_utils.py:87-110 tensor_to_image / torch_range_1_to_255, then the writers' uint8 cast) */
 int sgdfr_image_to_u8_f32(const float* x, unsigned char* y, int B, int H, int W, void* stream);
 
 /* K panels [B,3,H,W] fp32 side by side -> y [B,H,K*W,3] uint8 video frames, same scaling as above.
  * `panels` / `bstrides` are HOST arrays of K device pointers / batch strides in floats (0 = the same image in
- * every frame, e.g. the source).  Batched generate_grid_image + tensor_to_image + np.uint8
+ * every frame, e.g. the source; a NULL panel is skipped -- its columns keep what sgdfr_torgb_finish_u8_f32 wrote).
+ * Batched generate_grid_image + tensor_to_image + np.uint8
  * (libs/utilities/utils_inference.py:11-33, run_inference.py:188-194); swap_rb != 0 also applies that path's
  * cv2.cvtColor(.., COLOR_BGR2RGB) channel swap. */
 #define SGDFR_MAX_GRID_PANELS 4

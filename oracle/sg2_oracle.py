@@ -41,16 +41,19 @@ def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
 
     x [B,C,H,W]; zero-stuff by `up`, pad (negative pad crops), correlate with the
     *flipped* kernel (true convolution), keep every `down`-th sample.
-    pad is (p0, p1) applied to both axes or (x0, x1, y0, y1).
+    pad is (p0, p1) applied to both axes or (x0, x1, y0, y1); up / down are one factor for both axes or
+    (x, y) pairs -- `upfirdn2d_native` itself takes up_x, up_y, down_x, down_y (upfirdn2d.py:168-170).
     Written as an explicit sum over FIR taps (no conv library call).
     """
     if len(pad) == 2:
         pad = (pad[0], pad[1], pad[0], pad[1])
     px0, px1, py0, py1 = pad
+    up_x, up_y = up if isinstance(up, (tuple, list)) else (up, up)
+    down_x, down_y = down if isinstance(down, (tuple, list)) else (down, down)
     B, C, H, W = x.shape
     kh, kw = kernel.shape
-    u = x.new_zeros(B, C, H * up, W * up)
-    u[:, :, ::up, ::up] = x
+    u = x.new_zeros(B, C, H * up_y, W * up_x)
+    u[:, :, ::up_y, ::up_x] = x
     u = F.pad(u, [max(px0, 0), max(px1, 0), max(py0, 0), max(py1, 0)])
     u = u[:, :, max(-py0, 0): u.shape[2] - max(-py1, 0), max(-px0, 0): u.shape[3] - max(-px1, 0)]
     fh, fw = u.shape[2] - kh + 1, u.shape[3] - kw + 1
@@ -58,9 +61,9 @@ def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
     for a in range(kh):
         for b in range(kw):
             acc = acc + u[:, :, a:a + fh, b:b + fw] * kernel[kh - 1 - a, kw - 1 - b].to(x.dtype)
-    out = acc[:, :, ::down, ::down]
-    oh = (H * up + py0 + py1 - kh + down) // down
-    ow = (W * up + px0 + px1 - kw + down) // down
+    out = acc[:, :, ::down_y, ::down_x]
+    oh = (H * up_y + py0 + py1 - kh + down_y) // down_y
+    ow = (W * up_x + px0 + px1 - kw + down_x) // down_x
     assert out.shape[2:] == (oh, ow), (out.shape, oh, ow)
     return out
 

@@ -19,10 +19,15 @@ def load(dirn):
 
 
 def last(d, cname):
+    """Every dispatch of the LAST forward in the trace (from its first style launch on), in launch order: launches that share
+    a kernel name and grid (the capped grids of the blur levels) stay separate rows."""
+    keys = list(d.keys())
+    starts = [i for i, (disp, name, grid) in enumerate(keys) if name.startswith('styles_batched_kernel<0>')]
+    first = starts[-1] if starts else 0
     o = collections.OrderedDict()
-    for (disp, name, grid), c in d.items():
-        if cname in c:
-            o[(name, grid)] = (c[cname], disp)
+    for n, (disp, name, grid) in enumerate(keys[first:]):
+        if cname in d[(disp, name, grid)]:
+            o[(name, grid, n)] = (d[(disp, name, grid)][cname], disp)
     return o
 
 
@@ -40,7 +45,7 @@ L = ['# rocprofv3 PMC passes (%s)\n' % out,
      'as 64 B, so read bytes = 2 x FETCH_SIZE; WRITE_SIZE equals the algorithmic output bytes of every launch exactly.\n',
      '## HBM traffic of one forward (last forward in the trace)\n',
      '| kernel | grid (work-items) | FETCH_SIZE KiB raw | read MB (x2) | WRITE_SIZE KiB | write MB |', '|---|---|---|---|---|---|']
-tr = tw = 0
+tr = tw = br = bw = 0
 for k, (v, _) in ff.items():
     if not any(t in k[0] for t in CONV + ('blur', 'torgb')):
         continue
@@ -49,8 +54,13 @@ for k, (v, _) in ff.items():
     if any(t in k[0] for t in CONV):
         tr += 2 * v * 1024
         tw += wv * 1024
+    if 'blur' in k[0]:
+        br += 2 * v * 1024
+        bw += wv * 1024
 L.append('\nConv kernels per forward (13 launches): read %.2f GB (corrected) + write %.2f GB = %.2f GB, %.1f MB per launch, %.1f MB per image.'
          % (tr / 1e9, tw / 1e9, (tr + tw) / 1e9, (tr + tw) / 13 / 1e6, (tr + tw) / 64 / 1e6))
+L.append('Blur launches per forward: read %.2f GB (corrected) + write %.2f GB; read / written = %.2f (1.0 = every parity plane fetched once).'
+         % (br / 1e9, bw / 1e9, br / max(bw, 1)))
 L.append('\n## SQ counters per conv launch\n')
 L.append('GRBM_GUI_ACTIVE is summed over the 8 XCDs: clock = GRBM_GUI_ACTIVE / 8 / duration; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs).\n')
 L.append('| kernel | grid | dur us | clock GHz | MFMA busy % | wait_inst / wave_cycles | wait_any / wave_cycles | LDS bank-conflict cycles |')
@@ -67,7 +77,10 @@ for (name, grid), (disp, c) in seen.items():
         name, grid, dur / 1e3, gui / dur if dur else 0, 100 * c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (gui * 1024) if gui else 0,
         c.get('SQ_WAIT_INST_ANY', 0) / wc, c.get('SQ_WAIT_ANY', 0) / wc, c.get('SQ_LDS_BANK_CONFLICT', 0)))
 open('profiles/%s_pmc.md' % out, 'w').write('\n'.join(L) + '\n')
-json.dump({'config': {'batch': 64, 'cm': 1, 'size': 256, 'precision': precision}, 'conv_launches_per_forward': 13, 'read_bytes_per_forward': tr,
+sys.path.insert(0, '.')
+import bench
+json.dump({'config': {'batch': 64, 'cm': 1, 'size': 256, 'precision': precision}, 'source_hash': bench.kernel_source_hash(),
+           'conv_launches_per_forward': 13, 'read_bytes_per_forward': tr,
            'write_bytes_per_forward': tw, 'bytes_per_launch': (tr + tw) / 13,
            'source': 'profiles/%s_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)' % out},
           open('profiles/traffic_latest.json', 'w'), indent=1)

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libsgdfr_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -25,6 +25,7 @@ SIGNATURES = {
     'sgdfr_linear_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i64, _i, _i, _i, _f, _f, _i, _f, _f,
                          ctypes.c_void_p],
     'sgdfr_pixelnorm_f32': [_c_f32p, _c_f32p, _i, _i, _f, ctypes.c_void_p],
+    'sgdfr_pixelnorm_bwd_f32': [_c_f32p, _c_f32p, _c_f32p, _i, _i, _f, ctypes.c_void_p],
     'sgdfr_latent_prepare_f32': [_c_f32p, _i, _c_f32p, _i, _i, _c_f32p, _f, _c_f32p, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_modconv_prepack_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_modconv_prepack_t_f32': [_c_f32p, _c_f32p, _i, _i, _i, _i, ctypes.c_void_p],
@@ -53,6 +54,7 @@ SIGNATURES = {
     'sgdfr_modconv2d_split_xin_supported': [_i, _i, _i, _i, _i, _i],
     'sgdfr_modconv2d_split_ksplit_hint': [_i, _i, _i, _i, _i, _i],
     'sgdfr_torgb_finish_f32': [_c_f32p, _i, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],
+    'sgdfr_torgb_finish_u8_f32': [_c_f32p, _i, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _i64, _i, _i, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_image_to_u8_f32': [_c_f32p, ctypes.c_void_p, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_grid_to_u8_f32': [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), _i, ctypes.c_void_p, _i, _i, _i,
                              _i, ctypes.c_void_p],

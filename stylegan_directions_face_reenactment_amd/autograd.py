@@ -102,15 +102,16 @@ class EqualLinearFn(Function):
 class PixelNormFn(Function):
     @staticmethod
     def forward(ctx, x):
-        y = F_.pixel_norm(x)
-        ctx.save_for_backward(x, y)
-        return y
+        ctx.save_for_backward(x)
+        return F_.pixel_norm(x)
 
     @staticmethod
     def backward(ctx, g):
-        x, y = ctx.saved_tensors          # y = x*r, r = rsqrt(mean x^2 + eps)  =>  dx = r*g - x * r^3 * mean(g*x)
-        r = torch.rsqrt(x.pow(2).mean(1, keepdim=True) + 1e-8)
-        return r * g - x * r.pow(3) * (g * x).mean(1, keepdim=True)
+        x, = ctx.saved_tensors            # y = x*r, r = rsqrt(mean x^2 + eps)  =>  dx = r*g - x * r^3 * mean(g*x)
+        x2, g2 = N.f32c(x).reshape(x.shape[0], -1), N.f32c(g).reshape(x.shape[0], -1)
+        dx = torch.empty_like(x2)
+        N.call('sgdfr_pixelnorm_bwd_f32', N.ptr(x2), N.ptr(g2), N.ptr(dx), x2.shape[0], x2.shape[1], 1e-8, N.stream())
+        return dx.view(x.shape)
 
 
 class StyleFn(Function):

@@ -91,6 +91,28 @@ __global__ __launch_bounds__(256) void pixelnorm_kernel(const float* __restrict_
     for (int j = lane; j < D; j += 64) y[(int64_t)row * D + j] = xr[j] * r;
 }
 
+// adjoint of pixelnorm: y = x*r, r = rsqrt(mean x^2 + eps)  =>  dx = r*g - x * r^3 * mean(g*x); one wave per row
+__global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                           float* __restrict__ dx, int B, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float* xr = x + (int64_t)row * D;
+    const float* gr = g + (int64_t)row * D;
+    float sq = 0.f, gx = 0.f;
+    for (int j = lane; j < D; j += 64) {
+        sq = fmaf(xr[j], xr[j], sq);
+        gx = fmaf(gr[j], xr[j], gx);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sq += __shfl_xor(sq, o, 64);
+        gx += __shfl_xor(gx, o, 64);
+    }
+    const float r = rsqrtf(sq / (float)D + eps);
+    const float c = r * r * r * (gx / (float)D);
+    for (int j = lane; j < D; j += 64) dx[(int64_t)row * D + j] = r * gr[j] - xr[j] * c;
+}
+
 // ---------------------------------------------------------------- latent prepare
 __global__ __launch_bounds__(256) void latent_prepare_kernel(const float* __restrict__ w, int w_is_plus,
                                                             const float* __restrict__ shift, int shift_is_plus,
@@ -150,6 +172,7 @@ __global__ __launch_bounds__(256) void grid_to_u8_kernel(GridPanels g, unsigned 
         const int row = (int)(br % H);
         const int64_t b = br / H;
         const int k = col / W, c0 = col - k * W;
+        if (!g.x[k]) continue;                      // skipped panel: filled by the fused ToRGB finish
         const float* xp = g.x[k] + b * g.bstride[k] + row * W + c0;
         unsigned char* yp = y + i * 3;
 #pragma unroll
@@ -204,6 +227,14 @@ extern "C" int sgdfr_pixelnorm_f32(const float* x, float* y, int B, int D, float
     return check_launch("pixelnorm");
 }
 
+extern "C" int sgdfr_pixelnorm_bwd_f32(const float* x, const float* g, float* dx, int B, int D, float eps, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && D > 0, "pixelnorm_bwd: bad shape B=%d D=%d", B, D);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(x && g && dx, "pixelnorm_bwd: null pointer");
+    hipLaunchKernelGGL(pixelnorm_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(stream), x, g, dx, B, D, eps);
+    return check_launch("pixelnorm_bwd");
+}
+
 extern "C" int sgdfr_latent_prepare_f32(const float* w, int w_is_plus, const float* shift, int shift_is_plus,
                                         int shift_layers, const float* trunc, float psi, float* out, int B, int L,
                                         int D, void* stream) {
@@ -236,7 +267,7 @@ extern "C" int sgdfr_grid_to_u8_f32(const float* const* panels, const int64_t* b
     for (int k = 0; k < SGDFR_MAX_GRID_PANELS; ++k) {
         g.x[k] = k < K ? panels[k] : nullptr;
         g.bstride[k] = k < K ? bstrides[k] : 0;
-        SGDFR_REQUIRE(k >= K || g.x[k], "grid_to_u8: panel %d is null", k);
+        // a null panel is SKIPPED: its columns of y keep what sgdfr_torgb_finish_u8_f32 already wrote there
     }
     hipLaunchKernelGGL(grid_to_u8_kernel, dim3(grid_for((int64_t)B * H * K * W)), dim3(256), 0, as_stream(stream), g, y,
                        B, H, W, K, swap_rb);

@@ -698,9 +698,14 @@ extern "C" int sgdfr_modconv2d_fwd_f32(const float* x, int64_t x_bstride, const 
 // ToRGB finish: the 1x1 conv was accumulated per cout tile in the feeding conv's epilogue (split.hip); what is left is
 // y[b,j,p] = sum_t part[b, t*3+j, p] + bias[j] + upfirdn2d(skip[b,j], fir, up=2, pad=(2,1))[p].  One thread = 4 pixels of
 // a row x 3 channels; the polyphase upsample reads a 2x3 skip window per channel.
+// U8: the image leaves as uint8 HWC with the reference's tensor_to_image scaling (libs/utilities/image_utils.py:87-110, the
+// same expression as image_to_u8_kernel) instead of fp32 planes: y8[b][oy][x_off + ox][c], `pitch` bytes per row, so the
+// frame can be one panel of a wider video grid; swap_rb writes channel 2-c (the writers' cvtColor).
+template <bool U8>
 __global__ __launch_bounds__(256) void torgb_finish_kernel(const float* __restrict__ part, int T, const float* __restrict__ bias,
                                                           const float* __restrict__ skip, const float* __restrict__ fir,
-                                                          float* __restrict__ y, int B, int H, int W) {
+                                                          float* __restrict__ y, unsigned char* __restrict__ y8, int64_t pitch,
+                                                          int x_off, int swap_rb, int B, int H, int W) {
     __shared__ float kf[16];
     if (threadIdx.x < 16) kf[threadIdx.x] = fir ? fir[15 - threadIdx.x] : 0.f;  // flipped taps
     __syncthreads();
@@ -712,6 +717,7 @@ __global__ __launch_bounds__(256) void torgb_finish_kernel(const float* __restri
         const int oy = (int)((idx / W4) % H);
         const int b = (int)(idx / ((int64_t)W4 * H));
         const int ox = xq * 4;
+        float px[4][3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const float bj = bias ? bias[j] : 0.f;
@@ -744,7 +750,23 @@ __global__ __launch_bounds__(256) void torgb_finish_kernel(const float* __restri
                 }
                 acc.x += o[0]; acc.y += o[1]; acc.z += o[2]; acc.w += o[3];
             }
-            *reinterpret_cast<float4*>(y + ((int64_t)b * 3 + j) * HW + (int64_t)oy * W + ox) = acc;
+            if (!U8) *reinterpret_cast<float4*>(y + ((int64_t)b * 3 + j) * HW + (int64_t)oy * W + ox) = acc;
+            px[0][j] = acc.x; px[1][j] = acc.y; px[2][j] = acc.z; px[3][j] = acc.w;
+        }
+        if (U8) {
+            unsigned char q[12];
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float f = fminf(fmaxf(px[v][swap_rb ? 2 - c : c], -1.f), 1.f);
+                    f = (f + 1.f) / (2.f + 1e-5f) * 255.f;
+                    q[v * 3 + c] = (unsigned char)f;
+                }
+            unsigned* dst = reinterpret_cast<unsigned*>(y8 + ((int64_t)b * H + oy) * pitch + (int64_t)(x_off + ox) * 3);   // 12-byte runs: 4-aligned
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                dst[k] = (unsigned)q[4 * k] | ((unsigned)q[4 * k + 1] << 8) | ((unsigned)q[4 * k + 2] << 16) | ((unsigned)q[4 * k + 3] << 24);
         }
     }
 }
@@ -759,8 +781,28 @@ extern "C" int sgdfr_torgb_finish_f32(const float* part, int T, const float* bia
     SGDFR_REQUIRE(((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "torgb_finish: 16-byte alignment");
     int64_t g = ((int64_t)B * H * (W / 4) + 255) / 256;
     if (g > 256 * 16) g = 256 * 16;
-    hipLaunchKernelGGL(torgb_finish_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), part, T, bias, skip, fir, y, B, H, W);
+    hipLaunchKernelGGL(torgb_finish_kernel<false>, dim3((int)g), dim3(256), 0, as_stream(stream), part, T, bias, skip, fir, y, nullptr,
+                       (int64_t)0, 0, 0, B, H, W);
     return check_launch("torgb_finish");
+}
+
+extern "C" int sgdfr_torgb_finish_u8_f32(const float* part, int T, const float* bias, const float* skip, const float* fir,
+                                         unsigned char* y, int64_t row_pitch, int x_offset, int swap_rb, int B, int H, int W,
+                                         void* stream) {
+    SGDFR_REQUIRE(B >= 0 && T > 0 && H > 0 && W > 0 && W % 4 == 0, "torgb_finish_u8: bad shape B=%d T=%d H=%d W=%d (W %% 4 == 0)", B, T,
+                  H, W);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(part && y, "torgb_finish_u8: null pointer");
+    SGDFR_REQUIRE(!skip || (fir && H % 2 == 0), "torgb_finish_u8: skip needs fir taps and even H");
+    SGDFR_REQUIRE(x_offset >= 0 && x_offset % 4 == 0 && row_pitch >= (int64_t)(x_offset + W) * 3 && row_pitch % 4 == 0,
+                  "torgb_finish_u8: panel at pixel %d (multiple of 4) of %d does not fit rows of %lld bytes (multiple of 4)", x_offset, W,
+                  (long long)row_pitch);
+    SGDFR_REQUIRE((reinterpret_cast<uintptr_t>(part) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 3) == 0, "torgb_finish_u8: alignment");
+    int64_t g = ((int64_t)B * H * (W / 4) + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    hipLaunchKernelGGL(torgb_finish_kernel<true>, dim3((int)g), dim3(256), 0, as_stream(stream), part, T, bias, skip, fir, nullptr, y,
+                       row_pitch, x_offset, swap_rb, B, H, W);
+    return check_launch("torgb_finish_u8");
 }
 
 extern "C" int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, const float* bias,

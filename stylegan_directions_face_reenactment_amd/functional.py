@@ -517,13 +517,35 @@ def rgb_fusable(B, cin, cout, H, W):
         (not USE_SPLITK or _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cin, cout, H, W, N.MODE_PLAIN3) == 1)
 
 
-def torgb_finish(part, bias=None, skip=None, fir=None):
+class U8Target:
+    """Where a generator forward should leave its image as uint8 HWC (libs/utilities/image_utils.py:87-110 scaling) instead of
+    fp32 NCHW: `frames` [B, H, K*W, 3] uint8 on the device (K = 1: plain frames), the image goes to panel `panel` (columns
+    panel*W ...), swap_rb applies the video writers' channel swap.  frames=None: a fresh [B,H,W,3] tensor."""
+    __slots__ = ('frames', 'panel', 'swap_rb')
+
+    def __init__(self, frames=None, panel=0, swap_rb=False):
+        self.frames, self.panel, self.swap_rb = frames, int(panel), bool(swap_rb)
+
+
+def torgb_finish(part, bias=None, skip=None, fir=None, u8=None):
     """part [B, T*3, H, W] (from modconv_split(rgb=...)) -> rgb [B,3,H,W] = sum over the T cout tiles + bias + upsampled
-    skip (one small launch; the activation is not read again)."""
+    skip (one small launch; the activation is not read again).  u8 = U8Target: the result is written as uint8 HWC
+    straight from the sums (the fp32 image is never stored) and the uint8 tensor is returned."""
     N.require_device(part, bias, skip, fir)
     B, c3, H, W = part.shape
     if skip is not None and tuple(skip.shape) != (B, 3, H // 2, W // 2):
         raise RuntimeError('skip shape %s does not match output [%d,3,%d,%d]/2' % (tuple(skip.shape), B, H, W))
+    if u8 is not None:
+        frames = u8.frames
+        if frames is None:
+            frames = torch.empty(B, H, W, 3, device=part.device, dtype=torch.uint8)
+        if frames.dtype != torch.uint8 or not frames.is_cuda or not frames.is_contiguous() or frames.ndim != 4 or \
+                frames.shape[0] != B or frames.shape[1] != H or frames.shape[3] != 3 or frames.shape[2] < (u8.panel + 1) * W:
+            raise RuntimeError('uint8 target %s cannot hold panel %d of [%d,%d,%d,3] frames' % (tuple(frames.shape), u8.panel, B, H, W))
+        N.call('sgdfr_torgb_finish_u8_f32', N.ptr(part), c3 // 3, N.ptr(N.f32c(bias)) if bias is not None else None,
+               N.ptr(N.f32c(skip)) if skip is not None else None, N.ptr(N.f32c(fir)) if fir is not None else None, N.ptr(frames),
+               frames.shape[2] * 3, u8.panel * W, int(u8.swap_rb), B, H, W, N.stream())
+        return frames
     y = torch.empty(B, 3, H, W, device=part.device, dtype=torch.float32)
     N.call('sgdfr_torgb_finish_f32', N.ptr(part), c3 // 3, N.ptr(N.f32c(bias)) if bias is not None else None,
            N.ptr(N.f32c(skip)) if skip is not None else None, N.ptr(N.f32c(fir)) if fir is not None else None, N.ptr(y), B, H, W,

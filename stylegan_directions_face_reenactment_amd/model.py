@@ -328,16 +328,16 @@ class ToRGB(nn.Module):
             return AG.ToRGBFn.apply(input, s, conv.weight, self.bias, skip, fir)
         return F_.torgb(input, conv.weight.view(3, conv.in_channel), s, bias=self.bias.view(3), skip=skip, fir=fir)
 
-    def finish(self, part, skip=None):
+    def finish(self, part, skip=None, u8=None):
         """The rest of forward() when the 1x1 conv was accumulated in the feeding conv's epilogue (no-grad path):
-        sum of the per-cout-tile partials + bias + upsampled skip."""
+        sum of the per-cout-tile partials + bias + upsampled skip (u8: as uint8 HWC, functional.U8Target)."""
         fir = None
         if skip is not None:
             up = getattr(self, 'upsample', None)
             if up is None or tuple(up.kernel.shape) != (4, 4) or up.pad != (2, 1):
                 raise NotImplementedError('ToRGB skip path is built for the 4-tap 2x Upsample')
             fir = up.kernel
-        return F_.torgb_finish(part, bias=self.bias.view(3), skip=skip, fir=fir)
+        return F_.torgb_finish(part, bias=self.bias.view(3), skip=skip, fir=fir, u8=u8)
 
 
 class Generator(nn.Module):
@@ -470,7 +470,10 @@ class Generator(nn.Module):
 
     # ---- the path itself (model.py:471-539)
     def forward(self, styles, return_latents=False, return_features=False, inject_index=None, truncation=1,
-                truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=False):
+                truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=False, image_out=None):
+        """Reference signature (model.py:471-482) plus one optional extension: image_out = functional.U8Target makes a
+        no-grad forward return the image as uint8 HWC frames (the reference's tensor_to_image scaling), written by the last
+        ToRGB launch itself when that ToRGB is fused into its conv (otherwise converted by one extra launch)."""
         if not input_is_latent:
             styles = [self.style(s) for s in styles]
         if noise is None:
@@ -518,10 +521,10 @@ class Generator(nn.Module):
             sd = iter(F_.styles_batched(latent, specs, plans))
         if arith is not None and arith != F_.PRECISION:    # saturation / non-finite fallback: run this forward in `arith`
             with F_.precision(arith):
-                return self._synthesis(latent, list(sd), layers, to_rgbs, noise, grad, ranged, return_latents)
-        return self._synthesis(latent, list(sd), layers, to_rgbs, noise, grad, ranged, return_latents)
+                return self._synthesis(latent, list(sd), layers, to_rgbs, noise, grad, ranged, return_latents, image_out)
+        return self._synthesis(latent, list(sd), layers, to_rgbs, noise, grad, ranged, return_latents, image_out)
 
-    def _synthesis(self, latent, sd, layers, to_rgbs, noise, grad, ranged, return_latents):
+    def _synthesis(self, latent, sd, layers, to_rgbs, noise, grad, ranged, return_latents, image_out=None):
         """conv1 ... convs / to_rgbs with the (s, d) pairs of `sd` (one per entry of conv1, to_rgb1, (up, plain, to_rgb)*)."""
         batch = latent.shape[0]
         sd_of_layer = [0] + [2 + 3 * (i // 2) + (i % 2) for i in range(len(self.convs))]
@@ -537,12 +540,19 @@ class Generator(nn.Module):
         main = torch.cuda.current_stream() if side is not None else None
         on_side = [False]                          # is the latest `skip` being produced on the side stream?
 
-        def rgb(layer, x, part_in, skip_in, sdl):
+        if image_out is not None and grad:
+            raise RuntimeError('image_out (uint8 frames) is an inference output: call the generator under torch.no_grad()')
+        wrote_u8 = [False]
+
+        def rgb(layer, x, part_in, skip_in, sdl, last=False):
             if part_in is not None:
                 if on_side[0]:
                     main.wait_stream(side)
                     skip_in.record_stream(main)
                     on_side[0] = False
+                if last and image_out is not None:
+                    wrote_u8[0] = True
+                    return layer.finish(part_in, skip_in, u8=image_out)
                 return layer.finish(part_in, skip_in)
             run = lambda: layer(x, None, skip_in, sd=sdl)
             if side is None:
@@ -603,10 +613,20 @@ class Generator(nn.Module):
                     noise=nz, noise_weight=layer.noise.weight, bias=layer.activate.bias, batch=batch if first else None,
                     s_next=sd[sd_of_layer[li + 1]][0] if to_next else None, rgb=rgb_arg, want_y=want_y)
             if not up:
-                skip = rgb(to_rgbs[k], out, part, skip, sd[sd_of_rgb[k]])
+                skip = rgb(to_rgbs[k], out, part, skip, sd[sd_of_rgb[k]], last=li == len(layers) - 1)
             x = out
         if side is not None and on_side[0]:
             main.wait_stream(side)
             skip.record_stream(main)
         image = skip
+        if image_out is not None and not wrote_u8[0]:       # last ToRGB not fused (tiny batches / odd shapes): one extra launch
+            from .reenact import images_to_uint8, grid_frames_uint8
+            if image_out.frames is None and not image_out.swap_rb:
+                image = images_to_uint8(image)
+            else:
+                B, _, H, W = image.shape
+                frames = image_out.frames if image_out.frames is not None else torch.empty(B, H, W, 3, device=image.device, dtype=torch.uint8)
+                K = frames.shape[2] // W
+                grid_frames_uint8([image if k == image_out.panel else None for k in range(K)], swap_rb=image_out.swap_rb, out=frames)
+                image = frames
         return (image, latent) if return_latents else (image, None)

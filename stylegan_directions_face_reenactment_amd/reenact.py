@@ -31,28 +31,43 @@ def images_to_uint8(images):
     return y
 
 
-def grid_frames_uint8(panels, swap_rb=False):
+def grid_frames_uint8(panels, swap_rb=False, out=None):
     """Side-by-side video frames for a batch: panels = list of [B,3,H,W] or [1,3,H,W] (shown in every frame) fp32
     images in [-1,1] -> [B,H,K*W,3] uint8.  One launch for what the reference does per frame with
     generate_grid_image + tensor_to_image + np.uint8 (utils_inference.py:11-33, run_inference.py:188-194);
-    swap_rb applies that path's cvtColor channel swap."""
+    swap_rb applies that path's cvtColor channel swap.  A panel given as None is left untouched in `out` (the generator
+    already wrote it there: Generator.forward(image_out=U8Target(out, panel)))."""
     if not 1 <= len(panels) <= 4:
         raise RuntimeError('grid_frames_uint8 takes 1..4 panels, got %d' % len(panels))
     xs = []
     for x in panels:
+        if x is None:
+            xs.append(None)
+            continue
         N.require_device(x)
         xs.append(N.f32c(x if x.ndim == 4 else x.unsqueeze(0)))
-    B = max(x.shape[0] for x in xs)
-    _, C, H, W = xs[0].shape
-    for x in xs:
+    given = [x for x in xs if x is not None]
+    if not given and out is None:
+        raise RuntimeError('grid_frames_uint8: nothing to write')
+    if given:
+        B = max(x.shape[0] for x in given) if out is None else out.shape[0]
+        _, C, H, W = given[0].shape
+    else:
+        return out
+    for x in given:
         if x.shape[1:] != (3, H, W) or x.shape[0] not in (1, B):
             raise RuntimeError('grid panels must be [B or 1,3,%d,%d], got %s' % (H, W, tuple(x.shape)))
     K = len(xs)
-    ptrs = (ctypes.c_void_p * K)(*[x.data_ptr() for x in xs])
-    strides = (ctypes.c_int64 * K)(*[0 if (x.shape[0] == 1 and B > 1) else 3 * H * W for x in xs])
-    y = torch.empty(B, H, K * W, 3, device=xs[0].device, dtype=torch.uint8)
-    N.call('sgdfr_grid_to_u8_f32', ptrs, strides, K, N.ptr(y), B, H, W, int(bool(swap_rb)), N.stream())
-    return y
+    if any(x is None for x in xs) and out is None:
+        raise RuntimeError('grid_frames_uint8: a skipped panel needs the `out` tensor that already holds it')
+    ptrs = (ctypes.c_void_p * K)(*[None if x is None else x.data_ptr() for x in xs])
+    strides = (ctypes.c_int64 * K)(*[0 if (x is None or (x.shape[0] == 1 and B > 1)) else 3 * H * W for x in xs])
+    if out is None:
+        out = torch.empty(B, H, K * W, 3, device=given[0].device, dtype=torch.uint8)
+    elif tuple(out.shape) != (B, H, K * W, 3) or out.dtype != torch.uint8 or not out.is_cuda or not out.is_contiguous():
+        raise RuntimeError('grid_frames_uint8: out must be a contiguous uint8 [%d,%d,%d,3] device tensor' % (B, H, K * W))
+    N.call('sgdfr_grid_to_u8_f32', ptrs, strides, K, N.ptr(out), B, H, W, int(bool(swap_rb)), N.stream())
+    return out
 
 
 def save_latent_codes(directory, names, latents):
@@ -108,13 +123,14 @@ class ReenactmentSession:
     def reset_graph(self):
         self._graph = None
 
-    def _step(self, sv):
+    def _step(self, sv, image_out=None):
         shift = self.A(sv)                                              # [b, L, 512] (w_plus) or [b, 512]
         b = sv.shape[0]
         w = self.source.expand(b, -1, -1).contiguous()
         layers = shift.shape[1] if shift.ndim == 3 else self.A.num_layers
         latent = F_.latent_prepare(w, self.G.n_latent, shift=shift, shift_layers=layers)
-        img, _ = self.G([latent], input_is_latent=True, truncation=self.truncation, truncation_latent=self.trunc)
+        img, _ = self.G([latent], input_is_latent=True, truncation=self.truncation, truncation_latent=self.trunc,
+                        image_out=image_out)
         return img
 
     def _graphed_step(self, sv):
@@ -141,8 +157,11 @@ class ReenactmentSession:
         n = shift_vectors.shape[0]
         for lo in range(0, n, self.batch):
             sv = shift_vectors[lo:lo + self.batch]
-            img = self._graphed_step(sv) if (self.use_graph and sv.shape[0] == self.batch) else self._step(sv)
-            yield images_to_uint8(img) if as_uint8 else img
+            if self.use_graph and sv.shape[0] == self.batch:
+                img = self._graphed_step(sv)
+                yield images_to_uint8(img) if as_uint8 else img
+            else:       # uint8 frames come straight out of the last ToRGB launch (no fp32 image is stored)
+                yield self._step(sv, F_.U8Target() if as_uint8 else None)
 
     def render(self, shift_vectors, as_uint8=False):
         return torch.cat(list(self.frames(shift_vectors, as_uint8=as_uint8)), 0)
@@ -165,8 +184,16 @@ class ReenactmentSession:
     @torch.no_grad()
     def video_frames(self, source_image, target_images, shift_vectors, swap_rb=True):
         """source | target | reenacted frames [N,H,3W,3] uint8 (the --save_video output of run_inference.py:186-198)."""
-        out, lo = [], 0
-        for img in self.frames(shift_vectors):
-            out.append(grid_frames_uint8([source_image, target_images[lo:lo + img.shape[0]], img], swap_rb=swap_rb))
-            lo += img.shape[0]
-        return torch.cat(out, 0)
+        n = shift_vectors.shape[0]
+        H, W = source_image.shape[-2], source_image.shape[-1]
+        video = torch.empty(n, H, 3 * W, 3, device=shift_vectors.device, dtype=torch.uint8)
+        for lo in range(0, n, self.batch):
+            sv = shift_vectors[lo:lo + self.batch]
+            frames = video[lo:lo + sv.shape[0]]
+            if self.use_graph and sv.shape[0] == self.batch:
+                grid_frames_uint8([source_image, target_images[lo:lo + sv.shape[0]], self._graphed_step(sv)], swap_rb=swap_rb, out=frames)
+                continue
+            # the reenacted panel is written by the generator's last launch; the other two by one grid launch
+            self._step(sv, F_.U8Target(frames, panel=2, swap_rb=swap_rb))
+            grid_frames_uint8([source_image, target_images[lo:lo + sv.shape[0]], None], swap_rb=swap_rb, out=frames)
+        return video

@@ -130,3 +130,16 @@ def test_kat8_shift_vectors_bit_exact():
             rows = [SO.make_shift(cfg, ang_s[0:1], ang_t[i:i + 1], {k: v[0:1] for k, v in par_s.items()},
                                   {k: v[i:i + 1] for k, v in par_t.items()}) for i in range(ang_t.shape[0])]
             assert (torch.cat(rows, 0).numpy() == g[tag + '.infer']).all()
+
+
+def test_kat1b_upfirdn2d_per_axis_factors():
+    g = golden('kat1b_upfirdn_mixed.npz')
+    k = t(g['kernel'])
+    for i in range(int(g['n'])):
+        cfg = [int(v) for v in g['cfg%d' % i]]
+        up, down, pad = tuple(cfg[4:6]), tuple(cfg[6:8]), tuple(cfg[8:12])
+        x = t(g['x%d' % i]).requires_grad_(True)
+        y = O.upfirdn2d(x, k, up=up, down=down, pad=pad)
+        assert y.shape == g['y%d' % i].shape and maxabs(y, t(g['y%d' % i])) <= 2e-6
+        (y * t(g['g%d' % i])).sum().backward()
+        assert maxabs(x.grad, t(g['gx%d' % i])) <= 4e-6

@@ -104,3 +104,41 @@ def test_encode_then_reenact_flow():
                                           input_is_latent=True) for i in range(5)], 0)   # the per-frame loop
     assert maxabs(src, w_cpu) <= 1e-3 * float(w_cpu.abs().max())
     assert maxabs(out, ref) <= 1e-3
+
+
+@gpu
+def test_config3_joint_flow_at_256_batch32():
+    """BASELINE configs[2] as one flow at its real size: e4e(256) source code -> shift vectors from 3DMM parameters (device)
+    -> DirectionMatrix -> shift + truncation 0.7 -> Generator(256) at B=32 -> frames; three of the 32 frames are checked
+    against the CPU oracle running the reference's per-frame loop (run_inference.py:170-181) on the oracle's own e4e code
+    and the oracle's own shift vectors."""
+    from oracle import shift_oracle as SO
+    from stylegan_directions_face_reenactment_amd.direction_matrix import DirectionMatrix
+    from stylegan_directions_face_reenactment_amd.reenact import ReenactmentSession
+    from stylegan_directions_face_reenactment_amd.shift import ShiftVectors
+    from util import golden, hip_generator, synthetic_state
+    enc, P = _encoder(256, SEED)
+    enc = enc.cuda()
+    G = hip_generator(256, 1)
+    A = DirectionMatrix(512, input_dim=15, out_dim=512, w_plus=True, num_layers=8, verbose=False)
+    PA = S.synthetic_direction_state(SEED)
+    A.load_state_dict(PA)
+    A = A.cuda()
+    x256, _ = _inputs()
+    ranges = golden('kat8_shift.npz')['ranges_voxceleb']
+    ang_s, par_s = S.synthetic_shape_params(SEED, 'c3j.src', 1)
+    ang_t, par_t = S.synthetic_shape_params(SEED, 'c3j.tgt', 32)
+    trunc = S.counter_tensor(7, 'c3j.t', (1, 512))
+    cuda = lambda d: {k: v.cuda() for k, v in d.items()}
+    with torch.no_grad():
+        src = enc(x256[:1].cuda())
+        sess = ReenactmentSession(G, A, src, 0.7, trunc.cuda(), batch=32, shifts=ShiftVectors('voxceleb', 15, 6.0, ranges=ranges))
+        out = sess.render_targets(ang_s.cuda(), cuda(par_s), ang_t.cuda(), cuda(par_t))
+        assert out.shape == (32, 3, 256, 256)
+        cfg = SO.initialize_directions('voxceleb', 15, 6.0, ranges)
+        w_cpu = E.encoder_forward(P, x256[:1])
+        PG = synthetic_state(256, 1)
+        for i in (0, 13, 31):
+            sv = SO.make_shift(cfg, ang_s, ang_t[i:i + 1], par_s, {k: v[i:i + 1] for k, v in par_t.items()})
+            ref = O.generate_image(PG, w_cpu, 0.7, trunc, shift_code=O.direction_matrix(PA, sv), input_is_latent=True)
+            assert maxabs(out[i:i + 1], ref) <= 1e-3, i      # north-star contract, end to end incl. the encoder

@@ -79,8 +79,12 @@ def test_generator256_golden_and_oracle(cm):
         _check_digest(img_p, g, 'cm%d.p' % cm)
     if cm == 1:
         assert maxabs(img_p[0], t(g['cm1.p.full0'])) <= IMG_TOL     # one full image from the real reference
-        ref, _ = O.generator_forward(synthetic_state(256, 1), [w.cpu()], input_is_latent=True)
-        assert maxabs(img_p, ref) <= IMG_TOL                        # full tensors vs the oracle
+    # full tensors vs the oracle, both channel multipliers, synthesis-only and the truncated W+ path
+    ref, _ = O.generator_forward(synthetic_state(256, cm), [w.cpu()], input_is_latent=True)
+    assert maxabs(img_p, ref) <= IMG_TOL
+    ref_w, _ = O.generator_forward(synthetic_state(256, cm), [w.cpu()], input_is_latent=True, truncation=0.7,
+                                   truncation_latent=trunc.cpu())
+    assert maxabs(img_w, ref_w) <= IMG_TOL
 
 
 def test_generate_image_with_direction_shift():
@@ -296,3 +300,43 @@ def test_wide_layers_and_1024_generator():
         small = generate_image(G, w.cuda(), 1.0, None, input_is_latent=True)       # pooled to 256 like the reference
         assert small.shape == (1, 3, 256, 256)
         assert maxabs(small, torch.nn.functional.adaptive_avg_pool2d(ref, (256, 256))) <= IMG_TOL
+
+
+def test_uint8_frames_from_the_last_torgb_launch():
+    """SURVEY §8f-4 as worded: the [-1,1] -> uint8 HWC conversion is part of the final ToRGB launch (no fp32 image is
+    stored and re-read).  Bit-identical to converting the fp32 image afterwards, as plain frames and as one panel of the
+    source|target|reenacted video grid (with and without the channel swap), incl. the unfused fallback at tiny batches."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    from stylegan_directions_face_reenactment_amd.direction_matrix import DirectionMatrix
+    from stylegan_directions_face_reenactment_amd.reenact import ReenactmentSession, grid_frames_uint8, images_to_uint8
+    for size, B in ((256, 6), (64, 16), (64, 1)):
+        G = hip_generator(size, 1)
+        w = S.synthetic_latents(SEED, B, n_latent=G.n_latent, key='u8.w').cuda()
+        with torch.no_grad():
+            img, _ = G([w], input_is_latent=True)
+            u8, _ = G([w], input_is_latent=True, image_out=F_.U8Target())
+            assert u8.dtype == torch.uint8 and u8.shape == (B, size, size, 3)
+            assert torch.equal(u8, images_to_uint8(img))
+            for swap in (False, True):
+                grid = torch.zeros(B, size, 3 * size, 3, dtype=torch.uint8, device='cuda')
+                out, _ = G([w], input_is_latent=True, image_out=F_.U8Target(grid, panel=1, swap_rb=swap))
+                assert out.data_ptr() == grid.data_ptr()
+                expect = grid_frames_uint8([img * 0 - 1, img, img * 0 - 1], swap_rb=swap)     # black | image | black
+                assert torch.equal(grid, expect)
+    with pytest.raises(RuntimeError):
+        G([w.requires_grad_(True)], input_is_latent=True, image_out=F_.U8Target())
+    # the session's video path: reenacted panel from the generator, the other two from one grid launch
+    G = hip_generator(64, 1)
+    A = DirectionMatrix(512, input_dim=15, out_dim=512, w_plus=True, num_layers=8, verbose=False)
+    A.load_state_dict(S.synthetic_direction_state(SEED))
+    A = A.cuda()
+    src_code = S.synthetic_latents(45, 1, n_latent=G.n_latent, key='u8.src').cuda()
+    trunc = S.counter_tensor(45, 'u8.t', (1, 512)).cuda()
+    sv = S.counter_tensor(45, 'u8.sv', (21, 15), 0.0, 3.0).cuda()
+    src_img = S.counter_tensor(45, 'u8.si', (1, 3, 64, 64), 0.0, 0.6).cuda()
+    tgt_img = S.counter_tensor(45, 'u8.ti', (21, 3, 64, 64), 0.0, 0.6).cuda()
+    sess = ReenactmentSession(G, A, src_code, 0.7, trunc, batch=16)
+    video = sess.video_frames(src_img, tgt_img, sv)
+    ren = sess.render(sv)
+    assert torch.equal(video, grid_frames_uint8([src_img, tgt_img, ren], swap_rb=True))
+    assert torch.equal(sess.render(sv, as_uint8=True), images_to_uint8(ren))
