@@ -649,7 +649,11 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                     fetch(0, 0);
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
+#ifdef SGDFR_PROBE_NOFETCH      // ablation (wrong results): one fragment fetch per kernel row instead of three -- is the loop LDS-read bound?
+                        const int cur = 0;
+#else
                         const int cur = kx & 1;
+#endif
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int m = 0; m < MI; ++m)
@@ -658,7 +662,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                                 acc[0][m][n] =
                                     split_mfma<ET>(a[cur][0][m], b[cur][0][n], acc[0][m][n]);
                         __builtin_amdgcn_sched_barrier(0);
+#ifndef SGDFR_PROBE_NOFETCH
                         if (kx < 2) fetch(cur ^ 1, kx + 1);
+#endif
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int t = 1; t < 3; ++t)

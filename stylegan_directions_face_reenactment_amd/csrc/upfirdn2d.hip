@@ -180,12 +180,17 @@ __device__ __forceinline__ void blur_split2(float a, float b, unsigned& hi, unsi
 
 // QC: quad columns per channel wave-group (64: a full wave per channel, for W >= 64; 32: two channels per wave, less idle
 // lanes on the narrow layers); block = 8 * QC threads.
+// A block walks `nseg` consecutive row segments (BLUR_QV quad rows each) of its column tile with the SAME sliding window,
+// handing each segment over through LDS: only the first segment re-reads the 3 plane rows above it, so the planes are
+// fetched 1 + 3/(8*nseg) times instead of 1.375 (rocprofv3 FETCH_SIZE of the 128 -> 256 level: 2.03 x the planes with
+// nseg = 1, mostly served by the Infinity Cache -- the run time is the same, the DRAM traffic is not).
 template <int ET, int QC>
 __global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restrict__ t, const float* __restrict__ fir,
                                                         const float* __restrict__ noise, int64_t noise_bstride,
                                                         const float* __restrict__ noise_w, const float* __restrict__ bias,
                                                         const float* __restrict__ s_next, unsigned char* __restrict__ xs,
-                                                        int B, int C, int H, int W, int pstride, int act, float slope, float gain) {
+                                                        int B, int C, int H, int W, int pstride, int nseg, int act, float slope,
+                                                        float gain) {
     // fp32 results of the block's tile as [row 8][px 128][channel 8 (+1 pad: the lanes of a wave write px 2 apart ->
     // 18-dword stride, conflict-free)]; the hand-over to 16-byte chunks happens when the tile is read back.
     // 8 waves = 8 channels, a wave = 64 quad columns (256-byte coalesced plane reads, as the fp32 kernel).
@@ -197,43 +202,54 @@ __global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restr
     const int GW = W + 1, GH = H + 1;
     const int64_t plane_t = (int64_t)4 * pstride;          // pstride = floats between parity planes (>= GH*GW)
     const int G = C / 8, OW = 2 * W, OHW = 4 * H * W;
-    const int col_tiles = (W + QC - 1) / QC, row_tiles = (H + BLUR_QV - 1) / BLUR_QV;
-    const int64_t n_tiles = (int64_t)B * G * row_tiles * col_tiles;
+    const int col_tiles = (W + QC - 1) / QC, row_tiles = (H + BLUR_QV * nseg - 1) / (BLUR_QV * nseg);
+    // Two column tiles per row (W = 2 QC): ids i and i + 8 are the two halves of one row group.  Blocks i and i + 8 run on
+    // the same XCD at the same time, so the cache lines the halves share (odd row pitch: every 64-float run straddles lines)
+    // are fetched from memory once and found in that XCD's L2 by the other half.
+    const bool paired = col_tiles == 2;
+    const int64_t n_groups = (int64_t)B * G * row_tiles;
+    const int64_t n_tiles = paired ? ((n_groups + 7) / 8) * 16 : n_groups * col_tiles;
     const float nw = (noise && noise_w) ? noise_w[0] : 0.f;
     const float xsc = (ET == SGDFR_SPLIT_FP16) ? 0.0625f : 1.f;
     const int c8 = threadIdx.x / QC, nx = threadIdx.x % QC;
     unsigned sat = 0;
     for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
-        const int ct = (int)(tile_id % col_tiles);
-        int64_t r = tile_id / col_tiles;
+        const int ct = paired ? (int)((tile_id >> 3) & 1) : (int)(tile_id % col_tiles);
+        int64_t r = paired ? (tile_id >> 4) * 8 + (tile_id & 7) : tile_id / col_tiles;
+        if (r >= n_groups) continue;           // block-uniform (padding of the last group of 8 pairs)
         const int rt = (int)(r % row_tiles);
         r /= row_tiles;
         const int g = (int)(r % G);
         const int b = (int)(r / G);
         const int c = g * 8 + c8;
         const int n = ct * QC + nx;            // quad column
-        const int ms = rt * BLUR_QV;           // first quad row
         if (threadIdx.x < 8) sv[threadIdx.x] = s_next[(int64_t)b * C + g * 8 + threadIdx.x] * xsc;
+        const float* tp = t + ((int64_t)b * C + c) * plane_t;
+        const float bv = bias ? bias[c] : 0.f;
+        int coff[5];
+        bool cok[5];
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            const int tc = 2 * n - 1 + v;
+            cok[v] = tc >= 0 && n < W;
+            coff[v] = (tc & 1) * pstride + (tc >> 1);
+        }
+        float win[5][5];
+        auto load_row = [&](int tr, float (&dst)[5]) {
+            const bool rok = tr >= 0;
+            const int roff = (tr & 1) * 2 * pstride + (tr >> 1) * GW;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) dst[v] = (rok && cok[v]) ? tp[roff + coff[v]] : 0.f;
+        };
+        {
+            const int ms0 = rt * BLUR_QV * nseg;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) load_row(2 * ms0 - 1 + u, win[u]);
+        }
+        for (int sg = 0; sg < nseg; ++sg) {
+        const int ms = (rt * nseg + sg) * BLUR_QV;           // first quad row of the segment
+        if (ms >= H) break;                                   // block-uniform
         if (n < W) {
-            const float* tp = t + ((int64_t)b * C + c) * plane_t;
-            const float bv = bias ? bias[c] : 0.f;
-            int coff[5];
-            bool cok[5];
-#pragma unroll
-            for (int v = 0; v < 5; ++v) {
-                const int tc = 2 * n - 1 + v;
-                cok[v] = tc >= 0;
-                coff[v] = (tc & 1) * pstride + (tc >> 1);
-            }
-            float win[5][5];
-            auto load_row = [&](int tr, float (&dst)[5]) {
-                const bool rok = tr >= 0;
-                const int roff = (tr & 1) * 2 * pstride + (tr >> 1) * GW;
-#pragma unroll
-                for (int v = 0; v < 5; ++v) dst[v] = (rok && cok[v]) ? tp[roff + coff[v]] : 0.f;
-            };
-#pragma unroll
-            for (int u = 0; u < 3; ++u) load_row(2 * ms - 1 + u, win[u]);
 #pragma unroll
             for (int qv = 0; qv < BLUR_QV; ++qv) {
                 const int m = ms + qv;
@@ -292,6 +308,7 @@ __global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restr
             }
         }
         __syncthreads();
+        }       // segments
     }
     if (ET == SGDFR_SPLIT_FP16 && sat != 0) atomicAdd(&g_blur_saturated, sat);
 }
@@ -486,16 +503,24 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
     if (plane_stride == 0) plane_stride = (int64_t)(H + 1) * (W + 1);
     SGDFR_REQUIRE(plane_stride >= (int64_t)(H + 1) * (W + 1) && plane_stride < (1 << 30), "blur_bias_act_split: plane_stride < (H+1)*(W+1)");
     const int QC = W >= 64 ? 64 : 32;
-    const int64_t tiles = (int64_t)B * (C / 8) * ((H + BLUR_QV - 1) / BLUR_QV) * ((W + QC - 1) / QC);
+    // row segments per block: as many as keep >= 8 blocks per CU (the window slides across them: each plane row is read once)
+    static const int seg_env = getenv("SGDFR_BLUR_SEGMENTS") ? atoi(getenv("SGDFR_BLUR_SEGMENTS")) : 0;
+    const int64_t tiles1 = (int64_t)B * (C / 8) * ((H + BLUR_QV - 1) / BLUR_QV) * ((W + QC - 1) / QC);
+    int nseg = 1;
+    while (nseg < 8 && BLUR_QV * nseg * 2 <= H && tiles1 / (nseg * 2) >= 256 * 8) nseg *= 2;
+    if (seg_env > 0) nseg = seg_env;
+    const int64_t groups = (int64_t)B * (C / 8) * ((H + BLUR_QV * nseg - 1) / (BLUR_QV * nseg));
+    const int col_tiles = (W + QC - 1) / QC;
+    const int64_t tiles = col_tiles == 2 ? ((groups + 7) / 8) * 16 : groups * col_tiles;       // see `paired` in the kernel
     int64_t g = tiles;
-    if (g > 256 * 32) g = 256 * 32;
+    if (g > 256 * 32) g = 256 * 32;           // (a multiple of 16: the grid-stride loop keeps the pairing)
     unsigned char* out = reinterpret_cast<unsigned char*>(xs);
     void (*kern)(const float*, const float*, const float*, int64_t, const float*, const float*, const float*, unsigned char*, int,
-                 int, int, int, int, int, float, float);
+                 int, int, int, int, int, int, float, float);
     if (arith == SGDFR_SPLIT_FP16) kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_FP16, 64> : blur_split_kernel<SGDFR_SPLIT_FP16, 32>;
     else kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_BF16, 64> : blur_split_kernel<SGDFR_SPLIT_BF16, 32>;
     hipLaunchKernelGGL(kern, dim3((int)g), dim3(8 * QC), 0, as_stream(stream), t, fir, noise, noise_bstride, noise_w, bias, s_next,
-                       out, B, C, H, W, (int)plane_stride, act, slope, gain);
+                       out, B, C, H, W, (int)plane_stride, nseg, act, slope, gain);
     return check_launch("blur_bias_act_split");
 }
 
