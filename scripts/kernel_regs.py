@@ -1,7 +1,7 @@
 """Register / scratch usage of every kernel of one csrc file: python scripts/kernel_regs.py split.hip [filter]"""
 import re, subprocess, sys, os
 src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'stylegan_directions_face_reenactment_amd', 'csrc', sys.argv[1])
-out = subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-c', src, '-o', '/tmp/_regs.o',
+out = subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=on', '-fno-slp-vectorize', '-c', src, '-o', '/tmp/_regs.o',
                       '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True).stderr
 cur = None
 rows = {}

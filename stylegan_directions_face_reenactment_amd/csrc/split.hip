@@ -171,11 +171,18 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     constexpr int WTILE_BYTES = WSLOT_TAPS * WTAP;
     constexpr int WROW_BYTES = WT * WTILE_BYTES;          // weight bytes of one sub-stage: [pack tile][tap][part][k-half][64][8]
     constexpr int WCHUNKS = WROW_BYTES / 1024;            // 64-lane x 16-byte DMA pieces
+    // RING3 (pre-split input, row sub-stages): the weight ring has THREE slots and the slab of sub-stage u+2 is DMA'd while u
+    // computes.  Inside a tile that doubles the latency a slab may take; across the tiles of a persistent block it lets the
+    // last two sub-stages of a tile stage the first TWO slabs (and the first activation block) of the next tile BEFORE the
+    // epilogue's stores join the queue, so the next tile's first sub-stage has nothing to wait for -- loads and stores
+    // retire through the same in-order vmcnt, and with two slots the first wait of the next tile drained the stores.
+    constexpr bool RING3 = XIN && !DOWN && NSS == 3;
+    constexpr int NWS = RING3 ? 3 : 2;                    // weight ring slots
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int xbuf_bytes = 64 * p.xs;                    // [2 part][2 k-half][xs][8] bf16
     unsigned char* const xb0 = smem;
     unsigned char* const wb0 = smem + 2 * xbuf_bytes;
-    float* const ls = reinterpret_cast<float*>(wb0 + 2 * WROW_BYTES);
+    float* const ls = reinterpret_cast<float*>(wb0 + NWS * WROW_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     // Persistent blocks: the grid is one block per CU (or fewer); block b works on tiles base + map(b) of every round of
     // gridDim.x tiles.  map() keeps the tiles of one XCD (blockIdx & 7) contiguous, so neighbours share halos and weights in L2.
     // (only the plain conv is ever launched persistent, see launch_split; the fp32-input variants have no registers to spare)
-    constexpr bool PERSIST = XIN && MODE == SGDFR_MODE_PLAIN3;
+    constexpr bool PERSIST = XIN && (MODE == SGDFR_MODE_PLAIN3 || (UP && RING3));
     auto lid_of = [&](int base) -> int {        // tile of this block in the round starting at `base`, -1: none
         if (base >= p.total_blocks) return -1;
         const int nblk = PERSIST ? min((int)gridDim.x, p.total_blocks - base) : (int)gridDim.x, q8 = nblk >> 3, r8 = nblk & 7;
@@ -482,7 +489,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     float* const bl = dl + p.simgs * NT;                        // [NT]            bias
     float* const cw = bl + NT;                                  // [simgs][NT][4]  ToRGB coefficients
     float* const red = cw + p.simgs * NT * 4;                   // [WM][PT][3]     ToRGB cross-wave reduce
-    float* const sn = red + 2 * 512 * 3;                        // [simgs][NT]     next layer's style * range shift (xs_out)
+    float* const sn = red + WM * PT * 3;                        // [simgs][NT]     next layer's style * range shift (xs_out)
     const bool emit_xs = !UP && !DOWN && whole && p.xs_out != nullptr;
     auto fill_tables = [&]() {
         // one pass, every global load of an entry issued before the first LDS write (one exposed latency, not four)
@@ -520,6 +527,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 #pragma unroll
             for (int e = 0; e < NEX; ++e) issue_x(xs16[e], e, cb0, xb0 + xsel * xbuf_bytes);
             issue_w(wglb, cb0 * NSS, wsel);
+            if (RING3 && cb0 * NSS + 1 < ncb * NSS) issue_w(wglb, cb0 * NSS + 1, (wsel + 1) % NWS);
         }
         if (early) fill_tables();      // while the DMA is in flight
         split_wait_vmcnt<0>();
@@ -564,12 +572,35 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         for (int ss = 0; ss < NSS; ++ss) {
             const int u = cb * NSS + ss;
             const bool more_w = u + 1 < ncb * NSS;
-            if (more_w) issue_w(wglb, u + 1, wsel ^ 1);
+            if (RING3) {
+                // (the activation pieces of this sub-stage are issued first, see stage_part below, then the slab of u+2: the
+                // counted wait at the end of the sub-stage leaves exactly that slab in flight)
+            } else if (more_w) issue_w(wglb, u + 1, wsel ^ 1);
             else if (XIN && has_next) issue_w(wglb_n, cb0_n * NSS, wsel ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             constexpr int kSlots[3] = {(NEX + NSS - 1) / NSS, NSS == 3 ? (NEX + 1) / 3 : 0, NSS == 3 ? NEX / 3 : 0};
             // 1/NSS of the next channel block's activations: registers -> hi/lo -> LDS, then refill the registers
+            bool w_ahead = false;      // RING3: did this sub-stage issue a slab?
             auto stage_part = [&]() {
+                if (RING3) {
+                    // all activation pieces of the next block in the first two sub-stages (a whole sub-stage of slack before
+                    // the block is needed), then the weight slab two sub-stages ahead -- of the next tile at the end of this one
+                    if (ss < 2) {
+                        if (conv_next) {
+#pragma unroll
+                            for (int e = ss; e < NEX; e += 2) issue_x(xs16[e], e, cb + 1, xnext);
+                        } else if (pre_next) {
+#pragma unroll
+                            for (int e = ss; e < NEX; e += 2) issue_x(xin_addr(Tn, e), e, cb0_n, xnext);
+                        }
+                    }
+                    const int u1 = ncb * NSS;
+                    w_ahead = true;
+                    if (u + 2 < u1) issue_w(wglb, u + 2, (wsel + 2) % NWS);
+                    else if (has_next) issue_w(wglb_n, cb0_n * NSS + (u + 2 - u1), (wsel + 2) % NWS);
+                    else w_ahead = false;
+                    return;
+                }
                 if (conv_next) {
 #pragma unroll
                     for (int e = ss; e < NEX; e += NSS) {
@@ -735,6 +766,21 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             mfma_part();
             __builtin_amdgcn_sched_barrier(0);
             if (stagger) stage_part();
+            if (RING3) {
+                if (more_w) {
+                    // slab u+1 was issued one sub-stage ago: wait for everything older than this sub-stage's slab.  The FIRST
+                    // sub-stage of a tile whose operands were staged by the previous tile waits for nothing: slab u+1 landed
+                    // before that tile's epilogue, and what is in flight now are its stores.
+                    if (!(prefetched && u == cb0 * NSS)) {
+                        if (w_ahead) split_wait_vmcnt<WV>(); else split_wait_vmcnt<0>();
+                    }
+                    __builtin_amdgcn_s_barrier();
+                } else if (has_next) {
+                    split_wait_vmcnt<0>();      // the next tile's first stages have landed before this tile's stores join the queue
+                }
+                wsel = (wsel + 1) % NWS;
+                continue;
+            }
             if (more_w) {
                 if (XIN) {
                     split_wait_vmcnt<0>();
@@ -978,10 +1024,12 @@ static const SplitPlan kPlanUpNarrow = {3, 64, 256, 3, 8};      // transposed, C
 static const SplitPlan kPlanUpDeep = {4, 64, 256, 1, 8};        // transposed: 64 x 256, all 9 taps between barriers
 static const SplitPlan kPlanDown = {5, 128, 256, 1, 8};         // adjoint of the transposed conv: 128 x 256 positions, (block, phase) stages
 
-static size_t split_lds_bytes(const SplitParams& p, int NT, int nss, bool down = false) {
+// nws: weight ring slots (3 for a pre-split input with row sub-stages, see RING3 in the kernel; 2 otherwise)
+static size_t split_lds_bytes(const SplitParams& p, int NT, int nss, bool down = false, int nws = 2) {
     const size_t wslot = down ? (size_t)NT * 256 : (size_t)NT * 192 * (3 / nss);       // DOWN3: 4 taps x 64 bytes per cout
-    const size_t loop = 2 * (size_t)64 * p.xs + 2 * wslot + (down ? 0 : (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float));
-    const size_t epi = ((size_t)p.simgs * NT * 6 + NT + 2 * 512 * 3) * sizeof(float);   // d, bias, ToRGB coefficient / reduce, next-style tables
+    const size_t loop = 2 * (size_t)64 * p.xs + nws * wslot + (down ? 0 : (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float));
+    // d, bias, ToRGB coefficient / reduce ([WM][PT][3] = 1536 floats in every plan), next-style tables
+    const size_t epi = ((size_t)p.simgs * NT * 6 + NT + 512 * 3) * sizeof(float);
     if (p.simgs <= 2) return loop + epi;      // tables live beside the style table for the whole kernel
     return loop > epi ? loop : epi;           // tables overwrite the dead staging buffers after the K loop
 }
@@ -1042,11 +1090,14 @@ static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, cons
 // the plan used for a shape (first that fits), or nullptr
 static const SplitPlan* split_plan(int B, int Cin, int Cout, int H, int W, int mode, SplitParams* out) {
     static const int deep = getenv("SGDFR_SPLIT_DEEP") ? atoi(getenv("SGDFR_SPLIT_DEEP")) : 1;
-    const SplitPlan* order[4] = {nullptr, nullptr, nullptr, nullptr};
+    static const int narrow_first = getenv("SGDFR_SPLIT_UP_NARROW") ? atoi(getenv("SGDFR_SPLIT_UP_NARROW")) : 0;
+    const SplitPlan* order[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int n = 0;
     if (mode == SGDFR_MODE_UP3) {
         // deep stages need enough blocks per 64-cout tile to fill the chip; small layers keep the row sub-stages + K slices
-        if (deep && (int64_t)B * (H + 1) * (W + 1) * (Cout / 64) >= 256 * 256) order[n++] = &kPlanUpDeep;
+        const bool big = (int64_t)B * (H + 1) * (W + 1) * (Cout / 64) >= 256 * 256;
+        if (deep && big) order[n++] = &kPlanUpDeep;
+        if (narrow_first && big) order[n++] = &kPlanUpNarrow;     // row sub-stages + 3-slot ring + persistent blocks (pre-split input)
         if (Cout % 128 == 0) order[n++] = &kPlanUpWide;
         order[n++] = &kPlanUpNarrow;
     } else if (mode == SGDFR_MODE_PLAIN3) {
@@ -1133,7 +1184,9 @@ extern "C" long long sgdfr_split_saturation_count(int reset) {
 extern "C" int sgdfr_modconv2d_split_xin_supported(int B, int Cin, int Cout, int H, int W, int mode) {
     SplitParams p;
     const SplitPlan* plan = split_plan(B, Cin, Cout, H, W, mode, &p);
-    return (plan && (plan->cfg == 0 || plan->cfg == 1 || plan->cfg == 4 || plan->cfg == 5)) ? 1 : 0;     // the instantiations of launch_plan(xin)
+    if (!plan || !(plan->cfg == 0 || plan->cfg == 1 || plan->cfg == 3 || plan->cfg == 4 || plan->cfg == 5)) return 0;     // the instantiations of launch_plan(xin)
+    if (plan->nss == 3 && plan->cfg != 5 && split_lds_bytes(p, plan->nt, plan->nss, false, 3) > 160 * 1024) return 0;   // the 3-slot weight ring must fit
+    return 1;
 }
 
 extern "C" int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H, int W, int mode) {
@@ -1169,7 +1222,8 @@ static int launch_split(const SplitParams& p, hipStream_t st) {
     void (*kern)(SplitParams) = nex <= 2   ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 2, NSS, XIN>
                                 : nex == 3 ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 3, NSS, XIN>
                                            : split_mfma_kernel<MODE, ET, WM, WN, MI, NI, NEX_MAX, NSS, XIN>;
-    const size_t lds = split_lds_bytes(p, WM * MI * 32, NSS, MODE == SGDFR_MODE_DOWN3);
+    const size_t lds = split_lds_bytes(p, WM * MI * 32, NSS, MODE == SGDFR_MODE_DOWN3,
+                                       (XIN && MODE != SGDFR_MODE_DOWN3 && NSS == 3) ? 3 : 2);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess) {
         (void)hipGetLastError();
@@ -1180,12 +1234,17 @@ static int launch_split(const SplitParams& p, hipStream_t st) {
     SplitParams q = p;
     q.total_blocks = p.n_pix_tiles * p.n_cout_tiles * p.ksplit;
     // Persistent blocks (one per CU, each walking its share of the tiles and staging the next tile's first channel block
-    // while the current one finishes) pay off where a tile is short and stores little: measured at B=64, 64->64 @256x256
-    // (32 tiles per CU, ToRGB sums only) -6 %, 128->128 @128x128 -2.7 %.  A persistent block's first wait of the next tile
-    // also drains its own stores (loads and stores share the in-order vmcnt), which a fresh block never waits for: the
-    // transposed conv (262 KB of stores per tile) loses 2-7 %, the 8-tiles-per-CU layers gain nothing -> one block per tile.
+    // and first two weight slabs while the current one finishes; see RING3 in the kernel).  Round 1 (two weight slots: the
+    // next tile's first wait drained the tile's own stores) only gained on the layers of >= 12 short tiles per CU; with the
+    // three-slot ring the 4- and 8-tiles-per-CU plain layers gain too (same-box A/B at B=64: 807 -> 795, 895 -> 868,
+    // 1010 -> 995, 1161 -> 1132 us on the 32^2 .. 256^2 layers).  The transposed conv stays one block per tile: its row
+    // sub-stage plan (the only one whose ring fits three slots) is 5-12 % slower than all nine taps between two barriers.
     static const int persist = getenv("SGDFR_SPLIT_PERSIST") ? atoi(getenv("SGDFR_SPLIT_PERSIST")) : 256;
-    const bool persistent = XIN && MODE == SGDFR_MODE_PLAIN3 && persist > 0 && q.total_blocks >= 12 * persist;
+    static const int persist_min = getenv("SGDFR_SPLIT_PERSIST_MIN") ? atoi(getenv("SGDFR_SPLIT_PERSIST_MIN")) : 4;    // tiles per block
+    static const int persist_min_up = getenv("SGDFR_SPLIT_PERSIST_MIN_UP") ? atoi(getenv("SGDFR_SPLIT_PERSIST_MIN_UP")) : 4;    // (only reachable with SGDFR_SPLIT_UP_NARROW=1)
+    constexpr bool kCanPersist = XIN && NSS == 3 && (MODE == SGDFR_MODE_PLAIN3 || MODE == SGDFR_MODE_UP3);
+    const bool persistent = kCanPersist && persist > 0 &&
+                            q.total_blocks >= (MODE == SGDFR_MODE_UP3 ? persist_min_up : persist_min) * persist;
     const int grid = persistent ? persist : q.total_blocks;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, st, q);
     return check_launch("modconv2d_split");
@@ -1197,6 +1256,7 @@ static int launch_plan(int cfg, const SplitParams& p, hipStream_t st, bool xin) 
         switch (cfg) {
             case 0: return launch_split<SGDFR_MODE_PLAIN3, ET, 2, 4, 2, 2, 3, true>(p, st);
             case 1: return launch_split<SGDFR_MODE_PLAIN3, ET, 1, 8, 2, 2, 3, true>(p, st);
+            case 3: return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 3, true>(p, st);
             case 4: return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 1, true>(p, st);
             case 5: return launch_split<SGDFR_MODE_DOWN3, ET, 2, 4, 2, 2, 1, true>(p, st);
             default: set_error("modconv_split: pre-split input is not built for tiling plan %d", cfg); return 1;

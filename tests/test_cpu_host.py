@@ -169,3 +169,24 @@ def test_latent_store_roundtrip(tmp_path):
     np.save(str(tmp_path / 'bad.npy'), np.zeros((3, 512), np.float32))
     with pytest.raises(RuntimeError):
         load_latent_codes([paths[0], str(tmp_path / 'bad.npy')])
+
+
+def test_direction_tables_on_cpu_match_reference_coefficients():
+    """shift.initialize_directions (host logic, no GPU) == the reference's generic.initialize_directions as captured in kat8:
+    same (a, b) lines bit for bit, same direction layout for both datasets."""
+    import numpy as np
+    from stylegan_directions_face_reenactment_amd import shift as SH
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'kat8_shift.npz'))
+    for dataset, D, sc in (('voxceleb', 15, 6), ('ffhq', 12, 6.0), ('voxceleb', 15, 4.5)):
+        tag = '%s_%d_%s' % (dataset, D, str(sc).replace('.', 'p'))
+        count_pose, n_exp, dirs, jaw, scales, angle_dirs = SH.initialize_directions(dataset, D, sc, g['ranges_' + dataset])
+        coef = np.array([[jaw['a'], jaw['b']]] + [[d['a'], d['b']] for d in dirs])
+        assert (coef == g[tag + '.coef']).all()
+        assert count_pose == (4 if dataset == 'voxceleb' else 3) and n_exp == D - count_pose
+        assert [d['A_direction'] for d in dirs] == list(range(count_pose, D)) and list(scales) == [40.0, 20.0, 20.0]
+    with pytest.raises(FileNotFoundError):
+        SH.get_direction_ranges('/nonexistent/ranges.npy')
+    with pytest.raises(RuntimeError):
+        SH.ShiftVectors('voxceleb', 15, 6, ranges=g['ranges_voxceleb']).make_shift(
+            torch.zeros(1, 3), torch.zeros(2, 3), {'pose': torch.zeros(1, 6), 'alpha_exp': torch.zeros(1, 50)},
+            {'pose': torch.zeros(2, 6), 'alpha_exp': torch.zeros(2, 50)})      # CPU tensors: refused, no fallback
