@@ -185,7 +185,7 @@ __device__ __forceinline__ void blur_split2(float a, float b, unsigned& hi, unsi
 // fetched 1 + 3/(8*nseg) times instead of 1.375 (rocprofv3 FETCH_SIZE of the 128 -> 256 level: 2.03 x the planes with
 // nseg = 1, mostly served by the Infinity Cache -- the run time is the same, the DRAM traffic is not).
 template <int ET, int QC>
-__global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restrict__ t, const float* __restrict__ fir,
+__global__ __launch_bounds__(8 * QC, 4) void blur_split_kernel(const float* __restrict__ t, const float* __restrict__ fir,
                                                         const float* __restrict__ noise, int64_t noise_bstride,
                                                         const float* __restrict__ noise_w, const float* __restrict__ bias,
                                                         const float* __restrict__ s_next, unsigned char* __restrict__ xs,
@@ -239,12 +239,26 @@ __global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restr
             const bool rok = tr >= 0;
             const int roff = (tr & 1) * 2 * pstride + (tr >> 1) * GW;
 #pragma unroll
+#if defined(SGDFR_BLUR_PROBE) && SGDFR_BLUR_PROBE == 2      // ablation: no plane loads
+            for (int v = 0; v < 5; ++v) dst[v] = (float)(roff + v);
+#else
             for (int v = 0; v < 5; ++v) dst[v] = (rok && cok[v]) ? tp[roff + coff[v]] : 0.f;
+#endif
+        };
+        // The 2 * BLUR_QV new plane rows of a segment are requested together, and those of the NEXT segment right after this
+        // segment's arithmetic -- before its hand-over -- so a block's plane reads run under its own stores (measured on the
+        // 128 -> 256 level: loads alone 250 us, compute + stores alone 276 us, both in sequence 524 us).
+        float rows[2 * BLUR_QV][5];
+        auto load_segment = [&](int ms) {
+#pragma unroll
+            for (int i = 0; i < 2 * BLUR_QV; ++i)
+                if (ms + (i >> 1) < H) load_row(2 * ms + 2 + i, rows[i]);
         };
         {
             const int ms0 = rt * BLUR_QV * nseg;
 #pragma unroll
             for (int u = 0; u < 3; ++u) load_row(2 * ms0 - 1 + u, win[u]);
+            if (n < W) load_segment(ms0);
         }
         for (int sg = 0; sg < nseg; ++sg) {
         const int ms = (rt * nseg + sg) * BLUR_QV;           // first quad row of the segment
@@ -254,8 +268,11 @@ __global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restr
             for (int qv = 0; qv < BLUR_QV; ++qv) {
                 const int m = ms + qv;
                 if (m >= H) break;
-                load_row(2 * m + 2, win[3]);
-                load_row(2 * m + 3, win[4]);
+#pragma unroll
+                for (int v = 0; v < 5; ++v) {
+                    win[3][v] = rows[2 * qv][v];
+                    win[4][v] = rows[2 * qv + 1][v];
+                }
                 float nzq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
                 if (noise) {
 #pragma unroll
@@ -287,6 +304,7 @@ __global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restr
 #pragma unroll
                     for (int v = 0; v < 5; ++v) win[u][v] = win[u + 2][v];
             }
+            if (sg + 1 < nseg && ms + BLUR_QV < H) load_segment(ms + BLUR_QV);
         }
         __syncthreads();
         // 8 rows x 64 px pixels -> 8 channels each: multiply by the next layer's style, split, two 16-byte chunks
@@ -303,8 +321,13 @@ __global__ __launch_bounds__(8 * QC) void blur_split_kernel(const float* __restr
                 for (int cc = 0; cc < 4; ++cc)
                     blur_split2<ET>(tile[row][px][2 * cc] * sv[2 * cc], tile[row][px][2 * cc + 1] * sv[2 * cc + 1], ph[cc], pl[cc], sat);
                 unsigned char* dst = xs + ((((int64_t)b * G + g) * 2) * OHW + (int64_t)oy * OW + ox) * 16;
-                *reinterpret_cast<uint4*>(dst) = vh;
-                *reinterpret_cast<uint4*>(dst + (int64_t)OHW * 16) = vl;
+#if defined(SGDFR_BLUR_PROBE) && SGDFR_BLUR_PROBE == 1      // ablation: no stores (unless a value is NaN: keeps the work alive)
+                if (vh.x == 0x7fc07fc0u)
+#endif
+                {
+                    *reinterpret_cast<uint4*>(dst) = vh;
+                    *reinterpret_cast<uint4*>(dst + (int64_t)OHW * 16) = vl;
+                }
             }
         }
         __syncthreads();
