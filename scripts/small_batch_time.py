@@ -1,0 +1,21 @@
+"""Per-forward time of the eager no-grad generator at small batches (launch-bound regime): python scripts/small_batch_time.py"""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stylegan_directions_face_reenactment_amd import synthetic as S, functional as F_
+from stylegan_directions_face_reenactment_amd.model import Generator
+G = Generator(256, 512, 8, channel_multiplier=1)
+G.load_state_dict(S.synthetic_state_dict(G.state_dict(), seed=7))
+G = G.eval().cuda()
+for B in (1, 2, 4, 8):
+    w = S.synthetic_latents(7, B, n_latent=14).cuda()
+    with torch.no_grad():
+        for _ in range(5): G([w], input_is_latent=True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(50): G([w], input_is_latent=True)
+        torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 50
+        # host time alone: how long does Python need to ENQUEUE one forward?
+        t1 = time.perf_counter()
+        for _ in range(50): G([w], input_is_latent=True)
+        th = (time.perf_counter() - t1) / 50
+        torch.cuda.synchronize()
+    print('B=%d: %.3f ms per forward (%.0f frames/s), host enqueue %.3f ms  [RANGE_PLAN=%s]' % (B, t * 1e3, B / t, th * 1e3, F_.RANGE_PLAN), flush=True)

@@ -79,7 +79,11 @@ for (name, grid), (disp, c) in seen.items():
 open('profiles/%s_pmc.md' % out, 'w').write('\n'.join(L) + '\n')
 sys.path.insert(0, '.')
 import bench
-json.dump({'config': {'batch': 64, 'cm': 1, 'size': 256, 'precision': precision}, 'source_hash': bench.kernel_source_hash(),
+try:
+    src_hash = open('gpurun_out/source_hash_%s.txt' % tag).read().strip()      # written on the GPU box by profile_round.sh
+except OSError:
+    src_hash = bench.kernel_source_hash()
+json.dump({'config': {'batch': 64, 'cm': 1, 'size': 256, 'precision': precision}, 'source_hash': src_hash,
            'conv_launches_per_forward': 13, 'read_bytes_per_forward': tr,
            'write_bytes_per_forward': tw, 'bytes_per_launch': (tr + tw) / 13,
            'source': 'profiles/%s_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)' % out},

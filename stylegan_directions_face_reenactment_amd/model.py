@@ -385,6 +385,7 @@ class Generator(nn.Module):
                 m.invalidate_packs()
         self._chain_plans = {}
         self._range_state = None
+        self._plist = None
 
     # ---- latent-side helpers (model.py:449-469)
     def make_noise(self):
@@ -406,8 +407,16 @@ class Generator(nn.Module):
     SATURATION_POLL_EVERY = 64      # no-grad forwards between two reads of the device's saturation counter (each read syncs)
 
     def _weights_stamp(self):
-        w = self.conv1.conv.weight
-        return (w.data_ptr(), w.device, sum(p._version for p in self.parameters()))
+        """Cheap identity of the current weights: storage of one conv weight + the sum of all parameters' version counters
+        (the parameter list is walked once and cached; invalidate_packs() drops it)."""
+        plist = getattr(self, '_plist', None)
+        if plist is None:
+            plist = self._plist = list(self.parameters())
+        w = plist[0]
+        v = 0
+        for p in plist:
+            v += p._version
+        return (w.data_ptr(), w.device, v)
 
     def _calibrate_ranges(self, latent, noise, specs, layers):
         """One forward of (at most 8 rows of) this batch on the fp32 kernels, recording max |x| of every 3x3 conv's input:
