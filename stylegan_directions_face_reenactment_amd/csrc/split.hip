@@ -65,6 +65,23 @@ __device__ unsigned int g_split_saturated = 0;   // operand pairs clamped to the
 
 constexpr float SPLIT_F16_XSCALE = 0.0625f, SPLIT_F16_WSCALE = 64.f, SPLIT_F16_OUT = 0.25f, SPLIT_F16_MAX = 65504.f;
 
+// n / d for 0 <= n < 2^31 without a hardware divide: q = (n * mul) >> sh with mul = ceil(2^sh / d), sh = 31 + ceil(log2 d)
+// (exact: the error term n * (mul*d - 2^sh) < 2^31 * d <= 2^sh).  The per-tile index arithmetic of the kernel below does ~35
+// divisions by launch-constant divisors per tile (~25 VALU instructions each); the host precomputes their multipliers.
+struct FastDiv {
+    unsigned mul, sh;
+};
+static FastDiv make_fastdiv(int d) {
+    FastDiv f{0u, 31u};
+    if (d < 1) d = 1;
+    unsigned s = 0;
+    while ((1ll << s) < d) ++s;
+    f.sh = 31 + s;
+    f.mul = (unsigned)(((1ull << f.sh) + (unsigned long long)d - 1) / (unsigned long long)d);
+    return f;
+}
+__device__ __forceinline__ int fdiv(int n, FastDiv f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.sh); }
+
 struct SplitParams {
     const float* x;
     int64_t x_bstride;
@@ -99,7 +116,16 @@ struct SplitParams {
     int dbg;
     int total_blocks;            // tiles x cout tiles x K slices; the grid may be smaller (persistent blocks)
     int rps;                     // UP3: positions per image of the flat space = stride of one parity plane, >= R*P (see plane_stride)
+    // divisors of the per-tile index arithmetic (fill_fastdivs() on the host, after the geometry is final)
+    FastDiv fd_xs, fd_seglen, fd_P, fd_R, fd_RP, fd_rps, fd_HW, fd_W, fd_TC, fd_tiles_x, fd_per_img, fd_npt, fd_tps, fd_Cin;
 };
+
+static void fill_fastdivs(SplitParams& p) {
+    p.fd_xs = make_fastdiv(p.xs); p.fd_seglen = make_fastdiv(p.seglen); p.fd_P = make_fastdiv(p.P); p.fd_R = make_fastdiv(p.R);
+    p.fd_RP = make_fastdiv(p.R * p.P); p.fd_rps = make_fastdiv(p.rps); p.fd_HW = make_fastdiv(p.H * p.W); p.fd_W = make_fastdiv(p.W);
+    p.fd_TC = make_fastdiv(p.TC); p.fd_tiles_x = make_fastdiv(p.tiles_x); p.fd_per_img = make_fastdiv(p.tiles_x * p.tiles_y);
+    p.fd_npt = make_fastdiv(p.n_pix_tiles); p.fd_tps = make_fastdiv(p.n_pix_tiles * p.n_cout_tiles); p.fd_Cin = make_fastdiv(p.Cin);
+}
 
 constexpr int SPLIT_CB = 16;     // input channels per K block (one MFMA K)
 
@@ -205,26 +231,26 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     auto tile_org = [&](int lid) -> TileOrg {
         TileOrg t;
         const int tiles_per_slice = p.n_pix_tiles * p.n_cout_tiles;
-        t.ks = lid / tiles_per_slice;                 // K slice of this block (0 when ksplit == 1)
+        t.ks = fdiv(lid, p.fd_tps);                   // K slice of this block (0 when ksplit == 1)
         const int lt = lid - t.ks * tiles_per_slice;
-        t.ct = lt / p.n_pix_tiles;
+        t.ct = fdiv(lt, p.fd_npt);
         t.pt = lt - t.ct * p.n_pix_tiles;
         t.q0 = 0; t.row0 = 0; t.col0 = 0;
         if (p.patch) {
             const int per_img = p.tiles_x * p.tiles_y;
-            t.img0 = t.pt / per_img;
+            t.img0 = fdiv(t.pt, p.fd_per_img);
             const int rem = t.pt - t.img0 * per_img;
-            const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+            const int ty = fdiv(rem, p.fd_tiles_x), tx = rem - ty * p.tiles_x;
             t.row0 = ty * p.TR;
             t.col0 = tx * p.TC;
         } else if (UP || DOWN) {
             t.q0 = t.pt * PT;                       // super-pixels ARE positions of the padded flat space
-            t.img0 = t.q0 / (UP ? p.rps : p.R * p.P);
+            t.img0 = fdiv(t.q0, UP ? p.fd_rps : p.fd_RP);
         } else {
             const int p0 = t.pt * PT;
-            t.img0 = p0 / HW;
+            t.img0 = fdiv(p0, p.fd_HW);
             const int rem = p0 - t.img0 * HW;
-            const int a = rem / p.W, b = rem - a * p.W;
+            const int a = fdiv(rem, p.fd_W), b = rem - a * p.W;
             t.q0 = (t.img0 * p.R + a + 1) * p.P + b + 1 - p.P - 1;
         }
         return t;
@@ -233,33 +259,34 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     // -1: zero page; -2: no item (skip the DMA)
     auto xin_addr = [&](const TileOrg& t, int e) -> int64_t {
         const int i = tid + e * NTHR;
-        const int h = i / p.xs;
+        const int h = fdiv(i, p.fd_xs);
         const int j = i - h * p.xs;
         if (!(h < 2 && j < p.xs)) return -2;
         bool ok = j < p.xlen;
         int img, pix;
         if (p.patch) {
-            const int sg = j / p.seglen, cc = j - sg * p.seglen;
+            const int sg = fdiv(j, p.fd_seglen), cc = j - sg * p.seglen;
             const int row = t.row0 - 1 + sg, col = t.col0 - 1 + cc;
             img = t.img0;
             ok = ok && row >= 0 && row < p.H && col >= 0 && col < p.W && img < p.B;
             pix = row * p.W + col;
         } else if (DOWN) {        // the planes ARE the flat space
             const int q = t.q0 + j;
-            img = q / HWin;
+            img = fdiv(q, p.fd_RP);        // (DOWN: HWin = R*P)
             pix = q - img * HWin;
             ok = ok && img < p.B;
         } else if (UP) {          // position r of image img = grid point (r / P, r % P); r >= R*P is the stride padding
             const int q = t.q0 + j;
-            img = q / p.rps;
+            img = fdiv(q, p.fd_rps);
             const int r = q - img * p.rps;
-            const int pr = r / p.P, pc = r - pr * p.P;
+            const int pr = fdiv(r, p.fd_P), pc = r - pr * p.P;
             ok = ok && r < p.R * p.P && pc >= 1 && pr >= 1 && img < p.B;
             pix = (pr - 1) * p.W + (pc - 1);
         } else {
             const int q = t.q0 + j;
-            const int pir = q / p.P, pc = q - pir * p.P;
-            img = pir / p.R;
+            const int qq = q < 0 ? 0 : q;                      // (q < 0 only before the first image: masked by `ok` below)
+            const int pir = fdiv(qq, p.fd_P), pc = qq - pir * p.P;
+            img = fdiv(pir, p.fd_R);
             const int pr = pir - img * p.R;
             ok = ok && pc >= 1 && pr >= 1 && img < p.B && q >= 0;
             pix = (pr - 1) * p.W + (pc - 1);
@@ -302,7 +329,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             int64_t pix = (int64_t)pt * PT + l;
             const bool ok = pix < p.total_pix;
             if (!ok) pix = p.total_pix - 1;
-            const int img = (int)(pix / p.rps);
+            const int img = fdiv((int)pix, p.fd_rps);
             const int rem = (int)(pix - (int64_t)img * p.rps);
             boff[n] = l;
             ybase[n] = (ok && rem < RP) ? (int64_t)img * p.Cout * 4 * p.rps + rem : -1;      // (rem >= R*P: stride padding)
@@ -312,16 +339,16 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             int64_t pix = (int64_t)pt * PT + l;
             bool ok = pix < p.total_pix;
             if (!ok) pix = p.total_pix - 1;
-            const int img = (int)(pix / RP);
+            const int img = fdiv((int)pix, p.fd_RP);
             const int rem = (int)(pix - (int64_t)img * RP);
-            const int a = rem / p.P, b = rem - a * p.P;
+            const int a = fdiv(rem, p.fd_P), b = rem - a * p.P;
             ok = ok && a < p.H && b < p.W;
             boff[n] = l;
             ybase[n] = ok ? (int64_t)img * p.Cout * HW + a * p.W + b : -1;
             nzoff[n] = 0;
             dimg[n] = img;
         } else if (p.patch) {
-            const int r = l / p.TC, c = l - r * p.TC;
+            const int r = fdiv(l, p.fd_TC), c = l - r * p.TC;
             boff[n] = (r + 1) * p.seglen + c + 1;
             const int rem = (row0 + r) * p.W + col0 + c;
             const bool ok = img0 < p.B;
@@ -332,9 +359,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             int64_t pix = (int64_t)pt * PT + l;
             const bool ok = pix < p.total_pix;
             if (!ok) pix = p.total_pix - 1;
-            const int img = (int)(pix / HW);
+            const int img = fdiv((int)pix, p.fd_HW);
             const int rem = (int)(pix - (int64_t)img * HW);
-            const int a = rem / p.W, b = rem - a * p.W;
+            const int a = fdiv(rem, p.fd_W), b = rem - a * p.W;
             boff[n] = (img * p.R + a + 1) * p.P + b + 1 - q0;
             ybase[n] = ok ? (int64_t)img * p.Cout * HW + rem : -1;
             nzoff[n] = (int64_t)img * p.noise_bstride + rem;
@@ -356,28 +383,29 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             continue;
         }
         const int i = tid + e * NTHR;
-        const int h = i / p.xs;
+        const int h = fdiv(i, p.fd_xs);
         const int j = i - h * p.xs;
         const bool in_range = (h < 2) && (j < p.xlen);
         bool ok;
         int img, pix;
         if (p.patch) {
-            const int sg = j / p.seglen, cc = j - sg * p.seglen;
+            const int sg = fdiv(j, p.fd_seglen), cc = j - sg * p.seglen;
             const int row = row0 - 1 + sg, col = col0 - 1 + cc;
             img = img0;
             ok = in_range && row >= 0 && row < p.H && col >= 0 && col < p.W && img < p.B;
             pix = row * p.W + col;
         } else if (UP) {
             const int q = q0 + j;
-            img = q / p.rps;
+            img = fdiv(q, p.fd_rps);
             const int r = q - img * p.rps;
-            const int pr = r / p.P, pc = r - pr * p.P;
+            const int pr = fdiv(r, p.fd_P), pc = r - pr * p.P;
             ok = in_range && r < p.R * p.P && pc >= 1 && pr >= 1 && img < p.B;
             pix = (pr - 1) * p.W + (pc - 1);
         } else {
             const int q = q0 + j;
-            const int pir = q / p.P, pc = q - pir * p.P;
-            img = pir / p.R;
+            const int qq = q < 0 ? 0 : q;                      // (q < 0 only before the first image: masked by `ok` below)
+            const int pir = fdiv(qq, p.fd_P), pc = qq - pir * p.P;
+            img = fdiv(pir, p.fd_R);
             const int pr = pir - img * p.R;
             ok = in_range && pc >= 1 && pr >= 1 && img < p.B && q >= 0;
             pix = (pr - 1) * p.W + (pc - 1);
@@ -466,7 +494,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 #ifdef SGDFR_SPLIT_PROBE
         if (p.dbg & 8) return;
 #endif
-        const int h0 = i0 / p.xs, j0 = i0 - h0 * p.xs;
+        const int h0 = fdiv(i0, p.fd_xs), j0 = i0 - h0 * p.xs;
         const unsigned char* xbase = reinterpret_cast<const unsigned char*>(p.x);
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
@@ -533,7 +561,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         split_wait_vmcnt<0>();
     } else {
         for (int e = tid; e < p.simgs * p.Cin; e += NTHR) {
-            const int m = e / p.Cin;
+            const int m = fdiv(e, p.fd_Cin);
             ls[e] = (img0 + m < p.B) ? p.s[(int64_t)(img0 + m) * p.Cin + (e - m * p.Cin)] * (ET == SGDFR_SPLIT_FP16 ? SPLIT_F16_XSCALE : 1.f) : 0.f;
         }
         if (early) fill_tables();
@@ -1344,6 +1372,7 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
         const int blocks = p.n_pix_tiles * p.n_cout_tiles * ksplit;
         p.desync = (up && pct > 0 && blocks >= 1024) ? (int)((mfma_clk + store_clk) * pct / 100 / 4096) : 0;   // >= 4 rounds
     }
+    fill_fastdivs(p);
     hipStream_t st = as_stream(stream);
     const int rc = arith == SGDFR_SPLIT_FP16 ? launch_plan<SGDFR_SPLIT_FP16>(plan->cfg, p, st, x_is_split != 0)
                                              : launch_plan<SGDFR_SPLIT_BF16>(plan->cfg, p, st, x_is_split != 0);
