@@ -11,12 +11,6 @@
 
 namespace sgdfr {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 constexpr int kChunk = 2048;  // elements of one plane handled by one wave
 
 // g_pre = g_out * (out > 0 ? 1 : slope) * gain ;  sums[b,c,0] += sum g_pre ; [1] += sum g_pre*noise ;

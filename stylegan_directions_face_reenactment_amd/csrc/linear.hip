@@ -147,9 +147,7 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restr
             }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int r = 0; r < RB; ++r) acc[r] += __shfl_xor(acc[r], o, 64);
+        for (int r = 0; r < RB; ++r) acc[r] = wave_sum(acc[r]);
         if (lane < RB && m0 + lane < M) {
             float a = acc[0];
 #pragma unroll
@@ -188,60 +186,98 @@ __device__ __forceinline__ int range_exponent(float m, unsigned absmax_bits, int
     return min(max(18 - headroom - L - fl, -120), 120);
 }
 
+// A wave owns STYLE_NC consecutive output columns and STYLE_BU images per iteration: one column per wave re-read the whole
+// [B, K] input matrix for every column (5000 columns x 64 rows x 2 KB = 650 MB through L2 per forward: 93 + 56 us for ~10 us
+// of arithmetic in rocprofv3); with 4 columns the rows are read a quarter as often and 4 images' rows are in flight together.
+constexpr int STYLE_NC = 4, STYLE_BU = 2;
+
 template <int STAGE>
 __global__ __launch_bounds__(256) void styles_batched_kernel(StyleBatch sb) {
+    constexpr int NC = STYLE_NC, BU = STYLE_BU;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int col = blockIdx.x * 4 + wave;                      // global output column over all layers
+    const int grp = blockIdx.x * 4 + wave;                      // global column GROUP over all layers (tile_start counts groups)
     int li = 0;
-    while (li + 1 < sb.n_layers && col >= sb.tile_start[li + 1]) ++li;
-    if (col >= sb.tile_start[sb.n_layers]) return;
+    while (li + 1 < sb.n_layers && grp >= sb.tile_start[li + 1]) ++li;
+    if (grp >= sb.tile_start[sb.n_layers]) return;
     const sgdfr_style_layer& ly = sb.layer[li];
-    const int n = col - sb.tile_start[li];
+    const int n0 = (grp - sb.tile_start[li]) * NC;
     const int K = STAGE == 0 ? sb.D : ly.cin;
-    const float* wrow = (STAGE == 0 ? ly.mod_w : ly.q) + (int64_t)n * K;
+    const int ncols = STAGE == 0 ? ly.cin : ly.cout;
+    const float* wbase = STAGE == 0 ? ly.mod_w : ly.q;
     const float* xb = STAGE == 0 ? sb.latent + (int64_t)ly.latent_index * sb.D : ly.s;
     const int64_t ldx = STAGE == 0 ? (int64_t)sb.L * sb.D : ly.cin;
     float* out = STAGE == 0 ? ly.s : ly.d;
-    const int ldo = STAGE == 0 ? ly.cin : ly.cout;
+    const int ldo = ncols;
     constexpr int KPL = 8;                                       // K <= 512 -> at most 8 elements per lane
-    float w[KPL];
+    float w[NC][KPL], bias[NC];
 #pragma unroll
-    for (int j = 0; j < KPL; ++j) {
-        const int k = lane + 64 * j;
-        w[j] = k < K ? wrow[k] : 0.f;
-    }
-    const float bias = STAGE == 0 ? ly.mod_b[n] : 0.f;
-    const bool plan = STAGE == 1 && ly.s_n != nullptr;          // range plan: this wave also sees the whole style row
-    const unsigned absmax = (plan && ly.x_absmax) ? *ly.x_absmax : 0u;
-    for (int b = 0; b < sb.B; ++b) {
-        const float* xr = xb + b * ldx;
-        float acc = 0.f, m = 0.f;
-        float xv[KPL];
+    for (int c = 0; c < NC; ++c) {
+        const int n = min(n0 + c, ncols - 1);
 #pragma unroll
         for (int j = 0; j < KPL; ++j) {
             const int k = lane + 64 * j;
-            float v = k < K ? xr[k] : 0.f;
-            xv[j] = v;
-            if (STAGE == 1) {
-                m = fmaxf(m, fabsf(v));
-                v *= v;
+            w[c][j] = k < K ? wbase[(int64_t)n * K + k] : 0.f;
+        }
+        bias[c] = STAGE == 0 ? ly.mod_b[n] : 0.f;
+    }
+    const bool plan = STAGE == 1 && ly.s_n != nullptr;          // range plan: this wave also sees the whole style row
+    const unsigned absmax = (plan && ly.x_absmax) ? *ly.x_absmax : 0u;
+    // blockIdx.y = image chunk: the serial walk over the images (one exposed load latency per step, a handful of waves per
+    // CU) is cut into gridDim.y independent pieces
+    const int bchunk = (sb.B + gridDim.y - 1) / gridDim.y;
+    const int b_lo = blockIdx.y * bchunk, b_hi = min(sb.B, b_lo + bchunk);
+    for (int b0 = b_lo; b0 < b_hi; b0 += BU) {
+        float xv[BU][KPL];
+#pragma unroll
+        for (int u = 0; u < BU; ++u) {
+            const float* xr = xb + (int64_t)min(b0 + u, b_hi - 1) * ldx;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                const int k = lane + 64 * j;
+                xv[u][j] = k < K ? xr[k] : 0.f;
             }
-            acc = fmaf(v, w[j], acc);
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        const float r = STAGE == 0 ? acc * sb.wscale + bias : rsqrtf(acc + 1e-8f);
-        if (lane == 0) out[(int64_t)b * ldo + n] = r;
-        if (plan) {
+        for (int u = 0; u < BU; ++u) {
+            const int b = b0 + u;
+            if (b >= b_hi) break;
+            float m = 0.f;
+            float acc[NC];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-            const int e = range_exponent(m, absmax, ly.x_absmax != nullptr, ly.x_log2, ly.headroom);
-            if (lane == 0) ly.d_n[(int64_t)b * ldo + n] = ldexpf(r, -e);
-            if (n == 0) {                                        // the first column's wave also writes the scaled style row
+            for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                float v = xv[u][j];
+                if (STAGE == 1) {
+                    m = fmaxf(m, fabsf(v));
+                    v *= v;
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = fmaf(v, w[c][j], acc[c]);     // per column: the same order as one column per wave
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = wave_sum(acc[c]);
+            int e = 0;
+            if (plan) {
+                m = wave_max(m);
+                e = range_exponent(m, absmax, ly.x_absmax != nullptr, ly.x_log2, ly.headroom);
+            }
+            if (lane < NC && n0 + lane < ncols) {                // lane c stores column c
+                float a = acc[0];
+#pragma unroll
+                for (int c = 1; c < NC; ++c) a = lane == c ? acc[c] : a;
+                float bv = bias[0];
+#pragma unroll
+                for (int c = 1; c < NC; ++c) bv = lane == c ? bias[c] : bv;
+                const float r = STAGE == 0 ? a * sb.wscale + bv : rsqrtf(a + 1e-8f);
+                out[(int64_t)b * ldo + n0 + lane] = r;
+                if (plan) ly.d_n[(int64_t)b * ldo + n0 + lane] = ldexpf(r, -e);
+            }
+            if (plan && n0 == 0) {                               // the first group's wave also writes the scaled style row
 #pragma unroll
                 for (int j = 0; j < KPL; ++j) {
                     const int k = lane + 64 * j;
-                    if (k < K) ly.s_n[(int64_t)b * K + k] = ldexpf(xv[j], e);
+                    if (k < K) ly.s_n[(int64_t)b * K + k] = ldexpf(xv[u][j], e);
                 }
             }
         }
@@ -342,7 +378,7 @@ extern "C" int sgdfr_styles_batched_f32(const float* latent, int B, int L, int D
     sb.n_layers = n_layers; sb.latent = latent; sb.B = B; sb.L = L; sb.D = D;
     sb.wscale = 1.0f / sqrtf((float)D);
     SGDFR_REQUIRE(D <= 512, "styles_batched: style_dim %d > 512", D);
-    int tiles = 0, dl = 0;     // tile_start[] holds prefix sums of output COLUMNS (one wave each)
+    int tiles = 0, dl = 0;     // tile_start[] holds prefix sums of output column GROUPS (STYLE_NC columns, one wave each)
     for (int i = 0; i < n_layers; ++i) {
         const sgdfr_style_layer& ly = layers[i];
         SGDFR_REQUIRE(ly.mod_w && ly.mod_b && ly.s && ly.cin > 0, "styles_batched: layer %d incomplete", i);
@@ -354,10 +390,11 @@ extern "C" int sgdfr_styles_batched_f32(const float* latent, int B, int L, int D
         sb.layer[i] = ly;
         SGDFR_REQUIRE(ly.cin <= 512 || !ly.d, "styles_batched: layer %d has %d input channels (> 512)", i, ly.cin);
         sb.tile_start[i] = tiles;
-        tiles += ly.cin;
+        tiles += (ly.cin + STYLE_NC - 1) / STYLE_NC;      // column groups
     }
     sb.tile_start[n_layers] = tiles;
-    hipLaunchKernelGGL(styles_batched_kernel<0>, dim3((tiles + 3) / 4), dim3(256), 0, as_stream(stream), sb);
+    const int chunks = B >= 64 ? 8 : B >= 16 ? 4 : B >= 4 ? 2 : 1;       // image chunks (grid.y)
+    hipLaunchKernelGGL(styles_batched_kernel<0>, dim3((tiles + 3) / 4, chunks), dim3(256), 0, as_stream(stream), sb);
     if (int rc = check_launch("styles_batched(modulation)")) return rc;
     // demodulation coefficients: only layers that asked for d
     StyleBatch sd{};
@@ -367,13 +404,13 @@ extern "C" int sgdfr_styles_batched_f32(const float* latent, int B, int L, int D
         if (!layers[i].d) continue;
         sd.layer[dl] = layers[i];
         sd.tile_start[dl] = tiles;
-        tiles += layers[i].cout;
+        tiles += (layers[i].cout + STYLE_NC - 1) / STYLE_NC;
         ++dl;
     }
     if (dl == 0) return 0;
     sd.tile_start[dl] = tiles;
     sd.n_layers = dl;
-    hipLaunchKernelGGL(styles_batched_kernel<1>, dim3((tiles + 3) / 4), dim3(256), 0, as_stream(stream), sd);
+    hipLaunchKernelGGL(styles_batched_kernel<1>, dim3((tiles + 3) / 4, chunks), dim3(256), 0, as_stream(stream), sd);
     return check_launch("styles_batched(demod)");
 }
 
