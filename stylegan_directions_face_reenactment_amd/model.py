@@ -406,12 +406,17 @@ class Generator(nn.Module):
     # ---- range plan of the fp16-split arithmetic (functional.PRECISION == 'fp16x3')
     SATURATION_POLL_EVERY = 64      # no-grad forwards between two reads of the device's saturation counter (each read syncs)
 
-    def _weights_stamp(self):
-        """Cheap identity of the current weights: storage of one conv weight + the sum of all parameters' version counters
-        (the parameter list is walked once and cached; invalidate_packs() drops it)."""
+    def _params(self):
+        """The parameter list, walked once and cached (nn.Module.parameters() costs ~0.15 ms per call on this module tree:
+        a seventh of a small-batch forward's host time); invalidate_packs() drops it."""
         plist = getattr(self, '_plist', None)
         if plist is None:
             plist = self._plist = list(self.parameters())
+        return plist
+
+    def _weights_stamp(self):
+        """Cheap identity of the current weights: storage of one weight + the sum of all parameters' version counters."""
+        plist = self._params()
         w = plist[0]
         v = 0
         for p in plist:
@@ -491,7 +496,7 @@ class Generator(nn.Module):
         trunc = truncation_latent if truncation < 1 else None
         if truncation < 1 and truncation_latent is None:
             raise RuntimeError('truncation < 1 needs truncation_latent')
-        grad = _needs_grad(*styles, trunc, *self.parameters())
+        grad = _needs_grad(*styles, trunc, *self._params())
 
         def prepare(w, rows):
             if _needs_grad(w, trunc):
@@ -512,7 +517,7 @@ class Generator(nn.Module):
         for conv1, conv2, to_rgb in zip(self.convs[::2], self.convs[1::2], self.to_rgbs):
             order += [(conv1.conv, i), (conv2.conv, i + 1), (to_rgb.conv, i + 2)]
             i += 2
-        if grad and not any(p.requires_grad for p in self.parameters()):
+        if grad and not any(p.requires_grad for p in self._params()):
             # frozen generator (the direction trainer): the two batched launches, differentiable w.r.t. the latent only
             flat = iter(AG.StylesBatchedFn.apply(latent, order))
             sd = iter([(next(flat), next(flat) if (m.kernel_size == 3 and m.demodulate) else None) for m, _ in order])
