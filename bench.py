@@ -339,7 +339,7 @@ def run_synthesis(args, rank, world, dev):
                    'max_abs_between_the_two_paths': float((fast - exact).abs().max()), 'roofline': alt_roof}
     if rank != 0:
         return None
-    out = base_line(args, world, 'reenacted frames/sec @256x256', 'frames/s', B * world * args.steps / elapsed, elapsed,
+    out = base_line(args, world, 'reenacted frames/sec @%dx%d' % (args.size, args.size), 'frames/s', B * world * args.steps / elapsed, elapsed,
                     '%dxMI355X HIP synthesis-only: Generator(%d,512,8,cm=%d), random w+ [%d,14,512] per GPU, fixed noise, psi=1'
                     % (world, args.size, args.cm, B),
                     {'weight_broadcast_bytes': bcast_bytes, 'weight_broadcast_ms': round(bcast_ms, 2),
@@ -423,7 +423,7 @@ def run_inference(args, rank, world, dev):
         e4e_batch = (hi - lo) * 3 / (time.perf_counter() - tb)
     if rank != 0:
         return None
-    out = base_line(args, world, 'reenacted frames/sec @256x256', 'frames/s', B * world * args.steps / elapsed, elapsed,
+    out = base_line(args, world, 'reenacted frames/sec @%dx%d' % (args.size, args.size), 'frames/s', B * world * args.steps / elapsed, elapsed,
                     '%dxMI355X run_inference.py flow: e4e source W+ (once) + per batch of %d target frames: shift vectors from 3DMM '
                     'parameters -> DirectionMatrix -> shift + truncation psi=0.7 -> HIP Generator(%d,cm=%d) -> uint8 '
                     'source|target|reenacted frames' % (world, B, args.size, args.cm),
@@ -515,7 +515,7 @@ def run_trainer(args, rank, world, dev):
     finite = bool(torch.isfinite(torch.stack(losses)).all())
     if rank != 0:
         return None
-    out = base_line(args, world, 'direction-learning samples/sec @256x256', 'samples/s', B * world * args.steps / elapsed, elapsed,
+    out = base_line(args, world, 'direction-learning samples/sec @%dx%d' % (args.size, args.size), 'samples/s', B * world * args.steps / elapsed, elapsed,
                     '%dxMI355X libs/trainer.py step: 2 no-grad forwards + shape-model stand-in, make_shift_vector_50 on device, grad '
                     'forward + backward to A through the HIP Generator(%d,cm=%d) (frozen), IR-SE-50 id loss + LPIPS-shaped stack + '
                     'DECA stand-in (PyTorch-ROCm, random weights), all-reduce of dA, Adam; B=%d per GPU'

@@ -208,7 +208,8 @@ int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, cons
  * ModulatedConv2d.forward model.py:232-273): fp32 operands are split into bf16 hi + lo terms and contracted as
  * hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~2^-17 relative error per product; the
  * whole 256x256 generator stays within 1.1e-4 max-abs of the fp64 oracle, contract 1e-3).  Never selected implicitly.
- *   sgdfr_modconv_prepack_split_elems: uint16 elements of the packed weight buffer (= 2*9*Cout*Cin)
+ *   sgdfr_modconv_prepack_split_elems: uint16 elements of the packed weight buffer (= 2*9*Cin*Cout, Cout rounded up to the 64-wide cout tiles of the pack:
+ *     a forward pack may have Cout = 32 mod 64, its last tile is half padding)
  *   sgdfr_modconv_prepack_split_f32:   weight [Cout,Cin,3,3] -> 16-bit hi/lo of weight/sqrt(9 Cin) in kernel order;
  *                                      transpose_flip = 1 packs the adjoint conv (Cin outputs, Cout inputs, taps rotated),
  *                                      2 the adjoint of the transposed conv (channels swapped, taps stored phase by phase):

@@ -526,15 +526,16 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         const float rs = rsqrtf((float)p.Cout);
         for (int e = tid; e < p.simgs * NT; e += NTHR) {
             const int m = e / NT, c = e - m * NT;
-            const bool in = img0 + m < p.B;
+            const bool cok = n0 + c < p.Cout;              // Cout = 32 (mod 64): the upper half of the last 64-cout tile is padding
+            const bool in = img0 + m < p.B && cok;
             const int64_t bc = (int64_t)(img0 + m) * p.Cout + n0 + c;
             const float dv = (p.d && in) ? p.d[bc] : 1.f;
-            const float bv = (whole && p.bias) ? p.bias[n0 + c] : 0.f;
+            const float bv = (whole && p.bias && cok) ? p.bias[n0 + c] : 0.f;
             const float sv = (emit_xs && in) ? p.s_next[bc] : 0.f;
             // rgb[j] = sum_co y[co] * w_rgb[j][co] * s_rgb[b][co] / sqrt(Cout) over this block's couts
             const float rv = (fuse_rgb && in) ? p.rgb_s[bc] : 0.f;
-            const float w0 = fuse_rgb ? p.rgb_w[n0 + c] : 0.f, w1 = fuse_rgb ? p.rgb_w[p.Cout + n0 + c] : 0.f,
-                        w2 = fuse_rgb ? p.rgb_w[2 * p.Cout + n0 + c] : 0.f;
+            const float w0 = (fuse_rgb && cok) ? p.rgb_w[n0 + c] : 0.f, w1 = (fuse_rgb && cok) ? p.rgb_w[p.Cout + n0 + c] : 0.f,
+                        w2 = (fuse_rgb && cok) ? p.rgb_w[2 * p.Cout + n0 + c] : 0.f;
             dl[e] = dv * oscale;
             if (m == 0) bl[c] = bv;
             if (emit_xs) sn[e] = sv * xsc;
@@ -860,6 +861,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             float xsv[4];
 #pragma unroll
             for (int m = 0; m < MI; ++m) {
+                if (n0 + wm * (MI * 32) + m * 32 >= p.Cout) continue;     // padding rows of a half-filled cout tile (wave-uniform)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int cl = m * 32 + (r & 3) + 8 * (r >> 2);          // cout inside the wave's rows (without 4*hi)
@@ -1064,7 +1066,10 @@ static size_t split_lds_bytes(const SplitParams& p, int NT, int nss, bool down =
 
 // geometry of the pixel tiling for one plan; returns 0 when the shape cannot use it
 static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, const SplitPlan& plan, SplitParams* out) {
-    if (Cin % SPLIT_CB != 0 || Cout % plan.nt != 0 || B < 1) return 0;
+    // (NT = 64 plans also take Cout = 32 mod 64 -- the 512^2 / 1024^2 layers of the ffhq-1024 generator: the pack pads the last
+    // cout tile with zero rows, the epilogue skips them; forward modes only)
+    const bool half_tile = plan.nt == 64 && Cout % 64 == 32 && mode != SGDFR_MODE_DOWN3;
+    if (Cin % SPLIT_CB != 0 || (Cout % plan.nt != 0 && !half_tile) || B < 1) return 0;
     const bool down = mode == SGDFR_MODE_DOWN3;
     if (down) Cin *= 4;          // K channels = (plane channel, phase)
     SplitParams p{};
@@ -1106,9 +1111,9 @@ static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, cons
         p.n_pix_tiles = (int)((p.total_pix + PT - 1) / PT);
     }
     p.xs = plan.nw == 8 ? (p.xlen + 63) & ~63 : (p.xlen + 7) & ~7;
-    p.n_cout_tiles = Cout / plan.nt;
+    p.n_cout_tiles = (Cout + plan.nt - 1) / plan.nt;
     const int nthr = plan.nw * 64;
-    if ((2 * p.xs + nthr - 1) / nthr > (mode == SGDFR_MODE_PLAIN3 ? 4 : 3)) return 0;                 // staging slots
+    if ((2 * p.xs + nthr - 1) / nthr > (mode == SGDFR_MODE_DOWN3 ? 3 : 4)) return 0;                  // staging slots (512-wide transposed conv: 4)
     const size_t lds = split_lds_bytes(p, plan.nt, plan.nss, down);
     if (lds > (plan.nw == 8 ? 160 : 80) * 1024) return 0;
     if (out) *out = p;
@@ -1222,7 +1227,7 @@ extern "C" int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H,
     return split_plan(B, Cin, Cout, H, W, mode, &p) ? p.n_cout_tiles : 0;
 }
 
-extern "C" int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin) { return (int64_t)Cout * Cin * 9 * 2; }
+extern "C" int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin) { return (int64_t)((Cout + 63) / 64 * 64) * Cin * 9 * 2; }   // cout tiles of 64
 
 extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int arith,
                                                int transpose_flip, void* stream) {
@@ -1230,9 +1235,17 @@ extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned sho
     SGDFR_REQUIRE(transpose_flip >= 0 && transpose_flip <= 2, "prepack_split: transpose_flip is 0 (forward), 1 (adjoint of "
                   "the plain conv) or 2 (adjoint of the transposed conv)");
     const int n_out = transpose_flip ? Cin : Cout, n_in = transpose_flip ? Cout : Cin;
-    SGDFR_REQUIRE(Cout > 0 && Cin > 0 && n_in % SPLIT_CB == 0 && n_out % 64 == 0,
-                  "prepack_split: needs in-channels %% 16 == 0 and out-channels %% 64 == 0, got in=%d out=%d", n_in, n_out);
+    SGDFR_REQUIRE(Cout > 0 && Cin > 0 && n_in % SPLIT_CB == 0 && (n_out % 64 == 0 || (transpose_flip == 0 && n_out % 64 == 32)),
+                  "prepack_split: needs in-channels %% 16 == 0 and out-channels %% 64 == 0 (forward pack: %% 32), got in=%d out=%d",
+                  n_in, n_out);
     SGDFR_REQUIRE(weight && wsp, "prepack_split: null pointer");
+    if (n_out % 64 != 0) {       // zero rows for the padding half of the last 64-cout tile
+        if (hipMemsetAsync(wsp, 0, sizeof(unsigned short) * (size_t)sgdfr_modconv_prepack_split_elems(Cout, Cin), as_stream(stream)) !=
+            hipSuccess) {
+            set_error("prepack_split: hipMemsetAsync failed");
+            return 2;
+        }
+    }
     const int64_t n = (int64_t)Cout * Cin * 9;
     int64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
@@ -1245,7 +1258,7 @@ template <int MODE, int ET, int WM, int WN, int MI, int NI, int NSS = 3, bool XI
 static int launch_split(const SplitParams& p, hipStream_t st) {
     constexpr int NTHR = WM * WN * 64;
     const int nex = (2 * p.xs + NTHR - 1) / NTHR;
-    constexpr int NEX_MAX = (MODE == SGDFR_MODE_PLAIN3) ? 4 : 3;   // UP3 / DOWN3 stage at most PT + P + 2 positions
+    constexpr int NEX_MAX = (MODE == SGDFR_MODE_DOWN3) ? 3 : 4;    // staged positions <= 4 x 256 (UP3: PT + P + 2, 4 slots from P = 513 on)
     SGDFR_REQUIRE(nex <= NEX_MAX, "modconv_split: staged range %d too long for mode %d", p.xlen, MODE);
     void (*kern)(SplitParams) = nex <= 2   ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 2, NSS, XIN>
                                 : nex == 3 ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 3, NSS, XIN>

@@ -21,6 +21,9 @@ CASES = [  # cin, cout, H, B
     (16, 64, 256, 1),     # patches on a 256-wide image
     (16, 64, 256, 2),
     (32, 128, 128, 8),
+    (64, 32, 64, 2),      # Cout = 32 (mod 64): half-filled cout tile (the 512^2 / 1024^2 layers of the ffhq-1024 generator)
+    (32, 32, 128, 3),
+    (32, 96, 32, 4),
 ]
 
 
@@ -55,7 +58,7 @@ def test_split_conv_matches_fp64_oracle(cin, cout, H, B, arith):
 
 
 UP_CASES = [(64, 64, 16, 3), (128, 128, 8, 5), (32, 128, 4, 9), (64, 64, 64, 2), (32, 64, 128, 1), (48, 256, 32, 2),
-            (32, 64, 128, 8), (16, 128, 64, 33)]
+            (32, 64, 128, 8), (16, 128, 64, 33), (64, 32, 64, 2), (32, 96, 32, 3)]
 
 
 @pytest.mark.parametrize('arith', ['fp16x3', 'bf16x3'])
