@@ -1,0 +1,118 @@
+// What does v_mfma_f32_32x32x16_f16 sustain on this part with RANDOM operands (the chip clocks to its power budget, and
+// toggling sets the power)?  Arms: registers only / fragments from LDS at the split conv's ratio (8 ds_read_b128 per 12
+// MFMAs) / the same with a barrier every 36 MFMAs; zero-filled vs random data; 1 or 2 waves per SIMD.  Prints TFLOP/s, the
+// average shader clock (s_memtime ticks / wall time) and MFMA-pipe duty at that clock.
+//   hipcc --offload-arch=gfx950 -O3 scripts/mfma16_probe.hip -o gpurun_out/mfma16_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int frag128 __attribute__((ext_vector_type(4)));
+
+template <int WAVES, int USE_LDS, int BARRIER>
+__global__ __launch_bounds__(WAVES * 64, 1) void probe(float* out, const unsigned* seed, int iters, unsigned long long* clk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 65536 / 4; i += blockDim.x) reinterpret_cast<unsigned*>(lds)[i] = seed[i];
+    __syncthreads();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const unsigned char* pa = lds + ((lane >> 5) * 64 + (lane & 31)) * 16;
+    const unsigned char* pb = lds + 32768 + ((lane >> 5) * 512 + (wave & 3) * 64 + (lane & 31)) * 16;
+    frag128 a[2][2], b[2][2];
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            a[part][m] = *reinterpret_cast<const frag128*>(pa + part * 16384 + m * 512);
+            b[part][m] = *reinterpret_cast<const frag128*>(pb + part * 16384 + m * 512);
+        }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            if (USE_LDS) {
+#pragma unroll
+                for (int part = 0; part < 2; ++part)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        a[part][m] = *reinterpret_cast<const frag128*>(pa + part * 16384 + tap * 4096 + m * 512 + (it & 1) * 2048);
+                        b[part][m] = *reinterpret_cast<const frag128*>(pb + part * 16384 + (tap + m * 32 + (it & 7)) * 16);
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[t == 2][m]),
+                                                                           __builtin_bit_cast(f16x8, b[t == 1][n]), acc[m][n], 0, 0, 0);
+        }
+        if (BARRIER) __builtin_amdgcn_s_barrier();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[m][n][r];
+    out[blockIdx.x * blockDim.x + tid] = s;
+    if (blockIdx.x == 0 && tid == 0) clk[0] = t1 - t0;
+}
+
+static unsigned short f2h(float f) { _Float16 h = (_Float16)f; unsigned short u; __builtin_memcpy(&u, &h, 2); return u; }
+
+template <int WAVES, int USE_LDS, int BARRIER>
+void run(const char* name, const unsigned* seed_dev) {
+    float* out; unsigned long long* clk;
+    const int blocks = 256, iters = 4000;
+    hipMalloc(&out, sizeof(float) * blocks * WAVES * 64); hipMalloc(&clk, 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipFuncSetAttribute((const void*)probe<WAVES, USE_LDS, BARRIER>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    probe<WAVES, USE_LDS, BARRIER><<<blocks, WAVES * 64, 65536>>>(out, seed_dev, 200, clk);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    probe<WAVES, USE_LDS, BARRIER><<<blocks, WAVES * 64, 65536>>>(out, seed_dev, iters, clk);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long c; hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
+    const double flops = (double)blocks * WAVES * iters * 36 * 2.0 * 32 * 32 * 16;
+    const double ghz = c / (ms * 1e6);
+    const double duty = (double)iters * 36 * 32 * (WAVES / 4) / (double)c;
+    printf("%-34s waves %d: %8.3f ms %7.1f TFLOP/s (16-bit) = %6.1f fp32-equiv, clock %.2f GHz, MFMA duty %.2f\n", name, WAVES, ms,
+           flops / ms / 1e9, flops / ms / 1e9 / 3, ghz, duty);
+    hipFree(out); hipFree(clk);
+}
+
+int main() {
+    unsigned* h = (unsigned*)malloc(65536);
+    unsigned* dz; unsigned* dr;
+    hipMalloc(&dz, 65536); hipMalloc(&dr, 65536);
+    hipMemset(dz, 0, 65536);
+    srand(1);
+    for (int i = 0; i < 16384; ++i) {
+        float u0 = 0, u1 = 0;
+        for (int k = 0; k < 12; ++k) { u0 += rand() / (float)RAND_MAX; u1 += rand() / (float)RAND_MAX; }
+        h[i] = f2h((u0 - 6.f) * 4.f) | ((unsigned)f2h((u1 - 6.f) * 4.f) << 16);
+    }
+    hipMemcpy(dr, h, 65536, hipMemcpyHostToDevice);
+    for (int rep = 0; rep < 2; ++rep) {
+        run<8, 0, 0>("registers, zeros", dz);
+        run<8, 0, 0>("registers, random", dr);
+        run<4, 0, 0>("registers, random", dr);
+        run<8, 1, 0>("LDS fragments, zeros", dz);
+        run<8, 1, 0>("LDS fragments, random", dr);
+        run<4, 1, 0>("LDS fragments, random", dr);
+        run<8, 1, 1>("LDS + barrier/36, random", dr);
+    }
+    return 0;
+}

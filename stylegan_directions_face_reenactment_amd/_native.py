@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libsgdfr_hip.so')
+# (SGDFR_LIB: the probe build of scripts/build_probe.py, for the timing scripts only)
+LIB_PATH = os.environ.get('SGDFR_LIB') or os.path.join(_HERE, 'csrc', 'libsgdfr_hip.so')
 ABI_VERSION = 8
 
 _c_f32p = ctypes.c_void_p

@@ -63,6 +63,22 @@ __device__ __forceinline__ f32x16 split_mfma(frag128 a, frag128 b, f32x16 c) {
 }
 __device__ unsigned int g_split_saturated = 0;   // operand pairs clamped to the fp16 range by this translation unit's kernels
 
+#ifdef SGDFR_SPLIT_PROBE
+// scripts/tile_trace.py: s_memtime stamps of one wave of one block (SGDFR_SPLIT_DBG bit 6; block = dbg >> 8 & 0xff, wave =
+// dbg >> 16 & 7, bit 7 adds one stamp per sub-stage): [0] = count, then (event id << 48) | shader clock
+__device__ unsigned long long g_split_trace[4096];
+#define SPLIT_TRACE(id)                                                                                              \
+    do {                                                                                                             \
+        if (trace_on) {                                                                                              \
+            if (ntrace < 4094)                                                                                       \
+                g_split_trace[1 + ntrace] = ((unsigned long long)(id) << 48) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffull); \
+            ++ntrace;                                                                                                \
+        }                                                                                                            \
+    } while (0)
+#else
+#define SPLIT_TRACE(id) do {} while (0)
+#endif
+
 constexpr float SPLIT_F16_XSCALE = 0.0625f, SPLIT_F16_WSCALE = 64.f, SPLIT_F16_OUT = 0.25f, SPLIT_F16_MAX = 65504.f;
 
 // n / d for 0 <= n < 2^31 without a hardware divide: q = (n * mul) >> sh with mul = ceil(2^sh / d), sh = 31 + ceil(log2 d)
@@ -132,6 +148,21 @@ constexpr int SPLIT_CB = 16;     // input channels per K block (one MFMA K)
 template <int N>
 __device__ __forceinline__ void split_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n in 0..8 (the instruction takes an immediate)
+__device__ __forceinline__ void split_wait_vmcnt_dyn(int n) {
+    switch (n) {
+        case 0: split_wait_vmcnt<0>(); break;
+        case 1: split_wait_vmcnt<1>(); break;
+        case 2: split_wait_vmcnt<2>(); break;
+        case 3: split_wait_vmcnt<3>(); break;
+        case 4: split_wait_vmcnt<4>(); break;
+        case 5: split_wait_vmcnt<5>(); break;
+        case 6: split_wait_vmcnt<6>(); break;
+        case 7: split_wait_vmcnt<7>(); break;
+        default: split_wait_vmcnt<8>(); break;
+    }
 }
 
 // two floats -> packed hi pair and packed lo pair (lo = round(v - float(hi)), the subtraction is exact)
@@ -293,11 +324,28 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         }
         return ok ? ((((int64_t)img * (p.Cin / 8) + h) * 2) * HWin + pix) * 16 : -1;
     };
+    // DMA issue is not free: a wave sits ~100-200 clocks in every global_load_lds while the CU's address path takes its 1 KB,
+    // and a sub-stage issues 32-40 KB.  With all eight waves issuing at the top of a sub-stage the matrix cores idled for
+    // ~1000 of its ~3600 clocks (s_memtime trace, scripts/tile_trace.py).  So the two waves of a SIMD issue at different
+    // times: waves 0-3 at the top, waves 4-7 ("late") in the middle of their MFMA stream -- one always has MFMAs to run.
+    const bool late = XIN && !DOWN && NW == 8 && wave >= 4 && !(p.stagger & 4);
+    // activation DMA instructions this wave issues in sub-stage 0 / 1 of a channel block (RING3; see issue_x: slots beyond 2*xs are skipped)
+    int nxw[2] = {0, 0};
+    if (RING3) {
+#pragma unroll
+        for (int e = 0; e < NEX; ++e)
+            if (wave * 64 + e * NTHR < 2 * p.xs) nxw[e & 1] += 2;
+    }
     unsigned sat = 0;              // fp16 operand pairs this thread clamped
     int base = 0;
     int xsel = 0, wsel = 0;        // x buffer of the current channel block / weight slot of the current sub-stage
     bool prefetched = false;       // this tile's first channel block and weight slab were staged by the previous tile
+#ifdef SGDFR_SPLIT_PROBE
+    const bool trace_on = (p.dbg & 64) && (int)blockIdx.x == ((p.dbg >> 8) & 0xff) && tid == 64 * ((p.dbg >> 16) & 7);
+    int ntrace = 0;
+#endif
     do {
+    SPLIT_TRACE(1);
     const int lid = lid_of(base);
     if (lid < 0) break;
     const int lid_n = PERSIST ? lid_of(base + gridDim.x) : -1;
@@ -416,6 +464,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         xs16[e] = -2;
     }
 
+    SPLIT_TRACE(2);
     f32x16 acc[PH][MI][NI];
 #pragma unroll
     for (int ph = 0; ph < PH; ++ph)
@@ -580,8 +629,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             split_wait_vmcnt<0>();
         }
     }
+    SPLIT_TRACE(8);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    SPLIT_TRACE(3);
 
     // A fragment (m) of kernel row r (inside the sub-stage), tap kx, part: aoff[m] + r*WROW64 + (kx*2+part)*2048
     int aoff[MI];
@@ -601,15 +652,22 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         for (int ss = 0; ss < NSS; ++ss) {
             const int u = cb * NSS + ss;
             const bool more_w = u + 1 < ncb * NSS;
-            if (RING3) {
-                // (the activation pieces of this sub-stage are issued first, see stage_part below, then the slab of u+2: the
-                // counted wait at the end of the sub-stage leaves exactly that slab in flight)
-            } else if (more_w) issue_w(wglb, u + 1, wsel ^ 1);
-            else if (XIN && has_next) issue_w(wglb_n, cb0_n * NSS, wsel ^ 1);
+#ifdef SGDFR_SPLIT_PROBE
+            if (p.dbg & 128) SPLIT_TRACE(16 + (u & 15));
+#endif
+            auto issue_w_top = [&]() {
+                if (RING3) {
+                    // (the activation pieces of this sub-stage are issued first, see stage_part below, then the slab of u+2: the
+                    // counted wait at the end of the sub-stage leaves exactly this sub-stage's pieces in flight)
+                } else if (more_w) issue_w(wglb, u + 1, wsel ^ 1);
+                else if (XIN && has_next) issue_w(wglb_n, cb0_n * NSS, wsel ^ 1);
+            };
+            if (!late) issue_w_top();
             __builtin_amdgcn_sched_barrier(0);
             constexpr int kSlots[3] = {(NEX + NSS - 1) / NSS, NSS == 3 ? (NEX + 1) / 3 : 0, NSS == 3 ? NEX / 3 : 0};
             // 1/NSS of the next channel block's activations: registers -> hi/lo -> LDS, then refill the registers
             bool w_ahead = false;      // RING3: did this sub-stage issue a slab?
+            int n_issued = 0;          // RING3: DMA instructions this wave issued in this sub-stage
             auto stage_part = [&]() {
                 if (RING3) {
                     // all activation pieces of the next block in the first two sub-stages (a whole sub-stage of slack before
@@ -618,9 +676,11 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                         if (conv_next) {
 #pragma unroll
                             for (int e = ss; e < NEX; e += 2) issue_x(xs16[e], e, cb + 1, xnext);
+                            n_issued = nxw[ss & 1];
                         } else if (pre_next) {
 #pragma unroll
                             for (int e = ss; e < NEX; e += 2) issue_x(xin_addr(Tn, e), e, cb0_n, xnext);
+                            n_issued = nxw[ss & 1];
                         }
                     }
                     const int u1 = ncb * NSS;
@@ -628,6 +688,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                     if (u + 2 < u1) issue_w(wglb, u + 2, (wsel + 2) % NWS);
                     else if (has_next) issue_w(wglb_n, cb0_n * NSS + (u + 2 - u1), (wsel + 2) % NWS);
                     else w_ahead = false;
+                    if (w_ahead) n_issued += WV;
                     return;
                 }
                 if (conv_next) {
@@ -646,7 +707,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                 }
             };
             const unsigned char* wslot = wb0 + wsel * WROW_BYTES;
-            auto mfma_row = [&](int ky) {
+            // `mid`: called once inside the row, between the MFMAs of tap 1 and tap 2 (the late waves' DMA issue)
+            auto mfma_row = [&](int ky, auto&& mid) {
                 const unsigned char* wcur = wslot + (ky - ss * RPS) * WROW64;
                 if (UP) {
                     // taps (ky, kx): x[a-(ky==2), b-(kx==2)] -> offsets rowoff + {1, 1, 0}; phase = 2*(ky&1) + (kx&1).
@@ -687,6 +749,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                                 for (int n = 0; n < NI; ++n)
                                     acc[ph][m][n] = split_mfma<ET>(a[cur][t == 2][m], b[o][t == 1][n], acc[ph][m][n]);
                         __builtin_amdgcn_sched_barrier(0);
+                        if (kx == 1) mid();
                     }
                 } else {
                     // software pipeline over the 3 taps of the row: after the hi*hi MFMAs of tap kx are issued, the
@@ -733,6 +796,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 #pragma unroll
                                 for (int n = 0; n < NI; ++n)
                                     acc[0][m][n] = split_mfma<ET>(a[cur][t == 2][m], b[cur][t == 1][n], acc[0][m][n]);
+                        if (kx == 1) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            mid();
+                        }
                     }
                 }
             };
@@ -785,15 +852,41 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                     }
                     return;
                 }
+                // late waves (pre-split input): this sub-stage's DMA pieces go out between tap 1 and tap 2 of a one-row sub-stage,
+                // after the first kernel row of a whole-channel-block stage
 #pragma unroll
-                for (int r = 0; r < RPS; ++r) mfma_row(ss * RPS + r);
+                for (int r = 0; r < RPS; ++r) {
+                    if (RPS == 1) {
+                        mfma_row(ss * RPS + r, [&]() {
+                            if (late) {
+                                issue_w_top();
+                                stage_part();
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        });
+                    } else {
+                        mfma_row(ss * RPS + r, [&]() {});
+                        if (r == 0 && late) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue_w_top();
+                            stage_part();
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
             };
-            // the two waves of a SIMD (w, w+4) run the two parts in opposite order, so one converts while the other
+            // fp32 input: the two waves of a SIMD (w, w+4) run the two parts in opposite order, so one converts while the other
             // keeps the matrix core busy
-            if (!stagger) stage_part();
+            if (!stagger && !late) stage_part();
+#ifdef SGDFR_SPLIT_PROBE
+            if (p.dbg & 32) SPLIT_TRACE(32);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             mfma_part();
             __builtin_amdgcn_sched_barrier(0);
+#ifdef SGDFR_SPLIT_PROBE
+            if (p.dbg & 32) SPLIT_TRACE(33);
+#endif
             if (stagger) stage_part();
             if (RING3) {
                 if (more_w) {
@@ -801,9 +894,15 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                     // sub-stage of a tile whose operands were staged by the previous tile waits for nothing: slab u+1 landed
                     // before that tile's epilogue, and what is in flight now are its stores.
                     if (!(prefetched && u == cb0 * NSS)) {
-                        if (w_ahead) split_wait_vmcnt<WV>(); else split_wait_vmcnt<0>();
+                        split_wait_vmcnt_dyn(n_issued);
                     }
+#ifdef SGDFR_SPLIT_PROBE
+                    if (p.dbg & 32) SPLIT_TRACE(34);
+#endif
                     __builtin_amdgcn_s_barrier();
+#ifdef SGDFR_SPLIT_PROBE
+                    if (p.dbg & 32) SPLIT_TRACE(35);
+#endif
                 } else if (has_next) {
                     split_wait_vmcnt<0>();      // the next tile's first stages have landed before this tile's stores join the queue
                 }
@@ -830,6 +929,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         xsel ^= 1;
     }
     prefetched = XIN && has_next && ncb > cb0;
+    SPLIT_TRACE(4);
 
 #ifdef SGDFR_SPLIT_PROBE
     if (p.dbg & 2) { if (PERSIST) __syncthreads(); continue; }
@@ -915,6 +1015,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             }
         }
     }
+    SPLIT_TRACE(5);
     if (fuse_rgb) {      // block-uniform
         // the two lane halves hold different couts of the same pixels; the WM cout-waves of a pixel column meet in LDS
 #pragma unroll
@@ -940,9 +1041,14 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             }
         }
     }
+    SPLIT_TRACE(6);
     if (PERSIST) __syncthreads();      // the next tile refills the tables and the staging buffers
+    SPLIT_TRACE(7);
     } while (PERSIST && (base += gridDim.x) < p.total_blocks);
     if (ET == SGDFR_SPLIT_FP16) split_flush_saturation(sat);
+#ifdef SGDFR_SPLIT_PROBE
+    if (trace_on) g_split_trace[0] = (unsigned long long)ntrace;
+#endif
 }
 
 // x [B,Cin,HW] fp32 (NCHW) and s [B,Cin] -> XS [B][Cin/8][hi,lo][HW][8]: the split form of x*s (with the fp16 range shift)
@@ -1213,6 +1319,14 @@ extern "C" long long sgdfr_split_saturation_count(int reset) {
     }
     return (long long)v + (long long)blur_split_saturation_count(reset);
 }
+
+#ifdef SGDFR_SPLIT_PROBE
+extern "C" int sgdfr_split_trace_read(unsigned long long* out, int n) {     // probe builds only (scripts/tile_trace.py)
+    if (n > 4096) n = 4096;
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_split_trace), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int sgdfr_modconv2d_split_xin_supported(int B, int Cin, int Cout, int H, int W, int mode) {
     SplitParams p;
