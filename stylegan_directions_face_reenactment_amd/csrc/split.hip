@@ -953,44 +953,78 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 #pragma unroll
         for (int n = 0; n < NI; ++n) {
             if (ybase[n] < 0) continue;
-            const float* dln = dl + (dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi;
-            const float* bln = bl + wm * (MI * 32) + 4 * hi;
-            const float* cwn = cw + ((dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi) * 4;
-            const float* snn = sn + (dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi;
-            const int rem = UP ? 0 : (int)(ybase[n] - (int64_t)dimg[n] * p.Cout * HW);
-            float xsv[4];
+            const int io = (dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi;      // this lane's first row in the per-image tables
+            if (UP) {
+                const float* dln = dl + io;
 #pragma unroll
-            for (int m = 0; m < MI; ++m) {
-                if (n0 + wm * (MI * 32) + m * 32 >= p.Cout) continue;     // padding rows of a half-filled cout tile (wave-uniform)
+                for (int m = 0; m < MI; ++m) {
+                    if (n0 + wm * (MI * 32) + m * 32 >= p.Cout) continue;     // padding rows of a half-filled cout tile (wave-uniform)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int cl = m * 32 + (r & 3) + 8 * (r >> 2);          // cout inside the wave's rows (without 4*hi)
-                    const int co = n0 + wm * (MI * 32) + cl + 4 * hi;
-                    const float dv = dln[cl];
-                    if (UP) {
+                    for (int r = 0; r < 16; ++r) {
+                        const int cl = m * 32 + (r & 3) + 8 * (r >> 2);          // cout inside the wave's rows (without 4*hi)
+                        const int co = n0 + wm * (MI * 32) + cl + 4 * hi;
+                        const float dv = dln[cl];
                         float* dst = yout + ybase[n] + (int64_t)co * 4 * p.rps;
 #pragma unroll
                         for (int ph = 0; ph < PH; ++ph) dst[(int64_t)ph * p.rps] = acc[ph][m][n][r] * dv;
-                    } else {
-                        const float v = lrelu_gain(acc[0][m][n][r] * dv + nz[n] + bln[cl], e_slope, e_gain);
-                        if (HAS_Y) yout[ybase[n] + (int64_t)co * HW] = v;      // (no y: only the fused ToRGB / xs_out consume this layer)
-                        if (EMIT_XS) {        // rows r = 4g..4g+3 are 4 consecutive couts: half of one 8-channel chunk of this pixel
-                            xsv[r & 3] = v * snn[cl];
-                            if ((r & 3) == 3) {
-                                unsigned h01, l01, h23, l23;
-                                split_pair<ET>(xsv[0], xsv[1], h01, l01, sat);
-                                split_pair<ET>(xsv[2], xsv[3], h23, l23, sat);
-                                const int cg = (n0 + wm * (MI * 32) + m * 32) / 8 + (r >> 2);
-                                unsigned char* dst = p.xs_out + ((((int64_t)dimg[n] * (p.Cout / 8) + cg) * 2) * HW + rem) * 16 + 8 * hi;
-                                *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
-                                *reinterpret_cast<uint2*>(dst + (int64_t)HW * 16) = make_uint2(l01, l23);
-                            }
-                        }
-                        if (FUSE_RGB) {
-                            const float4 q = *reinterpret_cast<const float4*>(cwn + 4 * cl);
-                            rgb[n][0] = fmaf(v, q.x, rgb[n][0]);
-                            rgb[n][1] = fmaf(v, q.y, rgb[n][1]);
-                            rgb[n][2] = fmaf(v, q.z, rgb[n][2]);
+                    }
+                }
+                continue;
+            }
+            // Rows r = 4g .. 4g+3 of an accumulator are 4 consecutive couts (8g + 4*hi + j): their coefficients are ONE 16-byte
+            // LDS read per table, and the ToRGB quads of group g+1 are requested before group g is computed -- the element
+            // loop used to wait for an LDS round trip every one or two elements (ISA: ds_read2_b32 ... s_waitcnt lgkmcnt(0)).
+            // The lane-dependent part of every address lives in a base pointer; what is added per row is wave-uniform.
+            const float4* const d4p = reinterpret_cast<const float4*>(dl + io);
+            const float4* const b4p = reinterpret_cast<const float4*>(bl + wm * (MI * 32) + 4 * hi);
+            const float4* const s4p = reinterpret_cast<const float4*>(sn + io);
+            const float4* const cwp = reinterpret_cast<const float4*>(cw) + io;
+            const int rem = (int)(ybase[n] - (int64_t)dimg[n] * p.Cout * HW);
+            float* const yp = yout + ybase[n] + (int64_t)(n0 + wm * (MI * 32) + 4 * hi) * HW;
+            unsigned char* const xp =
+                p.xs_out + ((((int64_t)dimg[n] * (p.Cout / 8) + (n0 + wm * (MI * 32)) / 8) * 2) * HW + rem) * 16 + 8 * hi;
+#pragma unroll
+            for (int m = 0; m < MI; ++m) {
+                if (n0 + wm * (MI * 32) + m * 32 >= p.Cout) continue;     // padding rows of a half-filled cout tile (wave-uniform)
+                float4 d4[4], b4[4], s4[4], q[2][4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    d4[g] = d4p[m * 8 + 2 * g];
+                    b4[g] = b4p[m * 8 + 2 * g];
+                    if (EMIT_XS) s4[g] = s4p[m * 8 + 2 * g];
+                }
+                if (FUSE_RGB) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) q[0][j] = cwp[m * 32 + j];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (FUSE_RGB && g + 1 < 4) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) q[(g + 1) & 1][j] = cwp[m * 32 + (g + 1) * 8 + j];
+                    }
+                    const float dv[4] = {d4[g].x, d4[g].y, d4[g].z, d4[g].w}, bv[4] = {b4[g].x, b4[g].y, b4[g].z, b4[g].w};
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = lrelu_gain(acc[0][m][n][4 * g + j] * dv[j] + nz[n] + bv[j], e_slope, e_gain);
+                    if (HAS_Y) {      // (no y: only the fused ToRGB / xs_out consume this layer)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) yp[(int64_t)(m * 32 + 8 * g + j) * HW] = v[j];
+                    }
+                    if (EMIT_XS) {    // the 4 rows are half of one 8-channel chunk of this pixel
+                        unsigned h01, l01, h23, l23;
+                        split_pair<ET>(v[0] * s4[g].x, v[1] * s4[g].y, h01, l01, sat);
+                        split_pair<ET>(v[2] * s4[g].z, v[3] * s4[g].w, h23, l23, sat);
+                        unsigned char* dst = xp + (int64_t)(m * 4 + g) * 2 * HW * 16;
+                        *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+                        *reinterpret_cast<uint2*>(dst + (int64_t)HW * 16) = make_uint2(l01, l23);
+                    }
+                    if (FUSE_RGB) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            rgb[n][0] = fmaf(v[j], q[g & 1][j].x, rgb[n][0]);
+                            rgb[n][1] = fmaf(v[j], q[g & 1][j].y, rgb[n][1]);
+                            rgb[n][2] = fmaf(v[j], q[g & 1][j].z, rgb[n][2]);
                         }
                     }
                 }
