@@ -363,6 +363,58 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     const int ks = T.ks, ct = T.ct, pt = T.pt, q0 = T.q0, img0 = T.img0, row0 = T.row0, col0 = T.col0;
     const int n0 = ct * NT;
 
+    // ---- epilogue coefficient tables.  Loads and stores share the in-order vmcnt counter: a per-output `d` / bias load
+    // between two stores would make the wave wait for the previous store's HBM round trip, so every coefficient goes
+    // through LDS (lgkmcnt) and the noise values into registers.  Tiles inside <= 2 images fill their tables HERE, in a
+    // dedicated LDS region beside the style table (no barrier pair and no exposed global-load latency between the K loop
+    // and the stores); tiles spanning many small images (4x4, 8x8) fill them after the loop in the dead staging buffers.
+    const bool whole = p.ksplit == 1;     // K slices only scale by d; noise / bias / activation follow the reduction
+    const bool fuse_rgb = !UP && !DOWN && whole && p.rgb_part != nullptr;      // fused ToRGB partial sums (PLAIN3)
+    const bool early = p.simgs <= 2;
+    // (DOWN3 has no style table: its input arrives modulated)
+    float* const dl = early ? ls + (DOWN ? 0 : ((p.simgs * p.Cin + 3) & ~3)) : reinterpret_cast<float*>(smem);   // [simgs][NT]  d * output scale
+    float* const bl = dl + p.simgs * NT;                        // [NT]            bias
+    float* const cw = bl + NT;                                  // [simgs][NT][4]  ToRGB coefficients
+    float* const red = cw + p.simgs * NT * 4;                   // [WM][PT][3]     ToRGB cross-wave reduce
+    float* const sn = red + WM * PT * 3;                        // [simgs][NT]     next layer's style * range shift (xs_out)
+    const bool emit_xs = !UP && !DOWN && whole && p.xs_out != nullptr;
+    // An entry's global loads and its LDS writes are separate steps: tiles inside <= 2 images (one entry per thread at most)
+    // load at the top of the tile, so the round trip is hidden behind the descriptor arithmetic, and write in the prologue.
+    struct TabVals { float dv, bv, sv, rv, w0, w1, w2; };
+    auto tables_load = [&](int e) -> TabVals {
+        const int m = e / NT, c = e - m * NT;
+        const bool cok = n0 + c < p.Cout;              // Cout = 32 (mod 64): the upper half of the last 64-cout tile is padding
+        const bool in = img0 + m < p.B && cok;
+        const int64_t bc = (int64_t)(img0 + m) * p.Cout + n0 + c;
+        TabVals t;
+        t.dv = (p.d && in) ? p.d[bc] : 1.f;
+        t.bv = (whole && p.bias && cok) ? p.bias[n0 + c] : 0.f;
+        t.sv = (emit_xs && in) ? p.s_next[bc] : 0.f;
+        // rgb[j] = sum_co y[co] * w_rgb[j][co] * s_rgb[b][co] / sqrt(Cout) over this block's couts
+        t.rv = (fuse_rgb && in) ? p.rgb_s[bc] : 0.f;
+        t.w0 = (fuse_rgb && cok) ? p.rgb_w[n0 + c] : 0.f;
+        t.w1 = (fuse_rgb && cok) ? p.rgb_w[p.Cout + n0 + c] : 0.f;
+        t.w2 = (fuse_rgb && cok) ? p.rgb_w[2 * p.Cout + n0 + c] : 0.f;
+        return t;
+    };
+    auto tables_store = [&](int e, const TabVals& t) {
+        const float oscale = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_OUT : 1.f;
+        const float xsc = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_XSCALE : 1.f;
+        const float rs = rsqrtf((float)p.Cout);
+        const int m = e / NT, c = e - m * NT;
+        dl[e] = t.dv * oscale;
+        if (m == 0) bl[c] = t.bv;
+        if (emit_xs) sn[e] = t.sv * xsc;
+        if (fuse_rgb) *reinterpret_cast<float4*>(cw + 4 * e) = make_float4(t.w0 * (t.rv * rs), t.w1 * (t.rv * rs), t.w2 * (t.rv * rs), 0.f);
+    };
+    auto fill_tables = [&]() {
+        // one pass, every global load of an entry issued before the first LDS write (one exposed latency, not four)
+        for (int e = tid; e < p.simgs * NT; e += NTHR) tables_store(e, tables_load(e));
+    };
+    const bool tv_has = early && tid < p.simgs * NT;      // (simgs <= 2, NT <= 128: at most one entry per thread)
+    TabVals tv{};
+    if (tv_has) tv = tables_load(tid);
+
     // ---- this lane's two output pixels: position inside the staged range, and where they are stored
     int boff[NI];
     int64_t ybase[NI];    // (img*Cout)*HW + rem (UP3: (img*Cout*4)*RP + rem), or -1 when the pixel does not exist
@@ -553,44 +605,6 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         }
     };
 
-    // ---- epilogue coefficient tables.  Loads and stores share the in-order vmcnt counter: a per-output `d` / bias load
-    // between two stores would make the wave wait for the previous store's HBM round trip, so every coefficient goes
-    // through LDS (lgkmcnt) and the noise values into registers.  Tiles inside <= 2 images fill their tables HERE, in a
-    // dedicated LDS region beside the style table (no barrier pair and no exposed global-load latency between the K loop
-    // and the stores); tiles spanning many small images (4x4, 8x8) fill them after the loop in the dead staging buffers.
-    const bool whole = p.ksplit == 1;     // K slices only scale by d; noise / bias / activation follow the reduction
-    const bool fuse_rgb = !UP && !DOWN && whole && p.rgb_part != nullptr;      // fused ToRGB partial sums (PLAIN3)
-    const bool early = p.simgs <= 2;
-    // (DOWN3 has no style table: its input arrives modulated)
-    float* const dl = early ? ls + (DOWN ? 0 : ((p.simgs * p.Cin + 3) & ~3)) : reinterpret_cast<float*>(smem);   // [simgs][NT]  d * output scale
-    float* const bl = dl + p.simgs * NT;                        // [NT]            bias
-    float* const cw = bl + NT;                                  // [simgs][NT][4]  ToRGB coefficients
-    float* const red = cw + p.simgs * NT * 4;                   // [WM][PT][3]     ToRGB cross-wave reduce
-    float* const sn = red + WM * PT * 3;                        // [simgs][NT]     next layer's style * range shift (xs_out)
-    const bool emit_xs = !UP && !DOWN && whole && p.xs_out != nullptr;
-    auto fill_tables = [&]() {
-        // one pass, every global load of an entry issued before the first LDS write (one exposed latency, not four)
-        const float oscale = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_OUT : 1.f;
-        const float xsc = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_XSCALE : 1.f;
-        const float rs = rsqrtf((float)p.Cout);
-        for (int e = tid; e < p.simgs * NT; e += NTHR) {
-            const int m = e / NT, c = e - m * NT;
-            const bool cok = n0 + c < p.Cout;              // Cout = 32 (mod 64): the upper half of the last 64-cout tile is padding
-            const bool in = img0 + m < p.B && cok;
-            const int64_t bc = (int64_t)(img0 + m) * p.Cout + n0 + c;
-            const float dv = (p.d && in) ? p.d[bc] : 1.f;
-            const float bv = (whole && p.bias && cok) ? p.bias[n0 + c] : 0.f;
-            const float sv = (emit_xs && in) ? p.s_next[bc] : 0.f;
-            // rgb[j] = sum_co y[co] * w_rgb[j][co] * s_rgb[b][co] / sqrt(Cout) over this block's couts
-            const float rv = (fuse_rgb && in) ? p.rgb_s[bc] : 0.f;
-            const float w0 = (fuse_rgb && cok) ? p.rgb_w[n0 + c] : 0.f, w1 = (fuse_rgb && cok) ? p.rgb_w[p.Cout + n0 + c] : 0.f,
-                        w2 = (fuse_rgb && cok) ? p.rgb_w[2 * p.Cout + n0 + c] : 0.f;
-            dl[e] = dv * oscale;
-            if (m == 0) bl[c] = bv;
-            if (emit_xs) sn[e] = sv * xsc;
-            if (fuse_rgb) *reinterpret_cast<float4*>(cw + 4 * e) = make_float4(w0 * (rv * rs), w1 * (rv * rs), w2 * (rv * rs), 0.f);
-        }
-    };
     float nz[NI];
     {
         const float nw = (whole && p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
@@ -607,14 +621,14 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             issue_w(wglb, cb0 * NSS, wsel);
             if (RING3 && cb0 * NSS + 1 < ncb * NSS) issue_w(wglb, cb0 * NSS + 1, (wsel + 1) % NWS);
         }
-        if (early) fill_tables();      // while the DMA is in flight
+        if (tv_has) tables_store(tid, tv);      // (loaded at the top of the tile)
         split_wait_vmcnt<0>();
     } else {
         for (int e = tid; e < p.simgs * p.Cin; e += NTHR) {
             const int m = fdiv(e, p.fd_Cin);
             ls[e] = (img0 + m < p.B) ? p.s[(int64_t)(img0 + m) * p.Cin + (e - m * p.Cin)] * (ET == SGDFR_SPLIT_FP16 ? SPLIT_F16_XSCALE : 1.f) : 0.f;
         }
-        if (early) fill_tables();
+        if (tv_has) tables_store(tid, tv);
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < NEX; ++e) load_x(e, cb0);
@@ -955,18 +969,23 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             if (ybase[n] < 0) continue;
             const int io = (dimg[n] - img0) * NT + wm * (MI * 32) + 4 * hi;      // this lane's first row in the per-image tables
             if (UP) {
-                const float* dln = dl + io;
+                // (rows 4g .. 4g+3 = couts 8g + 4*hi + j: one 16-byte read of d; the lane-dependent part of the address is in
+                // the base pointer, the per-row / per-plane increments are wave-uniform)
+                const float4* const d4p = reinterpret_cast<const float4*>(dl + io);
+                float* const yp = yout + ybase[n] + (int64_t)(n0 + wm * (MI * 32) + 4 * hi) * 4 * p.rps;
 #pragma unroll
                 for (int m = 0; m < MI; ++m) {
                     if (n0 + wm * (MI * 32) + m * 32 >= p.Cout) continue;     // padding rows of a half-filled cout tile (wave-uniform)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int cl = m * 32 + (r & 3) + 8 * (r >> 2);          // cout inside the wave's rows (without 4*hi)
-                        const int co = n0 + wm * (MI * 32) + cl + 4 * hi;
-                        const float dv = dln[cl];
-                        float* dst = yout + ybase[n] + (int64_t)co * 4 * p.rps;
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 d4 = d4p[m * 8 + 2 * g];
+                        const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-                        for (int ph = 0; ph < PH; ++ph) dst[(int64_t)ph * p.rps] = acc[ph][m][n][r] * dv;
+                        for (int j = 0; j < 4; ++j) {
+                            float* dst = yp + (int64_t)(m * 32 + 8 * g + j) * 4 * p.rps;
+#pragma unroll
+                            for (int ph = 0; ph < PH; ++ph) dst[(int64_t)ph * p.rps] = acc[ph][m][n][4 * g + j] * dv[j];
+                        }
                     }
                 }
                 continue;
