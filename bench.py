@@ -227,7 +227,23 @@ def roofline_for(precision, step, steps, units_per_step):
                       units_per_step)
     r['peak_note'] = ('dense 16-bit MFMA peak 2500 TFLOP/s / 3 products per fp32 product; the same achieved figure is %.2fx '
                       'the 157.3 TFLOP/s fp32-MFMA peak' % (r['achieved'] / FP32_MFMA_PEAK_TFLOPS))
+    r['measured_mfma_ceiling'] = measured_ceiling(precision, r['achieved'])
     return r
+
+
+def measured_ceiling(precision, achieved):
+    """What the 16-bit MFMA sustains on THIS device (sgdfr_mfma_ceiling_probe, ~50 ms): the chip clocks to its power budget and
+    MFMA power follows operand toggling, so a bare MFMA loop on random operands runs well below the nominal 2.5 PFLOP/s that
+    `peak` is derived from.  All figures / 3 = fp32-product TFLOP/s, comparable with `achieved`."""
+    z = F_.mfma_ceiling(precision, lds_fragments=False, random_operands=False)
+    rr = F_.mfma_ceiling(precision, lds_fragments=False, random_operands=True)
+    rl = F_.mfma_ceiling(precision, lds_fragments=True, random_operands=True)
+    return {'unit': 'TFLOP/s (16-bit MFMA rate / 3 products)', 'zero_operands_register_loop': round(z / 3, 1),
+            'random_operands_register_loop': round(rr / 3, 1), 'random_operands_lds_fed_loop': round(rl / 3, 1),
+            'achieved_over_random_register_loop': round(achieved / (rr / 3), 3),
+            'achieved_over_random_lds_fed_loop': round(achieved / (rl / 3), 3),
+            'note': 'bare v_mfma_f32_32x32x16 loops, 8 waves per CU on 256 CUs: power-limited rates of this device; the '
+                    'lds-fed loop reads its fragments at the conv kernel\'s ratio (8 ds_read_b128 per 12 MFMAs)'}
 
 
 def cpu_baseline(size, cm, budget_s=24.0):

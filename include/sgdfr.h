@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 8
+#define SGDFR_ABI_VERSION 9
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -384,6 +384,15 @@ int sgdfr_modconv_wgrad_parts_f32(const float* g, const float* d, const float* x
                                   int B, int Cin, int Cout, int H, int W, int mode, void* stream);
 int sgdfr_modconv_wgrad_finish_parts_f32(const float* part, int ksplit, const float* wp, const float* dq, float* dweight,
                                          int Cout, int Cin, void* stream);
+
+/* Measurement aid (csrc/probe.hip; no reference counterpart): the rate v_mfma_f32_32x32x16_{f16,bf16} sustains on THIS device,
+ * in 16-bit TFLOP/s -- arith SGDFR_SPLIT_FP16/BF16; lds_fragments 1: operands re-read from LDS at the split conv's ratio
+ * (8 ds_read_b128 per 12 MFMAs), 0: register operands; random_operands 1: random mantissas, 0: zeros.  The chip clocks to its
+ * power budget and MFMA power follows operand toggling, so the random-operand figure (not the nominal 2.5 PFLOP/s) is what a
+ * kernel on real data can reach; bench.py prints it beside the roofline.  blocks <= 0: 256 (one 8-wave block per CU);
+ * scratch: blocks*512 floats of device memory.  Synchronises `stream`. */
+int sgdfr_mfma_ceiling_probe(int arith, int lds_fragments, int random_operands, int iters, int blocks, float* scratch,
+                             double* tflops16, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (SGDFR_LIB: the probe build of scripts/build_probe.py, for the timing scripts only)
 LIB_PATH = os.environ.get('SGDFR_LIB') or os.path.join(_HERE, 'csrc', 'libsgdfr_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -102,6 +102,7 @@ SIGNATURES['sgdfr_split_range_f32'] = [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctype
 SIGNATURES['sgdfr_absmax_f32'] = [_c_f32p, _i64, _i64, _i, ctypes.c_void_p, _i, ctypes.c_void_p]
 SIGNATURES['sgdfr_styles_batched_f32'] = [_c_f32p, _i, _i, _i, ctypes.POINTER(StyleLayer), _i, ctypes.c_void_p]
 MAX_STYLE_LAYERS = 40
+SIGNATURES['sgdfr_mfma_ceiling_probe'] = [_i, _i, _i, _i, _i, _c_f32p, ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]
 
 MODE_PLAIN3, MODE_UP3, MODE_DOWN3 = 0, 1, 2
 SPLIT_BF16, SPLIT_FP16 = 0, 1

@@ -273,6 +273,17 @@ def split_saturation_count(reset=True):
     return int(n)
 
 
+def mfma_ceiling(arith='fp16x3', lds_fragments=True, random_operands=True, iters=2000):
+    """Measured sustained rate of the 16-bit MFMA of the split kernels on the current device, TFLOP/s of 16-bit products
+    (sgdfr_mfma_ceiling_probe: the chip clocks to its power budget, so random operands run slower than the nominal peak)."""
+    import ctypes
+    scratch = torch.empty(256 * 512, device='cuda', dtype=torch.float32)
+    out = ctypes.c_double(0.0)
+    N.call('sgdfr_mfma_ceiling_probe', N.SPLIT_FP16 if arith == 'fp16x3' else N.SPLIT_BF16, int(bool(lds_fragments)),
+           int(bool(random_operands)), int(iters), 256, N.ptr(scratch), ctypes.byref(out), N.stream())
+    return float(out.value)
+
+
 def set_precision(mode):
     global PRECISION
     if mode not in ('fp32', 'fp16x3', 'bf16x3'):

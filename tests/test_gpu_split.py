@@ -514,3 +514,15 @@ def test_invalidate_packs_after_data_write():
     state = {k: v.cpu() for k, v in G.state_dict().items()}
     ref, _ = O.generator_forward(state, [w.cpu()], input_is_latent=True)
     assert maxabs(fresh, ref) <= 2e-4
+
+
+def test_mfma_ceiling_probe_is_ordered():
+    """The measurement aid behind bench.py's `measured_mfma_ceiling`: zero operands run faster than random ones (the chip is
+    power-bound), LDS-fed slower than register-fed, and everything sits under the nominal 2.5 PFLOP/s."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    z = F_.mfma_ceiling('fp16x3', lds_fragments=False, random_operands=False, iters=500)
+    r = F_.mfma_ceiling('fp16x3', lds_fragments=False, random_operands=True, iters=500)
+    l = F_.mfma_ceiling('fp16x3', lds_fragments=True, random_operands=True, iters=500)
+    b = F_.mfma_ceiling('bf16x3', lds_fragments=True, random_operands=True, iters=500)
+    assert 200.0 < l <= r * 1.05 and r <= z * 1.05 and z < 2600.0, (z, r, l)
+    assert 200.0 < b < 2600.0
