@@ -10,7 +10,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef int frag128 __attribute__((ext_vector_type(4)));
 
-template <int WAVES, int USE_LDS, int BARRIER>
+template <int WAVES, int USE_LDS, int BARRIER, int ORDER = 0>
 __global__ __launch_bounds__(WAVES * 64, 1) void probe(float* out, const unsigned* seed, int iters, unsigned long long* clk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -46,14 +46,28 @@ __global__ __launch_bounds__(WAVES * 64, 1) void probe(float* out, const unsigne
                         b[part][m] = *reinterpret_cast<const frag128*>(pb + part * 16384 + (tap + m * 32 + (it & 7)) * 16);
                     }
             }
+#define MF(PA, M, PB, N) acc[M][N] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[PA][M]), __builtin_bit_cast(f16x8, b[PB][N]), acc[M][N], 0, 0, 0)
+            if (ORDER == 0) {          // the conv kernel's order: product term outermost
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
+                for (int t = 0; t < 3; ++t)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                    for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[t == 2][m]),
-                                                                           __builtin_bit_cast(f16x8, b[t == 1][n]), acc[m][n], 0, 0, 0);
+                        for (int n = 0; n < 2; ++n) MF(t == 2, m, t == 1, n);
+            } else if (ORDER == 1) {   // snake inside a term: one operand changes per step
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { MF(t == 2, 0, t == 1, 0); MF(t == 2, 0, t == 1, 1); MF(t == 2, 1, t == 1, 1); MF(t == 2, 1, t == 1, 0); }
+            } else if (ORDER == 2) {   // A-stationary: a_hi[m] meets b_hi0 b_hi1 b_lo0 b_lo1, then a_lo[m] meets b_hi0 b_hi1
+#pragma unroll
+                for (int m = 0; m < 2; ++m) { MF(0, m, 0, 0); MF(0, m, 0, 1); MF(0, m, 1, 1); MF(0, m, 1, 0); MF(1, m, 0, 0); MF(1, m, 0, 1); }
+            } else if (ORDER == 3) {   // B-stationary
+#pragma unroll
+                for (int n = 0; n < 2; ++n) { MF(0, 0, 0, n); MF(0, 1, 0, n); MF(1, 1, 0, n); MF(1, 0, 0, n); MF(0, 0, 1, n); MF(0, 1, 1, n); }
+            } else {                   // full Gray path over the 12 products
+                MF(0, 0, 0, 0); MF(0, 0, 0, 1); MF(0, 0, 1, 1); MF(0, 0, 1, 0); MF(0, 1, 1, 0); MF(0, 1, 0, 0);
+                MF(0, 1, 0, 1); MF(0, 1, 1, 1); MF(1, 1, 0, 1); MF(1, 1, 0, 0); MF(1, 0, 0, 0); MF(1, 0, 0, 1);
+            }
+#undef MF
         }
         if (BARRIER) __builtin_amdgcn_s_barrier();
     }
@@ -71,17 +85,17 @@ __global__ __launch_bounds__(WAVES * 64, 1) void probe(float* out, const unsigne
 
 static unsigned short f2h(float f) { _Float16 h = (_Float16)f; unsigned short u; __builtin_memcpy(&u, &h, 2); return u; }
 
-template <int WAVES, int USE_LDS, int BARRIER>
+template <int WAVES, int USE_LDS, int BARRIER, int ORDER = 0>
 void run(const char* name, const unsigned* seed_dev) {
     float* out; unsigned long long* clk;
     const int blocks = 256, iters = 4000;
     hipMalloc(&out, sizeof(float) * blocks * WAVES * 64); hipMalloc(&clk, 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipFuncSetAttribute((const void*)probe<WAVES, USE_LDS, BARRIER>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    probe<WAVES, USE_LDS, BARRIER><<<blocks, WAVES * 64, 65536>>>(out, seed_dev, 200, clk);
+    hipFuncSetAttribute((const void*)probe<WAVES, USE_LDS, BARRIER, ORDER>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    probe<WAVES, USE_LDS, BARRIER, ORDER><<<blocks, WAVES * 64, 65536>>>(out, seed_dev, 200, clk);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    probe<WAVES, USE_LDS, BARRIER><<<blocks, WAVES * 64, 65536>>>(out, seed_dev, iters, clk);
+    probe<WAVES, USE_LDS, BARRIER, ORDER><<<blocks, WAVES * 64, 65536>>>(out, seed_dev, iters, clk);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long c; hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
@@ -113,6 +127,12 @@ int main() {
         run<8, 1, 0>("LDS fragments, random", dr);
         run<4, 1, 0>("LDS fragments, random", dr);
         run<8, 1, 1>("LDS + barrier/36, random", dr);
+        run<8, 1, 0, 1>("LDS random, snake order", dr);
+        run<8, 1, 0, 2>("LDS random, A-stationary", dr);
+        run<8, 1, 0, 3>("LDS random, B-stationary", dr);
+        run<8, 1, 0, 4>("LDS random, Gray path", dr);
+        run<8, 0, 0, 2>("registers random, A-stationary", dr);
+        run<8, 0, 0, 4>("registers random, Gray path", dr);
     }
     return 0;
 }

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     // last two sub-stages of a tile stage the first TWO slabs (and the first activation block) of the next tile BEFORE the
     // epilogue's stores join the queue, so the next tile's first sub-stage has nothing to wait for -- loads and stores
     // retire through the same in-order vmcnt, and with two slots the first wait of the next tile drained the stores.
-    constexpr bool RING3 = XIN && !DOWN && NSS == 3;
+    constexpr bool RING3 = XIN && !DOWN && NSS == 3 && NI <= 2;      // (the 128 x 512 tiles: two slots, see kPlanPlainXL)
     constexpr int NWS = RING3 ? 3 : 2;                    // weight ring slots
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int xbuf_bytes = 64 * p.xs;                    // [2 part][2 k-half][xs][8] bf16
@@ -768,7 +768,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                 } else {
                     // software pipeline over the 3 taps of the row: after the hi*hi MFMAs of tap kx are issued, the
                     // fragments of tap kx+1 are requested (second register set) and land behind the other 8 MFMAs
-                    frag128 a[2][2][MI], b[2][2][NI];     // [set][part][tile]
+                    // (NI = 4: 128 accumulator registers leave room for ONE fragment set; the other wave of the SIMD covers the
+                    // fetch latency at the top of a tap)
+                    constexpr int NSET = NI > 2 ? 1 : 2;
+                    frag128 a[NSET][2][MI], b[NSET][2][NI];     // [set][part][tile]
                     auto fetch = [&](int set, int kx) {
                         const int tapoff = (ky - 1) * pitch + (kx - 1);
 #pragma unroll
@@ -789,7 +792,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 #ifdef SGDFR_PROBE_NOFETCH      // ablation (wrong results): one fragment fetch per kernel row instead of three -- is the loop LDS-read bound?
                         const int cur = 0;
 #else
-                        const int cur = kx & 1;
+                        const int cur = kx & (NSET - 1);
+                        if (NSET == 1 && kx > 0) fetch(0, kx);
 #endif
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -800,7 +804,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                                     split_mfma<ET>(a[cur][0][m], b[cur][0][n], acc[0][m][n]);
                         __builtin_amdgcn_sched_barrier(0);
 #ifndef SGDFR_PROBE_NOFETCH
-                        if (kx < 2) fetch(cur ^ 1, kx + 1);
+                        if (NSET == 2 && kx < 2) fetch(cur ^ 1, kx + 1);
 #endif
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -908,6 +912,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                     // sub-stage of a tile whose operands were staged by the previous tile waits for nothing: slab u+1 landed
                     // before that tile's epilogue, and what is in flight now are its stores.
                     if (!(prefetched && u == cb0 * NSS)) {
+#ifdef SGDFR_SPLIT_PROBE
+                        if (!(p.dbg & 256))      // ablation (wrong results): never wait for a DMA inside the K loop
+#endif
                         split_wait_vmcnt_dyn(n_issued);
                     }
 #ifdef SGDFR_SPLIT_PROBE
@@ -1005,24 +1012,27 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 #pragma unroll
             for (int m = 0; m < MI; ++m) {
                 if (n0 + wm * (MI * 32) + m * 32 >= p.Cout) continue;     // padding rows of a half-filled cout tile (wave-uniform)
-                float4 d4[4], b4[4], s4[4], q[2][4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    d4[g] = d4p[m * 8 + 2 * g];
-                    b4[g] = b4p[m * 8 + 2 * g];
-                    if (EMIT_XS) s4[g] = s4p[m * 8 + 2 * g];
-                }
+                float4 d4[2], b4[2], s4[2], q[2][4];      // [row group parity]: group g+1 is requested before g is computed
+                d4[0] = d4p[m * 8];
+                b4[0] = b4p[m * 8];
+                if (EMIT_XS) s4[0] = s4p[m * 8];
                 if (FUSE_RGB) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) q[0][j] = cwp[m * 32 + j];
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    if (FUSE_RGB && g + 1 < 4) {
+                    if (g + 1 < 4) {
+                        d4[(g + 1) & 1] = d4p[m * 8 + 2 * (g + 1)];
+                        b4[(g + 1) & 1] = b4p[m * 8 + 2 * (g + 1)];
+                        if (EMIT_XS) s4[(g + 1) & 1] = s4p[m * 8 + 2 * (g + 1)];
+                        if (FUSE_RGB) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) q[(g + 1) & 1][j] = cwp[m * 32 + (g + 1) * 8 + j];
+                            for (int j = 0; j < 4; ++j) q[(g + 1) & 1][j] = cwp[m * 32 + (g + 1) * 8 + j];
+                        }
                     }
-                    const float dv[4] = {d4[g].x, d4[g].y, d4[g].z, d4[g].w}, bv[4] = {b4[g].x, b4[g].y, b4[g].z, b4[g].w};
+                    const float4 dq = d4[g & 1], bq = b4[g & 1], sq = s4[g & 1];
+                    const float dv[4] = {dq.x, dq.y, dq.z, dq.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w};
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = lrelu_gain(acc[0][m][n][4 * g + j] * dv[j] + nz[n] + bv[j], e_slope, e_gain);
@@ -1032,8 +1042,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                     }
                     if (EMIT_XS) {    // the 4 rows are half of one 8-channel chunk of this pixel
                         unsigned h01, l01, h23, l23;
-                        split_pair<ET>(v[0] * s4[g].x, v[1] * s4[g].y, h01, l01, sat);
-                        split_pair<ET>(v[2] * s4[g].z, v[3] * s4[g].w, h23, l23, sat);
+                        split_pair<ET>(v[0] * sq.x, v[1] * sq.y, h01, l01, sat);
+                        split_pair<ET>(v[2] * sq.z, v[3] * sq.w, h23, l23, sat);
                         unsigned char* dst = xp + (int64_t)(m * 4 + g) * 2 * HW * 16;
                         *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
                         *reinterpret_cast<uint2*>(dst + (int64_t)HW * 16) = make_uint2(l01, l23);
@@ -1212,13 +1222,17 @@ static const SplitPlan kPlanUpWide = {2, 128, 128, 3, 8};       // transposed: 1
 static const SplitPlan kPlanUpNarrow = {3, 64, 256, 3, 8};      // transposed, Cout % 128 != 0 (or as a fallback): 64 x 256
 static const SplitPlan kPlanUpDeep = {4, 64, 256, 1, 8};        // transposed: 64 x 256, all 9 taps between barriers
 static const SplitPlan kPlanDown = {5, 128, 256, 1, 8};         // adjoint of the transposed conv: 128 x 256 positions, (block, phase) stages
+// plain, pre-split input, >= 2 tiles per CU: 128 couts x 512 pixels, wave tile 64 x 128.  The chip is power-bound inside the K loop
+// (DESIGN 4.7): per MFMA this tile DMAs 0.58x the bytes of 128 x 256 (the weight slab is streamed once per 512 pixels) and
+// reads 0.75x the LDS fragments (12 ds_read_b128 per 24 MFMAs), and a layer has half as many tile prologues / epilogues.
+static const SplitPlan kPlanPlainXL = {6, 128, 512, 3, 8};
 
 // nws: weight ring slots (3 for a pre-split input with row sub-stages, see RING3 in the kernel; 2 otherwise)
-static size_t split_lds_bytes(const SplitParams& p, int NT, int nss, bool down = false, int nws = 2) {
+static size_t split_lds_bytes(const SplitParams& p, int NT, int nss, bool down = false, int nws = 2, int PT = 256) {
     const size_t wslot = down ? (size_t)NT * 256 : (size_t)NT * 192 * (3 / nss);       // DOWN3: 4 taps x 64 bytes per cout
     const size_t loop = 2 * (size_t)64 * p.xs + nws * wslot + (down ? 0 : (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float));
-    // d, bias, ToRGB coefficient / reduce ([WM][PT][3] = 1536 floats in every plan), next-style tables
-    const size_t epi = ((size_t)p.simgs * NT * 6 + NT + 512 * 3) * sizeof(float);
+    // d, bias, ToRGB coefficient / reduce ([WM][PT][3] = 1536 floats in every plan but the 128 x 512 one), next-style tables
+    const size_t epi = ((size_t)p.simgs * NT * 6 + NT + (NT * PT > 128 * 256 ? 1024 : 512) * 3) * sizeof(float);
     if (p.simgs <= 2) return loop + epi;      // tables live beside the style table for the whole kernel
     return loop > epi ? loop : epi;           // tables overwrite the dead staging buffers after the K loop
 }
@@ -1273,17 +1287,17 @@ static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, cons
     p.n_cout_tiles = (Cout + plan.nt - 1) / plan.nt;
     const int nthr = plan.nw * 64;
     if ((2 * p.xs + nthr - 1) / nthr > (mode == SGDFR_MODE_DOWN3 ? 3 : 4)) return 0;                  // staging slots (512-wide transposed conv: 4)
-    const size_t lds = split_lds_bytes(p, plan.nt, plan.nss, down);
+    const size_t lds = split_lds_bytes(p, plan.nt, plan.nss, down, 2, plan.pt);
     if (lds > (plan.nw == 8 ? 160 : 80) * 1024) return 0;
     if (out) *out = p;
     return 1;
 }
 
 // the plan used for a shape (first that fits), or nullptr
-static const SplitPlan* split_plan(int B, int Cin, int Cout, int H, int W, int mode, SplitParams* out) {
+static const SplitPlan* split_plan(int B, int Cin, int Cout, int H, int W, int mode, SplitParams* out, bool xin_whole = false) {
     static const int deep = getenv("SGDFR_SPLIT_DEEP") ? atoi(getenv("SGDFR_SPLIT_DEEP")) : 1;
     static const int narrow_first = getenv("SGDFR_SPLIT_UP_NARROW") ? atoi(getenv("SGDFR_SPLIT_UP_NARROW")) : 0;
-    const SplitPlan* order[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const SplitPlan* order[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int n = 0;
     if (mode == SGDFR_MODE_UP3) {
         // deep stages need enough blocks per 64-cout tile to fill the chip; small layers keep the row sub-stages + K slices
@@ -1293,6 +1307,12 @@ static const SplitPlan* split_plan(int B, int Cin, int Cout, int H, int W, int m
         if (Cout % 128 == 0) order[n++] = &kPlanUpWide;
         order[n++] = &kPlanUpNarrow;
     } else if (mode == SGDFR_MODE_PLAIN3) {
+        static const int xl = getenv("SGDFR_SPLIT_XL") ? atoi(getenv("SGDFR_SPLIT_XL")) : 1;
+        // (xin_whole: pre-split input, no K slices -- the only instantiation of the 128 x 512 tile; it keeps the cout tiling
+        // of the 128 x 256 plan, so buffers sized from a query without the flag stay right)
+        // (same-box A/B at B=64: 512->512@32^2 842 -> 808 us, 256->256@64^2 822 -> 798; the 128-wide patch tiles of 128^2 lose 1 %:
+        // four staging slots spill)
+        if (xl && xin_whole && W <= 64 && Cout % 128 == 0 && (int64_t)B * H * W * (Cout / 128) >= 2ll * 256 * 512) order[n++] = &kPlanPlainXL;
         if (Cout % 128 == 0) order[n++] = &kPlanPlainWide;
         order[n++] = &kPlanPlainNarrow;
     } else if (mode == SGDFR_MODE_DOWN3) {
@@ -1431,7 +1451,7 @@ static int launch_split(const SplitParams& p, hipStream_t st) {
                                 : nex == 3 ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 3, NSS, XIN>
                                            : split_mfma_kernel<MODE, ET, WM, WN, MI, NI, NEX_MAX, NSS, XIN>;
     const size_t lds = split_lds_bytes(p, WM * MI * 32, NSS, MODE == SGDFR_MODE_DOWN3,
-                                       (XIN && MODE != SGDFR_MODE_DOWN3 && NSS == 3) ? 3 : 2);
+                                       (XIN && MODE != SGDFR_MODE_DOWN3 && NSS == 3 && NI <= 2) ? 3 : 2, WN * NI * 32);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess) {
         (void)hipGetLastError();
@@ -1467,6 +1487,7 @@ static int launch_plan(int cfg, const SplitParams& p, hipStream_t st, bool xin) 
             case 3: return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 3, true>(p, st);
             case 4: return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 1, true>(p, st);
             case 5: return launch_split<SGDFR_MODE_DOWN3, ET, 2, 4, 2, 2, 1, true>(p, st);
+            case 6: return launch_split<SGDFR_MODE_PLAIN3, ET, 2, 4, 2, 4, 3, true>(p, st);
             default: set_error("modconv_split: pre-split input is not built for tiling plan %d", cfg); return 1;
         }
     }
@@ -1510,7 +1531,7 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
     SGDFR_REQUIRE(((reinterpret_cast<uintptr_t>(wsp) | reinterpret_cast<uintptr_t>(s)) & 15) == 0,
                   "modconv_split: wsp and s must be 16-byte aligned");
     SplitParams p;
-    const SplitPlan* plan = split_plan(B, Cin, Cout, H, W, mode, &p);
+    const SplitPlan* plan = split_plan(B, Cin, Cout, H, W, mode, &p, x_is_split != 0 && ksplit <= 1);
     if (plane_stride != 0) {
         // UP3 with padded parity planes y [B,Cout,4,plane_stride]: a multiple of 32 floats makes every 32-position store run of
         // the epilogue one whole 128-byte line (the dense (H+1)(W+1) planes are odd-sized: every run straddles two lines and
