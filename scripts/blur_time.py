@@ -12,7 +12,7 @@ def bench(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 fir = torch.tensor([[1., 3, 3, 1]], device='cuda'); fir = (fir.t() @ fir); fir = fir / fir.sum() * 4
 out = []
-for C, h in [(512, 16), (256, 32), (128, 64), (64, 128)]:
+for C, h in [(512, 4), (512, 8), (512, 16), (256, 32), (128, 64), (64, 128)]:
     B = 64
     ps = ((h + 1) * (h + 1) + 31) // 32 * 32
     planes = torch.randn(B, C, 4, ps, device='cuda')

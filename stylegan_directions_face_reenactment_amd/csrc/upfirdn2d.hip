@@ -178,14 +178,16 @@ __device__ __forceinline__ void blur_split2(float a, float b, unsigned& hi, unsi
     }
 }
 
-// QC: quad columns per channel wave-group (64: a full wave per channel, for W >= 64; 32: two channels per wave, less idle
-// lanes on the narrow layers); block = 8 * QC threads.
+// QC: quad columns per channel (64: a full wave per channel, for W >= 64; 32 / 16 / 8 / 4 for the narrower levels, so no lane
+// idles on a 4- or 8-wide plane); NG: (image, 8-channel group, row tile) groups per block, 256 / (8 * QC) for QC < 32 -- the block
+// stays 256 threads wide on the small levels (4 -> 8: 37 -> 9 us, 8 -> 16: 58 -> 17 us per launch at B=64); block = 8 * QC * NG
+// threads.
 // A block walks `nseg` consecutive row segments (BLUR_QV quad rows each) of its column tile with the SAME sliding window,
 // handing each segment over through LDS: only the first segment re-reads the 3 plane rows above it, so the planes are
 // fetched 1 + 3/(8*nseg) times instead of 1.375 (rocprofv3 FETCH_SIZE of the 128 -> 256 level: 2.03 x the planes with
 // nseg = 1, mostly served by the Infinity Cache -- the run time is the same, the DRAM traffic is not).
-template <int ET, int QC>
-__global__ __launch_bounds__(8 * QC, 4) void blur_split_kernel(const float* __restrict__ t, const float* __restrict__ fir,
+template <int ET, int QC, int NG>
+__global__ __launch_bounds__(8 * QC * NG, 4) void blur_split_kernel(const float* __restrict__ t, const float* __restrict__ fir,
                                                         const float* __restrict__ noise, int64_t noise_bstride,
                                                         const float* __restrict__ noise_w, const float* __restrict__ bias,
                                                         const float* __restrict__ s_next, unsigned char* __restrict__ xs,
@@ -194,8 +196,9 @@ __global__ __launch_bounds__(8 * QC, 4) void blur_split_kernel(const float* __re
     // fp32 results of the block's tile as [row 8][px 128][channel 8 (+1 pad: the lanes of a wave write px 2 apart ->
     // 18-dword stride, conflict-free)]; the hand-over to 16-byte chunks happens when the tile is read back.
     // 8 waves = 8 channels, a wave = 64 quad columns (256-byte coalesced plane reads, as the fp32 kernel).
-    __shared__ float tile[8][2 * QC][9];
-    __shared__ float sv[8];
+    __shared__ float tile_all[NG][8][2 * QC][9];
+    __shared__ float sv_all[NG][8];
+    static_assert(NG == 1 || QC < 32, "several groups per block only for the narrow levels");
     float kf[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) kf[i] = fir[15 - i];
@@ -208,22 +211,29 @@ __global__ __launch_bounds__(8 * QC, 4) void blur_split_kernel(const float* __re
     // are fetched from memory once and found in that XCD's L2 by the other half.
     const bool paired = col_tiles == 2;
     const int64_t n_groups = (int64_t)B * G * row_tiles;
-    const int64_t n_tiles = paired ? ((n_groups + 7) / 8) * 16 : n_groups * col_tiles;
+    const int64_t n_tiles = paired ? ((n_groups + 7) / 8) * 16 : ((n_groups + NG - 1) / NG) * col_tiles;      // (NG > 1: one column tile)
     const float nw = (noise && noise_w) ? noise_w[0] : 0.f;
     const float xsc = (ET == SGDFR_SPLIT_FP16) ? 0.0625f : 1.f;
-    const int c8 = threadIdx.x / QC, nx = threadIdx.x % QC;
+    const int sub = threadIdx.x / (8 * QC), lt = threadIdx.x % (8 * QC);      // group of this thread inside the block, thread inside the group
+    const int c8 = lt / QC, nx = lt % QC;
+    float (*const tile)[2 * QC][9] = tile_all[sub];
+    float* const sv = sv_all[sub];
     unsigned sat = 0;
     for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
         const int ct = paired ? (int)((tile_id >> 3) & 1) : (int)(tile_id % col_tiles);
-        int64_t r = paired ? (tile_id >> 4) * 8 + (tile_id & 7) : tile_id / col_tiles;
-        if (r >= n_groups) continue;           // block-uniform (padding of the last group of 8 pairs)
+        int64_t r = paired ? (tile_id >> 4) * 8 + (tile_id & 7) : (tile_id / col_tiles) * NG + sub;
+        // (a group beyond the last one -- padding of the last 8 pairs / of the last block's NG groups -- runs the barriers of the
+        // loop with its loads and stores masked; for NG = 1 the test is block-uniform)
+        if (NG == 1 && r >= n_groups) continue;
+        const bool valid = NG == 1 || r < n_groups;
+        if (!valid) r = n_groups - 1;
         const int rt = (int)(r % row_tiles);
         r /= row_tiles;
         const int g = (int)(r % G);
         const int b = (int)(r / G);
         const int c = g * 8 + c8;
         const int n = ct * QC + nx;            // quad column
-        if (threadIdx.x < 8) sv[threadIdx.x] = s_next[(int64_t)b * C + g * 8 + threadIdx.x] * xsc;
+        if (lt < 8) sv[lt] = s_next[(int64_t)b * C + g * 8 + lt] * xsc;
         const float* tp = t + ((int64_t)b * C + c) * plane_t;
         const float bv = bias ? bias[c] : 0.f;
         int coff[5];
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(8 * QC, 4) void blur_split_kernel(const float* __re
 #pragma unroll
         for (int v = 0; v < 5; ++v) {
             const int tc = 2 * n - 1 + v;
-            cok[v] = tc >= 0 && n < W;
+            cok[v] = tc >= 0 && n < W && valid;
             coff[v] = (tc & 1) * pstride + (tc >> 1);
         }
         float win[5][5];
@@ -262,8 +272,8 @@ __global__ __launch_bounds__(8 * QC, 4) void blur_split_kernel(const float* __re
         }
         for (int sg = 0; sg < nseg; ++sg) {
         const int ms = (rt * nseg + sg) * BLUR_QV;           // first quad row of the segment
-        if (ms >= H) break;                                   // block-uniform
-        if (n < W) {
+        if (NG == 1 && ms >= H) break;                        // block-uniform (NG > 1: groups may sit in different row tiles)
+        if (n < W && (NG == 1 || ms < H)) {
 #pragma unroll
             for (int qv = 0; qv < BLUR_QV; ++qv) {
                 const int m = ms + qv;
@@ -310,10 +320,10 @@ __global__ __launch_bounds__(8 * QC, 4) void blur_split_kernel(const float* __re
         // 8 rows x 64 px pixels -> 8 channels each: multiply by the next layer's style, split, two 16-byte chunks
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int item = threadIdx.x + 8 * QC * k;
+            const int item = lt + 8 * QC * k;
             const int px = item % (2 * QC), row = item / (2 * QC);
             const int oy = 2 * ms + row, ox = ct * 2 * QC + px;
-            if (oy < 2 * H && ox < OW) {
+            if (oy < 2 * H && ox < OW && valid && (NG == 1 || ms < H)) {
                 uint4 vh, vl;
                 unsigned* ph = reinterpret_cast<unsigned*>(&vh);
                 unsigned* pl = reinterpret_cast<unsigned*>(&vl);
@@ -525,7 +535,8 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
     SGDFR_REQUIRE(!noise || noise_w, "blur_bias_act_split: noise without noise_w");
     if (plane_stride == 0) plane_stride = (int64_t)(H + 1) * (W + 1);
     SGDFR_REQUIRE(plane_stride >= (int64_t)(H + 1) * (W + 1) && plane_stride < (1 << 30), "blur_bias_act_split: plane_stride < (H+1)*(W+1)");
-    const int QC = W >= 64 ? 64 : 32;
+    const int QC = W >= 64 ? 64 : W > 16 ? 32 : W > 8 ? 16 : W > 4 ? 8 : 4;
+    const int NG = QC < 32 ? 256 / (8 * QC) : 1;
     // row segments per block: as many as keep >= 8 blocks per CU (the window slides across them: each plane row is read once)
     static const int seg_env = getenv("SGDFR_BLUR_SEGMENTS") ? atoi(getenv("SGDFR_BLUR_SEGMENTS")) : 0;
     const int64_t tiles1 = (int64_t)B * (C / 8) * ((H + BLUR_QV - 1) / BLUR_QV) * ((W + QC - 1) / QC);
@@ -534,15 +545,21 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
     if (seg_env > 0) nseg = seg_env;
     const int64_t groups = (int64_t)B * (C / 8) * ((H + BLUR_QV * nseg - 1) / (BLUR_QV * nseg));
     const int col_tiles = (W + QC - 1) / QC;
-    const int64_t tiles = col_tiles == 2 ? ((groups + 7) / 8) * 16 : groups * col_tiles;       // see `paired` in the kernel
+    const int64_t tiles = col_tiles == 2 ? ((groups + 7) / 8) * 16 : ((groups + NG - 1) / NG) * col_tiles;       // see `paired` / NG in the kernel
     int64_t g = tiles;
     if (g > 256 * 32) g = 256 * 32;           // (a multiple of 16: the grid-stride loop keeps the pairing)
     unsigned char* out = reinterpret_cast<unsigned char*>(xs);
     void (*kern)(const float*, const float*, const float*, int64_t, const float*, const float*, const float*, unsigned char*, int,
                  int, int, int, int, int, int, float, float);
-    if (arith == SGDFR_SPLIT_FP16) kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_FP16, 64> : blur_split_kernel<SGDFR_SPLIT_FP16, 32>;
-    else kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_BF16, 64> : blur_split_kernel<SGDFR_SPLIT_BF16, 32>;
-    hipLaunchKernelGGL(kern, dim3((int)g), dim3(8 * QC), 0, as_stream(stream), t, fir, noise, noise_bstride, noise_w, bias, s_next,
+    if (arith == SGDFR_SPLIT_FP16)
+        kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_FP16, 64, 1> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_FP16, 32, 1>
+               : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_FP16, 16, 2> : QC == 8 ? blur_split_kernel<SGDFR_SPLIT_FP16, 8, 4>
+                                                                                  : blur_split_kernel<SGDFR_SPLIT_FP16, 4, 8>;
+    else
+        kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_BF16, 64, 1> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_BF16, 32, 1>
+               : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_BF16, 16, 2> : QC == 8 ? blur_split_kernel<SGDFR_SPLIT_BF16, 8, 4>
+                                                                                  : blur_split_kernel<SGDFR_SPLIT_BF16, 4, 8>;
+    hipLaunchKernelGGL(kern, dim3((int)g), dim3(8 * QC * NG), 0, as_stream(stream), t, fir, noise, noise_bstride, noise_w, bias, s_next,
                        out, B, C, H, W, (int)plane_stride, nseg, act, slope, gain);
     return check_launch("blur_bias_act_split");
 }

@@ -528,3 +528,21 @@ def test_mfma_ceiling_probe_is_ordered():
     b = F_.mfma_ceiling('bf16x3', lds_fragments=True, random_operands=True, iters=500)
     assert 200.0 < l <= r * 1.05 and r <= z * 1.05 and z < 2600.0, (z, r, l)
     assert 200.0 < b < 2600.0
+
+
+@pytest.mark.parametrize('C,H,B', [(16, 4, 5), (24, 8, 3), (8, 4, 1), (32, 16, 3), (16, 5, 2), (8, 12, 7)])
+def test_blur_split_on_narrow_planes(C, H, B):
+    """The 4 -> 8, 8 -> 16 and 16 -> 32 levels run several (image, channel group) groups per block (NG in upfirdn2d.hip), with a
+    ragged last block: same bits as the fp32 blur followed by the conversion."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    planes = S.counter_tensor(11, 'nb.t', (B, C, 4, H + 1, H + 1)).cuda()
+    fir = torch.tensor([[1., 3., 3., 1.]]).cuda()
+    fir = fir.t() @ fir
+    fir = fir / fir.sum() * 4
+    nz = S.counter_tensor(11, 'nb.n', (1, 1, 2 * H, 2 * H)).cuda()
+    nw = torch.full((1,), 0.3).cuda()
+    bias = S.counter_tensor(11, 'nb.b', (C,), 0.0, 0.1).cuda()
+    sn = S.counter_tensor(11, 'nb.s', (B, C), 1.0, 0.3).cuda()
+    y = F_.blur_bias_act(planes, fir, H, H, nz, nw, bias, True)
+    for arith in ('fp16x3', 'bf16x3'):
+        assert torch.equal(F_.blur_bias_act_split(planes, fir, H, H, sn, nz, nw, bias, True, arith=arith), F_.to_split(y, sn, arith))
