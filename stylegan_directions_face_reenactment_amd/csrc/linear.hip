@@ -304,25 +304,38 @@ __global__ __launch_bounds__(256) void split_range_kernel(const float* __restric
     for (int i = threadIdx.x; i < Cout; i += 256) d_n[(int64_t)b * Cout + i] = ldexpf(d[(int64_t)b * Cout + i], -e);
 }
 
-// max |x| per image (or over the batch) as an atomicMax on bit patterns
+// max |x| per image (or over the batch) as an atomicMax on bit patterns.  One atomic per BLOCK (the first version issued one per
+// wave from 1024 blocks per image: 4096 same-address atomics per image serialised in L2 -- 156 us per call in the autograd
+// forward of the direction trainer, 2.2 ms of a 14.6 ms step at B=16); four 16-byte loads in flight per thread.
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t x_bstride, int64_t n, unsigned* __restrict__ out,
                                                     int per_image) {
+    __shared__ unsigned wmax[4];
     const int b = blockIdx.y;
     const float* xb = x + (int64_t)b * x_bstride;
     unsigned m = 0u;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    auto take4 = [&](const float4& v) {
+        m = max(max(m, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+    };
     if ((n & 3) == 0 && (x_bstride & 3) == 0 && ((uintptr_t)x & 15) == 0) {
-        for (; i < n; i += stride * 4) {
-            const float4 v = *reinterpret_cast<const float4*>(xb + i);
-            m = max(max(m, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+        const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
+        const float4* x4 = reinterpret_cast<const float4*>(xb);
+        int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            const float4 v0 = x4[i], v1 = x4[i + stride], v2 = x4[i + 2 * stride], v3 = x4[i + 3 * stride];
+            take4(v0); take4(v1); take4(v2); take4(v3);
         }
+        for (; i < n4; i += stride) take4(x4[i]);
     } else {
-        for (i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = max(m, __float_as_uint(fabsf(xb[i])));
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = max(m, __float_as_uint(fabsf(xb[i])));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(out + (per_image ? b : 0), m);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (m != 0u) atomicMax(out + (per_image ? b : 0), m);
+    }
 }
 
 }  // namespace sgdfr
@@ -437,8 +450,11 @@ extern "C" int sgdfr_absmax_f32(const float* x, int64_t x_bstride, int64_t n_per
     if (B == 0 || n_per_image == 0) return 0;
     SGDFR_REQUIRE(x, "absmax: null input");
     const int nb = x_bstride == 0 ? 1 : B;                       // a broadcast image is read once
-    int gx = (int)((n_per_image + 4095) / 4096);
-    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    // 16 K floats per block (16 loads of 16 bytes per thread), at most ~2048 blocks over the batch: enough loads in flight for HBM
+    // speed, <= 128 atomics per image
+    int gx = (int)((n_per_image + 16383) / 16384);
+    const int cap = nb >= 16 ? 128 : 2048 / nb;
+    gx = gx < 1 ? 1 : (gx > cap ? cap : gx);
     hipLaunchKernelGGL(absmax_kernel, dim3(gx, nb), dim3(256), 0, as_stream(stream), x, x_bstride, n_per_image, out, x_bstride == 0 ? 0 : per_image);
     return check_launch("absmax");
 }
