@@ -117,10 +117,13 @@ static int launch_linear(const float* x, int64_t ldx, const float* w, const floa
 // row in registers (8 floats per lane) and walks the rows, 4 at a time for independent loads and butterflies.  The tiled
 // kernel above launches (N/32) x (M/32) blocks that each walk K serially: 54 us for the mapping network's 64 x 512 x 512
 // layers (67 such launches per trainer step); this form takes a few us.
+// XOP / EPI as in linear_tile (the demodulation-gradient GEMM of the trainer's backward, 13 launches of 40 us per step in the
+// tiled form, takes the same route).
+template <int XOP, int EPI>
 __global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y, int64_t ldy,
                                                            int M, int N, int K, float wscale, float bscale, int act,
-                                                           float slope, float gain) {
+                                                           float slope, float gain, LinearExtra ex) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + wave;
     if (n >= N) return;
@@ -143,7 +146,13 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restr
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
                 const int k = lane + 64 * j;
-                acc[r] = fmaf(k < K ? xr[k] : 0.f, wr[j], acc[r]);
+                float xv = k < K ? xr[k] : 0.f;
+                if (XOP == 1) xv = xv * xv;
+                if (XOP == 2) {
+                    const float a = k < K ? ex.xaux[(int64_t)m * ldx + k] : 0.f;
+                    xv = -xv * a * a * a;
+                }
+                acc[r] = fmaf(xv, wr[j], acc[r]);
             }
         }
 #pragma unroll
@@ -152,8 +161,15 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restr
             float a = acc[0];
 #pragma unroll
             for (int r = 1; r < RB; ++r) a = lane == r ? acc[r] : a;
-            float v = a * wscale + bv;
-            if (act == SGDFR_ACT_LRELU) v = lrelu_gain(v, slope, gain);
+            float v;
+            if (EPI == 0) {
+                v = a * wscale + bv;
+                if (act == SGDFR_ACT_LRELU) v = lrelu_gain(v, slope, gain);
+            } else if (EPI == 1) {
+                v = rsqrtf(a + wscale);
+            } else {
+                v = ex.add[(int64_t)(m0 + lane) * ldy + n] + ex.mul[(int64_t)(m0 + lane) * ldy + n] * (a * wscale);
+            }
             y[(int64_t)(m0 + lane) * ldy + n] = v;
         }
     }
@@ -351,8 +367,8 @@ extern "C" int sgdfr_linear_f32(const float* x, int64_t ldx, const float* w, con
     SGDFR_REQUIRE(ldx >= K && ldy >= N, "linear: leading dims too small");
     SGDFR_REQUIRE(act == SGDFR_ACT_NONE || act == SGDFR_ACT_LRELU, "linear: unknown act %d", act);
     if (M <= 128 && K <= 512 && N >= 64) {      // a batch of rows through a small layer: wave-per-column form
-        hipLaunchKernelGGL(linear_skinny_kernel, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream), x, ldx, w, bias, y, ldy, M, N,
-                           K, wscale, bscale, act, slope, gain);
+        hipLaunchKernelGGL((linear_skinny_kernel<0, 0>), dim3((N + 3) / 4), dim3(256), 0, as_stream(stream), x, ldx, w, bias, y, ldy, M, N,
+                           K, wscale, bscale, act, slope, gain, LinearExtra{nullptr, nullptr, nullptr});
         return check_launch("linear(skinny)");
     }
     return launch_linear<0, 0>(x, ldx, w, bias, y, ldy, M, N, K, wscale, bscale, act, slope, gain, stream);
@@ -368,8 +384,9 @@ extern "C" int sgdfr_style_demod_f32(const float* style, int64_t ld_style, const
     int rc;
     static const bool skinny_ok = !(getenv("SGDFR_STYLE_SKINNY") && atoi(getenv("SGDFR_STYLE_SKINNY")) == 0);
     if (skinny_ok && B <= 128 && D <= 512 && Cin >= 64) {      // a few rows through a small layer: the wave-per-column form (see sgdfr_linear_f32)
-        hipLaunchKernelGGL(linear_skinny_kernel, dim3((Cin + 3) / 4), dim3(256), 0, as_stream(stream), style, ld_style, mod_w, mod_b, s,
-                           (int64_t)Cin, B, Cin, D, 1.0f / sqrtf((float)D), 1.0f, SGDFR_ACT_NONE, 0.f, 1.f);
+        hipLaunchKernelGGL((linear_skinny_kernel<0, 0>), dim3((Cin + 3) / 4), dim3(256), 0, as_stream(stream), style, ld_style, mod_w, mod_b, s,
+                           (int64_t)Cin, B, Cin, D, 1.0f / sqrtf((float)D), 1.0f, SGDFR_ACT_NONE, 0.f, 1.f,
+                           LinearExtra{nullptr, nullptr, nullptr});
         rc = check_launch("style_demod(skinny)");
     } else {
         rc = launch_linear<0, 0>(style, ld_style, mod_w, mod_b, s, Cin, B, Cin, D, 1.0f / sqrtf((float)D), 1.0f,
@@ -465,6 +482,11 @@ extern "C" int sgdfr_demod_grad_f32(const float* gd, const float* d, const float
     if (B == 0) return 0;
     SGDFR_REQUIRE(gd && d && qt && s && gs && ds, "demod_grad: null pointer");
     // ds[b,i] = gs[b,i] + s[b,i] * sum_o (-gd[b,o] d[b,o]^3) * Q[o,i]      (qt = Q^T, [Cin, Cout])
+    if (B <= 128 && Cout <= 512 && Cin >= 64) {      // a batch of rows through a small layer: wave-per-column form
+        hipLaunchKernelGGL((linear_skinny_kernel<2, 2>), dim3((Cin + 3) / 4), dim3(256), 0, as_stream(stream), gd, (int64_t)Cout, qt,
+                           (const float*)nullptr, ds, (int64_t)Cin, B, Cin, Cout, 1.0f, 0.f, 0, 0.f, 1.f, LinearExtra{d, gs, s});
+        return check_launch("demod_grad(skinny)");
+    }
     return launch_linear<2, 2>(gd, Cout, qt, nullptr, ds, Cin, B, Cin, Cout, 1.0f, 0.f, 0, 0.f, 1.f, stream,
                                LinearExtra{d, gs, s});
 }
