@@ -1260,7 +1260,11 @@ static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, cons
         p.rps = p.R * p.P;
     } else if (W > 64) {
         p.patch = 1;
-        p.TC = 128;
+        // patch width: 64 columns (TR = PT / 64 rows) stage 0.85x the positions of 128-wide patches for the same pixels; the
+        // 128 x 512 tiles take 32 x 16 patches (three staging slots instead of four).  Same-box A/B at B=64: 128->128@128^2
+        // 899 -> 891 us (-> 874 with the 128 x 512 tiles), 64->64@256^2 961 -> 950.
+        static const int tc_env = getenv("SGDFR_SPLIT_TC") ? atoi(getenv("SGDFR_SPLIT_TC")) : 0;
+        p.TC = tc_env > 0 ? tc_env : (plan.nt == 128 && plan.pt == 512) ? 32 : 64;
         p.TR = PT / p.TC;
         if (W % p.TC != 0 || H % p.TR != 0) return 0;
         p.tiles_x = W / p.TC; p.tiles_y = H / p.TR;
@@ -1310,9 +1314,9 @@ static const SplitPlan* split_plan(int B, int Cin, int Cout, int H, int W, int m
         static const int xl = getenv("SGDFR_SPLIT_XL") ? atoi(getenv("SGDFR_SPLIT_XL")) : 1;
         // (xin_whole: pre-split input, no K slices -- the only instantiation of the 128 x 512 tile; it keeps the cout tiling
         // of the 128 x 256 plan, so buffers sized from a query without the flag stay right)
-        // (same-box A/B at B=64: 512->512@32^2 842 -> 808 us, 256->256@64^2 822 -> 798; the 128-wide patch tiles of 128^2 lose 1 %:
-        // four staging slots spill)
-        if (xl && xin_whole && W <= 64 && Cout % 128 == 0 && (int64_t)B * H * W * (Cout / 128) >= 2ll * 256 * 512) order[n++] = &kPlanPlainXL;
+        // (same-box A/B at B=64: 512->512@32^2 842 -> 808 us, 256->256@64^2 822 -> 798; with 128-wide patches 128^2 lost 1 % --
+        // four staging slots spill -- with 32 x 16 patches it gains 2.8 %)
+        if (xl && xin_whole && Cout % 128 == 0 && (int64_t)B * H * W * (Cout / 128) >= 2ll * 256 * 512) order[n++] = &kPlanPlainXL;
         if (Cout % 128 == 0) order[n++] = &kPlanPlainWide;
         order[n++] = &kPlanPlainNarrow;
     } else if (mode == SGDFR_MODE_DOWN3) {

@@ -199,7 +199,7 @@ def test_split_form_handover_pieces(arith):
 
 @pytest.mark.parametrize('cin,cout,H,B', [(16, 64, 256, 25), (48, 64, 256, 27), (32, 128, 128, 50),
                                          # pre-split input + >= 2 tiles per CU: the 128 x 512 tiles (ragged last round)
-                                         (16, 256, 64, 33), (32, 512, 32, 65), (16, 128, 64, 70)])
+                                         (16, 256, 64, 33), (32, 512, 32, 65), (16, 128, 64, 70), (32, 128, 128, 17), (16, 128, 256, 5)])
 def test_persistent_blocks_match_one_block_per_tile(cin, cout, H, B):
     """Layers with >= 12 tiles per CU and a pre-split input run as persistent blocks (one per CU, each staging its next
     tile's first channel block while the current tile finishes).  Same bits as the one-block-per-tile launch of the fp32
