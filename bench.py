@@ -71,8 +71,8 @@ DTYPE = {
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', choices=('synthesis', 'inference', 'trainer'), default='synthesis')
     ap.add_argument('--batch', type=int, default=None, help='per GPU (default: 64 synthesis / 32 inference / 16 trainer)')
     ap.add_argument('--cm', type=int, default=1, help='channel_multiplier (1 = voxceleb-256, the headline config)')
