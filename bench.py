@@ -46,6 +46,8 @@ import subprocess
 import sys
 import time
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC for RCCL; must be in place before the HIP runtime starts
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
