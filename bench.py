@@ -542,8 +542,8 @@ def run_trainer(args, rank, world, dev):
                      'per_rank_samples_per_s_min_max': spread, 'generator_only_ms_per_step': round(gen_ms, 3),
                      'loss_heads_and_optimizer_ms_per_step': round(elapsed / args.steps * 1e3 - gen_ms, 3),
                      'losses_finite': finite})
-    out['dtype'] = DTYPE[args.precision] + ('; backward: dL/dx convs in bf16 hi+lo terms (16 operand bits, f32 accumulate), '
-                                            'no weight gradients (G frozen), everything else f32' if args.precision != 'fp32' else '')
+    out['dtype'] = DTYPE[args.precision] + ('; backward: dL/dx convs in the same fp16 hi+lo arithmetic, range-planned per image from max|g| (bf16 hi+lo with '
+                                            'SGDFR_BWD_ARITH=bf16x3), no weight gradients (G frozen), everything else f32' if args.precision != 'fp32' else '')
     out['roofline'] = roof
     out['roofline']['note'] = ('conv launches of the generator legs of a step (2 no-grad forwards + grad forward + the dL/dx convs of '
                                'the backward), loss heads excluded')

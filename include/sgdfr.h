@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 9
+#define SGDFR_ABI_VERSION 10
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -132,8 +132,9 @@ int sgdfr_styles_batched_f32(const float* latent, int B, int L, int D, const sgd
                              void* stream);
 
 /* The range plan above for ONE layer whose s / d already exist (autograd forward, stand-alone layer calls):
- * s_n = s * 2^e_b, d_n = d * 2^-e_b.  x_absmax: device words of fp32 bit patterns, one per image (x_absmax_bstride 1), one
- * for the whole batch (0), or NULL (then |x| < 2^x_log2 is taken on trust). */
+ * s_n = s * 2^e_b, d_n = d * 2^-e_b.  x_absmax: device words of fp32 bit patterns, one per image (x_absmax_bstride 1), n per
+ * image whose maximum counts (x_absmax_bstride n > 1: the per-plane words of sgdfr_act_grad_reduce_f32), one for the whole batch
+ * (0), or NULL (then |x| < 2^x_log2 is taken on trust). */
 int sgdfr_split_range_f32(const float* s, const float* d, float* s_n, float* d_n, const unsigned* x_absmax,
                           int x_absmax_bstride, int x_log2, int headroom, int B, int Cin, int Cout, void* stream);
 
@@ -342,10 +343,12 @@ int sgdfr_make_shift_random_f32(const float* ang_s, const float* pose_s, const f
 /* Activation gradient + per-(b,c) reductions (op/fused_act.py:19-37 and the adjoints of model.py:287, :240):
  *   g_pre = g_out * (out > 0 ? 1 : slope) * gain
  *   sums[b,c,0] = sum g_pre ; sums[b,c,1] = sum g_pre * noise ;
- *   sums[b,c,2] = sum g_pre * y (want_y != 0), y = lrelu^-1(out) - noise_w*noise - bias[c]  (= d * conv output) */
+ *   sums[b,c,2] = sum g_pre * y (want_y != 0), y = lrelu^-1(out) - noise_w*noise - bias[c]  (= d * conv output)
+ * g_absmax (optional, [B,C] words): fp32 bit pattern of max |g_pre| per (image, channel) plane, from the same pass -- the range
+ * plan of the fp16-split dL/dx conv that consumes g_pre (sgdfr_split_range_f32 with x_absmax_bstride = C). */
 int sgdfr_act_grad_reduce_f32(const float* g_out, const float* out, const float* noise, int64_t noise_bstride,
                               const float* noise_w, const float* bias, float* g_pre, float* sums, int B, int C, int HW,
-                              float slope, float gain, int want_y, void* stream);
+                              float slope, float gain, int want_y, unsigned int* g_absmax, void* stream);
 
 /* Adjoint of the FIR of sgdfr_blur_bias_act_f32 (op/upfirdn2d.py:104-121 for pad (1,1)): g [B,C,2H,2W] ->
  * gt parity planes [B,C,4,H+1,W+1]; with t (forward planes) also asum[b,c] = sum gt * t. */

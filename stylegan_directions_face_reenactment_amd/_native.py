@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (SGDFR_LIB: the probe build of scripts/build_probe.py, for the timing scripts only)
 LIB_PATH = os.environ.get('SGDFR_LIB') or os.path.join(_HERE, 'csrc', 'libsgdfr_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -31,7 +31,7 @@ SIGNATURES = {
     'sgdfr_modconv_prepack_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_modconv_prepack_t_f32': [_c_f32p, _c_f32p, _i, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_act_grad_reduce_f32': [_c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _f,
-                                  _f, _i, ctypes.c_void_p],
+                                  _f, _i, ctypes.c_void_p, ctypes.c_void_p],
     'sgdfr_blur_adjoint_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_scale_reduce_f32': [_c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_torgb_bwd_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i, ctypes.c_void_p],

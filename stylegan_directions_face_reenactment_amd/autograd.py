@@ -214,24 +214,39 @@ class StyledConvFn(Function):
         B, cout = out.shape[0], out.shape[1]
         cin, H, W = x.shape[1], x.shape[2], x.shape[3]
         slope, gain = (0.2, 2 ** 0.5) if ctx.activate else (1.0, 1.0)
-        g_pre, sums = F_.act_grad_reduce(g, out, noise, noise_w, bias, want_y=(not up) and d is not None,
-                                         slope=slope, gain=gain)
-        ones_d = d if d is not None else torch.ones(B, cout, device=out.device, dtype=torch.float32)
+        bw_arith = F_.BACKWARD_ARITH if F_.PRECISION != 'fp32' else 'bf16x3'
+        if bw_arith == 'fp16x3':
+            g_pre, sums, g_max = F_.act_grad_reduce(g, out, noise, noise_w, bias, want_y=(not up) and d is not None,
+                                                    slope=slope, gain=gain, want_absmax=True)
+        else:
+            (g_pre, sums), g_max = F_.act_grad_reduce(g, out, noise, noise_w, bias, want_y=(not up) and d is not None,
+                                                      slope=slope, gain=gain), None
+        ones_d = d if d is not None else F_.ones_like_rows(B, cout, out.device)
+        # Arithmetic of the dL/dx convs on the split kernels.  'bf16x3': 8+8-bit terms, fp32 range -- needs no scale.
+        # 'fp16x3' (functional.BACKWARD_ARITH): 11+11-bit terms like the forward, made usable for gradients (which have no
+        # natural scale) by the same exact power-of-two plan as the forward: e from the true max |g| of each image, d * 2^e
+        # on the way in, 2^-e on the way out.
+        d_in, d_out = ones_d, None
+        if bw_arith == 'fp16x3':
+            # (max |g_pre| per image comes out of the act_grad_reduce pass; the plane gradient of the transposed conv is a convex
+            # combination of g_pre per phase, so the same bound holds for it)
+            d_in, d_out = F_.split_range(ones_d, F_.ones_like_rows(B, cin, out.device), g_max, headroom=1 if up else 0)
         if up:
             split_down = F_.PRECISION != 'fp32' and F_.split_ok(B, cout, cin, H, W, N.MODE_DOWN3)
             gT = None
             if split_down and not ctx.needs_input_grad[3]:
                 # frozen weights: only the conv below reads the plane gradient -> the blur adjoint writes it directly in the
                 # conv's split input form (no fp32 planes, no conversion pass)
-                gxs, A = F_.blur_adjoint_split(g_pre, mod.blur.kernel, planes if d is not None else None, d, 'bf16x3')
+                gxs, A = F_.blur_adjoint_split(g_pre, mod.blur.kernel, planes if d is not None else None,
+                                               d_in if (d is not None or d_out is not None) else None, bw_arith)
             else:
                 gT, A = F_.blur_adjoint(g_pre, mod.blur.kernel, planes if d is not None else None)
-                gxs = F_.planes_to_split(gT, d, 'bf16x3') if split_down else None
+                gxs = F_.planes_to_split(gT, d_in if (d is not None or d_out is not None) else None, bw_arith) if split_down else None
             if split_down:
-                # dL/d(x*s) of the transposed conv on the split kernels too (bf16 terms: gradients have no natural scale):
+                # dL/d(x*s) of the transposed conv on the split kernels too (bw_arith terms, see above):
                 # the planes times d come in the phase-major split form, the conv walks (channel block, phase) pairs
-                gu = F_.modconv_split(gxs, mod.packed_split(adjoint='down', arith='bf16x3'), None, None, cin, mode=N.MODE_DOWN3,
-                                      arith='bf16x3', x_split=(B, cout, H, W), batch=B,
+                gu = F_.modconv_split(gxs, mod.packed_split(adjoint='down', arith=bw_arith), None, d_out, cin, mode=N.MODE_DOWN3,
+                                      arith=bw_arith, x_split=(B, cout, H, W), batch=B,
                                       desc='bwd split down3 %d->%d @%dx%d' % (cout, cin, H, W))
             else:
                 gu = F_.modconv_raw(gT, mod.packed_t(), ones_d, None, cin, N.MODE_DOWN3, H, W,
@@ -239,10 +254,10 @@ class StyledConvFn(Function):
         else:
             A = sums[:, :, 2] if d is not None else None
             if F_.split_ok(B, cout, cin, H, W):    # dL/dx of a plain conv is a plain conv: same kernels, adjoint packs.
-                # Gradients have no natural scale (1e-8 is as likely as 1e+3), so the range-shifted fp16 terms do not
-                # apply: the backward conv always splits into bf16 terms (fp32 range, 2^-17 per product).
-                gu = F_.modconv_split(g_pre, mod.packed_split(adjoint=True, arith='bf16x3'), ones_d, None, cin,
-                                      desc='bwd split3 %d->%d @%dx%d' % (cout, cin, H, W), arith='bf16x3')
+                # Gradients have no natural scale (1e-8 is as likely as 1e+3): the fp16 terms are planned from max |g_pre| of each
+                # image (d_in / d_out above), bf16 terms (fp32 range, 2^-17 per product) need no plan.
+                gu = F_.modconv_split(g_pre, mod.packed_split(adjoint=True, arith=bw_arith), d_in, d_out, cin,
+                                      desc='bwd split3 %d->%d @%dx%d' % (cout, cin, H, W), arith=bw_arith)
             elif F_.wino_ok(B, cout, cin, H, W):
                 gu = F_.modconv_wino(g_pre, mod.packed_wino(adjoint=True), ones_d, None, cin,
                                      desc='bwd wino3 %d->%d @%dx%d' % (cout, cin, H, W))

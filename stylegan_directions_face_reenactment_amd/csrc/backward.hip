@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void act_grad_reduce_kernel(const float* __res
                                                              const float* __restrict__ noise_w,
                                                              const float* __restrict__ bias, float* __restrict__ g_pre,
                                                              float* __restrict__ sums, int B, int C, int HW, int chunks,
-                                                             float slope, float gain, int want_y) {
+                                                             float slope, float gain, int want_y,
+                                                             unsigned* __restrict__ g_absmax) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
     const int64_t nw_total = (int64_t)B * C * chunks;
@@ -33,12 +34,14 @@ __global__ __launch_bounds__(256) void act_grad_reduce_kernel(const float* __res
     const float bv = bias ? bias[c] : 0.f;
     const float inv_pos = 1.f / gain, inv_neg = 1.f / (gain * slope);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    unsigned gm = 0u;            // bit pattern of max |g_pre| over this wave's elements (the range plan of the fp16-split dL/dx conv)
     const int lo = ch * kChunk, hi = min(HW, lo + kChunk);
     const int64_t base = pl * HW;
     for (int p = lo + lane; p < hi; p += 64) {
         const float o = out[base + p], g = g_out[base + p];
         const float gp = g * (o > 0.f ? 1.f : slope) * gain;
         g_pre[base + p] = gp;
+        gm = max(gm, __float_as_uint(fabsf(gp)));
         const float nz = noise ? noise[(int64_t)b * noise_bstride + p] : 0.f;
         s0 += gp;
         s1 = fmaf(gp, nz, s1);
@@ -52,6 +55,13 @@ __global__ __launch_bounds__(256) void act_grad_reduce_kernel(const float* __res
         atomicAdd(&sums[pl * 3 + 0], s0);
         atomicAdd(&sums[pl * 3 + 1], s1);
         if (want_y) atomicAdd(&sums[pl * 3 + 2], s2);
+    }
+    if (g_absmax) {
+        // one word per (image, channel) plane, like the sums: the waves of a plane (<= 32) share it; a word per IMAGE would take
+        // thousands of same-address atomics, which serialise in L2 (see absmax_kernel, linear.hip)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gm = max(gm, (unsigned)__shfl_xor((int)gm, o, 64));
+        if (lane == 0 && gm != 0u) atomicMax(g_absmax + pl, gm);
     }
 }
 
@@ -220,17 +230,20 @@ static int wave_grid(int64_t waves) { return (int)((waves + 3) / 4); }
 
 extern "C" int sgdfr_act_grad_reduce_f32(const float* g_out, const float* out, const float* noise, int64_t noise_bstride,
                                          const float* noise_w, const float* bias, float* g_pre, float* sums, int B, int C,
-                                         int HW, float slope, float gain, int want_y, void* stream) {
+                                         int HW, float slope, float gain, int want_y, unsigned int* g_absmax, void* stream) {
     SGDFR_REQUIRE(B >= 0 && C > 0 && HW > 0, "act_grad_reduce: bad shape %d %d %d", B, C, HW);
     if (B == 0) return 0;
     SGDFR_REQUIRE(g_out && out && g_pre && sums, "act_grad_reduce: null pointer");
     SGDFR_REQUIRE(!noise || noise_w, "act_grad_reduce: noise without noise_w");
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(sums, 0, sizeof(float) * 3 * (size_t)B * C, st) != hipSuccess) return check_launch("memset");
+    // (g_absmax right behind sums: one memset clears both)
+    const bool adjacent = g_absmax && reinterpret_cast<float*>(g_absmax) == sums + 3 * (size_t)B * C;
+    if (hipMemsetAsync(sums, 0, sizeof(float) * (size_t)B * C * (adjacent ? 4 : 3), st) != hipSuccess) return check_launch("memset");
+    if (g_absmax && !adjacent && hipMemsetAsync(g_absmax, 0, sizeof(unsigned) * (size_t)B * C, st) != hipSuccess) return check_launch("memset");
     const int chunks = (HW + kChunk - 1) / kChunk;
     const int64_t waves = (int64_t)B * C * chunks;
     hipLaunchKernelGGL(act_grad_reduce_kernel, dim3(wave_grid(waves)), dim3(256), 0, st, g_out, out, noise, noise_bstride,
-                       noise_w, bias, g_pre, sums, B, C, HW, chunks, slope, gain, want_y);
+                       noise_w, bias, g_pre, sums, B, C, HW, chunks, slope, gain, want_y, g_absmax);
     return check_launch("act_grad_reduce");
 }
 

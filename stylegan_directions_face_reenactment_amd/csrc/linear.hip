@@ -306,15 +306,22 @@ __global__ __launch_bounds__(256) void split_range_kernel(const float* __restric
                                                          const unsigned* __restrict__ x_absmax, int x_absmax_bstride, int x_log2,
                                                          int headroom, int Cin, int Cout) {
     __shared__ float red[4];
+    __shared__ unsigned redu[4];
     const int b = blockIdx.x;
     float m = 0.f;
     for (int i = threadIdx.x; i < Cin; i += 256) m = fmaxf(m, fabsf(s[(int64_t)b * Cin + i]));
+    unsigned am = 0u;            // x_absmax_bstride words per image (0: one word for the batch): their maximum
+    if (x_absmax)
+        for (int i = threadIdx.x; i < max(x_absmax_bstride, 1); i += 256) am = max(am, x_absmax[(int64_t)b * x_absmax_bstride + i]);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    for (int o = 32; o > 0; o >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, o, 64));
+        am = max(am, (unsigned)__shfl_xor((int)am, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = m; redu[threadIdx.x >> 6] = am; }
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const unsigned absmax = x_absmax ? x_absmax[(int64_t)b * x_absmax_bstride] : 0u;
+    const unsigned absmax = max(max(redu[0], redu[1]), max(redu[2], redu[3]));
     const int e = range_exponent(m, absmax, x_absmax != nullptr, x_log2, headroom);
     for (int i = threadIdx.x; i < Cin; i += 256) s_n[(int64_t)b * Cin + i] = ldexpf(s[(int64_t)b * Cin + i], e);
     for (int i = threadIdx.x; i < Cout; i += 256) d_n[(int64_t)b * Cout + i] = ldexpf(d[(int64_t)b * Cout + i], -e);
@@ -450,7 +457,7 @@ extern "C" int sgdfr_split_range_f32(const float* s, const float* d, float* s_n,
     if (B == 0) return 0;
     SGDFR_REQUIRE(s && d && s_n && d_n, "split_range: null pointer");
     SGDFR_REQUIRE(headroom >= 0 && headroom <= 12 && abs(x_log2) <= 100, "split_range: bad plan (x_log2 %d, headroom %d)", x_log2, headroom);
-    SGDFR_REQUIRE(x_absmax_bstride == 0 || x_absmax_bstride == 1, "split_range: x_absmax_bstride must be 0 or 1");
+    SGDFR_REQUIRE(x_absmax_bstride >= 0, "split_range: x_absmax_bstride is 0 (one word), 1 (one per image) or the words per image");
     hipLaunchKernelGGL(split_range_kernel, dim3(B), dim3(256), 0, as_stream(stream), s, d, s_n, d_n, x_absmax, x_absmax_bstride, x_log2,
                        headroom, Cin, Cout);
     return check_launch("split_range");

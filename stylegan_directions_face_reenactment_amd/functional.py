@@ -212,12 +212,27 @@ def split_range(s, d, x_absmax=None, x_log2=DESIGN_X_LOG2, headroom=0):
     s_n, d_n = buf[:B * cin].view(B, cin), buf[B * cin:].view(B, cout)
     bstride = 0
     if x_absmax is not None:
-        if x_absmax.dtype != torch.int32 or not x_absmax.is_cuda or x_absmax.numel() not in (1, B):
-            raise RuntimeError('split_range: x_absmax must be the int32 device words made by absmax()')
-        bstride = int(x_absmax.numel() == B and B > 1)
+        if x_absmax.dtype != torch.int32 or not x_absmax.is_cuda or not x_absmax.is_contiguous() or \
+                (x_absmax.numel() != 1 and x_absmax.numel() % B != 0):
+            raise RuntimeError('split_range: x_absmax must be the int32 device words made by absmax() (1, B, or n per image)')
+        bstride = 0 if x_absmax.numel() == 1 and B > 1 else x_absmax.numel() // B
     N.call('sgdfr_split_range_f32', N.ptr(s), N.ptr(d), N.ptr(s_n), N.ptr(d_n), N.ptr(x_absmax), bstride, int(x_log2), int(headroom),
            B, cin, cout, N.stream())
     return s_n, d_n
+
+
+_ones = {}
+
+
+def ones_like_rows(B, C, device):
+    """cached [B, C] tensor of ones (the neutral output scale of a range plan)."""
+    key = (B, C, str(device))
+    t = _ones.get(key)
+    if t is None:
+        if len(_ones) > 64:
+            _ones.clear()
+        t = _ones[key] = torch.ones(B, C, device=device, dtype=torch.float32)
+    return t
 
 
 def _exact_range(x, s, d, batch):
@@ -242,6 +257,7 @@ def _noise_args(noise, B, H, W):
 USE_PLANE_PADDING = os.environ.get('SGDFR_PLANE_PADDING', '1') != '0'     # inference chain: parity planes of the transposed conv padded to whole 128-byte lines
 USE_SPLIT_CHAIN = os.environ.get('SGDFR_SPLIT_CHAIN', '1') != '0'   # activations between split convs only in split form
 USE_RGB_FUSION = True        # ToRGB partial sums in the epilogue of the split conv that feeds it (no-grad path)
+BACKWARD_ARITH = os.environ.get('SGDFR_BWD_ARITH', 'fp16x3')      # dL/dx convs of the split kernels: 'bf16x3' | 'fp16x3' (ranged per image, autograd.py)
 USE_SPLITK = True            # K-sliced launches for convs that cannot fill the chip (small batch / 4x4, 8x8 layers)
 USE_WINOGRAD = True          # plain 3x3 layers: Winograd F(2x2,3x3) MFMA kernel when the shape allows it
 WINOGRAD_MIN_BLOCKS = 256    # below this many (64 cout x 64 tile) blocks the direct kernel's smaller tiles win
@@ -720,18 +736,21 @@ def affine(x, weight, bias=None):
 
 # ------------------------------------------------------------------ backward launches
 
-def act_grad_reduce(g_out, out, noise, noise_weight, bias, want_y, slope=0.2, gain=SQRT2):
-    """g_pre and sums [B,C,3] = (sum g_pre, sum g_pre*noise, sum g_pre*y)."""
+def act_grad_reduce(g_out, out, noise, noise_weight, bias, want_y, slope=0.2, gain=SQRT2, want_absmax=False):
+    """g_pre and sums [B,C,3] = (sum g_pre, sum g_pre*noise, sum g_pre*y); want_absmax: also absmax-style words [B,C] (bit pattern
+    of max |g_pre| per plane, from the same pass: split_range() takes them for the plan of the fp16-split dL/dx conv)."""
     N.require_device(g_out, out, noise_weight, bias)
     g_out, out = N.f32c(g_out), N.f32c(out)
     B, C, H, W = out.shape
     nz, nzb = _noise_args(noise, B, H, W)
     g_pre = torch.empty_like(out)
-    sums = torch.empty(B, C, 3, device=out.device, dtype=torch.float32)
+    buf = torch.empty(B * C * (4 if want_absmax else 3), device=out.device, dtype=torch.float32)      # one memset clears both
+    sums = buf[:B * C * 3].view(B, C, 3)
+    gmax = buf[B * C * 3:].view(torch.int32).view(B, C) if want_absmax else None
     N.call('sgdfr_act_grad_reduce_f32', N.ptr(g_out), N.ptr(out), N.ptr(nz), nzb,
            N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(g_pre), N.ptr(sums), B, C, H * W,
-           float(slope), float(gain), int(bool(want_y)), N.stream())
-    return g_pre, sums
+           float(slope), float(gain), int(bool(want_y)), N.ptr(gmax), N.stream())
+    return (g_pre, sums, gmax) if want_absmax else (g_pre, sums)
 
 
 def blur_adjoint(g, fir, planes=None):
