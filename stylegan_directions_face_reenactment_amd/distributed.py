@@ -54,6 +54,105 @@ def shutdown():
         dist.destroy_process_group()
 
 
+# ---- CPU placement of the ranks.  Every rank issues ~65 launches per forward from Python; on a 2-socket host the ranks must not
+# migrate across sockets or pile onto the same cores.  (The reference is single-process: run_inference.py:31, trainer.py:25.)
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' (sysfs cpulist syntax) -> [0, 1, 2, 3, 8, 10, 11]."""
+    cpus = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        a, _, b = part.partition('-')
+        cpus.extend(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def format_cpulist(cpus):
+    cpus = sorted(set(cpus))
+    runs, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        runs.append('%d-%d' % (cpus[i], cpus[j]) if j > i else '%d' % cpus[i])
+        i = j + 1
+    return ','.join(runs)
+
+
+def plan_affinity(local_rank, local_world, gpu_numa, node_cpus, allowed):
+    """CPUs for `local_rank` (pure function; see bind_rank).  gpu_numa[r]: NUMA node of rank r's GPU or None/-1 when unknown;
+    node_cpus: {node: [cpu, ...]}; allowed: the CPUs this process may use.  Ranks whose GPUs hang off the same node share that
+    node's allowed CPUs in equal contiguous slices; with unknown topology the allowed CPUs are sliced evenly over all ranks.
+    Never returns an empty set (falls back to `allowed`)."""
+    allowed = sorted(set(allowed))
+    known = all(n is not None and n >= 0 and node_cpus.get(n) for n in gpu_numa) and len(gpu_numa) == local_world
+    if known:
+        node = gpu_numa[local_rank]
+        peers = [r for r in range(local_world) if gpu_numa[r] == node]
+        pool = [c for c in sorted(node_cpus[node]) if c in set(allowed)]
+        j, k = peers.index(local_rank), len(peers)
+    else:
+        node, pool, j, k = None, allowed, local_rank, local_world
+    lo, hi = shard_range(len(pool), j, k)
+    mine = pool[lo:hi]
+    if not mine:
+        mine = pool or allowed
+    return node, mine
+
+
+def gpu_numa_node(index):
+    """NUMA node of HIP device `index` from sysfs (PCI address of the device), or None."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = '%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        with open('/sys/bus/pci/devices/%s/numa_node' % bdf) as f:
+            n = int(f.read().strip())
+        return n if n >= 0 else None
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None
+
+
+def host_numa_cpus():
+    """{node: [cpus]} from /sys/devices/system/node (empty when the host does not expose it)."""
+    out, base = {}, '/sys/devices/system/node'
+    try:
+        for name in os.listdir(base):
+            if name.startswith('node') and name[4:].isdigit():
+                with open(os.path.join(base, name, 'cpulist')) as f:
+                    out[int(name[4:])] = parse_cpulist(f.read())
+    except OSError:
+        pass
+    return out
+
+
+def bind_rank(local_rank, local_world, max_threads=16, use_gpu=True):
+    """Pin this process to its slice of the CPUs of its GPU's NUMA node and cap torch's intra-op threads; returns what was done
+    (echoed into bench.py's line).  SGDFR_NO_AFFINITY=1 leaves the process alone."""
+    if os.environ.get('SGDFR_NO_AFFINITY') == '1' or not hasattr(os, 'sched_setaffinity'):
+        return {'bound': False}
+    allowed = sorted(os.sched_getaffinity(0))
+    gpu = use_gpu and torch.cuda.is_available()
+    numa = [gpu_numa_node(r) if gpu and r < torch.cuda.device_count() else None for r in range(local_world)]
+    node, cpus = plan_affinity(local_rank, local_world, numa, host_numa_cpus(), allowed)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return {'bound': False}
+    threads = max(1, min(len(cpus), max_threads))
+    torch.set_num_threads(threads)
+    return {'bound': True, 'numa_node': node, 'cpus': format_cpulist(cpus), 'n_cpus': len(cpus), 'torch_threads': threads}
+
+
+def gather_objects(obj):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (small python objects)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def shard_range(total, rank, world):
     """Contiguous [start, stop) of `total` items owned by `rank`; sizes differ by at most one."""
     base, extra = divmod(total, world)

@@ -101,6 +101,45 @@ def test_bench_gpus2_spawns_two_ranks_host_check():
     assert line['weight_broadcast_bytes'] > 4 * 20e6
 
 
+@pytest.mark.timeout(600)
+def test_bench_gpus8_host_check_with_rank_affinity():
+    """The 8-rank launch the driver's SCALE step uses, on CPU over gloo: 8 shards of 64, identical weights everywhere, and
+    every rank pinned to its own non-empty CPU slice (distributed.bind_rank)."""
+    r, line = _run_bench('--gpus', '8', '--host-check', '--size', '32', '--batch', '64', timeout=560)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line['n_gpus'] == 8 and line['backend'] == 'gloo'
+    assert line['shards'] == [[64 * i, 64 * (i + 1)] for i in range(8)]
+    assert line['weights_identical_on_all_ranks'] is True
+    aff = line['rank_affinity']
+    assert len(aff) == 8 and all(a['bound'] and a['n_cpus'] >= 1 for a in aff)
+    host = len(os.sched_getaffinity(0))
+    if host >= 8:       # disjoint slices that cover the host's allowed CPUs
+        from stylegan_directions_face_reenactment_amd.distributed import parse_cpulist
+        sets = [set(parse_cpulist(a['cpus'])) for a in aff]
+        assert sum(len(s) for s in sets) == len(set().union(*sets)) == host
+
+
+def test_affinity_plan_two_sockets():
+    from stylegan_directions_face_reenactment_amd.distributed import plan_affinity, parse_cpulist, format_cpulist
+    node_cpus = {0: parse_cpulist('0-63,128-191'), 1: parse_cpulist('64-127,192-255')}
+    allowed = list(range(256))
+    numa = [0, 0, 0, 0, 1, 1, 1, 1]
+    seen = set()
+    for r in range(8):
+        node, cpus = plan_affinity(r, 8, numa, node_cpus, allowed)
+        assert node == numa[r] and len(cpus) == 32 and set(cpus) <= set(node_cpus[node]) and not (seen & set(cpus))
+        seen |= set(cpus)
+    assert len(seen) == 256
+    # unknown topology: even split of the allowed set; a restricted cpuset is respected
+    node, cpus = plan_affinity(1, 2, [None, None], {}, [3, 4, 5, 6])
+    assert node is None and cpus == [5, 6]
+    node, cpus = plan_affinity(0, 2, [0, 1], node_cpus, list(range(0, 8)))      # rank 1's node has no allowed CPU -> falls back
+    assert cpus == list(range(0, 8))
+    node, cpus = plan_affinity(1, 2, [0, 1], node_cpus, list(range(0, 8)))
+    assert cpus == list(range(0, 8))
+    assert format_cpulist(parse_cpulist('0-3,8,10-11')) == '0-3,8,10-11'
+
+
 @pytest.mark.timeout(120)
 def test_bench_refuses_more_ranks_than_gpus():
     """--gpus N on a host with fewer than N devices must fail loudly, never measure fewer GPUs and report N (or 1)."""

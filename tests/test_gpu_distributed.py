@@ -85,4 +85,9 @@ def test_bench_inference_and_trainer_configs_small():
     r, line = _run_bench('--config', 'trainer', '--steps', '2', '--warmup', '1', '--batch', '4', timeout=700)
     assert r.returncode == 0, r.stderr[-3000:]
     assert line['unit'] == 'samples/s' and line['value'] > 0 and line['config']['losses_finite'] is True
-    assert 'bf16' in line['dtype']
+    # the arithmetic that actually ran, not a substring of the prose: forward = the bench default, backward = functional.BACKWARD_ARITH
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    assert line['config']['forward_arithmetic'] == 'fp16x3' and line['config']['backward_arithmetic'] == F_.BACKWARD_ARITH
+    assert line['roofline']['frac'] > 0 and line['config']['generator_only_ms_per_step'] > 0
+    first, last = line['config']['loss_first_last']
+    assert first > 0 and last > 0
