@@ -446,8 +446,10 @@ def run_synthesis(args, rank, world, dev):
         out['max_abs_vs_oracle'] = oracle_delta(args.size, args.cm, w[:2], head)
     out['roofline'] = roof
     if args.precision == 'fp16x3':
-        # operand pairs the fp16-split kernels had to clamp / found non-finite during this whole run: 0 = the fp32-grade claim holds
-        out['fp16_saturated_pairs'] = F_.split_saturation_count(reset=False)
+        # operand pairs this generator's fp16-split launches had to clamp / found non-finite during the whole run (its own
+        # saturation word): 0 = the fp32-grade claim holds
+        out['fp16_saturated_pairs'] = G.saturated_pairs()
+        out['fp16_range_mode'] = G.range_mode()
     if alt is not None:
         out['alt_arithmetic'] = alt
     if args.layers:
@@ -564,7 +566,7 @@ def run_inference(args, rank, world, dev):
                      'not_in_the_timed_step': 'DECA / face detection of the targets (out of scope, SURVEY.md §2); e4e of the one source image'})
     out['roofline'] = roof
     if args.precision == 'fp16x3':
-        out['fp16_saturated_pairs'] = F_.split_saturation_count(reset=False)
+        out['fp16_saturated_pairs'] = G.saturated_pairs()
     return out
 
 
@@ -656,6 +658,7 @@ def run_trainer(args, rank, world, dev):
                      'per_rank_samples_per_s_min_max': spread, 'generator_only_ms_per_step': round(gen_ms, 3),
                      'loss_heads_and_optimizer_ms_per_step': round(elapsed / args.steps * 1e3 - gen_ms, 3),
                      'losses_finite': finite, 'loss_first_last': [round(float(losses[0]), 5), round(float(losses[-1]), 5)],
+                     'fp16_saturated_pairs_fwd_and_bwd': G.saturated_pairs() if args.precision == 'fp16x3' else None,
                      'forward_arithmetic': args.precision,
                      'backward_arithmetic': 'fp32' if args.precision == 'fp32' else F_.BACKWARD_ARITH})
     out['dtype'] = DTYPE[args.precision] + ('; backward: dL/dx convs in the same fp16 hi+lo arithmetic, range-planned per image from max|g| (bf16 hi+lo with '

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 10
+#define SGDFR_ABI_VERSION 11
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -198,17 +198,34 @@ int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const float* noise
  * parity planes of t (0 = dense (H+1)*(W+1), see sgdfr_modconv2d_split_f32). */
 int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, const float* noise, int64_t noise_bstride,
                                   const float* noise_w, const float* bias, const float* s_next, unsigned short* xs, int B, int C,
-                                  int H, int W, int64_t plane_stride, int arith, int act, float slope, float gain, void* stream);
+                                  int H, int W, int64_t plane_stride, int arith, int act, float slope, float gain,
+                                  unsigned int* sat, void* stream);
 
 /* y[b,j,p] = sum_i w_rgb[j*Cin+i]/sqrt(Cin) * s[b,i] * x[b,i,p] + bias[j]
  *          + (skip ? upfirdn2d(skip[b,j] (H/2 x W/2), fir[4,4], up=2, pad=(2,1))[p] : 0),  j<3 */
 int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, const float* bias, const float* skip,
                         const float* fir, float* y, int B, int Cin, int H, int W, void* stream);
 
-/* Opt-in "bf16x3" precision mode of the 3x3 modulated convs (same contract as sgdfr_modconv2d_fwd_f32 modes PLAIN3 / UP3,
- * ModulatedConv2d.forward model.py:232-273): fp32 operands are split into bf16 hi + lo terms and contracted as
- * hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~2^-17 relative error per product; the
- * whole 256x256 generator stays within 1.1e-4 max-abs of the fp64 oracle, contract 1e-3).  Never selected implicitly.
+/* Split-operand arithmetic of the 3x3 modulated convs (same contract as sgdfr_modconv2d_fwd_f32 modes PLAIN3 / UP3,
+ * ModulatedConv2d.forward model.py:232-273): fp32 operands are split into two 16-bit terms hi + lo and contracted as
+ * hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_{f16,bf16} with fp32 accumulation.  `arith` selects the terms:
+ *   SGDFR_SPLIT_FP16  fp16 hi+lo = 22 operand bits (fp32-grade; 7.7e-6 max-abs vs an fp64 evaluation of the 256x256 generator).
+ *                     THE DEFAULT of the Python host layer (functional.PRECISION = 'fp16x3') for inference and the autograd
+ *                     forward.  fp16 has 5 exponent bits: the host supplies styles / demodulation scaled by an exact power of
+ *                     two per image (the "range plan", sgdfr_styles_batched_f32 / sgdfr_split_range_f32) so the largest operand
+ *                     sits a few binades under 65504.  Operands that still leave the range, or are NaN/Inf, are CLAMPED AND
+ *                     COUNTED in the caller's saturation word (below) -- never silently.
+ *   SGDFR_SPLIT_BF16  bf16 hi+lo = 16 operand bits, full fp32 exponent range (~1.2e-4 on the same images; contract 1e-3).
+ *                     Selected AUTOMATICALLY by the host layer as the fallback of a generator whose saturation word became
+ *                     non-zero (the affected batch is re-rendered before it is returned by the verified entry points:
+ *                     generate_image, ReenactmentSession, Generator.forward(verify_range=True)), or explicitly.
+ * A caller pins an arithmetic with functional.set_precision('fp32' | 'fp16x3' | 'bf16x3') / SGDFR_PRECISION, or per call through
+ * the `arith` argument here ('fp32' = the sgdfr_modconv2d_fwd_f32 / _wino_f32 kernels, no split entry point involved).
+ *
+ * Saturation words: every entry point that converts to the fp16 terms takes `unsigned int* sat`: a device word the kernel
+ * atomically adds its count of clamped / non-finite operand pairs to (one word per generator, or per batch in flight: the
+ * owner zeroes and reads it; nothing is shared between generators or streams).  NULL = the legacy device-wide counter read
+ * by sgdfr_split_saturation_count().
  *   sgdfr_modconv_prepack_split_elems: uint16 elements of the packed weight buffer (= 2*9*Cin*Cout, Cout rounded up to the 64-wide cout tiles of the pack:
  *     a forward pack may have Cout = 32 mod 64, its last tile is half padding)
  *   sgdfr_modconv_prepack_split_f32:   weight [Cout,Cin,3,3] -> 16-bit hi/lo of weight/sqrt(9 Cin) in kernel order;
@@ -234,14 +251,14 @@ int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, cons
                                 |x*s| saturates at 1.04e6 */
 int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin);
 int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int arith, int transpose_flip,
-                                    void* stream);
+                                    unsigned int* sat, void* stream);
 int sgdfr_modconv2d_split_supported(int B, int Cin, int Cout, int H, int W, int mode);
 int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned short* wsp, const float* s, const float* d,
                               const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
                               const float* zeros, float* y, float* partials, int ksplit, const float* rgb_w,
                               const float* rgb_s, float* rgb_part, int x_is_split, unsigned short* xs_out, const float* s_next,
                               int B, int Cin, int Cout, int H, int W, int mode, int64_t plane_stride, int arith, int act,
-                              float slope, float gain, void* stream);
+                              float slope, float gain, unsigned int* sat, void* stream);
 /* plane_stride (UP3, ksplit <= 1; 0 = dense): floats between the parity planes of y, >= (H+1)*(W+1).  A multiple of 32 makes
  * every 32-position store run of the kernel one whole 128-byte line (dense planes are odd-sized, their stores run at half the
  * write bandwidth); sgdfr_blur_bias_act_split_f32 takes the same stride. */
@@ -249,11 +266,12 @@ int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned 
  * stages it; sgdfr_modconv2d_split_f32(x = xs, s = NULL, x_is_split = 1) then fills LDS by DMA only.  Producers can emit
  * that form directly: sgdfr_modconv2d_split_f32(xs_out, s_next = the NEXT layer's modulation [B,Cout]) (y may then be NULL)
  * and sgdfr_blur_bias_act_f32's split variant, so activations between layers never exist as fp32 in HBM. */
-/* fp16-split operand pairs clamped to +-65504 (|x*s| > 1.04e6) by any split kernel on the current device since the last
- * reset -- the fp16x3 arithmetic never saturates silently.  Synchronises the device; < 0 on a HIP error. */
+/* fp16-split operand pairs clamped to +-65504 by split launches that were given sat = NULL, on the current device since the
+ * last reset (launches with their own saturation word do not count here).  Synchronises the device; < 0 on a HIP error. */
 long long sgdfr_split_saturation_count(int reset);
 int sgdfr_modconv2d_split_xin_supported(int B, int Cin, int Cout, int H, int W, int mode);   /* x_is_split allowed for this shape */
-int sgdfr_to_split_f32(const float* x, const float* s, unsigned short* xs, int B, int Cin, int H, int W, int arith, void* stream);
+int sgdfr_to_split_f32(const float* x, const float* s, unsigned short* xs, int B, int Cin, int H, int W, int arith,
+                       unsigned int* sat, void* stream);
 /* Backward of the transposed conv on the split kernels (autograd of ModulatedConv2d.forward model.py:246-256; consumers
  * trainer.py:188, optimization.py:67): dL/d(x*s) = the stride-2 3x3 conv of the gradient's parity planes with the transposed
  * kernel = sgdfr_modconv2d_split_f32(mode = SGDFR_MODE_DOWN3, x_is_split = 1, Cin = plane channels C, Cout = channels of
@@ -262,12 +280,12 @@ int sgdfr_to_split_f32(const float* x, const float* s, unsigned short* xs, int B
  *                              scale: the layer's demodulation) -> xs [B][(ph*C + c)/8][2][(H+1)*(W+1)][8] 16-bit, the
  *                              phase-major split form of gt*d (16-byte aligned, 4 bytes per element). */
 int sgdfr_planes_to_split_f32(const float* gt, const float* d, unsigned short* xs, int B, int C, int H, int W, int arith,
-                              void* stream);
+                              unsigned int* sat, void* stream);
 /* sgdfr_blur_adjoint_f32 followed by sgdfr_planes_to_split_f32 in one pass (frozen generator: nothing else reads the fp32
  * plane gradient): g [B,C,2H,2W] -> xs as above (times d [B,C] or 1), asum[b,c] = sum gT*t when the forward planes
  * t [B,C,4,H+1,W+1] are given (the demodulation gradient; asum is zeroed first). */
 int sgdfr_blur_adjoint_split_f32(const float* g, const float* fir, const float* t, const float* d, unsigned short* xs,
-                                 float* asum, int B, int C, int H, int W, int arith, void* stream);
+                                 float* asum, int B, int C, int H, int W, int arith, unsigned int* sat, void* stream);
 int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H, int W, int mode);
 int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, int mode);
 

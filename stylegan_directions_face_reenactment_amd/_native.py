@@ -12,9 +12,18 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (SGDFR_LIB: the probe build of scripts/build_probe.py, for the timing scripts only)
-LIB_PATH = os.environ.get('SGDFR_LIB') or os.path.join(_HERE, 'csrc', 'libsgdfr_hip.so')
-ABI_VERSION = 10
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libsgdfr_hip.so')
+# SGDFR_LIB redirects the load to a probe build (scripts/build_probe.py, timing scripts only); it is honoured only together
+# with SGDFR_ALLOW_LIB_OVERRIDE=1 and announced on stderr -- a stray variable must not swap the production library silently
+if os.environ.get('SGDFR_LIB'):
+    if os.environ.get('SGDFR_ALLOW_LIB_OVERRIDE') == '1':
+        import sys as _sys
+        LIB_PATH = os.environ['SGDFR_LIB']
+        _sys.stderr.write('stylegan_directions_face_reenactment_amd: loading the native library from SGDFR_LIB=%s\n' % LIB_PATH)
+    else:
+        import warnings as _warnings
+        _warnings.warn('SGDFR_LIB is set but ignored (set SGDFR_ALLOW_LIB_OVERRIDE=1 to load a probe build)', RuntimeWarning)
+ABI_VERSION = 11
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -43,14 +52,15 @@ SIGNATURES = {
     'sgdfr_modconv2d_wino_supported': [_i, _i, _i, _i, _i],
     'sgdfr_modconv2d_wino_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
                                  _c_f32p, _i, _i, _i, _i, _i, _i, _f, _f, ctypes.c_void_p],
-    'sgdfr_modconv_prepack_split_f32': [_c_f32p, ctypes.c_void_p, _i, _i, _i, _i, ctypes.c_void_p],
+    'sgdfr_modconv_prepack_split_f32': [_c_f32p, ctypes.c_void_p, _i, _i, _i, _i, ctypes.c_void_p, ctypes.c_void_p],
     'sgdfr_modconv2d_split_supported': [_i, _i, _i, _i, _i, _i],
     'sgdfr_modconv2d_split_f32': [_c_f32p, _i64, ctypes.c_void_p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
                                   _c_f32p, _c_f32p, _i, _c_f32p, _c_f32p, _c_f32p, _i, ctypes.c_void_p, _c_f32p, _i, _i, _i, _i,
-                                  _i, _i, _i64, _i, _i, _f, _f, ctypes.c_void_p],
-    'sgdfr_to_split_f32': [_c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i, ctypes.c_void_p],
-    'sgdfr_planes_to_split_f32': [_c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i, ctypes.c_void_p],
-    'sgdfr_blur_adjoint_split_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _c_f32p, _i, _i, _i, _i, _i, ctypes.c_void_p],
+                                  _i, _i, _i64, _i, _i, _f, _f, ctypes.c_void_p, ctypes.c_void_p],
+    'sgdfr_to_split_f32': [_c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i, ctypes.c_void_p, ctypes.c_void_p],
+    'sgdfr_planes_to_split_f32': [_c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i, ctypes.c_void_p, ctypes.c_void_p],
+    'sgdfr_blur_adjoint_split_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _c_f32p, _i, _i, _i, _i, _i, ctypes.c_void_p,
+                                     ctypes.c_void_p],
     'sgdfr_modconv2d_split_cout_tiles': [_i, _i, _i, _i, _i, _i],
     'sgdfr_modconv2d_split_xin_supported': [_i, _i, _i, _i, _i, _i],
     'sgdfr_modconv2d_split_ksplit_hint': [_i, _i, _i, _i, _i, _i],
@@ -70,7 +80,7 @@ SIGNATURES = {
     'sgdfr_blur_bias_act_f32': [_c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i, _i, _f,
                                 _f, ctypes.c_void_p],
     'sgdfr_blur_bias_act_split_f32': [_c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i64,
-                                      _i, _i, _f, _f, ctypes.c_void_p],
+                                      _i, _i, _f, _f, ctypes.c_void_p, ctypes.c_void_p],
     'sgdfr_torgb_fwd_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i,
                             ctypes.c_void_p],
 }
@@ -102,7 +112,8 @@ SIGNATURES['sgdfr_split_range_f32'] = [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctype
 SIGNATURES['sgdfr_absmax_f32'] = [_c_f32p, _i64, _i64, _i, ctypes.c_void_p, _i, ctypes.c_void_p]
 SIGNATURES['sgdfr_styles_batched_f32'] = [_c_f32p, _i, _i, _i, ctypes.POINTER(StyleLayer), _i, ctypes.c_void_p]
 MAX_STYLE_LAYERS = 40
-SIGNATURES['sgdfr_mfma_ceiling_probe'] = [_i, _i, _i, _i, _i, _c_f32p, ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]
+# measurement-only symbols: bound when present, never required of a production library (bench.py's measured_mfma_ceiling)
+OPTIONAL_SIGNATURES = {'sgdfr_mfma_ceiling_probe': [_i, _i, _i, _i, _i, _c_f32p, ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]}
 
 MODE_PLAIN3, MODE_UP3, MODE_DOWN3 = 0, 1, 2
 SPLIT_BF16, SPLIT_FP16 = 0, 1
@@ -133,6 +144,11 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
+    for name, argtypes in OPTIONAL_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
     _lib = lib
     return lib
 

@@ -205,10 +205,16 @@ class StyledConvFn(Function):
                                 activate=activate, batch=batch, wino=mod.packed_wino, split=mod.packed_split)
         ctx.save_for_backward(x, s, d, out, noise_w, bias, noise, planes)
         ctx.mod, ctx.activate = mod, activate
+        ctx.sat = F_.current_sink()         # the owning generator's saturation word: the backward's launches count there too
         return out
 
     @staticmethod
     def backward(ctx, g):
+        with F_.saturation_sink(ctx.sat):
+            return StyledConvFn._backward(ctx, g)
+
+    @staticmethod
+    def _backward(ctx, g):
         x, s, d, out, noise_w, bias, noise, planes = ctx.saved_tensors
         mod, up = ctx.mod, ctx.mod.upsample
         B, cout = out.shape[0], out.shape[1]
@@ -228,9 +234,10 @@ class StyledConvFn(Function):
         # on the way in, 2^-e on the way out.
         d_in, d_out = ones_d, None
         if bw_arith == 'fp16x3':
-            # (max |g_pre| per image comes out of the act_grad_reduce pass; the plane gradient of the transposed conv is a convex
-            # combination of g_pre per phase, so the same bound holds for it)
-            d_in, d_out = F_.split_range(ones_d, F_.ones_like_rows(B, cin, out.device), g_max, headroom=1 if up else 0)
+            # (max |g_pre| per image comes out of the act_grad_reduce pass.  The plane gradient of the transposed conv is the
+            # adjoint of the 4x4 blur FIR, whose taps are scaled by factor^2 and sum to 4 (model.py:78-79): |gT| <= 4 max |g_pre|,
+            # two binades of headroom; with the true maximum and that headroom finite gradients cannot saturate)
+            d_in, d_out = F_.split_range(ones_d, F_.ones_like_rows(B, cin, out.device), g_max, headroom=2 if up else 0)
         if up:
             split_down = F_.PRECISION != 'fp32' and F_.split_ok(B, cout, cin, H, W, N.MODE_DOWN3)
             gT = None

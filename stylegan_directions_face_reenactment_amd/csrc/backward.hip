@@ -138,8 +138,11 @@ __global__ __launch_bounds__(256) void blur_adjoint_kernel(const float* __restri
                 for (int v = 0; v < 5; ++v) win[u][v] = win[u + 2][v];
         }
         if (t) {      // the lanes of a wave almost always sit in one plane: one atomic per wave then
+            // wave_sum needs ALL 64 lanes (its v_readlane ignores EXEC): the tail wave of the grid-stride loop, whose upper
+            // lanes have left the loop, takes the per-lane atomics like a wave that straddles two planes
             const int pl_lo = (int)pl;
-            if (__all(pl_lo == __builtin_amdgcn_readfirstlane(pl_lo))) {
+            const bool full = __builtin_popcountll(__ballot(1)) == 64;
+            if (full && __all(pl_lo == __builtin_amdgcn_readfirstlane(pl_lo))) {
                 const float sum = wave_sum(acc_a);
                 if ((threadIdx.x & 63) == 0) atomicAdd(&asum[pl], sum);
             } else {

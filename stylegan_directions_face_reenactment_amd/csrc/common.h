@@ -33,6 +33,10 @@ constexpr int kWave = 64;  // gfx950 wavefront
 // Sum / max over the 64 lanes of a wave, the same value in every lane.  Four DPP steps inside each row of 16 lanes (quad
 // swaps, half-row mirror, row mirror: VALU speed) and three v_readlane for the four row totals -- instead of six dependent
 // ds_bpermute_b32 round trips (the __shfl_xor butterfly), which made the skinny style / mapping GEMMs butterfly-bound.
+// PRECONDITION: all 64 lanes of the wave are active at the call.  v_readlane ignores EXEC, so a row whose lanes have left a
+// loop or taken another branch contributes stale registers.  Call it only after reconvergence (wave-uniform control flow), or
+// guard with `__builtin_popcountll(__ballot(1)) == 64` and fall back to per-lane atomics / __shfl_xor (backward.hip's
+// blur_adjoint_kernel does).
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));

@@ -115,6 +115,7 @@ struct SplitParams {
     float* rgb_part;
     unsigned char* xs_out;       // PLAIN3, ksplit == 1: the activation in the NEXT layer's split input form (x * s_next, see XIN)
     const float* s_next;         //   [B][Cout] modulation of the next layer
+    unsigned* sat;               // the caller's saturation word (null: the device-wide counter)
     int B, Cin, Cout, H, W;
     int P, R;                    // padded pitch / rows per image of the flat space (W+1, H+1)
     int n_pix_tiles, n_cout_tiles;
@@ -194,8 +195,10 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
     }
 }
 
-__device__ __forceinline__ void split_flush_saturation(unsigned sat) {
-    if (__builtin_expect(sat != 0, 0)) atomicAdd(&g_split_saturated, sat);
+// `word`: the caller's saturation word (one per generator / per consumer of the result, sgdfr.h "saturation words"); null = the
+// device-wide legacy counter read by sgdfr_split_saturation_count.
+__device__ __forceinline__ void split_flush_saturation(unsigned sat, unsigned* word) {
+    if (__builtin_expect(sat != 0, 0)) atomicAdd(word ? word : &g_split_saturated, sat);
 }
 
 // MODE PLAIN3: y = conv3x3(x*s) * d (+ noise, bias, activation).  MODE UP3: stride-2 transposed conv into the four
@@ -1108,7 +1111,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     if (PERSIST) __syncthreads();      // the next tile refills the tables and the staging buffers
     SPLIT_TRACE(7);
     } while (PERSIST && (base += gridDim.x) < p.total_blocks);
-    if (ET == SGDFR_SPLIT_FP16) split_flush_saturation(sat);
+    if (ET == SGDFR_SPLIT_FP16) split_flush_saturation(sat, p.sat);
 #ifdef SGDFR_SPLIT_PROBE
     if (trace_on) g_split_trace[0] = (unsigned long long)ntrace;
 #endif
@@ -1118,7 +1121,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 // that split_mfma_kernel<..., XIN> stages by DMA.  One thread = one pixel of one 8-channel group.
 template <int ET>
 __global__ __launch_bounds__(256) void to_split_kernel(const float* __restrict__ x, const float* __restrict__ s,
-                                                      unsigned char* __restrict__ xs, int B, int Cin, int HW) {
+                                                      unsigned char* __restrict__ xs, int B, int Cin, int HW,
+                                                      unsigned* __restrict__ sat_word) {
     const int G = Cin / 8;
     const int64_t n = (int64_t)B * G * HW;
     unsigned sat = 0;
@@ -1140,14 +1144,15 @@ __global__ __launch_bounds__(256) void to_split_kernel(const float* __restrict__
         *reinterpret_cast<uint4*>(dst) = vh;
         *reinterpret_cast<uint4*>(dst + (int64_t)HW * 16) = vl;
     }
-    if (ET == SGDFR_SPLIT_FP16) split_flush_saturation(sat);
+    if (ET == SGDFR_SPLIT_FP16) split_flush_saturation(sat, sat_word);
 }
 
 // gT [B,C,4,RP] fp32 parity planes and d [B,C] (or null) -> the phase-major split form of gT*d that the DOWN3 kernel stages:
 // [B][(ph*C + c)/8][hi,lo][RP][8].  One thread = one position of one 8-channel group of one phase.
 template <int ET>
 __global__ __launch_bounds__(256) void planes_to_split_kernel(const float* __restrict__ gt, const float* __restrict__ d,
-                                                             unsigned char* __restrict__ xs, int B, int C, int RP) {
+                                                             unsigned char* __restrict__ xs, int B, int C, int RP,
+                                                             unsigned* __restrict__ sat_word) {
     const int G = C / 8;
     const int64_t n = (int64_t)B * 4 * G * RP;
     unsigned sat = 0;
@@ -1173,13 +1178,14 @@ __global__ __launch_bounds__(256) void planes_to_split_kernel(const float* __res
         *reinterpret_cast<uint4*>(dst) = vh;
         *reinterpret_cast<uint4*>(dst + (int64_t)RP * 16) = vl;
     }
-    if (ET == SGDFR_SPLIT_FP16) split_flush_saturation(sat);
+    if (ET == SGDFR_SPLIT_FP16) split_flush_saturation(sat, sat_word);
 }
 
 // weight [Cout,Cin,3,3] fp32 -> bf16 hi/lo of Wc = weight/sqrt(9 Cin) in the kernel's LDS order:
 //   [cout tile][cin block][ky][kx][part][k-half][cout in tile (NT)][8 cin]
 __global__ __launch_bounds__(256) void prepack_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
-                                                           int Cout, int Cin, int NT, float scale, int et, int transpose_flip) {
+                                                           int Cout, int Cin, int NT, float scale, int et, int transpose_flip,
+                                                           unsigned* __restrict__ sat_word) {
     // packed conv: n_out x n_in channels.  transpose_flip 1: the adjoint conv (dL/dx of the plain conv): channels swapped, taps
     // rotated by 180 degrees; 2: the adjoint of the transposed conv (DOWN3): channels swapped, taps as they are but stored
     // phase by phase ((0,0) (0,2) (2,0) (2,2) | (0,1) (2,1) | (1,0) (1,2) | (1,1)); weight stays indexed [Cout][Cin][3][3]
@@ -1195,7 +1201,7 @@ __global__ __launch_bounds__(256) void prepack_split_kernel(const float* __restr
         unsigned hp, lp, sat = 0;
         if (et == SGDFR_SPLIT_FP16) split_pair<SGDFR_SPLIT_FP16>(v, 0.f, hp, lp, sat);
         else split_pair<SGDFR_SPLIT_BF16>(v, 0.f, hp, lp, sat);
-        split_flush_saturation(sat);
+        split_flush_saturation(sat, sat_word);
         const unsigned hbits = hp & 0xffffu, lbits = lp & 0xffffu;
         const int ctile = co / NT, col = co - ctile * NT, cb = ci / SPLIT_CB, h = (ci % SPLIT_CB) / 8, c8 = ci % 8;
         const int down_pos[9] = {0, 4, 1, 6, 8, 7, 2, 5, 3};      // tap ky*3+kx -> slot in the phase-by-phase order
@@ -1349,7 +1355,7 @@ extern "C" int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H
 }
 
 extern "C" int sgdfr_to_split_f32(const float* x, const float* s, unsigned short* xs, int B, int Cin, int H, int W, int arith,
-                                  void* stream) {
+                                  unsigned int* sat, void* stream) {
     SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cin % 8 == 0 && H > 0 && W > 0, "to_split: bad shape B=%d Cin=%d H=%d W=%d (Cin %% 8)", B, Cin, H, W);
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "to_split: arith must be SGDFR_SPLIT_BF16/FP16");
     if (B == 0) return 0;
@@ -1358,15 +1364,15 @@ extern "C" int sgdfr_to_split_f32(const float* x, const float* s, unsigned short
     if (g > 256 * 32) g = 256 * 32;
     if (arith == SGDFR_SPLIT_FP16)
         hipLaunchKernelGGL(to_split_kernel<SGDFR_SPLIT_FP16>, dim3((int)g), dim3(256), 0, as_stream(stream), x, s,
-                           reinterpret_cast<unsigned char*>(xs), B, Cin, H * W);
+                           reinterpret_cast<unsigned char*>(xs), B, Cin, H * W, sat);
     else
         hipLaunchKernelGGL(to_split_kernel<SGDFR_SPLIT_BF16>, dim3((int)g), dim3(256), 0, as_stream(stream), x, s,
-                           reinterpret_cast<unsigned char*>(xs), B, Cin, H * W);
+                           reinterpret_cast<unsigned char*>(xs), B, Cin, H * W, sat);
     return check_launch("to_split");
 }
 
 extern "C" int sgdfr_planes_to_split_f32(const float* gt, const float* d, unsigned short* xs, int B, int C, int H, int W,
-                                        int arith, void* stream) {
+                                        int arith, unsigned int* sat, void* stream) {
     SGDFR_REQUIRE(B >= 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "planes_to_split: bad shape B=%d C=%d H=%d W=%d (C %% 8)", B, C, H, W);
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "planes_to_split: arith must be SGDFR_SPLIT_BF16/FP16");
     if (B == 0) return 0;
@@ -1376,10 +1382,10 @@ extern "C" int sgdfr_planes_to_split_f32(const float* gt, const float* d, unsign
     if (g > 256 * 32) g = 256 * 32;
     if (arith == SGDFR_SPLIT_FP16)
         hipLaunchKernelGGL(planes_to_split_kernel<SGDFR_SPLIT_FP16>, dim3((int)g), dim3(256), 0, as_stream(stream), gt, d,
-                           reinterpret_cast<unsigned char*>(xs), B, C, RP);
+                           reinterpret_cast<unsigned char*>(xs), B, C, RP, sat);
     else
         hipLaunchKernelGGL(planes_to_split_kernel<SGDFR_SPLIT_BF16>, dim3((int)g), dim3(256), 0, as_stream(stream), gt, d,
-                           reinterpret_cast<unsigned char*>(xs), B, C, RP);
+                           reinterpret_cast<unsigned char*>(xs), B, C, RP, sat);
     return check_launch("planes_to_split");
 }
 
@@ -1421,7 +1427,7 @@ extern "C" int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H,
 extern "C" int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin) { return (int64_t)((Cout + 63) / 64 * 64) * Cin * 9 * 2; }   // cout tiles of 64
 
 extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int arith,
-                                               int transpose_flip, void* stream) {
+                                               int transpose_flip, unsigned int* sat, void* stream) {
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "prepack_split: arith must be SGDFR_SPLIT_BF16/FP16");
     SGDFR_REQUIRE(transpose_flip >= 0 && transpose_flip <= 2, "prepack_split: transpose_flip is 0 (forward), 1 (adjoint of "
                   "the plain conv) or 2 (adjoint of the transposed conv)");
@@ -1441,7 +1447,7 @@ extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned sho
     int64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(prepack_split_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), weight, wsp, Cout, Cin,
-                       64, (arith == SGDFR_SPLIT_FP16 ? SPLIT_F16_WSCALE : 1.f) / sqrtf((float)Cin * 9), arith, transpose_flip);
+                       64, (arith == SGDFR_SPLIT_FP16 ? SPLIT_F16_WSCALE : 1.f) / sqrtf((float)Cin * 9), arith, transpose_flip, sat);
     return check_launch("modconv_prepack_split");
 }
 
@@ -1513,7 +1519,8 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
                                          const float* bias, const float* zeros, float* y, float* partials, int ksplit,
                                          const float* rgb_w, const float* rgb_s, float* rgb_part, int x_is_split,
                                          unsigned short* xs_out, const float* s_next, int B, int Cin, int Cout, int H, int W,
-                                         int mode, int64_t plane_stride, int arith, int act, float slope, float gain, void* stream) {
+                                         int mode, int64_t plane_stride, int arith, int act, float slope, float gain,
+                                         unsigned int* sat, void* stream) {
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "modconv_split: arith must be SGDFR_SPLIT_BF16/FP16");
     SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "modconv_split: bad shape B=%d Cin=%d Cout=%d H=%d W=%d",
                   B, Cin, Cout, H, W);
@@ -1551,7 +1558,7 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
     }
     p.x = x; p.x_bstride = x_bstride; p.wsp = wsp; p.s = s; p.d = d; p.noise = noise; p.noise_bstride = noise_bstride;
     p.noise_w = noise_w; p.bias = bias; p.zeros = zeros; p.y = y;
-    p.act = act; p.slope = slope; p.gain = gain;
+    p.act = act; p.slope = slope; p.gain = gain; p.sat = sat;
     if (ksplit < 1) ksplit = 1;
     SGDFR_REQUIRE(!rgb_part || (rgb_w && rgb_s && mode == SGDFR_MODE_PLAIN3 && ksplit == 1),
                   "modconv_split: the fused ToRGB needs rgb_w, rgb_s, mode PLAIN3 and ksplit == 1");

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(8 * QC * NG, 4) void blur_split_kernel(const float*
                                                         const float* __restrict__ noise_w, const float* __restrict__ bias,
                                                         const float* __restrict__ s_next, unsigned char* __restrict__ xs,
                                                         int B, int C, int H, int W, int pstride, int nseg, int act, float slope,
-                                                        float gain) {
+                                                        float gain, unsigned* __restrict__ sat_word) {
     // fp32 results of the block's tile as [row 8][px 128][channel 8 (+1 pad: the lanes of a wave write px 2 apart ->
     // 18-dword stride, conflict-free)]; the hand-over to 16-byte chunks happens when the tile is read back.
     // 8 waves = 8 channels, a wave = 64 quad columns (256-byte coalesced plane reads, as the fp32 kernel).
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(8 * QC * NG, 4) void blur_split_kernel(const float*
         __syncthreads();
         }       // segments
     }
-    if (ET == SGDFR_SPLIT_FP16 && sat != 0) atomicAdd(&g_blur_saturated, sat);
+    if (ET == SGDFR_SPLIT_FP16 && sat != 0) atomicAdd(sat_word ? sat_word : &g_blur_saturated, sat);
 }
 
 
@@ -359,7 +359,7 @@ template <int ET, int QC>
 __global__ __launch_bounds__(8 * QC) void blur_adjoint_split_kernel(const float* __restrict__ g, const float* __restrict__ fir,
                                                                 const float* __restrict__ t, const float* __restrict__ d,
                                                                 unsigned char* __restrict__ xs, float* __restrict__ asum,
-                                                                int B, int C, int H, int W) {
+                                                                int B, int C, int H, int W, unsigned* __restrict__ sat_word) {
     __shared__ float tile[4][BLUR_QV][QC + 1][9];
     __shared__ float sv[8];
     float k[16];
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(8 * QC) void blur_adjoint_split_kernel(const float*
         }
         __syncthreads();
     }
-    if (ET == SGDFR_SPLIT_FP16 && sat != 0) atomicAdd(&g_blur_saturated, sat);
+    if (ET == SGDFR_SPLIT_FP16 && sat != 0) atomicAdd(sat_word ? sat_word : &g_blur_saturated, sat);
 }
 
 }  // namespace sgdfr
@@ -527,7 +527,7 @@ extern "C" int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const f
 extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, const float* noise, int64_t noise_bstride,
                                              const float* noise_w, const float* bias, const float* s_next, unsigned short* xs,
                                              int B, int C, int H, int W, int64_t plane_stride, int arith, int act, float slope,
-                                             float gain, void* stream) {
+                                             float gain, unsigned int* sat, void* stream) {
     SGDFR_REQUIRE(B >= 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "blur_bias_act_split: bad shape %d %d %d %d (C %% 8)", B, C, H, W);
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "blur_bias_act_split: arith must be SGDFR_SPLIT_BF16/FP16");
     if (B == 0) return 0;
@@ -550,7 +550,7 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
     if (g > 256 * 32) g = 256 * 32;           // (a multiple of 16: the grid-stride loop keeps the pairing)
     unsigned char* out = reinterpret_cast<unsigned char*>(xs);
     void (*kern)(const float*, const float*, const float*, int64_t, const float*, const float*, const float*, unsigned char*, int,
-                 int, int, int, int, int, int, float, float);
+                 int, int, int, int, int, int, float, float, unsigned*);
     if (arith == SGDFR_SPLIT_FP16)
         kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_FP16, 64, 1> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_FP16, 32, 1>
                : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_FP16, 16, 2> : QC == 8 ? blur_split_kernel<SGDFR_SPLIT_FP16, 8, 4>
@@ -560,12 +560,12 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
                : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_BF16, 16, 2> : QC == 8 ? blur_split_kernel<SGDFR_SPLIT_BF16, 8, 4>
                                                                                   : blur_split_kernel<SGDFR_SPLIT_BF16, 4, 8>;
     hipLaunchKernelGGL(kern, dim3((int)g), dim3(8 * QC * NG), 0, as_stream(stream), t, fir, noise, noise_bstride, noise_w, bias, s_next,
-                       out, B, C, H, W, (int)plane_stride, nseg, act, slope, gain);
+                       out, B, C, H, W, (int)plane_stride, nseg, act, slope, gain, sat);
     return check_launch("blur_bias_act_split");
 }
 
 extern "C" int sgdfr_blur_adjoint_split_f32(const float* g, const float* fir, const float* t, const float* d, unsigned short* xs,
-                                            float* asum, int B, int C, int H, int W, int arith, void* stream) {
+                                            float* asum, int B, int C, int H, int W, int arith, unsigned int* sat, void* stream) {
     SGDFR_REQUIRE(B >= 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "blur_adjoint_split: bad shape %d %d %d %d (C %% 8)", B, C, H, W);
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "blur_adjoint_split: arith must be SGDFR_SPLIT_BF16/FP16");
     if (B == 0) return 0;
@@ -579,9 +579,9 @@ extern "C" int sgdfr_blur_adjoint_split_f32(const float* g, const float* fir, co
     int64_t grid = tiles;
     if (grid > 256 * 32) grid = 256 * 32;
     unsigned char* out = reinterpret_cast<unsigned char*>(xs);
-    void (*kern)(const float*, const float*, const float*, const float*, unsigned char*, float*, int, int, int, int);
+    void (*kern)(const float*, const float*, const float*, const float*, unsigned char*, float*, int, int, int, int, unsigned*);
     if (arith == SGDFR_SPLIT_FP16) kern = QC == 64 ? blur_adjoint_split_kernel<SGDFR_SPLIT_FP16, 64> : blur_adjoint_split_kernel<SGDFR_SPLIT_FP16, 32>;
     else kern = QC == 64 ? blur_adjoint_split_kernel<SGDFR_SPLIT_BF16, 64> : blur_adjoint_split_kernel<SGDFR_SPLIT_BF16, 32>;
-    hipLaunchKernelGGL(kern, dim3((int)grid), dim3(8 * QC), 0, st, g, fir, t, d, out, asum, B, C, H, W);
+    hipLaunchKernelGGL(kern, dim3((int)grid), dim3(8 * QC), 0, st, g, fir, t, d, out, asum, B, C, H, W, sat);
     return check_launch("blur_adjoint_split");
 }

@@ -6,6 +6,7 @@ nothing here computes with torch ops.  Reference lines each function stands for 
 """
 import functools
 import os
+import threading
 
 import torch
 from torch.autograd import Function
@@ -178,8 +179,16 @@ def styles_batched(latent, specs, plans=None):
     return out
 
 
-# ---- range plan of the fp16-split conv (SGDFR_RANGE_PLAN=0 switches it off: the fixed 2^-4 pre-scale of round 1)
-RANGE_PLAN = os.environ.get('SGDFR_RANGE_PLAN', '1') != '0'
+# ---- range plan of the fp16-split conv.  SGDFR_RANGE_PLAN / functional.RANGE_PLAN:
+#   True  ('1', default)  Generator: calibrated once per weight version (max |x| of every conv input on the fp32 kernels, 6 binades
+#                         of headroom), checked through the generator's saturation word; stand-alone layers: exact (below)
+#   'exact'               every conv input's true per-image max |x| is measured on the device before the conv (absmax +
+#                         split_range, headroom 0): fp16 saturation is impossible for finite inputs, no calibration and no host
+#                         read -- at the price of fp32 hand-over between layers (no split chain, no fused ToRGB) and one extra
+#                         read of every activation
+#   False ('0')           off: the fixed 2^-4 pre-scale of round 1
+_rp = os.environ.get('SGDFR_RANGE_PLAN', '1')
+RANGE_PLAN = False if _rp == '0' else ('exact' if _rp == 'exact' else True)
 DESIGN_X_LOG2 = 10          # uncalibrated bound taken on trust for a conv input: |x| < 2^10
 CALIBRATION_HEADROOM = 6    # binades kept free above a calibrated activation maximum before the fp16 terms saturate
 
@@ -279,10 +288,47 @@ PRECISION = os.environ.get('SGDFR_PRECISION', 'fp16x3')
 _zeros = {}
 
 
+# ---- saturation words.  Every launch that converts operands to the fp16 terms adds its count of clamped / non-finite operand
+# pairs to ONE device word chosen by the caller (include/sgdfr.h "saturation words"): a Generator owns one, so saturation is
+# attributed to the generator (and batch) that caused it, never to a neighbour in the same process.  `saturation_sink(word)`
+# names the word for the launches issued inside the block by this host thread; autograd Functions remember it for their
+# backward.  Outside any block the launches count into the device-wide legacy counter (split_saturation_count()).
+_sink = threading.local()
+
+
+def current_sink():
+    return getattr(_sink, 'word', None)
+
+
+class saturation_sink:
+    """`with saturation_sink(word):` -- word: int32 device tensor [1] (new_saturation_word) or None (legacy counter)."""
+
+    def __init__(self, word):
+        if word is not None and (word.dtype != torch.int32 or not word.is_cuda or word.numel() != 1):
+            raise RuntimeError('a saturation word is one int32 on the device (new_saturation_word)')
+        self.word, self.prev = word, None
+
+    def __enter__(self):
+        self.prev = current_sink()
+        _sink.word = self.word
+        return self.word
+
+    def __exit__(self, *exc):
+        _sink.word = self.prev
+
+
+def new_saturation_word(device):
+    return torch.zeros(1, device=device, dtype=torch.int32)
+
+
+def _sat():
+    return N.ptr(getattr(_sink, 'word', None))
+
+
 def split_saturation_count(reset=True):
-    """How many operand pairs the fp16x3 kernels had to clamp to the fp16 range, or found NaN/Inf, on this device since the
-    last reset: 0 means the fp32-grade accuracy claim held for everything computed so far; otherwise use 'bf16x3' or 'fp32'
-    (Generator.forward polls this and switches by itself).  Synchronises the device."""
+    """The device-wide LEGACY counter: operand pairs clamped (or NaN/Inf) by fp16x3 launches issued outside any
+    saturation_sink on this device since the last reset (stand-alone functional calls; a Generator counts into its own
+    word, Generator.saturated_pairs()).  Synchronises the device."""
     n = N.load().sgdfr_split_saturation_count(int(bool(reset)))
     if n < 0:
         raise RuntimeError('sgdfr_split_saturation_count failed')
@@ -293,6 +339,8 @@ def mfma_ceiling(arith='fp16x3', lds_fragments=True, random_operands=True, iters
     """Measured sustained rate of the 16-bit MFMA of the split kernels on the current device, TFLOP/s of 16-bit products
     (sgdfr_mfma_ceiling_probe: the chip clocks to its power budget, so random operands run slower than the nominal peak)."""
     import ctypes
+    if not hasattr(N.load(), 'sgdfr_mfma_ceiling_probe'):
+        raise RuntimeError('this build of libsgdfr_hip.so has no sgdfr_mfma_ceiling_probe (measurement-only symbol)')
     scratch = torch.empty(256 * 512, device='cuda', dtype=torch.float32)
     out = ctypes.c_double(0.0)
     N.call('sgdfr_mfma_ceiling_probe', N.SPLIT_FP16 if arith == 'fp16x3' else N.SPLIT_BF16, int(bool(lds_fragments)),
@@ -379,7 +427,7 @@ def prepack_split(weight, arith=None, adjoint=False):
     n = N.load().sgdfr_modconv_prepack_split_elems(cout, cin)
     wsp = torch.empty(n, device=w.device, dtype=torch.int16)
     N.call('sgdfr_modconv_prepack_split_f32', N.ptr(w), N.ptr(wsp), cout, cin, arith, 2 if adjoint == 'down' else int(bool(adjoint)),
-           N.stream())
+           _sat(), N.stream())
     return wsp
 
 
@@ -432,7 +480,7 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
         if not want_y and rgb is None and s_next is None:
             raise RuntimeError('modconv_split: want_y=False only makes sense with the fused ToRGB (rgb=...) or s_next')
         y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32) if want_y else None
-    st = N.stream()
+    st, sat = N.stream(), _sat()
     ks = _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cin, cout, H, W, mode) if USE_SPLITK else 1
     if ks > 1 and y is None:
         raise RuntimeError('modconv_split: this launch is K-sliced and cannot fuse ToRGB (check rgb_fusable first)')
@@ -457,7 +505,7 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
         N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(_zero_words(x.device)), N.ptr(y),
         N.ptr(partials), ks, N.ptr(rgb_w), N.ptr(rgb_s), N.ptr(part), int(x_split is not None), N.ptr(xs_out),
         N.ptr(s_next) if s_next is not None else None, B, cin, cout, H, W, mode, int(plane_stride), arith, int(activate),
-        float(slope), float(gain), st))
+        float(slope), float(gain), sat, st))
     if s_next is not None:      # (activation or None, ToRGB partials or None, the activation in the next layer's split form)
         return y, part, xs_out
     return y if rgb is None else (y, part)
@@ -472,7 +520,7 @@ def planes_to_split(gt, d, arith=None):
     B, C, _, R, P = gt.shape
     xs = torch.empty(B, 4 * C // 8, 2, R * P, 8, device=gt.device, dtype=torch.int16)
     N.call('sgdfr_planes_to_split_f32', N.ptr(gt), N.ptr(N.f32c(d)) if d is not None else None, N.ptr(xs), B, C, R - 1, P - 1, arith,
-           N.stream())
+           _sat(), N.stream())
     return xs
 
 
@@ -484,7 +532,7 @@ def to_split(x, s, arith=None):
     x, s = N.f32c(x), N.f32c(s)
     B, cin, H, W = x.shape
     xs = torch.empty(B, cin // 8, 2, H * W, 8, device=x.device, dtype=torch.int16)
-    N.call('sgdfr_to_split_f32', N.ptr(x), N.ptr(s), N.ptr(xs), B, cin, H, W, arith, N.stream())
+    N.call('sgdfr_to_split_f32', N.ptr(x), N.ptr(s), N.ptr(xs), B, cin, H, W, arith, _sat(), N.stream())
     return xs
 
 
@@ -639,7 +687,7 @@ def blur_bias_act_split(planes, fir, H, W, s_next, noise=None, noise_weight=None
     xs = torch.empty(B, C // 8, 2, 4 * H * W, 8, device=planes.device, dtype=torch.int16)
     N.call('sgdfr_blur_bias_act_split_f32', N.ptr(planes), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
            N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(N.f32c(s_next)), N.ptr(xs), B, C, H, W,
-           int(plane_stride), arith, int(activate), float(slope), float(gain), N.stream())
+           int(plane_stride), arith, int(activate), float(slope), float(gain), _sat(), N.stream())
     return xs
 
 
@@ -777,7 +825,7 @@ def blur_adjoint_split(g, fir, planes=None, d=None, arith=None):
     xs = torch.empty(B, 4 * C // 8, 2, (H + 1) * (W + 1), 8, device=g.device, dtype=torch.int16)
     asum = torch.empty(B, C, device=g.device, dtype=torch.float32) if planes is not None else None
     N.call('sgdfr_blur_adjoint_split_f32', N.ptr(g), N.ptr(N.f32c(fir)), N.ptr(planes), N.ptr(N.f32c(d)) if d is not None else None,
-           N.ptr(xs), N.ptr(asum), B, C, H, W, arith, N.stream())
+           N.ptr(xs), N.ptr(asum), B, C, H, W, arith, _sat(), N.stream())
     return xs, asum
 
 

@@ -48,6 +48,23 @@ def _side_stream(device):
     return st
 
 
+class RangeToken:
+    """One no-grad fp16x3 forward's claim on its generator's saturation word: `snap` (pinned host int32) receives the word's
+    value right after the forward's last launch, `event` marks that copy; `delta` = pairs clamped by THIS forward, filled in
+    when the token is checked (Generator.range_ok / the non-blocking poll of the next forward)."""
+    __slots__ = ('event', 'snap', 'delta')
+
+    def __init__(self, event, snap):
+        self.event, self.snap, self.delta = event, snap, None
+
+
+_PINNED_WORDS = []      # free list of pinned int32 [1] host tensors (a fresh pin_memory() per forward would cost ~20 us)
+
+
+def _pinned_word():
+    return _PINNED_WORDS.pop() if _PINNED_WORDS else torch.zeros(1, dtype=torch.int32).pin_memory()
+
+
 def _needs_grad(*tensors):
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
@@ -378,14 +395,25 @@ class Generator(nn.Module):
 
     def invalidate_packs(self):
         """Forget every cached weight re-pack and launch plan.  Needed only after in-place edits through `.data`
-        (weight blending, EMA, `p.data.copy_()`), which PyTorch's version counter does not see; optimizer steps,
-        `load_state_dict`, `.to()` / `.cuda()` are tracked or invalidate on their own."""
+        (weight blending, EMA, `p.data.copy_()`), which PyTorch's version counter does not see, or after replacing a
+        Parameter object by assignment; optimizer steps, `load_state_dict` (also `assign=True`), `.to()` / `.cuda()` are
+        tracked or invalidate on their own."""
         for m in self.modules():
             if isinstance(m, ModulatedConv2d):
                 m.invalidate_packs()
         self._chain_plans = {}
         self._range_state = None
         self._plist = None
+        self._stamp_list = None
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)       # .to() / .cuda() / .float(): parameters may be new objects
+        self._chain_plans, self._range_state, self._plist, self._stamp_list = {}, None, None, None
+        return out
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)  # called once per load_state_dict (assign=True swaps the Parameters)
+        self._chain_plans, self._range_state, self._plist, self._stamp_list = {}, None, None, None
 
     # ---- latent-side helpers (model.py:449-469)
     def make_noise(self):
@@ -403,25 +431,132 @@ class Generator(nn.Module):
     def get_latent(self, input):
         return self.style(input)
 
-    # ---- range plan of the fp16-split arithmetic (functional.PRECISION == 'fp16x3')
-    SATURATION_POLL_EVERY = 64      # no-grad forwards between two reads of the device's saturation counter (each read syncs)
+    # ---- range plan of the fp16-split arithmetic (functional.PRECISION == 'fp16x3') and this generator's saturation word
+    MAX_PENDING_TOKENS = 8          # unchecked forwards in flight before a forward stops adding snapshots (host far ahead)
 
     def _params(self):
         """The parameter list, walked once and cached (nn.Module.parameters() costs ~0.15 ms per call on this module tree:
-        a seventh of a small-batch forward's host time); invalidate_packs() drops it."""
+        a seventh of a small-batch forward's host time); invalidate_packs() / .to() / load_state_dict drop it."""
         plist = getattr(self, '_plist', None)
         if plist is None:
             plist = self._plist = list(self.parameters())
         return plist
 
     def _weights_stamp(self):
-        """Cheap identity of the current weights: storage of one weight + the sum of all parameters' version counters."""
-        plist = self._params()
-        w = plist[0]
+        """Cheap identity of the current weights: storage of one weight + the sum of the version counters of all parameters
+        and of the fixed noise maps (they enter the activation ranges too)."""
+        tl = getattr(self, '_stamp_list', None)
+        if tl is None:
+            tl = self._stamp_list = self._params() + list(self.noises.buffers())
+        w = tl[0]
         v = 0
-        for p in plist:
+        for p in tl:
             v += p._version
         return (w.data_ptr(), w.device, v)
+
+    def _sat_word(self):
+        """This generator's saturation word (functional.saturation_sink): one int32 on the weights' device, owned by the
+        instance -- not a buffer (never in the state_dict), deep-copied with the module, re-made after .to(device)."""
+        dev = self.input.input.device
+        w = self.__dict__.get('_sat')
+        if w is None or w.device != dev:
+            w = self.__dict__['_sat'] = F_.new_saturation_word(dev)
+            self.__dict__['_sat_seen'] = 0
+            self.__dict__['_sat_tokens'] = []
+        return w
+
+    def __deepcopy__(self, memo):
+        # (optimization.py:28 deep-copies G) the copy gets its own word and no tokens of the original
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        skip = ('_sat', '_sat_seen', '_sat_tokens', '_graphs')
+        for k, v in self.__dict__.items():
+            if k not in skip:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        for k in ('_sat', '_sat_seen', '_sat_tokens', '_graphs'):
+            st.pop(k, None)
+        return st
+
+    def _snapshot(self):
+        """Queue an async copy of the saturation word into pinned host memory behind everything launched so far on the current
+        stream; returns the RangeToken (None while capturing a graph)."""
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        word = self._sat_word()
+        snap = _pinned_word()
+        snap.copy_(word, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        tok = RangeToken(ev, snap)
+        self._sat_tokens.append(tok)
+        return tok
+
+    def _check_tokens(self, upto=None):
+        """Resolve queued tokens in order: all that are complete (upto=None, never blocks) or everything up to and including
+        `upto` (blocks on its event).  Returns the number of newly seen saturated pairs."""
+        toks = self.__dict__.get('_sat_tokens')
+        new = 0
+        while toks:
+            tok = toks[0]
+            if upto is not None:
+                tok.event.synchronize()
+            elif not tok.event.query():
+                break
+            toks.pop(0)
+            val = int(tok.snap[0]) & 0xffffffff
+            tok.delta = (val - self._sat_seen) & 0xffffffff
+            self.__dict__['_sat_seen'] = val
+            new += tok.delta
+            _PINNED_WORDS.append(tok.snap)
+            tok.snap = None
+            if tok is upto:
+                break
+        return new
+
+    def saturated_pairs(self):
+        """fp16 operand pairs this generator's launches (forward and backward) clamped or found non-finite so far
+        (synchronises the device).  0 = the fp32-grade claim of the fp16x3 arithmetic held for everything it produced."""
+        return int(self._sat_word().item()) & 0xffffffff
+
+    def _fall_back(self, pairs, where):
+        st = getattr(self, '_range_state', None)
+        if st is not None and st['mode'] == 'fp16x3':
+            st['mode'] = 'bf16x3'
+            warnings.warn('Generator: %d fp16 operand pairs left the planned range (or were NaN/Inf) %s; this generator now runs '
+                          'the bf16x3 arithmetic (fp32 exponent range) until its weights change' % (pairs, where),
+                          RuntimeWarning, stacklevel=4)
+
+    def range_ok(self, token):
+        """Did the forward behind `token` stay inside the fp16 range plan?  Blocks until that forward has finished (and only that
+        far).  False: it clamped operands -- the generator has switched itself to bf16x3, re-render the batch."""
+        if token is None:
+            return True
+        if token.delta is None:
+            self._check_tokens(upto=token)
+        if token.delta:
+            self._fall_back(token.delta, 'in the forward just checked')
+            return False
+        return True
+
+    def range_mode(self):
+        """Arithmetic the next no-grad forward of this generator will run in ('fp16x3' with a live range plan, its fallback, or
+        functional.PRECISION when no plan applies)."""
+        st = getattr(self, '_range_state', None)
+        if F_.PRECISION == 'fp16x3' and F_.RANGE_PLAN is True and st is not None:
+            return st['mode']
+        return F_.PRECISION
+
+    def take_range_token(self):
+        """The RangeToken of the latest no-grad forward (None when that forward did not run in fp16x3)."""
+        tok = self.__dict__.get('_last_token')
+        self.__dict__['_last_token'] = None
+        return tok
 
     def _calibrate_ranges(self, latent, noise, specs, layers):
         """One forward of (at most 8 rows of) this batch on the fp32 kernels, recording max |x| of every 3x3 conv's input:
@@ -456,26 +591,25 @@ class Generator(nn.Module):
         st = getattr(self, '_range_state', None)
         stamp = self._weights_stamp()
         capturing = torch.cuda.is_current_stream_capturing()
+        self._sat_word()
         if st is None or st['stamp'] != stamp:
             if capturing:
                 raise RuntimeError('Generator: the first forward after a weight change calibrates activation ranges (one host '
                                    'read) and cannot run inside a graph capture: run one forward before capturing')
             x_log2, bad = self._calibrate_ranges(latent, noise, specs, layers)
-            st = self._range_state = {'stamp': stamp, 'x_log2': x_log2, 'mode': 'fp16x3', 'calls': 0,
-                                      'sat_seen': F_.split_saturation_count(reset=False)}
+            if self._sat_tokens:                        # forwards of the previous weights: settle them (the calibration synced anyway)
+                self._check_tokens(upto=self._sat_tokens[-1])
+            st = self._range_state = {'stamp': stamp, 'x_log2': x_log2, 'mode': 'fp16x3'}
             if bad:
                 st['mode'] = 'fp32'
                 warnings.warn('Generator: non-finite activations during range calibration; this generator runs on the fp32 '
                               'kernels until its weights change', RuntimeWarning, stacklevel=3)
-        elif st['mode'] == 'fp16x3' and not capturing and st['calls'] % self.SATURATION_POLL_EVERY == 1 % self.SATURATION_POLL_EVERY:
-            seen = F_.split_saturation_count(reset=False)       # results of the forwards so far (the first one included)
-            if seen > st['sat_seen']:
-                st['mode'] = 'bf16x3'
-                warnings.warn('Generator: %d fp16 operand pairs left the planned range (or were NaN/Inf) in earlier forwards; '
-                              'falling back to the bf16x3 arithmetic (fp32 exponent range) for this generator until its '
-                              'weights change' % (seen - st['sat_seen']), RuntimeWarning, stacklevel=3)
-            st['sat_seen'] = seen
-        st['calls'] += 1
+        elif st['mode'] == 'fp16x3' and not capturing and self._sat_tokens:
+            # every earlier forward left a token; the ones already finished are checked here WITHOUT blocking, so a
+            # saturating batch is noticed one or two forwards later even by callers that never ask (verify_range=False)
+            seen = self._check_tokens()
+            if seen:
+                self._fall_back(seen, 'in earlier forwards')
         if st['mode'] != 'fp16x3':
             return None, st['mode']
         conv_layer = {id(l.conv): i for i, l in enumerate(layers)}
@@ -484,10 +618,15 @@ class Generator(nn.Module):
 
     # ---- the path itself (model.py:471-539)
     def forward(self, styles, return_latents=False, return_features=False, inject_index=None, truncation=1,
-                truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=False, image_out=None):
-        """Reference signature (model.py:471-482) plus one optional extension: image_out = functional.U8Target makes a
-        no-grad forward return the image as uint8 HWC frames (the reference's tensor_to_image scaling), written by the last
-        ToRGB launch itself when that ToRGB is fused into its conv (otherwise converted by one extra launch)."""
+                truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=False, image_out=None,
+                verify_range=False):
+        """Reference signature (model.py:471-482) plus two optional extensions (no-grad forwards only):
+        image_out = functional.U8Target returns the image as uint8 HWC frames (the reference's tensor_to_image scaling), written
+        by the last ToRGB launch itself when that ToRGB is fused into its conv (otherwise converted by one extra launch);
+        verify_range=True waits for this forward and, if any fp16 operand left the range plan, re-renders the batch in the
+        bf16x3 arithmetic before returning (what generate_image and ReenactmentSession use: a clamped frame is never handed
+        back).  Without it the forward returns at once and leaves a RangeToken (take_range_token / range_ok); unchecked
+        tokens are polled without blocking by the following forwards."""
         if not input_is_latent:
             styles = [self.style(s) for s in styles]
         if noise is None:
@@ -510,33 +649,50 @@ class Generator(nn.Module):
             if inject_index is None:
                 inject_index = random.randint(1, self.n_latent - 1)
             latent = torch.cat([prepare(styles[0], inject_index), prepare(styles[1], self.n_latent - inject_index)], 1)
-        batch = latent.shape[0]
 
         order = [(self.conv1.conv, 0), (self.to_rgb1.conv, 1)]
         i = 1
         for conv1, conv2, to_rgb in zip(self.convs[::2], self.convs[1::2], self.to_rgbs):
             order += [(conv1.conv, i), (conv2.conv, i + 1), (to_rgb.conv, i + 2)]
             i += 2
-        if grad and not any(p.requires_grad for p in self._params()):
-            # frozen generator (the direction trainer): the two batched launches, differentiable w.r.t. the latent only
-            flat = iter(AG.StylesBatchedFn.apply(latent, order))
-            sd = iter([(next(flat), next(flat) if (m.kernel_size == 3 and m.demodulate) else None) for m, _ in order])
-        elif grad:   # differentiable per-layer modulation (autograd routes dL/ds back into the latent rows and the weights)
-            sd = iter([m.styles(latent[:, li]) for m, li in order])
         layers = [self.conv1] + list(self.convs)           # StyledConvs in execution order: plain, (up, plain) x n
         to_rgbs = [self.to_rgb1] + list(self.to_rgbs)      # to_rgbs[k] follows layers[2k]
-        ranged, arith = False, None                        # arith: this generator's fallback arithmetic, when it has one
-        if not grad:   # every layer's s = A_l(w_l) and demodulation d_l in two launches (instead of 33)
+        self.__dict__['_last_token'] = None
+        with F_.saturation_sink(self._sat_word()):         # every split launch below (and its backward) counts into OUR word
+            if grad:
+                if not any(p.requires_grad for p in self._params()):
+                    # frozen generator (the direction trainer): the two batched launches, differentiable w.r.t. the latent only
+                    flat = iter(AG.StylesBatchedFn.apply(latent, order))
+                    sd = [(next(flat), next(flat) if (m.kernel_size == 3 and m.demodulate) else None) for m, _ in order]
+                else:   # differentiable per-layer modulation (autograd routes dL/ds back into the latent rows and the weights)
+                    sd = [m.styles(latent[:, li]) for m, li in order]
+                # (the autograd forward plans every conv from the true max |x| of each image: it cannot saturate on finite data)
+                return self._synthesis(latent, sd, layers, to_rgbs, noise, True, False, return_latents, image_out)
+            # no-grad: every layer's s = A_l(w_l) and demodulation d_l in two launches (instead of 33)
             specs = [m.style_spec(li) for m, li in order]
-            plans = None
-            if F_.PRECISION == 'fp16x3' and F_.RANGE_PLAN:
+            plans, arith = None, None                      # arith: this generator's fallback arithmetic, when it has one
+            if F_.PRECISION == 'fp16x3' and F_.RANGE_PLAN is True:
                 plans, arith = self._range_plans(latent, noise, specs, order, layers)
-                ranged = plans is not None
-            sd = iter(F_.styles_batched(latent, specs, plans))
-        if arith is not None and arith != F_.PRECISION:    # saturation / non-finite fallback: run this forward in `arith`
-            with F_.precision(arith):
-                return self._synthesis(latent, list(sd), layers, to_rgbs, noise, grad, ranged, return_latents, image_out)
-        return self._synthesis(latent, list(sd), layers, to_rgbs, noise, grad, ranged, return_latents, image_out)
+            if arith is not None and arith != F_.PRECISION:    # saturation / non-finite fallback: run this forward in `arith`
+                with F_.precision(arith):
+                    return self._synthesis(latent, F_.styles_batched(latent, specs), layers, to_rgbs, noise, False, False,
+                                           return_latents, image_out)
+            out = self._synthesis(latent, F_.styles_batched(latent, specs, plans), layers, to_rgbs, noise, False,
+                                  plans is not None, return_latents, image_out)
+            if plans is None:
+                return out
+            toks = self._sat_tokens
+            if not verify_range and len(toks) >= self.MAX_PENDING_TOKENS:
+                return out                                 # the host is far ahead of the device: the next poll catches up
+            tok = self._snapshot()
+            if not verify_range or tok is None:
+                self.__dict__['_last_token'] = tok
+                return out
+            if self.range_ok(tok):
+                return out
+            with F_.precision('bf16x3'):                   # this batch clamped operands: render it again, now in bf16 terms
+                return self._synthesis(latent, F_.styles_batched(latent, specs), layers, to_rgbs, noise, False, False,
+                                       return_latents, image_out)
 
     def _synthesis(self, latent, sd, layers, to_rgbs, noise, grad, ranged, return_latents, image_out=None):
         """conv1 ... convs / to_rgbs with the (s, d) pairs of `sd` (one per entry of conv1, to_rgb1, (up, plain, to_rgb)*)."""
@@ -546,7 +702,8 @@ class Generator(nn.Module):
         # inference on the split kernels: layers are launched through functional.styled_conv_split, not through their
         # modules -- unless somebody hooked a layer's forward (per-layer probes), then every module really runs
         hooked = any(m._forward_hooks or m._forward_pre_hooks for m in layers + to_rgbs)
-        chain = (not grad) and (not hooked) and F_.PRECISION in ('fp16x3', 'bf16x3')
+        chain = (not grad) and (not hooked) and F_.PRECISION in ('fp16x3', 'bf16x3') and \
+            not (F_.PRECISION == 'fp16x3' and F_.RANGE_PLAN == 'exact')       # 'exact': fp32 hand-over, max |x| measured per layer
 
         # The RGB branch: a fused ToRGB (partial sums from the conv epilogue) is finished by a small launch on the main
         # stream; an unfused one (HBM-bound kernel re-reading the activation) runs on a side HIP stream next to the conv chain.

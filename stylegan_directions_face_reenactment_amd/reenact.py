@@ -134,6 +134,9 @@ class ReenactmentSession:
         return img
 
     def _graphed_step(self, sv):
+        mode = self.G.range_mode()
+        if self._graph is not None and self._graph[3] != mode:          # the generator changed arithmetic (fallback / new weights)
+            self._graph = None
         if self._graph is None:
             static_sv = sv.clone()
             side = torch.cuda.Stream()
@@ -142,26 +145,57 @@ class ReenactmentSession:
                 for _ in range(2):
                     self._step(static_sv)
             torch.cuda.current_stream().wait_stream(side)
+            mode = self.G.range_mode()                                      # (the warm-up may have calibrated / fallen back)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 static_out = self._step(static_sv)
-            self._graph = (g, static_sv, static_out)
-        g, static_sv, static_out = self._graph
+            self._graph = (g, static_sv, static_out, mode)
+        g, static_sv, static_out, mode = self._graph
         static_sv.copy_(sv)
         g.replay()
-        return static_out.clone()
+        # the captured launches add to the generator's saturation word like eager ones: snapshot it behind the replay
+        tok = self.G._snapshot() if mode == 'fp16x3' else None
+        return static_out.clone(), tok
+
+    def _pipeline(self, shift_vectors, target_for=None):
+        """(lo, image batch) for every chunk of `shift_vectors`, each VERIFIED against the generator's fp16 range plan before
+        it is yielded: chunk i+1 is queued first, then chunk i's RangeToken is awaited (the GPU never idles for the check), and
+        a chunk that clamped operands is rendered again in the generator's fallback arithmetic.  target_for(lo, b) ->
+        functional.U8Target or None (eager chunks: the last ToRGB launch writes uint8 frames)."""
+        n = shift_vectors.shape[0]
+        pending = None
+
+        def launch(lo):
+            sv = shift_vectors[lo:lo + self.batch]
+            u8 = target_for(lo, sv.shape[0]) if target_for is not None else None
+            if self.use_graph and sv.shape[0] == self.batch:
+                img, tok = self._graphed_step(sv)
+                return [lo, sv, u8, img, tok, True]
+            img = self._step(sv, u8)
+            return [lo, sv, u8, img, self.G.take_range_token(), False]
+
+        def settle(item):
+            lo, sv, u8, img, tok, graphed = item
+            if not self.G.range_ok(tok):                                    # clamped: this chunk again, eagerly, in bf16x3
+                self._graph = None
+                img, graphed = self._step(sv, u8), False
+            return lo, sv, u8, img, graphed
+
+        for lo in range(0, n, self.batch):
+            cur = launch(lo)
+            if pending is not None:
+                yield settle(pending)
+            pending = cur
+        if pending is not None:
+            yield settle(pending)
 
     @torch.no_grad()
     def frames(self, shift_vectors, as_uint8=False):
         """shift_vectors [N, input_dim] -> generator of image batches (same result as N generate_image calls)."""
-        n = shift_vectors.shape[0]
-        for lo in range(0, n, self.batch):
-            sv = shift_vectors[lo:lo + self.batch]
-            if self.use_graph and sv.shape[0] == self.batch:
-                img = self._graphed_step(sv)
-                yield images_to_uint8(img) if as_uint8 else img
-            else:       # uint8 frames come straight out of the last ToRGB launch (no fp32 image is stored)
-                yield self._step(sv, F_.U8Target() if as_uint8 else None)
+        for lo, sv, u8, img, graphed in self._pipeline(shift_vectors, (lambda lo, b: F_.U8Target()) if as_uint8 else None):
+            # eager uint8 frames come straight out of the last ToRGB launch (no fp32 image is stored); a replayed graph
+            # produced fp32 images
+            yield images_to_uint8(img) if (as_uint8 and graphed) else img
 
     def render(self, shift_vectors, as_uint8=False):
         return torch.cat(list(self.frames(shift_vectors, as_uint8=as_uint8)), 0)
@@ -187,13 +221,9 @@ class ReenactmentSession:
         n = shift_vectors.shape[0]
         H, W = source_image.shape[-2], source_image.shape[-1]
         video = torch.empty(n, H, 3 * W, 3, device=shift_vectors.device, dtype=torch.uint8)
-        for lo in range(0, n, self.batch):
-            sv = shift_vectors[lo:lo + self.batch]
+        # eager chunks: the reenacted panel is written by the generator's last launch; the other two by one grid launch
+        target_for = lambda lo, b: F_.U8Target(video[lo:lo + b], panel=2, swap_rb=swap_rb)
+        for lo, sv, u8, img, graphed in self._pipeline(shift_vectors, target_for):
             frames = video[lo:lo + sv.shape[0]]
-            if self.use_graph and sv.shape[0] == self.batch:
-                grid_frames_uint8([source_image, target_images[lo:lo + sv.shape[0]], self._graphed_step(sv)], swap_rb=swap_rb, out=frames)
-                continue
-            # the reenacted panel is written by the generator's last launch; the other two by one grid launch
-            self._step(sv, F_.U8Target(frames, panel=2, swap_rb=swap_rb))
-            grid_frames_uint8([source_image, target_images[lo:lo + sv.shape[0]], None], swap_rb=swap_rb, out=frames)
+            grid_frames_uint8([source_image, target_images[lo:lo + sv.shape[0]], img if graphed else None], swap_rb=swap_rb, out=frames)
         return video

@@ -10,8 +10,15 @@ The reference pulls every 3DMM parameter to the host (``.detach().cpu().numpy()`
 uploads the 15 numbers again -- once per target frame.  Here ``params_*`` / ``angles_*`` stay device tensors for the whole
 batch ([N,3] angles, ``params['pose']`` [N,6], ``params['alpha_exp']`` [N,50]) and one launch of ``sgdfr_make_shift_f32``
 writes the [N, learned_directions] matrix; nothing synchronises.  The per-direction recipe (which parameter, which affine
-map) is a small host table handed to the kernel by value.  Both reference call sites' arithmetic is reproduced bit for bit
-(float64 numpy scalars in run_inference.py, float32 tensors in utils_train.py): see csrc/shift.hip.
+map) is a small host table handed to the kernel by value.  Both reference call sites' arithmetic is mirrored operation by
+operation (float64 numpy scalars in run_inference.py, float32 tensors in utils_train.py; csrc/shift.hip) and is bit-identical
+to goldens captured from the real functions run on CPU tensors (tests/test_gpu_shift.py); against the reference on a CUDA
+device the float32 path can differ by 1 ulp where that device's division is not correctly rounded.
+
+Inputs: device tensors (float32), or numpy arrays / lists, which are uploaded to the current device; CPU torch tensors are
+refused like everywhere in this package.  One deliberate difference in return types: `make_shift_vector_50` returns
+`target_indices` as an int32 DEVICE tensor (no host sync in the training step) where utils_train.py:184-188 returns a host
+numpy array -- pass `indices_on_host=True` for the reference's type.
 """
 import os
 
@@ -84,10 +91,9 @@ def _table(entries, D):
 
 
 def _dev(t, like=None):
-    if not isinstance(t, torch.Tensor):
+    if not isinstance(t, torch.Tensor):     # numpy / lists: uploaded next to `like`, or to the current device
         t = torch.as_tensor(np.asarray(t), dtype=torch.float32)
-        if like is not None:
-            t = t.to(like.device)
+        t = t.to(like.device if like is not None else torch.device('cuda', torch.cuda.current_device()))
     N.require_device(t)
     return N.f32c(t)
 
@@ -148,10 +154,13 @@ class ShiftVectors:
         """utils_train.py:127-175: [B, learned_directions] in float32 tensor arithmetic."""
         return self._launch(self._table_train, 1, angles_source, angles_target, param_source, param_target)
 
-    def make_shift_vector_50(self, param_source, param_target, angles_source, angles_target, target_indices=None, u=None):
+    def make_shift_vector_50(self, param_source, param_target, angles_source, angles_target, target_indices=None, u=None,
+                             indices_on_host=False):
         """utils_train.py:177-288: first half of the batch = full reenactment shift, second half = one random direction
-        each.  Returns (shift_vector [B,D], target_indices [B/2] int32 on the device).  `target_indices` / `u` may be given
-        (the reference draws them with np.random.choice / torch.rand); by default they are drawn on the device."""
+        each.  Returns (shift_vector [B,D], target_indices [B/2]): the indices as an int32 device tensor, or -- with
+        indices_on_host=True -- as the host numpy array the reference returns (one device->host sync).  `target_indices` /
+        `u` may be given (the reference draws them with np.random.choice / torch.rand); by default they are drawn on the
+        device."""
         ang_s, ang_t = _dev(angles_source), _dev(angles_target)
         B = ang_s.shape[0]
         if B % 2 != 0:
@@ -173,4 +182,4 @@ class ShiftVectors:
         a2, p2, e2 = ang_s[h:], ps[h:], es[h:]                                    # row slices of contiguous tensors
         N.call('sgdfr_make_shift_random_f32', N.ptr(a2), N.ptr(p2), N.ptr(e2), p2.shape[1], e2.shape[1],
                N.ptr(which), N.ptr(u), float(self.shift_scale), self._table_train, D, N.ptr(out[h:]), h, N.stream())
-        return out, which
+        return out, (which.cpu().numpy() if indices_on_host else which)

@@ -452,9 +452,8 @@ def test_generator_with_low_magnitude_layers():
     w = S.synthetic_latents(SEED, 2, n_latent=G.n_latent, key='lowmag.w')
     with torch.no_grad():
         ref, _ = O.generator_forward(O.cast_state(state, torch.float64), [w.double()], input_is_latent=True)
-        F_.split_saturation_count(reset=True)
         img, _ = G([w.cuda()], input_is_latent=True)
-        assert F_.split_saturation_count(reset=True) == 0 and G._range_state['mode'] == 'fp16x3'
+        assert G.saturated_pairs() == 0 and G._range_state['mode'] == 'fp16x3'
         with F_.precision('fp32'):
             img32, _ = G([w.cuda()], input_is_latent=True)
     scale = max(1.0, float(ref.abs().max()))
@@ -465,24 +464,28 @@ def test_generator_with_low_magnitude_layers():
 
 def test_saturation_is_counted_and_generator_falls_back():
     """Activations far outside the calibrated range (here: a noise map 1e9 times stronger than the calibrated one) clamp,
-    are COUNTED, and the generator switches itself to bf16x3 at its next poll, with a warning -- never silently."""
+    are COUNTED in the generator's own word, and the generator switches itself to bf16x3 with a warning -- never silently.
+    A plain forward (verify_range=False) does not block: the following forward's non-blocking poll notices."""
     import warnings
     from stylegan_directions_face_reenactment_amd import functional as F_
     G = hip_generator(64, 1)
-    G.SATURATION_POLL_EVERY = 1
     w = S.synthetic_latents(SEED, 16, n_latent=G.n_latent, key='sat.w').cuda()
     noises = [getattr(G.noises, 'noise_%d' % i) for i in range(G.num_layers)]
     with torch.no_grad():
         F_.split_saturation_count(reset=True)
         ok, _ = G([w], input_is_latent=True)
-        assert G._range_state['mode'] == 'fp16x3'
+        assert G._range_state['mode'] == 'fp16x3' and G.saturated_pairs() == 0
         loud = [n * 1e9 if i == 4 else n for i, n in enumerate(noises)]
         G([w], input_is_latent=True, noise=loud)
-        assert F_.split_saturation_count(reset=False) > 0
+        tok = G.take_range_token()
+        assert tok is not None and G.saturated_pairs() > 0
+        assert F_.split_saturation_count(reset=False) == 0          # a generator's launches never touch the device-wide counter
+        torch.cuda.synchronize()                                    # (the poll below is non-blocking: let the forward finish)
         with warnings.catch_warnings(record=True) as rec:
             warnings.simplefilter('always')
             again, _ = G([w], input_is_latent=True)
-        assert G._range_state['mode'] == 'bf16x3' and any('falling back' in str(r.message) for r in rec)
+        assert G._range_state['mode'] == 'bf16x3' and any('bf16x3' in str(r.message) for r in rec)
+        assert tok.delta and not G.range_ok(tok)
         with F_.precision('bf16x3'):
             bf, _ = G([w], input_is_latent=True)
         assert torch.equal(again, bf) and not torch.equal(again, ok)
@@ -490,14 +493,108 @@ def test_saturation_is_counted_and_generator_falls_back():
         G.load_state_dict(synthetic_state(64, 1))
         G([w], input_is_latent=True)
         assert G._range_state['mode'] == 'fp16x3'
-        # NaN operands are counted too (v_med3 would turn them into finite values)
+        # NaN operands are counted too (v_med3 would turn them into finite values); stand-alone launches: the legacy counter
         F_.split_saturation_count(reset=True)
         x = S.counter_tensor(15, 'nan.x', (2, 64, 16, 16)).cuda()
         x[1, 3, 2, 2] = float('nan')
         s = S.counter_tensor(15, 'nan.s', (2, 64), 1.0, 0.3).cuda()
         d = torch.ones(2, 64).cuda()
-        F_.modconv_split(x, F_.prepack_split(S.counter_tensor(15, 'nan.w', (1, 64, 64, 3, 3)).cuda(), 'fp16x3'), s, d, 64, arith='fp16x3')
+        wsp = F_.prepack_split(S.counter_tensor(15, 'nan.w', (1, 64, 64, 3, 3)).cuda(), 'fp16x3')
+        F_.modconv_split(x, wsp, s, d, 64, arith='fp16x3')
         assert F_.split_saturation_count(reset=True) > 0
+        # ... or the caller's own word
+        word = F_.new_saturation_word(x.device)
+        with F_.saturation_sink(word):
+            F_.modconv_split(x, wsp, s, d, 64, arith='fp16x3')
+        assert int(word.item()) > 0 and F_.split_saturation_count(reset=True) == 0
+
+
+def _loud_noise(G, factor=2.0 ** 14, layer=4):
+    return [getattr(G.noises, 'noise_%d' % i) * (factor if i == layer else 1.0) for i in range(G.num_layers)]
+
+
+def test_a_clamped_batch_is_never_returned_and_neighbours_are_unaffected():
+    """VERDICT r2 #2.  Batch 1 calibrates the range plan; batch 2 drives one layer's input ~2^8 past the plan's headroom (a
+    2^14 times stronger noise map at one level), so its fp16 operands clamp.  Every frame the verified entry points return
+    (Generator.forward(verify_range=True), generate_image, ReenactmentSession) must still match the oracle -- the batch is
+    re-rendered in bf16x3 before it is handed back -- and a second generator in the same process keeps its own word, its
+    arithmetic and its bits."""
+    import warnings
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    from stylegan_directions_face_reenactment_amd.generic import generate_image
+    if F_.PRECISION != 'fp16x3':
+        pytest.skip('range plan / saturation are fp16x3 matters')
+    state = synthetic_state(64, 1)
+    G, G2 = hip_generator(64, 1), hip_generator(64, 1)
+    w = S.synthetic_latents(SEED, 6, n_latent=G.n_latent, key='clamp.w')
+    wd = w.cuda()
+    with torch.no_grad():
+        first, _ = G([wd], input_is_latent=True, verify_range=True)             # batch 1: calibrates, in range
+        other, _ = G2([wd], input_is_latent=True, verify_range=True)
+        assert torch.equal(first, other) and G.saturated_pairs() == 0
+        loud = _loud_noise(G)
+        ref, _ = O.generator_forward(O.cast_state(state, torch.float64), [w.double()], input_is_latent=True,
+                                     noise=[n.cpu().double() for n in loud])
+        scale = float(ref.abs().max())
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter('always')
+            got, _ = G([wd], input_is_latent=True, noise=loud, verify_range=True)     # batch 2: clamps -> re-rendered
+        assert G.saturated_pairs() > 0 and G._range_state['mode'] == 'bf16x3'
+        assert any('bf16x3' in str(r.message) for r in rec)
+        err = maxabs(got, ref)
+        print('clamped batch: max|ref| %.1f, returned frames vs fp64 oracle %.2e (rel %.1e)' % (scale, err, err / scale))
+        assert err <= 1e-3 * max(1.0, scale)
+        # what an unverified fp16x3 forward of the same batch would have handed back is NOT within the bar: the test bites
+        G3 = hip_generator(64, 1)
+        G3([wd], input_is_latent=True)
+        bad, _ = G3([wd], input_is_latent=True, noise=loud)
+        assert maxabs(bad, ref) > 1e-3 * max(1.0, scale)
+        # the neighbour: own word untouched, still fp16x3, same bits as before
+        after, _ = G2([wd], input_is_latent=True, verify_range=True)
+        assert G2.saturated_pairs() == 0 and G2._range_state['mode'] == 'fp16x3' and torch.equal(after, other)
+        # generate_image verifies by itself (fresh generator: calibrate on the quiet batch, then the loud one through its buffers)
+        G4 = hip_generator(64, 1)
+        quiet = generate_image(G4, wd, 1.0, None, input_is_latent=True)
+        assert maxabs(quiet, first) == 0.0
+        G4.noises.noise_4.mul_(2.0 ** 14)
+        st4 = G4._range_state
+        G4._range_state = dict(st4, stamp=G4._weights_stamp())        # keep the quiet calibration: the buffers changed under the plan
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            img = generate_image(G4, wd, 1.0, None, input_is_latent=True)
+        assert G4.saturated_pairs() > 0 and maxabs(img, ref) <= 1e-3 * max(1.0, scale)
+
+
+def test_reenactment_session_rerenders_a_clamped_batch():
+    """ReenactmentSession checks batch i's token while batch i+1 is already queued (one batch of look-ahead, no idle GPU) and
+    re-renders what clamped: the frames it yields equal a bf16x3 / fp32-grade rendering, eager and graph-replayed alike."""
+    import warnings
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    from stylegan_directions_face_reenactment_amd.direction_matrix import DirectionMatrix
+    from stylegan_directions_face_reenactment_amd.reenact import ReenactmentSession
+    if F_.PRECISION != 'fp16x3':
+        pytest.skip('range plan / saturation are fp16x3 matters')
+    A = DirectionMatrix(512, input_dim=15, out_dim=512, w_plus=True, num_layers=8, verbose=False)
+    A.load_state_dict(S.synthetic_direction_state(SEED))
+    A = A.cuda().eval()
+    src = S.synthetic_latents(SEED, 1, n_latent=10, key='sess.src').cuda()
+    sv = S.counter_tensor(SEED, 'sess.sv', (10, 15), 0.0, 3.0).cuda()
+    for graph in (False, True):
+        G = hip_generator(64, 1)
+        sess = ReenactmentSession(G, A, src, truncation=1.0, batch=4, graph=graph)
+        with torch.no_grad():
+            quiet = sess.render(sv)                                   # calibrates; in range
+            assert G.saturated_pairs() == 0
+            G.noises.noise_4.mul_(2.0 ** 14)
+            G._range_state = dict(G._range_state, stamp=G._weights_stamp())       # keep the quiet plan
+            sess.reset_graph()
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                loud = sess.render(sv)
+            assert G.saturated_pairs() > 0 and G._range_state['mode'] == 'bf16x3'
+            with F_.precision('bf16x3'):
+                want = ReenactmentSession(G, A, src, truncation=1.0, batch=4).render(sv)
+            assert torch.equal(loud, want) and not torch.equal(loud, quiet), graph
 
 
 def test_invalidate_packs_after_data_write():
