@@ -17,6 +17,7 @@ The discriminator-side classes of the reference file (model.py:542-709: ConvLaye
 Discriminator, Encoder, ...) are never instantiated by the reenactment scripts and are out of scope.
 """
 import math
+import os
 import random
 import struct
 import warnings
@@ -38,6 +39,7 @@ def make_kernel(k):
 
 
 _SIDE_STREAMS = {}
+USE_GRAPHS = os.environ.get('SGDFR_GRAPHS', '1') != '0'      # hipGraph replay of repeated no-grad forwards (Generator.forward)
 
 
 def _side_stream(device):
@@ -405,15 +407,18 @@ class Generator(nn.Module):
         self._range_state = None
         self._plist = None
         self._stamp_list = None
+        self._drop_graphs()
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)       # .to() / .cuda() / .float(): parameters may be new objects
         self._chain_plans, self._range_state, self._plist, self._stamp_list = {}, None, None, None
+        self._drop_graphs()
         return out
 
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)  # called once per load_state_dict (assign=True swaps the Parameters)
         self._chain_plans, self._range_state, self._plist, self._stamp_list = {}, None, None, None
+        self._drop_graphs()
 
     # ---- latent-side helpers (model.py:449-469)
     def make_noise(self):
@@ -471,7 +476,7 @@ class Generator(nn.Module):
         cls = self.__class__
         new = cls.__new__(cls)
         memo[id(self)] = new
-        skip = ('_sat', '_sat_seen', '_sat_tokens', '_graphs')
+        skip = ('_sat', '_sat_seen', '_sat_tokens', '_graphs', '_graph_calls', '_last_token', '_plist', '_stamp_list', '_all_mods')
         for k, v in self.__dict__.items():
             if k not in skip:
                 new.__dict__[k] = copy.deepcopy(v, memo)
@@ -479,7 +484,7 @@ class Generator(nn.Module):
 
     def __getstate__(self):
         st = dict(self.__dict__)
-        for k in ('_sat', '_sat_seen', '_sat_tokens', '_graphs'):
+        for k in ('_sat', '_sat_seen', '_sat_tokens', '_graphs', '_graph_calls', '_last_token', '_plist', '_stamp_list', '_all_mods'):
             st.pop(k, None)
         return st
 
@@ -617,9 +622,114 @@ class Generator(nn.Module):
         return plans, 'fp16x3'
 
     # ---- the path itself (model.py:471-539)
+    GRAPH_AFTER = 2                 # eager no-grad forwards of one signature before the next one is captured as a hipGraph
+    MAX_GRAPHS = 4                  # captured signatures kept per generator (each holds its intermediates in a private pool)
+
+    def _drop_graphs(self):
+        self.__dict__.pop('_graphs', None)
+        self.__dict__.pop('_graph_calls', None)
+
+    def _graph_key(self, styles, return_latents, inject_index, truncation, truncation_latent, input_is_latent, noise,
+                   randomize_noise, image_out):
+        """Signature under which a no-grad forward may be replayed as a hipGraph, or None when it must run eagerly: gradients,
+        style mixing, caller-supplied or fresh noise, a caller-owned uint8 target, hooks, an enclosing capture, bench timing."""
+        if not USE_GRAPHS or not getattr(self, 'use_graphs', True) or torch.is_grad_enabled() or F_.CONV_TIMING is not None:
+            return None
+        if len(styles) != 1 or inject_index is not None or noise is not None or randomize_noise:
+            return None
+        w = styles[0]
+        if not isinstance(w, torch.Tensor) or not w.is_cuda or w.dtype != torch.float32 or w.requires_grad:
+            return None
+        if image_out is not None and image_out.frames is not None:
+            return None
+        if truncation < 1 and truncation_latent is None:
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        mods = self.__dict__.get('_all_mods')
+        if mods is None:
+            mods = self.__dict__['_all_mods'] = list(self.modules())
+        for m in mods:
+            if m._forward_hooks or m._forward_pre_hooks:
+                return None
+        u8 = None if image_out is None else ('u8', image_out.swap_rb)
+        return (tuple(w.shape), bool(input_is_latent), bool(return_latents), float(truncation),
+                None if truncation >= 1 else tuple(truncation_latent.shape), u8, F_.PRECISION, F_.RANGE_PLAN, F_.USE_SPLIT_CHAIN,
+                F_.USE_RGB_FUSION, F_.USE_SPLITK, F_.USE_PLANE_PADDING, bool(self.overlap_rgb), w.device)
+
     def forward(self, styles, return_latents=False, return_features=False, inject_index=None, truncation=1,
                 truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=False, image_out=None,
-                verify_range=False):
+                verify_range=False, graph=None):
+        """Reference signature (model.py:471-482) plus optional extensions (no-grad forwards only): image_out / verify_range
+        (see _forward_impl) and graph (None: the default policy below, False: always launch eagerly).
+
+        hipGraph replay.  A no-grad forward is ~65 dependent launches (~6.5 us apart on the device, ~1 ms of Python at any
+        batch size).  From the third forward of one signature (input shape, flags, arithmetic) on, the launch sequence is
+        captured once and REPLAYED: the latent (and truncation latent) are copied into the graph's static inputs, one graph
+        launch runs the identical kernels on the identical arguments (bit-identical images), and the outputs are cloned out of
+        the graph's static buffers.  Weight changes (tracked like the weight packs; after `.data` edits call
+        invalidate_packs()), a change of arithmetic / range plan, hooks, style mixing, caller-supplied noise and
+        randomize_noise run eagerly.  Switch off: `G.use_graphs = False` or SGDFR_GRAPHS=0."""
+        key = None if graph is False else self._graph_key(styles, return_latents, inject_index, truncation, truncation_latent,
+                                                           input_is_latent, noise, randomize_noise, image_out)
+        if key is None:
+            return self._forward_impl(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
+                                      input_is_latent, noise, randomize_noise, image_out, verify_range)
+        graphs = self.__dict__.setdefault('_graphs', {})
+        calls = self.__dict__.setdefault('_graph_calls', {})
+        stamp, mode = self._weights_stamp(), self.range_mode()
+        entry = graphs.get(key)
+        if entry is not None and (entry['stamp'] != stamp or entry['mode'] != mode):
+            self._drop_graphs()                            # new weights / the generator changed arithmetic: every graph is stale
+            graphs = self.__dict__.setdefault('_graphs', {})
+            calls = self.__dict__.setdefault('_graph_calls', {})
+            entry = None
+        w = styles[0]
+        trunc = truncation_latent if truncation < 1 else None
+        if entry is None:
+            n = calls.get(key, 0)
+            if n < self.GRAPH_AFTER:                       # not yet: packs, launch plans and the range calibration settle eagerly
+                calls[key] = n + 1
+                return self._forward_impl(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
+                                          input_is_latent, None, False, image_out, verify_range)
+            st = getattr(self, '_range_state', None)
+            if F_.PRECISION == 'fp16x3' and F_.RANGE_PLAN is True and (st is None or st['stamp'] != stamp):
+                return self._forward_impl(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
+                                          input_is_latent, None, False, image_out, verify_range)       # calibrate first (host read)
+            s_in = w.detach().clone()
+            s_tr = trunc.detach().clone() if trunc is not None else None
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._forward_impl([s_in], return_latents, False, None, truncation, s_tr, input_is_latent, None, False,
+                                         None if image_out is None else F_.U8Target(None, 0, image_out.swap_rb), False)
+            mode = self.range_mode()
+            entry = {'graph': g, 'in': s_in, 'trunc': s_tr, 'out': out, 'stamp': stamp, 'mode': mode}
+            while len(graphs) >= self.MAX_GRAPHS:
+                graphs.pop(next(iter(graphs)))
+            graphs[key] = entry
+        entry['in'].copy_(w)
+        if entry['trunc'] is not None:
+            entry['trunc'].copy_(trunc)
+        entry['graph'].replay()
+        img, lat = entry['out']
+        res = (img.clone(), lat.clone() if lat is not None else None)
+        self.__dict__['_last_token'] = None
+        if entry['mode'] == 'fp16x3' and F_.PRECISION == 'fp16x3' and F_.RANGE_PLAN is True:
+            # the captured launches add to this generator's saturation word like eager ones: snapshot it behind the replay
+            if verify_range or len(self._sat_tokens) < self.MAX_PENDING_TOKENS:
+                tok = self._snapshot()
+                if not verify_range:
+                    self.__dict__['_last_token'] = tok
+                elif not self.range_ok(tok):               # this batch clamped operands: render it again (eagerly, now in bf16x3)
+                    self._drop_graphs()
+                    return self._forward_impl(styles, return_latents, return_features, inject_index, truncation,
+                                              truncation_latent, input_is_latent, None, False, image_out, False)
+        return res
+
+    def _forward_impl(self, styles, return_latents=False, return_features=False, inject_index=None, truncation=1,
+                      truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=False, image_out=None,
+                      verify_range=False):
         """Reference signature (model.py:471-482) plus two optional extensions (no-grad forwards only):
         image_out = functional.U8Target returns the image as uint8 HWC frames (the reference's tensor_to_image scaling), written
         by the last ToRGB launch itself when that ToRGB is fused into its conv (otherwise converted by one extra launch);

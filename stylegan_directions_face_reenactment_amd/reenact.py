@@ -129,8 +129,10 @@ class ReenactmentSession:
         w = self.source.expand(b, -1, -1).contiguous()
         layers = shift.shape[1] if shift.ndim == 3 else self.A.num_layers
         latent = F_.latent_prepare(w, self.G.n_latent, shift=shift, shift_layers=layers)
+        # (a session with graph=True captures the whole step itself -- DirectionMatrix and latent shift included -- so the
+        # generator's own per-forward graphs stay out of it)
         img, _ = self.G([latent], input_is_latent=True, truncation=self.truncation, truncation_latent=self.trunc,
-                        image_out=image_out)
+                        image_out=image_out, graph=False if self.use_graph else None)
         return img
 
     def _graphed_step(self, sv):

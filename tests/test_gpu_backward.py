@@ -155,6 +155,94 @@ def test_direction_matrix_gradient_golden():
         assert _rel(A.linear.bias.grad, t(g['%s.gAb' % path])) <= 1e-4, path
 
 
+_C5_ORACLE = {}
+
+
+def _config5_oracle(B, lr, wd):
+    """fp64 oracle of one direction-learning step at config 5's per-rank shape, by torch autograd, in chunks of 2 images
+    (bounded memory); cached: both arithmetics compare against the same numbers."""
+    if B in _C5_ORACLE:
+        return _C5_ORACLE[B]
+    from oracle import shift_oracle as SO
+    g8 = golden('kat8_shift.npz')
+    cfg = SO.initialize_directions('voxceleb', 15, 6.0, g8['ranges_voxceleb'])
+    ang_s, par_s = S.synthetic_shape_params(SEED, 'c5.src', B)
+    ang_t, par_t = S.synthetic_shape_params(SEED, 'c5.tgt', B)
+    which = (torch.arange(B // 2) * 7 + 3) % 15                              # injected draws (np.random.choice / torch.rand in
+    u = S.counter_tensor(SEED, 'c5.u', (B // 2,), 0.5, 0.25).clamp_(0.0, 1.0)   # utils_train.py:184-190)
+    sv = torch.as_tensor(SO.make_shift_vector_50(cfg, par_s, par_t, ang_s, ang_t, which.numpy(), u))
+    P = O.cast_state(synthetic_state(256, 1), torch.float64)
+    A0 = S.synthetic_direction_state(SEED)
+    A = {k: v.double().requires_grad_(True) for k, v in A0.items()}
+    z = S.synthetic_z(SEED, B, key='c5.z')
+    trunc = O.mapping(P, S.synthetic_z(SEED, 64, key='c5.tz').double()).mean(0, keepdim=True)      # mean latent of a fixed z batch
+    loss = 0.0
+    for lo in range(0, B, 2):
+        img = O.generate_image(P, z[lo:lo + 2].double(), 0.7, trunc, shift_code=O.direction_matrix(A, sv[lo:lo + 2].double()),
+                               input_is_latent=False)
+        part = (img ** 2).sum() / (B * img[0].numel())                      # L = mean(img^2) over the whole batch
+        part.backward()
+        loss += float(part)
+    grads = {k: v.grad.clone() for k, v in A.items()}
+    opt = torch.optim.Adam(list(A.values()), lr=lr, weight_decay=wd)        # trainer.py:145
+    opt.step()
+    _C5_ORACLE[B] = dict(sv=sv, which=which, u=u, z=z, trunc=trunc.float(), loss=loss, grads=grads,
+                         stepped={k: v.detach().clone() for k, v in A.items()}, A0=A0,
+                         shape=((ang_s, par_s), (ang_t, par_t)))
+    return _C5_ORACLE[B]
+
+
+@pytest.mark.timeout(1500)
+def test_config5_direction_step_at_per_rank_size():
+    """BASELINE configs[4] at its REAL per-rank shape (B=16, 256x256, cm=1): the step of libs/trainer.py:155-189
+    with G frozen -- make_shift_vector_50 (injected draws, utils_train.py:177-288) -> A -> shift -> generate_image(z, psi=0.7)
+    -> L = mean(img^2) -> backward -> Adam(lr 1e-4, weight decay 5e-4) -- against torch autograd of the fp64 oracle: shift
+    vectors bit-exact, loss, dL/dA, dL/db within 1e-4 relative, and the updated A."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    from stylegan_directions_face_reenactment_amd.direction_matrix import DirectionMatrix
+    from stylegan_directions_face_reenactment_amd.generic import generate_image
+    from stylegan_directions_face_reenactment_amd.shift import ShiftVectors
+    B, lr, wd = 16, 1e-4, 5e-4
+    ref = _config5_oracle(B, lr, wd)
+    G = hip_generator(256, 1)
+    for p in G.parameters():
+        p.requires_grad_(False)                                             # only A is optimised (trainer.py:144)
+    A = DirectionMatrix(512, input_dim=15, out_dim=512, w_plus=True, num_layers=8, verbose=False)
+    A.load_state_dict(ref['A0'])
+    A = A.cuda()
+    opt = torch.optim.Adam(A.parameters(), lr=lr, weight_decay=wd)
+    (ang_s, par_s), (ang_t, par_t) = ref['shape']
+    cu = lambda d: {k: v.cuda() for k, v in d.items()}
+    shifts = ShiftVectors('voxceleb', 15, 6.0, ranges=golden('kat8_shift.npz')['ranges_voxceleb'])
+    sv, which = shifts.make_shift_vector_50(cu(par_s), cu(par_t), ang_s.cuda(), ang_t.cuda(), target_indices=ref['which'].numpy(),
+                                            u=ref['u'].cuda())
+    assert torch.equal(sv.cpu(), ref['sv'].float()) and torch.equal(which.cpu().long(), ref['which'])
+    img = generate_image(G, ref['z'].cuda(), 0.7, ref['trunc'].cuda(), shift_code=A(sv), input_is_latent=False)
+    assert img.shape == (B, 3, 256, 256)
+    loss = (img ** 2).mean()
+    A.zero_grad()
+    loss.backward()
+    gw, gb = A.linear.weight.grad.clone(), A.linear.bias.grad.clone()
+    opt.step()
+    ew, eb = _rel(gw, ref['grads']['linear.weight']), _rel(gb, ref['grads']['linear.bias'])
+    el = abs(float(loss) - ref['loss']) / abs(ref['loss'])
+    # Adam's first step is lr * g / (|g| + 1e-8) ~ lr * sign(g): where the gradient is not vanishing against the largest one
+    # (elements at <= 1e-3 of it carry the 1e-4 relative error as a 10 % or larger error of their own) the updates must agree
+    sig_w = ref['grads']['linear.weight'].abs() >= 1e-3 * ref['grads']['linear.weight'].abs().max()
+    sig_b = ref['grads']['linear.bias'].abs() >= 1e-3 * ref['grads']['linear.bias'].abs().max()
+    dw = (A.linear.weight.detach().cpu().double() - ref['stepped']['linear.weight']).abs()
+    db = (A.linear.bias.detach().cpu().double() - ref['stepped']['linear.bias']).abs()
+    step_sig = max(float(dw[sig_w].max()), float(db[sig_b].max()))
+    step_all = max(float(dw.max()), float(db.max()))
+    print('config 5 @B=16 256^2 [%s fwd / %s bwd]: loss rel %.1e, dL/dA rel %.2e, dL/db rel %.2e; A after Adam (lr %.0e): max abs diff '
+          '%.2e on the %.0f %% significant elements, %.2e overall'
+          % (F_.PRECISION, F_.BACKWARD_ARITH if F_.PRECISION != 'fp32' else 'fp32', el, ew, eb, lr, step_sig,
+             100.0 * float(sig_w.float().mean()), step_all))
+    assert el <= 1e-5 and ew <= 1e-4 and eb <= 1e-4
+    assert step_sig <= 0.02 * lr and step_all <= 2.0 * lr + 1e-9
+    assert G.saturated_pairs() == 0                  # nothing, forward or backward, left the fp16 range plans
+
+
 @pytest.mark.parametrize('cin,cout,h,up,B', [(16, 8, 8, False, 3), (8, 16, 4, True, 3), (64, 128, 16, False, 2),
                                               (128, 64, 16, True, 2), (64, 64, 64, False, 1), (32, 64, 64, True, 1),
                                               (6, 10, 7, False, 2), (10, 6, 5, True, 2), (64, 64, 128, False, 1)])

@@ -224,6 +224,62 @@ def test_split_chain_is_bit_identical_to_layer_by_layer():
         assert G.saturated_pairs() == 0 or F_.PRECISION != 'fp16x3'     # nothing of this generator hit the fp16 clamp
 
 
+def test_generator_forward_replays_a_hipgraph_by_default():
+    """from the third no-grad forward of one signature on, Generator.forward replays a captured hipGraph --
+    bit-identical to the eager launches for new inputs, through generate_image too; a weight change, a different batch size,
+    caller-supplied noise, hooks and grad mode fall back to eager launches (and never to stale results)."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    from stylegan_directions_face_reenactment_amd.generic import generate_image
+    G = hip_generator(64, 1)
+    tr = S.counter_tensor(SEED, 'graph.t', (1, 512)).cuda()
+    ws = [S.synthetic_latents(SEED, 3, n_latent=G.n_latent, key='graph.w%d' % i).cuda() for i in range(5)]
+    with torch.no_grad():
+        G.use_graphs = False
+        eager = [G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr, return_latents=True) for w in ws]
+        G.use_graphs = True
+        got = [G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr, return_latents=True) for w in ws]
+        assert len(G._graphs) == 1                                  # calls 0, 1 eager, call 2 captured, calls 3, 4 replayed
+        for (a, la), (b, lb) in zip(eager, got):
+            assert torch.equal(a, b) and torch.equal(la, lb)
+        assert got[3][0].data_ptr() != got[4][0].data_ptr()         # results are clones, not the graph's static buffer
+        # the reference's glue on top (verified forwards): same bits
+        imgs = [generate_image(G, w, 0.7, tr, input_is_latent=True) for w in ws]
+        assert all(torch.equal(a[0], b) for a, b in zip(eager, imgs))
+        # uint8 frames out of the last ToRGB launch, graphed
+        u8 = [G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr, image_out=F_.U8Target())[0] for w in ws]
+        G.use_graphs = False
+        u8e = G([ws[4]], input_is_latent=True, truncation=0.7, truncation_latent=tr, image_out=F_.U8Target())[0]
+        G.use_graphs = True
+        assert u8[4].dtype == torch.uint8 and torch.equal(u8[4], u8e)
+        # another batch size: its own signature; caller-supplied noise and hooks: eager
+        n_graphs = len(G._graphs)
+        small, _ = G([ws[0][:1]], input_is_latent=True, truncation=0.7, truncation_latent=tr)
+        assert torch.equal(small, eager[0][0][:1]) and len(G._graphs) == n_graphs
+        noises = [getattr(G.noises, 'noise_%d' % i) * 1.0 for i in range(G.num_layers)]
+        a, _ = G([ws[1]], input_is_latent=True, truncation=0.7, truncation_latent=tr, noise=noises)
+        assert torch.equal(a, eager[1][0])
+        # new weights: the graphs are dropped, the next forwards are right (and re-captured later)
+        G.convs[3].conv.weight.mul_(1.5)
+        G.use_graphs = False
+        want, _ = G([ws[2]], input_is_latent=True, truncation=0.7, truncation_latent=tr)
+        G.use_graphs = True
+        for _ in range(4):
+            b, _ = G([ws[2]], input_is_latent=True, truncation=0.7, truncation_latent=tr)
+            assert torch.equal(b, want)
+        assert not torch.equal(want, eager[2][0]) and len(G._graphs) == 1
+    # grad mode never replays
+    w = ws[0].clone().requires_grad_(True)
+    img, _ = G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr)
+    img.square().mean().backward()
+    assert w.grad is not None and bool(torch.isfinite(w.grad).all())
+    # deepcopy / pickle leave the graphs behind
+    import copy
+    G2 = copy.deepcopy(G)
+    assert '_graphs' not in G2.__dict__
+    with torch.no_grad():
+        assert torch.equal(G2([ws[2]], input_is_latent=True, truncation=0.7, truncation_latent=tr)[0], want)
+
+
 def test_graphed_reenactment_session_is_bit_identical():
     """hipGraph replay of the per-batch step (small-batch latency path) == eager launches, incl. a ragged tail."""
     from stylegan_directions_face_reenactment_amd.direction_matrix import DirectionMatrix
