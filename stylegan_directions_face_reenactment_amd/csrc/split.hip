@@ -236,7 +236,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     // last two sub-stages of a tile stage the first TWO slabs (and the first activation block) of the next tile BEFORE the
     // epilogue's stores join the queue, so the next tile's first sub-stage has nothing to wait for -- loads and stores
     // retire through the same in-order vmcnt, and with two slots the first wait of the next tile drained the stores.
-    constexpr bool RING3 = XIN && !DOWN && NSS == 3 && NI <= 2;      // (the 128 x 512 tiles: two slots, see kPlanPlainXL)
+    constexpr bool RING3 = XIN && !DOWN && NSS == 3 && NI <= 2 && NW == 8;      // (the 128 x 512 tiles: two slots, see kPlanPlainXL;
+                                                                               //  4-wave blocks run two per CU: 80 KB each, two slots)
     constexpr int NWS = RING3 ? 3 : 2;                    // weight ring slots
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int xbuf_bytes = 64 * p.xs;                    // [2 part][2 k-half][xs][8] bf16
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     // Persistent blocks: the grid is one block per CU (or fewer); block b works on tiles base + map(b) of every round of
     // gridDim.x tiles.  map() keeps the tiles of one XCD (blockIdx & 7) contiguous, so neighbours share halos and weights in L2.
     // (only the plain conv is ever launched persistent, see launch_split; the fp32-input variants have no registers to spare)
-    constexpr bool PERSIST = XIN && (MODE == SGDFR_MODE_PLAIN3 || (UP && RING3));
+    constexpr bool PERSIST = XIN && NW == 8 && (MODE == SGDFR_MODE_PLAIN3 || (UP && RING3));
     auto lid_of = [&](int base) -> int {        // tile of this block in the round starting at `base`, -1: none
         if (base >= p.total_blocks) return -1;
         const int nblk = PERSIST ? min((int)gridDim.x, p.total_blocks - base) : (int)gridDim.x, q8 = nblk >> 3, r8 = nblk & 7;
@@ -375,7 +376,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     const bool fuse_rgb = !UP && !DOWN && whole && p.rgb_part != nullptr;      // fused ToRGB partial sums (PLAIN3)
     const bool early = p.simgs <= 2;
     // (DOWN3 has no style table: its input arrives modulated)
-    float* const dl = early ? ls + (DOWN ? 0 : ((p.simgs * p.Cin + 3) & ~3)) : reinterpret_cast<float*>(smem);   // [simgs][NT]  d * output scale
+    constexpr bool SLIM = XIN && NW == 4;       // (split_lds_bytes(slim): pre-split 4-wave plans carry no style table either)
+    float* const dl = early ? ls + ((DOWN || SLIM) ? 0 : ((p.simgs * p.Cin + 3) & ~3)) : reinterpret_cast<float*>(smem);   // [simgs][NT]  d * output scale
     float* const bl = dl + p.simgs * NT;                        // [NT]            bias
     float* const cw = bl + NT;                                  // [simgs][NT][4]  ToRGB coefficients
     float* const red = cw + p.simgs * NT * 4;                   // [WM][PT][3]     ToRGB cross-wave reduce
@@ -1232,13 +1234,21 @@ static const SplitPlan kPlanDown = {5, 128, 256, 1, 8};         // adjoint of th
 // (DESIGN 4.7): per MFMA this tile DMAs 0.58x the bytes of 128 x 256 (the weight slab is streamed once per 512 pixels) and
 // reads 0.75x the LDS fragments (12 ds_read_b128 per 24 MFMAs), and a layer has half as many tile prologues / epilogues.
 static const SplitPlan kPlanPlainXL = {6, 128, 512, 3, 8};
+// 4-wave blocks, TWO per CU (<= 80 KB of LDS each, pre-split input only): the wave tiles of the 8-wave plans above (transposed:
+// 32 couts x 64 super-pixels x 4 phases; plain: 64 x 64), half the pixels per block.  One block's epilogue -- the 4 plane stores
+// of the transposed conv, the element loop + ToRGB reduce of the short-K 64 -> 64 layer -- runs while the other block of the
+// CU is in its K loop, instead of every wave of the CU leaving the matrix cores idle together.
+static const SplitPlan kPlanUp4 = {7, 64, 128, 3, 4};
+static const SplitPlan kPlanPlain4 = {8, 64, 256, 3, 4};
 
 // nws: weight ring slots (3 for a pre-split input with row sub-stages, see RING3 in the kernel; 2 otherwise)
-static size_t split_lds_bytes(const SplitParams& p, int NT, int nss, bool down = false, int nws = 2, int PT = 256) {
+static size_t split_lds_bytes(const SplitParams& p, int NT, int nss, bool down = false, int nws = 2, int PT = 256, bool slim = false) {
     const size_t wslot = down ? (size_t)NT * 256 : (size_t)NT * 192 * (3 / nss);       // DOWN3: 4 taps x 64 bytes per cout
-    const size_t loop = 2 * (size_t)64 * p.xs + nws * wslot + (down ? 0 : (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float));
+    // (slim: the pre-split 4-wave plans -- no style table (the input arrives modulated); the transposed conv only has d and bias tables)
+    const size_t loop = 2 * (size_t)64 * p.xs + nws * wslot + ((down || slim) ? 0 : (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float));
     // d, bias, ToRGB coefficient / reduce ([WM][PT][3] = 1536 floats in every plan but the 128 x 512 one), next-style tables
-    const size_t epi = ((size_t)p.simgs * NT * 6 + NT + (NT * PT > 128 * 256 ? 1024 : 512) * 3) * sizeof(float);
+    const size_t epi = slim && PT == 128 ? ((size_t)p.simgs * NT + NT) * sizeof(float)
+                                         : ((size_t)p.simgs * NT * 6 + NT + (NT * PT > 128 * 256 ? 1024 : 512) * 3) * sizeof(float);
     if (p.simgs <= 2) return loop + epi;      // tables live beside the style table for the whole kernel
     return loop > epi ? loop : epi;           // tables overwrite the dead staging buffers after the K loop
 }
@@ -1270,7 +1280,7 @@ static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, cons
         // 128 x 512 tiles take 32 x 16 patches (three staging slots instead of four).  Same-box A/B at B=64: 128->128@128^2
         // 899 -> 891 us (-> 874 with the 128 x 512 tiles), 64->64@256^2 961 -> 950.
         static const int tc_env = getenv("SGDFR_SPLIT_TC") ? atoi(getenv("SGDFR_SPLIT_TC")) : 0;
-        p.TC = tc_env > 0 ? tc_env : (plan.nt == 128 && plan.pt == 512) ? 32 : 64;
+        p.TC = tc_env > 0 ? tc_env : ((plan.nt == 128 && plan.pt == 512) || plan.cfg == 8) ? 32 : 64;
         p.TR = PT / p.TC;
         if (W % p.TC != 0 || H % p.TR != 0) return 0;
         p.tiles_x = W / p.TC; p.tiles_y = H / p.TR;
@@ -1293,12 +1303,14 @@ static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, cons
         p.xlen = span + 2 * p.P + 3;
         p.n_pix_tiles = (int)((p.total_pix + PT - 1) / PT);
     }
-    p.xs = plan.nw == 8 ? (p.xlen + 63) & ~63 : (p.xlen + 7) & ~7;
+    const bool slim = plan.cfg == 7 || plan.cfg == 8;     // 4-wave plans of the pre-split input (DMA staging: whole 64-lane pieces)
+    p.xs = (plan.nw == 8 || slim) ? (p.xlen + 63) & ~63 : (p.xlen + 7) & ~7;
     p.n_cout_tiles = (Cout + plan.nt - 1) / plan.nt;
     const int nthr = plan.nw * 64;
     if ((2 * p.xs + nthr - 1) / nthr > (mode == SGDFR_MODE_DOWN3 ? 3 : 4)) return 0;                  // staging slots (512-wide transposed conv: 4)
-    const size_t lds = split_lds_bytes(p, plan.nt, plan.nss, down, 2, plan.pt);
+    const size_t lds = split_lds_bytes(p, plan.nt, plan.nss, down, 2, plan.pt, slim);
     if (lds > (plan.nw == 8 ? 160 : 80) * 1024) return 0;
+    if (slim && p.simgs > 2) return 0;                    // (their tables live beside the staging buffers)
     if (out) *out = p;
     return 1;
 }
@@ -1312,6 +1324,8 @@ static const SplitPlan* split_plan(int B, int Cin, int Cout, int H, int W, int m
     if (mode == SGDFR_MODE_UP3) {
         // deep stages need enough blocks per 64-cout tile to fill the chip; small layers keep the row sub-stages + K slices
         const bool big = (int64_t)B * (H + 1) * (W + 1) * (Cout / 64) >= 256 * 256;
+        const int up4 = getenv("SGDFR_SPLIT_UP4") ? atoi(getenv("SGDFR_SPLIT_UP4")) : 0;      // (read per call: same-process A/B)
+        if (up4 && xin_whole && (int64_t)B * (H + 1) * (W + 1) * (Cout / 64) >= 4ll * 512 * 128 && W + 1 >= up4) order[n++] = &kPlanUp4;
         if (deep && big) order[n++] = &kPlanUpDeep;
         if (narrow_first && big) order[n++] = &kPlanUpNarrow;     // row sub-stages + 3-slot ring + persistent blocks (pre-split input)
         if (Cout % 128 == 0) order[n++] = &kPlanUpWide;
@@ -1323,6 +1337,8 @@ static const SplitPlan* split_plan(int B, int Cin, int Cout, int H, int W, int m
         // (same-box A/B at B=64: 512->512@32^2 842 -> 808 us, 256->256@64^2 822 -> 798; with 128-wide patches 128^2 lost 1 % --
         // four staging slots spill -- with 32 x 16 patches it gains 2.8 %)
         if (xl && xin_whole && Cout % 128 == 0 && (int64_t)B * H * W * (Cout / 128) >= 2ll * 256 * 512) order[n++] = &kPlanPlainXL;
+        const int p4 = getenv("SGDFR_SPLIT_P4") ? atoi(getenv("SGDFR_SPLIT_P4")) : 0;
+        if (p4 && xin_whole && Cout % 128 != 0 && Cin <= p4 && (int64_t)B * H * W * (Cout / 64) >= 4ll * 512 * 256) order[n++] = &kPlanPlain4;
         if (Cout % 128 == 0) order[n++] = &kPlanPlainWide;
         order[n++] = &kPlanPlainNarrow;
     } else if (mode == SGDFR_MODE_DOWN3) {
@@ -1461,7 +1477,8 @@ static int launch_split(const SplitParams& p, hipStream_t st) {
                                 : nex == 3 ? split_mfma_kernel<MODE, ET, WM, WN, MI, NI, 3, NSS, XIN>
                                            : split_mfma_kernel<MODE, ET, WM, WN, MI, NI, NEX_MAX, NSS, XIN>;
     const size_t lds = split_lds_bytes(p, WM * MI * 32, NSS, MODE == SGDFR_MODE_DOWN3,
-                                       (XIN && MODE != SGDFR_MODE_DOWN3 && NSS == 3 && NI <= 2) ? 3 : 2, WN * NI * 32);
+                                       (XIN && MODE != SGDFR_MODE_DOWN3 && NSS == 3 && NI <= 2 && WM * WN == 8) ? 3 : 2, WN * NI * 32,
+                                       XIN && WM * WN == 4);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess) {
         (void)hipGetLastError();
@@ -1480,7 +1497,7 @@ static int launch_split(const SplitParams& p, hipStream_t st) {
     static const int persist = getenv("SGDFR_SPLIT_PERSIST") ? atoi(getenv("SGDFR_SPLIT_PERSIST")) : 256;
     static const int persist_min = getenv("SGDFR_SPLIT_PERSIST_MIN") ? atoi(getenv("SGDFR_SPLIT_PERSIST_MIN")) : 4;    // tiles per block
     static const int persist_min_up = getenv("SGDFR_SPLIT_PERSIST_MIN_UP") ? atoi(getenv("SGDFR_SPLIT_PERSIST_MIN_UP")) : 4;    // (only reachable with SGDFR_SPLIT_UP_NARROW=1)
-    constexpr bool kCanPersist = XIN && NSS == 3 && (MODE == SGDFR_MODE_PLAIN3 || MODE == SGDFR_MODE_UP3);
+    constexpr bool kCanPersist = XIN && NSS == 3 && WM * WN == 8 && (MODE == SGDFR_MODE_PLAIN3 || MODE == SGDFR_MODE_UP3);
     const bool persistent = kCanPersist && persist > 0 &&
                             q.total_blocks >= (MODE == SGDFR_MODE_UP3 ? persist_min_up : persist_min) * persist;
     const int grid = persistent ? persist : q.total_blocks;
@@ -1498,6 +1515,8 @@ static int launch_plan(int cfg, const SplitParams& p, hipStream_t st, bool xin) 
             case 4: return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 1, true>(p, st);
             case 5: return launch_split<SGDFR_MODE_DOWN3, ET, 2, 4, 2, 2, 1, true>(p, st);
             case 6: return launch_split<SGDFR_MODE_PLAIN3, ET, 2, 4, 2, 4, 3, true>(p, st);
+            case 7: return launch_split<SGDFR_MODE_UP3, ET, 2, 2, 1, 2, 3, true>(p, st);
+            case 8: return launch_split<SGDFR_MODE_PLAIN3, ET, 1, 4, 2, 2, 3, true>(p, st);
             default: set_error("modconv_split: pre-split input is not built for tiling plan %d", cfg); return 1;
         }
     }

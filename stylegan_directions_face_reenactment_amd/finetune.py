@@ -5,6 +5,8 @@ replayed as a hipGraph: at one source per step the eager step is bound by its ~5
 ~6 ms (scripts/pti_step_bench.py)."""
 import torch
 
+from . import functional as F_
+
 
 def pti_parameters(generator, optimize_all=False):
     """optimization.py:31-40: convs[4..11] (pt_l2_lambda 100) or every parameter (pt_l2_lambda 1)."""
@@ -31,7 +33,7 @@ class GraphedStep:
                 step_fn()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with F_.capture_graph(self.graph):
             self.out = step_fn()          # recorded, not executed: the first replay is step warmup + 1
         self.steps_done = warmup
 

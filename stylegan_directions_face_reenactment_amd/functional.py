@@ -348,6 +348,37 @@ def mfma_ceiling(arith='fp16x3', lds_fragments=True, random_operands=True, iters
     return float(out.value)
 
 
+class capture_graph:
+    """`with capture_graph(g):` -- torch.cuda.graph(g) with the garbage collector held off for the duration of the capture.
+    A collection that runs mid-capture can finalise an unrelated CUDAGraph (an old generator's or session's), and
+    hipGraphDestroy is "not permitted when stream is capturing": the process aborts in the destructor.  torch.cuda.graph
+    collects once on entry; nothing is collected until the capture has ended."""
+
+    def __init__(self, g):
+        self.ctx = torch.cuda.graph(g, capture_error_mode='thread_local')
+        self.was = False
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            return self.ctx.__enter__()
+        except BaseException:
+            if self.was:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self.ctx.__exit__(*exc)
+        finally:
+            if self.was:
+                gc.enable()
+
+
 def set_precision(mode):
     global PRECISION
     if mode not in ('fp32', 'fp16x3', 'bf16x3'):

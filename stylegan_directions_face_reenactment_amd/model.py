@@ -700,7 +700,7 @@ class Generator(nn.Module):
             s_tr = trunc.detach().clone() if trunc is not None else None
             torch.cuda.current_stream().synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with F_.capture_graph(g):
                 out = self._forward_impl([s_in], return_latents, False, None, truncation, s_tr, input_is_latent, None, False,
                                          None if image_out is None else F_.U8Target(None, 0, image_out.swap_rb), False)
             mode = self.range_mode()

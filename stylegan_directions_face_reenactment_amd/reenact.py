@@ -149,7 +149,7 @@ class ReenactmentSession:
             torch.cuda.current_stream().wait_stream(side)
             mode = self.G.range_mode()                                      # (the warm-up may have calibrated / fallen back)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with F_.capture_graph(g):
                 static_out = self._step(static_sv)
             self._graph = (g, static_sv, static_out, mode)
         g, static_sv, static_out, mode = self._graph
