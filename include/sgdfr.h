@@ -287,6 +287,8 @@ int sgdfr_planes_to_split_f32(const float* gt, const float* d, unsigned short* x
 int sgdfr_blur_adjoint_split_f32(const float* g, const float* fir, const float* t, const float* d, unsigned short* xs,
                                  float* asum, int B, int C, int H, int W, int arith, unsigned int* sat, void* stream);
 int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H, int W, int mode);
+/* the cout tiling of a launch with x_is_split = 1 and ksplit <= 1 (its tiling plan may differ: T of rgb_part [B][T*3][H*W]) */
+int sgdfr_modconv2d_split_cout_tiles_xin(int B, int Cin, int Cout, int H, int W, int mode);
 int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, int mode);
 
 /* The rest of ToRGB.forward (model.py:350-359) when its 1x1 conv was accumulated by sgdfr_modconv2d_split_f32(rgb_part):

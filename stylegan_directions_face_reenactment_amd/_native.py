@@ -62,6 +62,7 @@ SIGNATURES = {
     'sgdfr_blur_adjoint_split_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _c_f32p, _i, _i, _i, _i, _i, ctypes.c_void_p,
                                      ctypes.c_void_p],
     'sgdfr_modconv2d_split_cout_tiles': [_i, _i, _i, _i, _i, _i],
+    'sgdfr_modconv2d_split_cout_tiles_xin': [_i, _i, _i, _i, _i, _i],
     'sgdfr_modconv2d_split_xin_supported': [_i, _i, _i, _i, _i, _i],
     'sgdfr_modconv2d_split_ksplit_hint': [_i, _i, _i, _i, _i, _i],
     'sgdfr_torgb_finish_f32': [_c_f32p, _i, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],

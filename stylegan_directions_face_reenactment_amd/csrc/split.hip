@@ -1234,21 +1234,21 @@ static const SplitPlan kPlanDown = {5, 128, 256, 1, 8};         // adjoint of th
 // (DESIGN 4.7): per MFMA this tile DMAs 0.58x the bytes of 128 x 256 (the weight slab is streamed once per 512 pixels) and
 // reads 0.75x the LDS fragments (12 ds_read_b128 per 24 MFMAs), and a layer has half as many tile prologues / epilogues.
 static const SplitPlan kPlanPlainXL = {6, 128, 512, 3, 8};
-// 4-wave blocks, TWO per CU (<= 80 KB of LDS each, pre-split input only): the wave tiles of the 8-wave plans above (transposed:
-// 32 couts x 64 super-pixels x 4 phases; plain: 64 x 64), half the pixels per block.  One block's epilogue -- the 4 plane stores
-// of the transposed conv, the element loop + ToRGB reduce of the short-K 64 -> 64 layer -- runs while the other block of the
-// CU is in its K loop, instead of every wave of the CU leaving the matrix cores idle together.
-static const SplitPlan kPlanUp4 = {7, 64, 128, 3, 4};
+// 4-wave blocks, TWO per CU (<= 80 KB of LDS each, pre-split input only), for the plain layers whose K loop is short: 64 couts x
+// 256 pixels, the wave tile of the 64 x 512 plan (64 x 64).  A tile of the 64 -> 64 @ 256^2 layer spends 31 % of its time outside
+// the K loop (element loop, ToRGB reduce, descriptors, tables); with one 8-wave block per CU every wave leaves the matrix cores
+// idle together, with two independent blocks one is in its K loop while the other runs its epilogue.  Same-process A/B at B=64
+// (scripts/layer_ab.py): 996 -> 858 us, bit-identical.  (The same arrangement for the transposed conv -- 64 couts x 128
+// super-pixels, row sub-stages because all nine taps do not fit 80 KB -- lost 4-11 %: twice the weight and halo DMA per MFMA.)
 static const SplitPlan kPlanPlain4 = {8, 64, 256, 3, 4};
 
 // nws: weight ring slots (3 for a pre-split input with row sub-stages, see RING3 in the kernel; 2 otherwise)
 static size_t split_lds_bytes(const SplitParams& p, int NT, int nss, bool down = false, int nws = 2, int PT = 256, bool slim = false) {
     const size_t wslot = down ? (size_t)NT * 256 : (size_t)NT * 192 * (3 / nss);       // DOWN3: 4 taps x 64 bytes per cout
-    // (slim: the pre-split 4-wave plans -- no style table (the input arrives modulated); the transposed conv only has d and bias tables)
+    // (slim: the pre-split 4-wave plan -- no style table, the input arrives modulated)
     const size_t loop = 2 * (size_t)64 * p.xs + nws * wslot + ((down || slim) ? 0 : (size_t)((p.simgs * p.Cin + 3) & ~3) * sizeof(float));
     // d, bias, ToRGB coefficient / reduce ([WM][PT][3] = 1536 floats in every plan but the 128 x 512 one), next-style tables
-    const size_t epi = slim && PT == 128 ? ((size_t)p.simgs * NT + NT) * sizeof(float)
-                                         : ((size_t)p.simgs * NT * 6 + NT + (NT * PT > 128 * 256 ? 1024 : 512) * 3) * sizeof(float);
+    const size_t epi = ((size_t)p.simgs * NT * 6 + NT + (NT * PT > 128 * 256 ? 1024 : 512) * 3) * sizeof(float);
     if (p.simgs <= 2) return loop + epi;      // tables live beside the style table for the whole kernel
     return loop > epi ? loop : epi;           // tables overwrite the dead staging buffers after the K loop
 }
@@ -1303,7 +1303,7 @@ static int split_geometry(int B, int Cin, int Cout, int H, int W, int mode, cons
         p.xlen = span + 2 * p.P + 3;
         p.n_pix_tiles = (int)((p.total_pix + PT - 1) / PT);
     }
-    const bool slim = plan.cfg == 7 || plan.cfg == 8;     // 4-wave plans of the pre-split input (DMA staging: whole 64-lane pieces)
+    const bool slim = plan.cfg == 8;                      // 4-wave plan of the pre-split input (DMA staging: whole 64-lane pieces)
     p.xs = (plan.nw == 8 || slim) ? (p.xlen + 63) & ~63 : (p.xlen + 7) & ~7;
     p.n_cout_tiles = (Cout + plan.nt - 1) / plan.nt;
     const int nthr = plan.nw * 64;
@@ -1324,8 +1324,6 @@ static const SplitPlan* split_plan(int B, int Cin, int Cout, int H, int W, int m
     if (mode == SGDFR_MODE_UP3) {
         // deep stages need enough blocks per 64-cout tile to fill the chip; small layers keep the row sub-stages + K slices
         const bool big = (int64_t)B * (H + 1) * (W + 1) * (Cout / 64) >= 256 * 256;
-        const int up4 = getenv("SGDFR_SPLIT_UP4") ? atoi(getenv("SGDFR_SPLIT_UP4")) : 0;      // (read per call: same-process A/B)
-        if (up4 && xin_whole && (int64_t)B * (H + 1) * (W + 1) * (Cout / 64) >= 4ll * 512 * 128 && W + 1 >= up4) order[n++] = &kPlanUp4;
         if (deep && big) order[n++] = &kPlanUpDeep;
         if (narrow_first && big) order[n++] = &kPlanUpNarrow;     // row sub-stages + 3-slot ring + persistent blocks (pre-split input)
         if (Cout % 128 == 0) order[n++] = &kPlanUpWide;
@@ -1337,9 +1335,14 @@ static const SplitPlan* split_plan(int B, int Cin, int Cout, int H, int W, int m
         // (same-box A/B at B=64: 512->512@32^2 842 -> 808 us, 256->256@64^2 822 -> 798; with 128-wide patches 128^2 lost 1 % --
         // four staging slots spill -- with 32 x 16 patches it gains 2.8 %)
         if (xl && xin_whole && Cout % 128 == 0 && (int64_t)B * H * W * (Cout / 128) >= 2ll * 256 * 512) order[n++] = &kPlanPlainXL;
-        const int p4 = getenv("SGDFR_SPLIT_P4") ? atoi(getenv("SGDFR_SPLIT_P4")) : 0;
-        if (p4 && xin_whole && Cout % 128 != 0 && Cin <= p4 && (int64_t)B * H * W * (Cout / 64) >= 4ll * 512 * 256) order[n++] = &kPlanPlain4;
+        // (SGDFR_SPLIT_P4: 0 = off, n = layers with Cin <= n; read per call so scripts/layer_ab.py can flip it in one process.
+        //  Cout % 128 == 0 layers take it only when asked for (n >= 128): their cout tiling changes from 128 to 64 wide, which
+        //  sgdfr_modconv2d_split_cout_tiles_xin reports)
+        const int p4 = getenv("SGDFR_SPLIT_P4") ? atoi(getenv("SGDFR_SPLIT_P4")) : 64;
+        const bool p4_ok = p4 > 0 && xin_whole && Cin <= p4 && (int64_t)B * H * W * ((Cout + 63) / 64) >= 4ll * 512 * 256;
+        if (p4_ok && Cout % 128 == 0 && p4 >= 128) order[n++] = &kPlanPlain4;
         if (Cout % 128 == 0) order[n++] = &kPlanPlainWide;
+        if (p4_ok) order[n++] = &kPlanPlain4;
         order[n++] = &kPlanPlainNarrow;
     } else if (mode == SGDFR_MODE_DOWN3) {
         order[n++] = &kPlanDown;
@@ -1440,6 +1443,12 @@ extern "C" int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H,
     return split_plan(B, Cin, Cout, H, W, mode, &p) ? p.n_cout_tiles : 0;
 }
 
+// the same for a launch with a pre-split input and no K slices (x_is_split = 1, ksplit <= 1): the plan such a launch really takes
+extern "C" int sgdfr_modconv2d_split_cout_tiles_xin(int B, int Cin, int Cout, int H, int W, int mode) {
+    SplitParams p;
+    return split_plan(B, Cin, Cout, H, W, mode, &p, true) ? p.n_cout_tiles : 0;
+}
+
 extern "C" int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin) { return (int64_t)((Cout + 63) / 64 * 64) * Cin * 9 * 2; }   // cout tiles of 64
 
 extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int arith,
@@ -1515,7 +1524,6 @@ static int launch_plan(int cfg, const SplitParams& p, hipStream_t st, bool xin) 
             case 4: return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 1, true>(p, st);
             case 5: return launch_split<SGDFR_MODE_DOWN3, ET, 2, 4, 2, 2, 1, true>(p, st);
             case 6: return launch_split<SGDFR_MODE_PLAIN3, ET, 2, 4, 2, 4, 3, true>(p, st);
-            case 7: return launch_split<SGDFR_MODE_UP3, ET, 2, 2, 1, 2, 3, true>(p, st);
             case 8: return launch_split<SGDFR_MODE_PLAIN3, ET, 1, 4, 2, 2, 3, true>(p, st);
             default: set_error("modconv_split: pre-split input is not built for tiling plan %d", cfg); return 1;
         }

@@ -528,7 +528,8 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
             raise RuntimeError('modconv_split: this launch cannot fuse ToRGB (check rgb_fusable first)')
         rgb_w, rgb_s = N.f32c(rgb[0]), N.f32c(rgb[1])
         N.require_device(rgb_w, rgb_s)
-        tiles = _shape_query('sgdfr_modconv2d_split_cout_tiles', B, cin, cout, H, W, mode)
+        tiles = _shape_query('sgdfr_modconv2d_split_cout_tiles_xin' if (x_split is not None and ks <= 1) else
+                             'sgdfr_modconv2d_split_cout_tiles', B, cin, cout, H, W, mode)
         part = torch.empty(B, tiles * 3, H, W, device=x.device, dtype=torch.float32)
     _timed_conv(desc or ('split mode%d %d->%d @%dx%d%s' % (mode, cin, cout, H, W, ' K/%d' % ks if ks > 1 else '')),
                 B * conv_flops(cin, cout, H, W), lambda: N.call(
