@@ -186,6 +186,13 @@ __device__ __forceinline__ void blur_split2(float a, float b, unsigned& hi, unsi
 // handing each segment over through LDS: only the first segment re-reads the 3 plane rows above it, so the planes are
 // fetched 1 + 3/(8*nseg) times instead of 1.375 (rocprofv3 FETCH_SIZE of the 128 -> 256 level: 2.03 x the planes with
 // nseg = 1, mostly served by the Infinity Cache -- the run time is the same, the DRAM traffic is not).
+// Round 3, tried on the two wide levels and dropped (same-process A/B at B=64, scripts/blur_ab.py, all bit-identical): 4-wave
+// blocks (QC = 32, four per CU) 491 -> 519 us; each lane loading only its own super-pixel column and taking the window's three
+// neighbour entries from lanes -1 / +1 by DPP wave shifts (2 loads per row instead of 5 overlapping ones; the wave's edge
+// lanes fetch the outside column in divergent branches) 491 -> 825 us; a producer / consumer block (8 waves load + filter into
+// one of two LDS tiles, 8 waves split + store the other: a wave's in-order vmcnt then holds loads OR stores) 514 -> 682 us --
+// half as many loading waves per CU.  The kernel is bound by loads in flight and DRAM locality of its 32 streams per block,
+// not by load instructions or by the shared load / store queue.
 template <int ET, int QC, int NG>
 __global__ __launch_bounds__(8 * QC * NG, 4) void blur_split_kernel(const float* __restrict__ t, const float* __restrict__ fir,
                                                         const float* __restrict__ noise, int64_t noise_bstride,
@@ -248,10 +255,11 @@ __global__ __launch_bounds__(8 * QC * NG, 4) void blur_split_kernel(const float*
         auto load_row = [&](int tr, float (&dst)[5]) {
             const bool rok = tr >= 0;
             const int roff = (tr & 1) * 2 * pstride + (tr >> 1) * GW;
-#pragma unroll
 #if defined(SGDFR_BLUR_PROBE) && SGDFR_BLUR_PROBE == 2      // ablation: no plane loads
+#pragma unroll
             for (int v = 0; v < 5; ++v) dst[v] = (float)(roff + v);
 #else
+#pragma unroll
             for (int v = 0; v < 5; ++v) dst[v] = (rok && cok[v]) ? tp[roff + coff[v]] : 0.f;
 #endif
         };
@@ -345,6 +353,7 @@ __global__ __launch_bounds__(8 * QC * NG, 4) void blur_split_kernel(const float*
     }
     if (ET == SGDFR_SPLIT_FP16 && sat != 0) atomicAdd(sat_word ? sat_word : &g_blur_saturated, sat);
 }
+
 
 
 // Adjoint of the blur feeding the split-kernel backward of the transposed conv (autograd of Blur, model.py:72-88, consumers
@@ -538,7 +547,7 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
     const int QC = W >= 64 ? 64 : W > 16 ? 32 : W > 8 ? 16 : W > 4 ? 8 : 4;
     const int NG = QC < 32 ? 256 / (8 * QC) : 1;
     // row segments per block: as many as keep >= 8 blocks per CU (the window slides across them: each plane row is read once)
-    static const int seg_env = getenv("SGDFR_BLUR_SEGMENTS") ? atoi(getenv("SGDFR_BLUR_SEGMENTS")) : 0;
+    const int seg_env = getenv("SGDFR_BLUR_SEGMENTS") ? atoi(getenv("SGDFR_BLUR_SEGMENTS")) : 0;
     const int64_t tiles1 = (int64_t)B * (C / 8) * ((H + BLUR_QV - 1) / BLUR_QV) * ((W + QC - 1) / QC);
     int nseg = 1;
     while (nseg < 8 && BLUR_QV * nseg * 2 <= H && tiles1 / (nseg * 2) >= 256 * 8) nseg *= 2;
