@@ -629,16 +629,22 @@ class Generator(nn.Module):
         self.__dict__.pop('_graphs', None)
         self.__dict__.pop('_graph_calls', None)
 
+    GRAPH_MAX_WORK = 6              # default policy: replay when batch * (size / 256)^2 <= this (host-bound forwards), or when verified
+
     def _graph_key(self, styles, return_latents, inject_index, truncation, truncation_latent, input_is_latent, noise,
-                   randomize_noise, image_out):
+                   randomize_noise, image_out, verify_range, graph):
         """Signature under which a no-grad forward may be replayed as a hipGraph, or None when it must run eagerly: gradients,
-        style mixing, caller-supplied or fresh noise, a caller-owned uint8 target, hooks, an enclosing capture, bench timing."""
-        if not USE_GRAPHS or not getattr(self, 'use_graphs', True) or torch.is_grad_enabled() or F_.CONV_TIMING is not None:
+        style mixing, caller-supplied or fresh noise, a caller-owned uint8 target, hooks, an enclosing capture, bench timing --
+        and, unless graph=True, forwards that are neither host-bound nor verified (see forward)."""
+        if graph is False or not USE_GRAPHS or not getattr(self, 'use_graphs', True) or torch.is_grad_enabled() or \
+                F_.CONV_TIMING is not None:
             return None
         if len(styles) != 1 or inject_index is not None or noise is not None or randomize_noise:
             return None
         w = styles[0]
         if not isinstance(w, torch.Tensor) or not w.is_cuda or w.dtype != torch.float32 or w.requires_grad:
+            return None
+        if graph is None and not verify_range and w.shape[0] * (self.size / 256.0) ** 2 > self.GRAPH_MAX_WORK:
             return None
         if image_out is not None and image_out.frames is not None:
             return None
@@ -661,17 +667,20 @@ class Generator(nn.Module):
                 truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=False, image_out=None,
                 verify_range=False, graph=None):
         """Reference signature (model.py:471-482) plus optional extensions (no-grad forwards only): image_out / verify_range
-        (see _forward_impl) and graph (None: the default policy below, False: always launch eagerly).
+        (see _forward_impl) and graph (None: the default policy below, True: replay whenever possible, False: always eager).
 
-        hipGraph replay.  A no-grad forward is ~65 dependent launches (~6.5 us apart on the device, ~1 ms of Python at any
-        batch size).  From the third forward of one signature (input shape, flags, arithmetic) on, the launch sequence is
-        captured once and REPLAYED: the latent (and truncation latent) are copied into the graph's static inputs, one graph
-        launch runs the identical kernels on the identical arguments (bit-identical images), and the outputs are cloned out of
-        the graph's static buffers.  Weight changes (tracked like the weight packs; after `.data` edits call
-        invalidate_packs()), a change of arithmetic / range plan, hooks, style mixing, caller-supplied noise and
-        randomize_noise run eagerly.  Switch off: `G.use_graphs = False` or SGDFR_GRAPHS=0."""
-        key = None if graph is False else self._graph_key(styles, return_latents, inject_index, truncation, truncation_latent,
-                                                           input_is_latent, noise, randomize_noise, image_out)
+        hipGraph replay.  A no-grad forward is ~65 dependent launches = ~1 ms of Python at any batch size.  From the third
+        forward of one signature (input shape, flags, arithmetic) on, the launch sequence is captured once and REPLAYED: the
+        latent (and truncation latent) are copied into the graph's static inputs, one graph launch runs the identical kernels
+        on the identical arguments (bit-identical images), and the outputs are cloned out of the graph's static buffers.
+        Default policy (measured, scripts/small_batch_time.py): a replay costs the device ~80 us more than the eager launches
+        (B=8: 1.34 -> 1.43 ms), so it pays where the HOST is the bound -- small batches (B=1: 917 -> 1462 frames/s, B=4 +3 %),
+        i.e. batch * (size/256)^2 <= GRAPH_MAX_WORK -- and for verified forwards, whose wait exposes the enqueue time at every
+        batch size (generate_image at B=32: 7.8 k -> 8.3 k frames/s).  Weight changes (tracked like the weight packs; after
+        `.data` edits call invalidate_packs()), a change of arithmetic / range plan, hooks, style mixing, caller-supplied
+        noise and randomize_noise run eagerly.  Switch off: `G.use_graphs = False` or SGDFR_GRAPHS=0."""
+        key = self._graph_key(styles, return_latents, inject_index, truncation, truncation_latent, input_is_latent, noise,
+                              randomize_noise, image_out, verify_range, graph)
         if key is None:
             return self._forward_impl(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
                                       input_is_latent, noise, randomize_noise, image_out, verify_range)
