@@ -83,6 +83,95 @@ __global__ __launch_bounds__(WAVES * 64, 1) void probe(float* out, const unsigne
     if (blockIdx.x == 0 && tid == 0) clk[0] = t1 - t0;
 }
 
+
+// 1-D Winograd F(2,3) pricing.  Per 16-channel block a plain wave tile (64 couts x 64 pixels) issues 9 taps x 12
+// MFMAs fed by 9 x 8 ds_read_b128; the Winograd form of the SAME 4096 outputs (32 couts x 64 two-pixel tiles, four transform
+// positions = 8 accumulators) issues 12 (ky, t) steps x 6 MFMAs fed by 12 x 6 reads -- 2/3 of the MFMAs, the same fragment reads.
+// SHAPE 0: 1 A tile x 2 B tiles per step (6 reads / 6 MFMAs); SHAPE 1: one wave per SIMD with 16 accumulators (2 x 2 tiles x 4
+// positions = 256 registers): 8 reads / 12 MFMAs per step.
+template <int WAVES, int SHAPE>
+__global__ __launch_bounds__(WAVES * 64, 1) void probe_wino(float* out, const unsigned* seed, int iters, unsigned long long* clk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 65536 / 4; i += blockDim.x) reinterpret_cast<unsigned*>(lds)[i] = seed[i];
+    __syncthreads();
+    constexpr int MI = SHAPE ? 2 : 1, NI = 2;
+    f32x16 acc[4][MI][NI];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < MI; ++m)
+#pragma unroll
+            for (int n = 0; n < NI; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][m][n][r] = 0.f;
+    const unsigned char* pa = lds + ((lane >> 5) * 64 + (lane & 31)) * 16;
+    const unsigned char* pb = lds + 32768 + ((lane >> 5) * 512 + (wave & 3) * 64 + (lane & 31)) * 16;
+    frag128 a[2][MI], b[2][NI];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int step = 0; step < 12; ++step) {      // (ky, t)
+            const int t = step & 3;
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+#pragma unroll
+                for (int m = 0; m < MI; ++m)
+                    a[part][m] = *reinterpret_cast<const frag128*>(pa + part * 16384 + (step % 3) * 4096 + m * 512 + (it & 1) * 2048);
+#pragma unroll
+                for (int n = 0; n < NI; ++n)
+                    b[part][n] = *reinterpret_cast<const frag128*>(pb + part * 16384 + (step + n * 32 + (it & 7)) * 16);
+            }
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int m = 0; m < MI; ++m)
+#pragma unroll
+                    for (int n = 0; n < NI; ++n)
+                        acc[t][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[term == 2][m]),
+                                                                               __builtin_bit_cast(f16x8, b[term == 1][n]), acc[t][m][n], 0, 0, 0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < MI; ++m)
+#pragma unroll
+            for (int n = 0; n < NI; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[t][m][n][r];
+    out[blockIdx.x * blockDim.x + tid] = s;
+    if (blockIdx.x == 0 && tid == 0) clk[0] = t1 - t0;
+}
+
+template <int WAVES, int SHAPE>
+void run_wino(const char* name, const unsigned* seed_dev) {
+    float* out; unsigned long long* clk;
+    const int blocks = 256, iters = 3000;
+    constexpr int MI = SHAPE ? 2 : 1;
+    hipMalloc(&out, sizeof(float) * blocks * WAVES * 64); hipMalloc(&clk, 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipFuncSetAttribute((const void*)probe_wino<WAVES, SHAPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    probe_wino<WAVES, SHAPE><<<blocks, WAVES * 64, 65536>>>(out, seed_dev, 200, clk);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    probe_wino<WAVES, SHAPE><<<blocks, WAVES * 64, 65536>>>(out, seed_dev, iters, clk);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long c; hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
+    const double mfmas = (double)iters * 12 * 6 * MI;               // per wave
+    const double flops = (double)blocks * WAVES * mfmas * 2.0 * 32 * 32 * 16;
+    const double ghz = c / (ms * 1e6);
+    const double duty = mfmas * 32 * (WAVES / 4) / (double)c;
+    // outputs per step-set: 32*MI couts x 64 tiles x 2 pixels, K = 16 channels x 9 taps -> algorithmic fp32 flops
+    const double alg = (double)blocks * WAVES * iters * (32.0 * MI) * 128 * 2.0 * 16 * 9;
+    printf("%-34s waves %d: %8.3f ms %7.1f TFLOP/s (16-bit issued), %6.1f algorithmic fp32 TFLOP/s, clock %.2f GHz, MFMA duty %.2f\n",
+           name, WAVES, ms, flops / ms / 1e9, alg / ms / 1e9, ghz, duty);
+    hipFree(out); hipFree(clk);
+}
+
 static unsigned short f2h(float f) { _Float16 h = (_Float16)f; unsigned short u; __builtin_memcpy(&u, &h, 2); return u; }
 
 template <int WAVES, int USE_LDS, int BARRIER, int ORDER = 0>
@@ -133,6 +222,9 @@ int main() {
         run<8, 1, 0, 4>("LDS random, Gray path", dr);
         run<8, 0, 0, 2>("registers random, A-stationary", dr);
         run<8, 0, 0, 4>("registers random, Gray path", dr);
+        run_wino<8, 0>("Winograd F(2,3) 1x2x4, random", dr);
+        run_wino<4, 1>("Winograd F(2,3) 2x2x4, random", dr);
+        run_wino<8, 0>("Winograd F(2,3) 1x2x4, zeros", dz);
     }
     return 0;
 }
