@@ -10,8 +10,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef int frag128 __attribute__((ext_vector_type(4)));
 
-template <int WAVES, int USE_LDS, int BARRIER, int ORDER = 0>
-__global__ __launch_bounds__(WAVES * 64, 1) void probe(float* out, const unsigned* seed, int iters, unsigned long long* clk) {
+typedef __attribute__((address_space(3))) void lds_void_p;
+typedef const __attribute__((address_space(1))) void glb_void_p;
+// DMA6: global_load_lds pieces per wave per SIX iterations (6 x 36 = 216 MFMAs = one channel block of the 128 x 512 tile: 14)
+template <int WAVES, int USE_LDS, int BARRIER, int ORDER = 0, int DMA6 = 0>
+__global__ __launch_bounds__(WAVES * 64, 1) void probe(float* out, const unsigned* seed, int iters, unsigned long long* clk, const unsigned char* src = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 65536 / 4; i += blockDim.x) reinterpret_cast<unsigned*>(lds)[i] = seed[i];
@@ -35,6 +38,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void probe(float* out, const unsigne
         }
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
+        if (DMA6) {
+            const int ph = it % 6, n0 = ph * DMA6 / 6, n1 = (ph + 1) * DMA6 / 6;
+            for (int v = n0; v < n1; ++v)
+                __builtin_amdgcn_global_load_lds((glb_void_p*)(src + ((((size_t)blockIdx.x * 61 + it * 17 + wave * DMA6 + v) & 4095) << 10) + lane * 16),
+                                                 (lds_void_p*)(lds + 65536 + ((wave * DMA6 + v) & 63) * 1024), 16, 0, 0);
+        }
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) {
             if (USE_LDS) {
@@ -89,8 +98,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void probe(float* out, const unsigne
 // positions = 8 accumulators) issues 12 (ky, t) steps x 6 MFMAs fed by 12 x 6 reads -- 2/3 of the MFMAs, the same fragment reads.
 // SHAPE 0: 1 A tile x 2 B tiles per step (6 reads / 6 MFMAs); SHAPE 1: one wave per SIMD with 16 accumulators (2 x 2 tiles x 4
 // positions = 256 registers): 8 reads / 12 MFMAs per step.
-template <int WAVES, int SHAPE>
-__global__ __launch_bounds__(WAVES * 64, 1) void probe_wino(float* out, const unsigned* seed, int iters, unsigned long long* clk) {
+// DMA: global_load_lds pieces (64 lanes x 16 B = 1 KB) per wave and iteration (one 16-channel block = 72 MFMAs per wave), read
+// from a 4 MB L2-resident buffer into a scratch LDS region: 128 couts x 128 tiles per block stage 40 KB of V + 96 KB of U per
+// channel block = 17 pieces per wave (the plain 128 x 512 tile: 110 KB per 216 MFMAs per wave).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+template <int WAVES, int SHAPE, int DMA>
+__global__ __launch_bounds__(WAVES * 64, 1) void probe_wino(float* out, const unsigned* seed, int iters, unsigned long long* clk, const unsigned char* src) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 65536 / 4; i += blockDim.x) reinterpret_cast<unsigned*>(lds)[i] = seed[i];
@@ -113,6 +127,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void probe_wino(float* out, const un
 #pragma unroll
         for (int step = 0; step < 12; ++step) {      // (ky, t)
             const int t = step & 3;
+            if (DMA) {
+                const int n0 = step * DMA / 12, n1 = (step + 1) * DMA / 12;
+#pragma unroll
+                for (int v = n0; v < n1; ++v)
+                    __builtin_amdgcn_global_load_lds((glb_void_t*)(src + ((((size_t)blockIdx.x * 61 + it * 17 + wave * DMA + v) & 4095) << 10) + lane * 16),
+                                                     (lds_void_t*)(lds + 65536 + ((wave * DMA + v) & 63) * 1024), 16, 0, 0);
+            }
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
 #pragma unroll
@@ -146,18 +167,18 @@ __global__ __launch_bounds__(WAVES * 64, 1) void probe_wino(float* out, const un
     if (blockIdx.x == 0 && tid == 0) clk[0] = t1 - t0;
 }
 
-template <int WAVES, int SHAPE>
-void run_wino(const char* name, const unsigned* seed_dev) {
+template <int WAVES, int SHAPE, int DMA = 0>
+void run_wino(const char* name, const unsigned* seed_dev, const unsigned char* src = nullptr) {
     float* out; unsigned long long* clk;
     const int blocks = 256, iters = 3000;
     constexpr int MI = SHAPE ? 2 : 1;
     hipMalloc(&out, sizeof(float) * blocks * WAVES * 64); hipMalloc(&clk, 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipFuncSetAttribute((const void*)probe_wino<WAVES, SHAPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    probe_wino<WAVES, SHAPE><<<blocks, WAVES * 64, 65536>>>(out, seed_dev, 200, clk);
+    hipFuncSetAttribute((const void*)probe_wino<WAVES, SHAPE, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    probe_wino<WAVES, SHAPE, DMA><<<blocks, WAVES * 64, 131072>>>(out, seed_dev, 200, clk, src);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    probe_wino<WAVES, SHAPE><<<blocks, WAVES * 64, 65536>>>(out, seed_dev, iters, clk);
+    probe_wino<WAVES, SHAPE, DMA><<<blocks, WAVES * 64, 131072>>>(out, seed_dev, iters, clk, src);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long c; hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
@@ -174,17 +195,17 @@ void run_wino(const char* name, const unsigned* seed_dev) {
 
 static unsigned short f2h(float f) { _Float16 h = (_Float16)f; unsigned short u; __builtin_memcpy(&u, &h, 2); return u; }
 
-template <int WAVES, int USE_LDS, int BARRIER, int ORDER = 0>
-void run(const char* name, const unsigned* seed_dev) {
+template <int WAVES, int USE_LDS, int BARRIER, int ORDER = 0, int DMA6 = 0>
+void run(const char* name, const unsigned* seed_dev, const unsigned char* src = nullptr) {
     float* out; unsigned long long* clk;
     const int blocks = 256, iters = 4000;
     hipMalloc(&out, sizeof(float) * blocks * WAVES * 64); hipMalloc(&clk, 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipFuncSetAttribute((const void*)probe<WAVES, USE_LDS, BARRIER, ORDER>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    probe<WAVES, USE_LDS, BARRIER, ORDER><<<blocks, WAVES * 64, 65536>>>(out, seed_dev, 200, clk);
+    hipFuncSetAttribute((const void*)probe<WAVES, USE_LDS, BARRIER, ORDER, DMA6>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    probe<WAVES, USE_LDS, BARRIER, ORDER, DMA6><<<blocks, WAVES * 64, 131072>>>(out, seed_dev, 200, clk, src);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    probe<WAVES, USE_LDS, BARRIER, ORDER><<<blocks, WAVES * 64, 65536>>>(out, seed_dev, iters, clk);
+    probe<WAVES, USE_LDS, BARRIER, ORDER, DMA6><<<blocks, WAVES * 64, 131072>>>(out, seed_dev, iters, clk, src);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long c; hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
@@ -208,6 +229,9 @@ int main() {
         h[i] = f2h((u0 - 6.f) * 4.f) | ((unsigned)f2h((u1 - 6.f) * 4.f) << 16);
     }
     hipMemcpy(dr, h, 65536, hipMemcpyHostToDevice);
+    unsigned char* src;                       // 4 MB + slack of random halves for the DMA arms
+    hipMalloc(&src, (4096 + 64) * 1024);
+    for (int i = 0; i < (4096 + 64) / 64; ++i) hipMemcpy(src + (size_t)i * 65536, h, 65536, hipMemcpyHostToDevice);
     for (int rep = 0; rep < 2; ++rep) {
         run<8, 0, 0>("registers, zeros", dz);
         run<8, 0, 0>("registers, random", dr);
@@ -225,6 +249,12 @@ int main() {
         run_wino<8, 0>("Winograd F(2,3) 1x2x4, random", dr);
         run_wino<4, 1>("Winograd F(2,3) 2x2x4, random", dr);
         run_wino<8, 0>("Winograd F(2,3) 1x2x4, zeros", dz);
+        run<8, 1, 1, 0, 14>("LDS + barrier + DMA 14/216, random", dr, src);
+        run<8, 1, 1, 0, 28>("LDS + barrier + DMA 28/216, random", dr, src);
+        run_wino<8, 0, 17>("Winograd 1x2x4 + DMA 17/72", dr, src);
+        run_wino<8, 0, 12>("Winograd 1x2x4 + DMA 12/72", dr, src);
+        run_wino<8, 0, 9>("Winograd 1x2x4 + DMA 9/72", dr, src);
+        run_wino<4, 1, 24>("Winograd 2x2x4 + DMA 24/144", dr, src);
     }
     return 0;
 }

@@ -62,6 +62,23 @@ __device__ __forceinline__ float wave_max(float v) {
                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48))));
 }
 
+// n / d for 0 <= n < 2^31 without a hardware divide: q = (n * mul) >> sh with mul = ceil(2^sh / d), sh = 31 + ceil(log2 d)
+// (exact: the error term n * (mul*d - 2^sh) < 2^31 * d <= 2^sh).  The per-tile index arithmetic of the split conv kernels does
+// ~35 divisions by launch-constant divisors per tile (~25 VALU instructions each); the host precomputes their multipliers.
+struct FastDiv {
+    unsigned mul, sh;
+};
+static inline FastDiv make_fastdiv(int d) {
+    FastDiv f{0u, 31u};
+    if (d < 1) d = 1;
+    unsigned s = 0;
+    while ((1ll << s) < d) ++s;
+    f.sh = 31 + s;
+    f.mul = (unsigned)(((1ull << f.sh) + (unsigned long long)d - 1) / (unsigned long long)d);
+    return f;
+}
+__device__ __forceinline__ int fdiv(int n, FastDiv f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.sh); }
+
 __device__ __forceinline__ float lrelu_gain(float v, float slope, float gain) {
     return (v > 0.f ? v : v * slope) * gain;
 }

@@ -81,23 +81,6 @@ __device__ unsigned long long g_split_trace[4096];
 
 constexpr float SPLIT_F16_XSCALE = 0.0625f, SPLIT_F16_WSCALE = 64.f, SPLIT_F16_OUT = 0.25f, SPLIT_F16_MAX = 65504.f;
 
-// n / d for 0 <= n < 2^31 without a hardware divide: q = (n * mul) >> sh with mul = ceil(2^sh / d), sh = 31 + ceil(log2 d)
-// (exact: the error term n * (mul*d - 2^sh) < 2^31 * d <= 2^sh).  The per-tile index arithmetic of the kernel below does ~35
-// divisions by launch-constant divisors per tile (~25 VALU instructions each); the host precomputes their multipliers.
-struct FastDiv {
-    unsigned mul, sh;
-};
-static FastDiv make_fastdiv(int d) {
-    FastDiv f{0u, 31u};
-    if (d < 1) d = 1;
-    unsigned s = 0;
-    while ((1ll << s) < d) ++s;
-    f.sh = 31 + s;
-    f.mul = (unsigned)(((1ull << f.sh) + (unsigned long long)d - 1) / (unsigned long long)d);
-    return f;
-}
-__device__ __forceinline__ int fdiv(int n, FastDiv f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.sh); }
-
 struct SplitParams {
     const float* x;
     int64_t x_bstride;
@@ -1415,6 +1398,7 @@ extern "C" int sgdfr_planes_to_split_f32(const float* gt, const float* d, unsign
 }
 
 unsigned int blur_split_saturation_count(int reset);     // upfirdn2d.hip's counter
+namespace sgdfr { unsigned int wsplit_saturation_count(int reset); }     // wsplit.hip's
 
 // Number of fp16-split operand pairs that hit the +-65504 clamp (|x*s| > 1.04e6) since the last reset, over all split
 // kernels on the current device; synchronises the device.  Negative: HIP error.
@@ -1425,7 +1409,7 @@ extern "C" long long sgdfr_split_saturation_count(int reset) {
         const unsigned int z = 0;
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_split_saturated), &z, sizeof(z)) != hipSuccess) return -1;
     }
-    return (long long)v + (long long)blur_split_saturation_count(reset);
+    return (long long)v + (long long)blur_split_saturation_count(reset) + (long long)sgdfr::wsplit_saturation_count(reset);
 }
 
 #ifdef SGDFR_SPLIT_PROBE

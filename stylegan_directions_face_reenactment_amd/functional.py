@@ -543,6 +543,67 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
     return y if rgb is None else (y, part)
 
 
+# ---- 1-D Winograd F(2,3) form of the plain split conv (csrc/wsplit.hip): 2/3 of the MFMA work of the direct split kernel
+def prepack_wsplit(weight, arith=None):
+    """weight [1,Cout,Cin,3,3] -> int16 buffer of the hi/lo terms of U = G (weight/sqrt(9 Cin)) per kernel row in wsplit.hip's
+    LDS order (Cout % 128 == 0)."""
+    arith = _SPLIT_ARITH[arith or PRECISION]
+    N.require_device(weight)
+    w = N.f32c(weight)
+    _, cout, cin, k, _ = w.shape
+    wsp = torch.empty(N.load().sgdfr_modconv_prepack_wsplit_elems(cout, cin), device=w.device, dtype=torch.int16)
+    N.call('sgdfr_modconv_prepack_wsplit_f32', N.ptr(w), N.ptr(wsp), cout, cin, arith, _sat(), N.stream())
+    return wsp
+
+
+def wsplit_ok(B, cin, cout, H, W):
+    return PRECISION in _SPLIT_ARITH and bool(_shape_query('sgdfr_modconv2d_wsplit_supported', B, cin, cout, H, W))
+
+
+def to_wsplit(x, s, arith=None):
+    """x [B,Cin,H,W], s [B,Cin] -> int16 buffer [B, Cin/8, 4, 2, H*W/2, 8]: the Winograd input transform of x*s per output pair,
+    split (the "WS" form modconv_wsplit stages by DMA)."""
+    arith = _SPLIT_ARITH[arith or PRECISION]
+    N.require_device(x, s)
+    x, s = N.f32c(x), N.f32c(s)
+    B, cin, H, W = x.shape
+    vs = torch.empty(B, cin // 8, 4, 2, H * W // 2, 8, device=x.device, dtype=torch.int16)
+    N.call('sgdfr_to_wsplit_f32', N.ptr(x), N.ptr(s), N.ptr(vs), B, cin, H, W, arith, _sat(), N.stream())
+    return vs
+
+
+def modconv_wsplit(vs, shape, wsp, d, cout, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2,
+                   arith=None, rgb=None, want_y=True, s_next=None, desc=None):
+    """Plain 3x3 modulated conv of a WS input (to_wsplit / the blur's Winograd hand-over; shape = (B, Cin, H, W)) with the pack of
+    prepack_wsplit.  Outputs as modconv_split with a pre-split input: y | (y, part) | (y, part, xs_out)."""
+    arith = _SPLIT_ARITH[arith or PRECISION]
+    N.require_device(d, bias, noise_weight)
+    if not vs.is_cuda or vs.dtype != torch.int16 or not wsp.is_cuda or wsp.dtype != torch.int16:
+        raise RuntimeError('modconv_wsplit: vs / wsp are the int16 device buffers made by to_wsplit / prepack_wsplit')
+    B, cin, H, W = shape
+    nz, nzb = _noise_args(noise, B, H, W)
+    if not want_y and rgb is None and s_next is None:
+        raise RuntimeError('modconv_wsplit: want_y=False only makes sense with the fused ToRGB (rgb=...) or s_next')
+    y = torch.empty(B, cout, H, W, device=vs.device, dtype=torch.float32) if want_y else None
+    rgb_w = rgb_s = part = xs_out = None
+    if s_next is not None:
+        N.require_device(s_next)
+        s_next = N.f32c(s_next)
+        xs_out = torch.empty(B, cout // 8, 2, H * W, 8, device=vs.device, dtype=torch.int16)
+    if rgb is not None:
+        rgb_w, rgb_s = N.f32c(rgb[0]), N.f32c(rgb[1])
+        N.require_device(rgb_w, rgb_s)
+        part = torch.empty(B, (cout // 128) * 3, H, W, device=vs.device, dtype=torch.float32)
+    _timed_conv(desc or ('wsplit %d->%d @%dx%d' % (cin, cout, H, W)), B * conv_flops(cin, cout, H, W), lambda: N.call(
+        'sgdfr_modconv2d_wsplit_f32', N.ptr(vs), N.ptr(wsp), N.ptr(d), N.ptr(nz), nzb,
+        N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(_zero_words(vs.device)), N.ptr(y), N.ptr(rgb_w),
+        N.ptr(rgb_s), N.ptr(part), N.ptr(xs_out), N.ptr(s_next) if s_next is not None else None, B, cin, cout, H, W, arith,
+        int(activate), float(slope), float(gain), _sat(), N.stream()))
+    if s_next is not None:
+        return y, part, xs_out
+    return y if rgb is None else (y, part)
+
+
 def planes_to_split(gt, d, arith=None):
     """gt [B,C,4,H+1,W+1] (gradient of the transposed conv's parity planes), d [B,C] or None -> int16 buffer
     [B, 4*C/8, 2, (H+1)*(W+1), 8]: gt*d in the phase-major split form that modconv_split(mode=DOWN3) stages."""

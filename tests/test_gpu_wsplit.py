@@ -1,0 +1,99 @@
+"""1-D Winograd F(2,3) form of the plain split conv (csrc/wsplit.hip): the input transform B^T(x*s) and the weight transform
+G W are applied in fp32 BEFORE the hi/lo split, so the kernel is held to the same per-layer bound as the direct split kernels
+(2e-5 * scale vs the fp64 oracle in fp16x3, 1e-4 in bf16x3) -- reference ModulatedConv2d.forward model.py:232-273."""
+import pytest
+import torch
+
+from util import S, maxabs
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # cin, cout, H, B
+    (32, 128, 16, 3),      # 8 tile columns: one image per patch
+    (64, 128, 32, 2),      # 16 tile columns = whole rows, 4 patches per image
+    (48, 256, 64, 1),      # 2 patches across, 3 channel blocks, 2 cout tiles
+    (16, 128, 128, 2),     # 4 patches across
+    (16, 128, 256, 1),
+    (128, 384, 32, 5),
+]
+TOL = {'fp16x3': 2e-5, 'bf16x3': 1e-4}
+
+
+def _oracle(x, w, s, d, noise, nw, bias):
+    x, w, s, d = x.double().cpu(), w.double().cpu(), s.double().cpu(), d.double().cpu()
+    cin = x.shape[1]
+    y = torch.nn.functional.conv2d(x * s[:, :, None, None], w[0] / (cin * 9) ** 0.5, padding=1) * d[:, :, None, None]
+    y = y + nw.double().cpu() * noise.double().cpu() + bias.double().cpu().view(1, -1, 1, 1)
+    return torch.nn.functional.leaky_relu(y, 0.2) * 2 ** 0.5
+
+
+def _inputs(cin, cout, H, B, tag='wsplit'):
+    key = '%s.%d.%d.%d.%d' % (tag, cin, cout, H, B)
+    w = S.counter_tensor(5, key + '.w', (1, cout, cin, 3, 3)).cuda()
+    x = S.counter_tensor(5, key + '.x', (B, cin, H, H)).cuda()
+    s = S.counter_tensor(5, key + '.s', (B, cin), 1.0, 0.3).cuda()
+    d = S.counter_tensor(5, key + '.d', (B, cout), 1.0, 0.2).cuda()
+    noise = S.counter_tensor(5, key + '.n', (1, 1, H, H)).cuda()
+    nw = torch.full((1,), 0.1).cuda()
+    bias = S.counter_tensor(5, key + '.b', (cout,), 0.0, 0.1).cuda()
+    return w, x, s, d, noise, nw, bias
+
+
+@pytest.mark.parametrize('arith', ['fp16x3', 'bf16x3'])
+@pytest.mark.parametrize('cin,cout,H,B', CASES)
+def test_wsplit_conv_matches_fp64_oracle(cin, cout, H, B, arith):
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    w, x, s, d, noise, nw, bias = _inputs(cin, cout, H, B)
+    assert F_.N.load().sgdfr_modconv2d_wsplit_supported(B, cin, cout, H, H)
+    vs = F_.to_wsplit(x, s, arith)
+    y = F_.modconv_wsplit(vs, (B, cin, H, H), F_.prepack_wsplit(w, arith), d, cout, noise, nw, bias, True, arith=arith)
+    ref = _oracle(x, w, s, d, noise, nw, bias)
+    err = maxabs(y, ref)
+    assert err <= TOL[arith] * max(1.0, float(ref.abs().max())), err
+
+
+def _decode_split(xs, arith):
+    """[B, C/8, 2, HW, 8] int16 hi/lo -> fp32 [B, C, HW] (hi + lo)."""
+    dt = torch.float16 if arith == 'fp16x3' else torch.bfloat16
+    v = xs.view(dt).float()
+    v = v[:, :, 0] + v[:, :, 1]                       # [B, C/8, HW, 8]
+    B, G, HW, _ = v.shape
+    return v.permute(0, 1, 3, 2).reshape(B, G * 8, HW)
+
+
+@pytest.mark.parametrize('arith', ['fp16x3', 'bf16x3'])
+def test_wsplit_chain_outputs_match_the_direct_split_kernel(arith):
+    """xs_out (the next conv's split input) and the fused ToRGB partial sums, without y: same contract as modconv_split."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    cin, cout, H, B = 64, 256, 32, 3
+    w, x, s, d, noise, nw, bias = _inputs(cin, cout, H, B, 'wsplit.chain')
+    s_next = S.counter_tensor(5, 'wsplit.chain.sn', (B, cout), 1.0, 0.3).cuda()
+    rgb_w = S.counter_tensor(5, 'wsplit.chain.rw', (3, cout)).cuda()
+    rgb_s = S.counter_tensor(5, 'wsplit.chain.rs', (B, cout), 1.0, 0.3).cuda()
+    vs = F_.to_wsplit(x, s, arith)
+    y, part, xs = F_.modconv_wsplit(vs, (B, cin, H, H), F_.prepack_wsplit(w, arith), d, cout, noise, nw, bias, True, arith=arith,
+                                    rgb=(rgb_w, rgb_s), s_next=s_next, want_y=False)
+    assert y is None
+    ref = _oracle(x, w, s, d, noise, nw, bias)                                   # [B, cout, H, H] fp64
+    scale = max(1.0, float(ref.abs().max()))
+    xscale = 0.0625 if arith == 'fp16x3' else 1.0
+    got = _decode_split(xs, arith).view(B, cout, H, H).cpu().double() / xscale
+    want = ref * s_next.double().cpu()[:, :, None, None]
+    assert maxabs(got, want) <= 2 * TOL[arith] * max(1.0, float(want.abs().max()))
+    rgb = part.view(B, cout // 128, 3, H, H).sum(1).cpu().double()
+    want_rgb = torch.einsum('bchw,jc,bc->bjhw', ref, rgb_w.double().cpu(), rgb_s.double().cpu()) / cout ** 0.5
+    assert maxabs(rgb, want_rgb) <= 4 * TOL[arith] * max(1.0, float(want_rgb.abs().max()), scale)
+    # y together with the other outputs is the same y
+    y2, part2, xs2 = F_.modconv_wsplit(vs, (B, cin, H, H), F_.prepack_wsplit(w, arith), d, cout, noise, nw, bias, True, arith=arith,
+                                       rgb=(rgb_w, rgb_s), s_next=s_next, want_y=True)
+    assert maxabs(y2, ref) <= TOL[arith] * scale
+    assert torch.equal(xs2, xs) and torch.equal(part2, part)
+
+
+def test_wsplit_rejects_unsupported_shapes():
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    lib = F_.N.load()
+    assert not lib.sgdfr_modconv2d_wsplit_supported(2, 64, 64, 32, 32)        # Cout % 128
+    assert not lib.sgdfr_modconv2d_wsplit_supported(2, 64, 128, 8, 8)         # too narrow
+    assert not lib.sgdfr_modconv2d_wsplit_supported(2, 24, 128, 32, 32)       # Cin % 16
+    assert lib.sgdfr_modconv2d_wsplit_supported(64, 512, 512, 32, 32)
