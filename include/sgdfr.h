@@ -195,10 +195,11 @@ int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const float* noise
 
 /* sgdfr_blur_bias_act_f32 with the result multiplied by the NEXT layer's modulation s_next [B,C] and written in that layer's
  * split input form xs [B][C/8][2][2H*2W][8] (see sgdfr_to_split_f32) instead of fp32 NCHW.  plane_stride: floats between the
- * parity planes of t (0 = dense (H+1)*(W+1), see sgdfr_modconv2d_split_f32). */
+ * parity planes of t (0 = dense (H+1)*(W+1), see sgdfr_modconv2d_split_f32).  wino = 1 (W = 8 ... 64): xs receives the
+ * Winograd input form [B][C/8][4][2][2H*W][8] of sgdfr_to_wsplit_f32 instead (twice the bytes), for sgdfr_modconv2d_wsplit_f32. */
 int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, const float* noise, int64_t noise_bstride,
                                   const float* noise_w, const float* bias, const float* s_next, unsigned short* xs, int B, int C,
-                                  int H, int W, int64_t plane_stride, int arith, int act, float slope, float gain,
+                                  int H, int W, int64_t plane_stride, int arith, int wino, int act, float slope, float gain,
                                   unsigned int* sat, void* stream);
 
 /* y[b,j,p] = sum_i w_rgb[j*Cin+i]/sqrt(Cin) * s[b,i] * x[b,i,p] + bias[j]

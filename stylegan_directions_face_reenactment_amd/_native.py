@@ -81,7 +81,7 @@ SIGNATURES = {
     'sgdfr_blur_bias_act_f32': [_c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i, _i, _f,
                                 _f, ctypes.c_void_p],
     'sgdfr_blur_bias_act_split_f32': [_c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i64,
-                                      _i, _i, _f, _f, ctypes.c_void_p, ctypes.c_void_p],
+                                      _i, _i, _i, _f, _f, ctypes.c_void_p, ctypes.c_void_p],
     'sgdfr_torgb_fwd_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i,
                             ctypes.c_void_p],
 }

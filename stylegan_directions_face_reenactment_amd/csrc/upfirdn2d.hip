@@ -193,8 +193,12 @@ __device__ __forceinline__ void blur_split2(float a, float b, unsigned& hi, unsi
 // one of two LDS tiles, 8 waves split + store the other: a wave's in-order vmcnt then holds loads OR stores) 514 -> 682 us --
 // half as many loading waves per CU.  The kernel is bound by loads in flight and DRAM locality of its 32 streams per block,
 // not by load instructions or by the shared load / store queue.
-template <int ET, int QC, int NG>
-__global__ __launch_bounds__(8 * QC * NG, 4) void blur_split_kernel(const float* __restrict__ t, const float* __restrict__ fir,
+// WINO: the hand-over writes the Winograd F(2,3) input transform of the result instead ("WS" form of wsplit.hip:
+// [B][C/8][t 4][hi,lo][2H * W][8], V = B^T (y * s_next) per output pair; bit-identical to sgdfr_to_wsplit_f32 of the fp32
+// result).  A thread takes one output pair and reads its two row neighbours from the LDS tile, so the tile must span whole
+// rows (one column tile: 2W <= 128).
+template <int ET, int QC, int NG, bool WINO = false>
+__global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(const float* __restrict__ t, const float* __restrict__ fir,
                                                         const float* __restrict__ noise, int64_t noise_bstride,
                                                         const float* __restrict__ noise_w, const float* __restrict__ bias,
                                                         const float* __restrict__ s_next, unsigned char* __restrict__ xs,
@@ -325,6 +329,46 @@ __global__ __launch_bounds__(8 * QC * NG, 4) void blur_split_kernel(const float*
             if (sg + 1 < nseg && ms + BLUR_QV < H) load_segment(ms + BLUR_QV);
         }
         __syncthreads();
+        if (WINO) {
+            // 8 rows x QC output pairs -> 8 channels each: d_j = y[2*tc - 1 + j] * s_next, V = B^T d, split, 4 x 2 chunks
+            const int tc = lt % QC, row = lt / QC;
+            const int oy = 2 * ms + row;
+            if (oy < 2 * H && 2 * tc < OW && valid && (NG == 1 || ms < H)) {
+                const int HT = 2 * H * W;                 // output pairs per channel
+                unsigned char* dst = xs + (((((int64_t)b * G + g) * 4) * 2) * HT + (int64_t)oy * W + tc) * 16;
+                // one transform position at a time (V1 and V2 share d1, d2; then d0, then d3), so at most two pixels of the
+                // tile are live beside the sliding window: with all four at once the window spilled (112 B of scratch per lane)
+                auto emit = [&](int tt, const float (&vv)[8]) {
+                    uint4 vh, vl;
+                    unsigned* ph = reinterpret_cast<unsigned*>(&vh);
+                    unsigned* pl = reinterpret_cast<unsigned*>(&vl);
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) blur_split2<ET>(vv[2 * cc], vv[2 * cc + 1], ph[cc], pl[cc], sat);
+                    *reinterpret_cast<uint4*>(dst + (int64_t)(2 * tt) * HT * 16) = vh;
+                    *reinterpret_cast<uint4*>(dst + (int64_t)(2 * tt + 1) * HT * 16) = vl;
+                };
+                float d1[8], d2[8], vv[8];
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) {
+                    d1[cc] = tile[row][2 * tc][cc] * sv[cc];
+                    d2[cc] = tile[row][2 * tc + 1][cc] * sv[cc];
+                }
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) vv[cc] = d1[cc] + d2[cc];
+                emit(1, vv);
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) vv[cc] = d2[cc] - d1[cc];
+                emit(2, vv);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) vv[cc] = (tc > 0 ? tile[row][2 * tc - 1][cc] * sv[cc] : 0.f) - d2[cc];
+                emit(0, vv);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) vv[cc] = d1[cc] - (2 * tc + 2 < OW ? tile[row][2 * tc + 2][cc] * sv[cc] : 0.f);
+                emit(3, vv);
+            }
+        } else {
         // 8 rows x 64 px pixels -> 8 channels each: multiply by the next layer's style, split, two 16-byte chunks
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -347,6 +391,7 @@ __global__ __launch_bounds__(8 * QC * NG, 4) void blur_split_kernel(const float*
                     *reinterpret_cast<uint4*>(dst + (int64_t)OHW * 16) = vl;
                 }
             }
+        }
         }
         __syncthreads();
         }       // segments
@@ -535,9 +580,11 @@ extern "C" int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const f
 
 extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, const float* noise, int64_t noise_bstride,
                                              const float* noise_w, const float* bias, const float* s_next, unsigned short* xs,
-                                             int B, int C, int H, int W, int64_t plane_stride, int arith, int act, float slope,
-                                             float gain, unsigned int* sat, void* stream) {
+                                             int B, int C, int H, int W, int64_t plane_stride, int arith, int wino, int act,
+                                             float slope, float gain, unsigned int* sat, void* stream) {
     SGDFR_REQUIRE(B >= 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "blur_bias_act_split: bad shape %d %d %d %d (C %% 8)", B, C, H, W);
+    SGDFR_REQUIRE(!wino || (W >= 8 && W <= 64 && (W & (W - 1)) == 0), "blur_bias_act_split: the Winograd hand-over takes W = 8, 16, 32 or 64 "
+                  "(output rows inside one column tile), got %d", W);
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "blur_bias_act_split: arith must be SGDFR_SPLIT_BF16/FP16");
     if (B == 0) return 0;
     SGDFR_REQUIRE(t && fir && s_next && xs && (reinterpret_cast<uintptr_t>(xs) & 15) == 0, "blur_bias_act_split: null / misaligned pointer");
@@ -560,6 +607,14 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
     unsigned char* out = reinterpret_cast<unsigned char*>(xs);
     void (*kern)(const float*, const float*, const float*, int64_t, const float*, const float*, const float*, unsigned char*, int,
                  int, int, int, int, int, int, float, float, unsigned*);
+    if (wino) {
+        if (arith == SGDFR_SPLIT_FP16)
+            kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_FP16, 64, 1, true> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_FP16, 32, 1, true>
+                   : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_FP16, 16, 2, true> : blur_split_kernel<SGDFR_SPLIT_FP16, 8, 4, true>;
+        else
+            kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_BF16, 64, 1, true> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_BF16, 32, 1, true>
+                   : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_BF16, 16, 2, true> : blur_split_kernel<SGDFR_SPLIT_BF16, 8, 4, true>;
+    } else
     if (arith == SGDFR_SPLIT_FP16)
         kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_FP16, 64, 1> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_FP16, 32, 1>
                : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_FP16, 16, 2> : QC == 8 ? blur_split_kernel<SGDFR_SPLIT_FP16, 8, 4>

@@ -269,6 +269,11 @@ USE_RGB_FUSION = True        # ToRGB partial sums in the epilogue of the split c
 BACKWARD_ARITH = os.environ.get('SGDFR_BWD_ARITH', 'fp16x3')      # dL/dx convs of the split kernels: 'bf16x3' | 'fp16x3' (ranged per image, autograd.py)
 USE_SPLITK = True            # K-sliced launches for convs that cannot fill the chip (small batch / 4x4, 8x8 layers)
 USE_WINOGRAD = True          # plain 3x3 layers: Winograd F(2x2,3x3) MFMA kernel when the shape allows it
+# Inference chain, plain layers fed by a transposed conv + blur: 1-D Winograd F(2,3) form of the split conv (csrc/wsplit.hip).
+# The blur then writes 8 instead of 4 bytes per element, so it pays where the conv's K loop dominates: layers with at least
+# WSPLIT_MIN_CIN input channels (same-box A/B at B=64, scripts/wsplit_ab.py; 0 = never).
+USE_WSPLIT = os.environ.get('SGDFR_WSPLIT', '1') != '0'
+WSPLIT_MIN_CIN = int(os.environ.get('SGDFR_WSPLIT_MIN_CIN', '256'))
 WINOGRAD_MIN_BLOCKS = 256    # below this many (64 cout x 64 tile) blocks the direct kernel's smaller tiles win
 # Arithmetic of the 3x3 modulated convs (inference path, autograd forward, and dL/dx of the plain convs; the strided dL/dx of
 # the transposed convs and the weight gradients always use the fp32 MFMA kernels):
@@ -560,6 +565,12 @@ def wsplit_ok(B, cin, cout, H, W):
     return PRECISION in _SPLIT_ARITH and bool(_shape_query('sgdfr_modconv2d_wsplit_supported', B, cin, cout, H, W))
 
 
+def wsplit_chain_ok(B, cin, cout, H, W):
+    """Should the inference chain run this plain layer (fed by a transposed conv + blur) in Winograd form?"""
+    return USE_WSPLIT and USE_SPLIT_CHAIN and WSPLIT_MIN_CIN > 0 and cin >= WSPLIT_MIN_CIN and W <= 128 and \
+        wsplit_ok(B, cin, cout, H, W)
+
+
 def to_wsplit(x, s, arith=None):
     """x [B,Cin,H,W], s [B,Cin] -> int16 buffer [B, Cin/8, 4, 2, H*W/2, 8]: the Winograd input transform of x*s per output pair,
     split (the "WS" form modconv_wsplit stages by DMA)."""
@@ -631,11 +642,12 @@ def to_split(x, s, arith=None):
 
 class SplitAct:
     """An activation that only exists in the NEXT conv's split input form (x * s_next as 16-bit hi/lo pairs,
-    [B, C/8, 2, H*W, 8] int16): written by the producing kernel's epilogue, staged by DMA in the consumer."""
-    __slots__ = ('xs', 'shape')
+    [B, C/8, 2, H*W, 8] int16): written by the producing kernel's epilogue, staged by DMA in the consumer.  wino=True: the
+    Winograd input form of that conv instead ([B, C/8, 4, 2, H*W/2, 8], see to_wsplit / modconv_wsplit)."""
+    __slots__ = ('xs', 'shape', 'wino')
 
-    def __init__(self, xs, shape):
-        self.xs, self.shape = xs, tuple(shape)
+    def __init__(self, xs, shape, wino=False):
+        self.xs, self.shape, self.wino = xs, tuple(shape), bool(wino)
 
 
 def xin_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
@@ -645,10 +657,22 @@ def xin_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
 
 
 def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, noise_weight=None, bias=None, batch=None,
-                      s_next=None, rgb=None, want_y=True):
+                      s_next=None, rgb=None, want_y=True, wino_next=False):
     """One StyledConv on the split kernels with the inference-only dataflow options: x may be a SplitAct (then `s` is
     already applied), s_next asks for the output as a SplitAct for the next conv, rgb for the fused ToRGB partial sums.
+    A SplitAct in Winograd form (x.wino) runs on modconv_wsplit with `wsp` = the prepack_wsplit pack; wino_next (transposed
+    conv + blur only) asks for the output in that form.
     Returns (activation: fp32 tensor | SplitAct | None, ToRGB partials | None)."""
+    if isinstance(x, SplitAct) and x.wino:
+        if upsample:
+            raise RuntimeError('styled_conv_split: the Winograd input form feeds plain convs only')
+        B, cin, H, W = x.shape
+        res = modconv_wsplit(x.xs, x.shape, wsp, d, cout, noise, noise_weight, bias, True, rgb=rgb,
+                             want_y=want_y and s_next is None, s_next=s_next)
+        if s_next is not None:
+            _, part, xs = res
+            return SplitAct(xs, (B, cout, H, W)), part
+        return res if rgb is not None else (res, None)
     if isinstance(x, SplitAct):
         B, cin, H, W = x.shape
         xin, x_split, s_arg = x.xs, x.shape, None
@@ -669,12 +693,12 @@ def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, 
         # parity planes padded to whole 128-byte lines: the odd-sized dense planes make every store run straddle two lines
         ps = ((H + 1) * (W + 1) + 31) // 32 * 32
         planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split, plane_stride=ps)
-        xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, plane_stride=ps)
-        return SplitAct(xs, (B, cout, 2 * H, 2 * W)), None
+        xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, plane_stride=ps, wino=wino_next)
+        return SplitAct(xs, (B, cout, 2 * H, 2 * W), wino_next), None
     planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split)
     if s_next is not None:
-        xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True)
-        return SplitAct(xs, (B, cout, 2 * H, 2 * W)), None
+        xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, wino=wino_next)
+        return SplitAct(xs, (B, cout, 2 * H, 2 * W), wino_next), None
     return blur_bias_act(planes, fir, H, W, noise, noise_weight, bias, True), None
 
 
@@ -769,18 +793,22 @@ def blur_bias_act(planes, fir, H, W, noise=None, noise_weight=None, bias=None, a
 
 
 def blur_bias_act_split(planes, fir, H, W, s_next, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2,
-                        gain=SQRT2, arith=None, plane_stride=0):
+                        gain=SQRT2, arith=None, plane_stride=0, wino=False):
     """blur_bias_act whose result goes out as the next layer's split input (x * s_next as 16-bit hi/lo pairs,
     [B, C/8, 2, 2H*2W, 8] int16) instead of fp32 NCHW.  plane_stride: floats between the parity planes when `planes` is the
-    padded [B, C, 4, plane_stride] buffer of modconv_split(mode=UP3, plane_stride=...)."""
+    padded [B, C, 4, plane_stride] buffer of modconv_split(mode=UP3, plane_stride=...).  wino=True: the Winograd input form of
+    to_wsplit instead ([B, C/8, 4, 2, 2H*W, 8], for modconv_wsplit)."""
     arith = _SPLIT_ARITH[arith or PRECISION]
     N.require_device(planes, fir, bias, noise_weight, s_next)
     B, C = planes.shape[0], planes.shape[1]
     nz, nzb = _noise_args(noise, B, 2 * H, 2 * W)
-    xs = torch.empty(B, C // 8, 2, 4 * H * W, 8, device=planes.device, dtype=torch.int16)
+    if wino:
+        xs = torch.empty(B, C // 8, 4, 2, 2 * H * W, 8, device=planes.device, dtype=torch.int16)
+    else:
+        xs = torch.empty(B, C // 8, 2, 4 * H * W, 8, device=planes.device, dtype=torch.int16)
     N.call('sgdfr_blur_bias_act_split_f32', N.ptr(planes), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
            N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(N.f32c(s_next)), N.ptr(xs), B, C, H, W,
-           int(plane_stride), arith, int(activate), float(slope), float(gain), _sat(), N.stream())
+           int(plane_stride), arith, int(bool(wino)), int(activate), float(slope), float(gain), _sat(), N.stream())
     return xs
 
 

@@ -205,7 +205,8 @@ def test_batched_reenactment_equals_per_frame_loop():
 
 def test_split_chain_is_bit_identical_to_layer_by_layer():
     """Inference dataflow of the split kernels (activations handed over only in the next conv's split form, ToRGB fused,
-    last activation never stored) == the same kernels run layer by layer through fp32 activations, bit for bit."""
+    last activation never stored) == the same kernels run layer by layer through fp32 activations, bit for bit.  (With the
+    Winograd form of the wide plain layers switched off: that one changes the arithmetic, see the next test.)"""
     from stylegan_directions_face_reenactment_amd import functional as F_
     if F_.PRECISION == 'fp32':
         pytest.skip('the chain exists only for the split arithmetics')
@@ -213,15 +214,49 @@ def test_split_chain_is_bit_identical_to_layer_by_layer():
         G = hip_generator(size, 1)
         w = S.synthetic_latents(SEED, B, n_latent=G.n_latent, key='chain.w').cuda()
         tr = S.counter_tensor(SEED, 'chain.t', (1, 512)).cuda()
-        with torch.no_grad():
-            a, _ = G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr)
-            F_.USE_SPLIT_CHAIN = False
-            try:
-                b, _ = G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr)
-            finally:
-                F_.USE_SPLIT_CHAIN = True
+        F_.USE_WSPLIT = False
+        try:
+            with torch.no_grad():
+                a, _ = G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr)
+                F_.USE_SPLIT_CHAIN = False
+                try:
+                    b, _ = G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr)
+                finally:
+                    F_.USE_SPLIT_CHAIN = True
+        finally:
+            F_.USE_WSPLIT = True
         assert torch.equal(a, b)
         assert G.saturated_pairs() == 0 or F_.PRECISION != 'fp16x3'     # nothing of this generator hit the fp16 clamp
+
+
+def test_winograd_chain_layers_stay_within_the_per_image_bound():
+    """The wide plain layers of the chain run in 1-D Winograd F(2,3) form (csrc/wsplit.hip, fed by the blur's transformed
+    hand-over): a different summation order, so not bit-identical to the direct split kernels -- held to the fp64 oracle with
+    the same image bound, and to the direct chain within twice the arithmetic's noise."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    if F_.PRECISION == 'fp32':
+        pytest.skip('the chain exists only for the split arithmetics')
+    size, B = 256, 16                                     # (smaller batches K-slice these layers: no fused ToRGB, no chain form)
+    G = hip_generator(size, 1)
+    w = S.synthetic_latents(SEED, B, n_latent=G.n_latent, key='wchain.w').cuda()
+    P64 = O.cast_state(synthetic_state(size, 1), torch.float64)
+    with torch.no_grad():
+        ref, _ = O.generator_forward(P64, [w[:2].double().cpu()], input_is_latent=True)
+        assert F_.USE_WSPLIT
+        a, _ = G([w], input_is_latent=True)
+        used = sorted(G._wino_inputs(B, [G.conv1] + list(G.convs)))
+        F_.USE_WSPLIT = False
+        try:
+            b, _ = G([w], input_is_latent=True)
+        finally:
+            F_.USE_WSPLIT = True
+    assert used == [6, 8], used                          # 512 @ 32^2, 256 @ 64^2 (512 @ 16^2 joins from B = 48)
+    assert not torch.equal(a, b)
+    bound = 2e-4 if F_.PRECISION == 'fp16x3' else 5e-4
+    ea, eb = maxabs(a[:2], ref), maxabs(b[:2], ref)
+    print('256^2 images vs fp64 oracle: winograd chain %.2e, direct chain %.2e' % (ea, eb))
+    assert ea <= bound and eb <= bound
+    assert G.saturated_pairs() == 0 or F_.PRECISION != 'fp16x3'
 
 
 def test_generator_forward_replays_a_hipgraph_by_default():

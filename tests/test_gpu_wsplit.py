@@ -97,3 +97,28 @@ def test_wsplit_rejects_unsupported_shapes():
     assert not lib.sgdfr_modconv2d_wsplit_supported(2, 64, 128, 8, 8)         # too narrow
     assert not lib.sgdfr_modconv2d_wsplit_supported(2, 24, 128, 32, 32)       # Cin % 16
     assert lib.sgdfr_modconv2d_wsplit_supported(64, 512, 512, 32, 32)
+
+
+@pytest.mark.parametrize('arith', ['fp16x3', 'bf16x3'])
+@pytest.mark.parametrize('C,H,B', [(16, 8, 5), (64, 16, 3), (24, 32, 2), (16, 64, 2)])
+def test_blur_winograd_handover_is_bit_identical_to_transforming_the_fp32_result(C, H, B, arith):
+    """sgdfr_blur_bias_act_split_f32(wino=1) == sgdfr_to_wsplit_f32(sgdfr_blur_bias_act_f32(...), s_next), dense and padded planes."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    key = 'wblur.%d.%d.%d' % (C, H, B)
+    fir = torch.tensor([[1., 3., 3., 1.]]).cuda()
+    fir = fir.t() @ fir
+    fir = fir / fir.sum() * 4
+    planes = S.counter_tensor(6, key + '.t', (B, C, 4, H + 1, H + 1)).cuda()
+    noise = S.counter_tensor(6, key + '.n', (1, 1, 2 * H, 2 * H)).cuda()
+    nw = torch.full((1,), 0.3).cuda()
+    bias = S.counter_tensor(6, key + '.b', (C,), 0.0, 0.1).cuda()
+    sn = S.counter_tensor(6, key + '.s', (B, C), 1.0, 0.3).cuda()
+    y = F_.blur_bias_act(planes, fir, H, H, noise, nw, bias, True)
+    want = F_.to_wsplit(y, sn, arith)
+    got = F_.blur_bias_act_split(planes, fir, H, H, sn, noise, nw, bias, True, arith=arith, wino=True)
+    assert got.shape == want.shape and torch.equal(got, want)
+    ps = ((H + 1) * (H + 1) + 31) // 32 * 32
+    padded = torch.zeros(B, C, 4, ps, device='cuda')
+    padded[..., :(H + 1) * (H + 1)] = planes.view(B, C, 4, -1)
+    got2 = F_.blur_bias_act_split(padded, fir, H, H, sn, noise, nw, bias, True, arith=arith, plane_stride=ps, wino=True)
+    assert torch.equal(got2, want)
