@@ -22,8 +22,9 @@
 // (no registers, no VALU); weight pack [cout tile 128][cin block][ky][t][hi,lo][k-half][128][8].  Block = 8 waves = 128 couts x
 // 128 tiles (256 pixels) as a TR x TCT patch of tile space (TCT = min(16, W/2) tile columns: Winograd tiles do not overlap
 // along x, so a patch has only a vertical halo: (TR+2) x TCT staged positions); wave tile 32 couts x 64 tiles x 4 positions = 8
-// accumulators.  K loop: 16-channel blocks x 3 barrier-delimited sub-stages (one kernel row: 4 positions x 6 MFMAs per wave),
-// V double-buffered per channel block (40 KB each), U in a 2-slot ring (32 KB per sub-stage), everything one sub-stage ahead.
+// accumulators.  K loop: 16-channel blocks x 6 barrier-delimited half-stages (kernel row x position pair: 12 MFMAs per wave),
+// V double-buffered per channel block (40 KB each), U in a 4-slot ring of 16 KB half-slabs DMA'd three half-stages ahead; the
+// first fragments of a half-stage are requested before the barrier that precedes it (see the loop).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -103,11 +104,22 @@ __device__ __forceinline__ void ws_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n in 0..4 (the instruction takes an immediate)
+__device__ __forceinline__ void ws_wait_vmcnt_dyn(int n) {
+    switch (n) {
+        case 0: ws_wait_vmcnt<0>(); break;
+        case 1: ws_wait_vmcnt<1>(); break;
+        case 2: ws_wait_vmcnt<2>(); break;
+        case 3: ws_wait_vmcnt<3>(); break;
+        default: ws_wait_vmcnt<4>(); break;
+    }
+}
+
 template <int ET>
 __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
     constexpr int NT = 128, NI = 2, NEXV = 5;
     constexpr int WSLOT = 32768;                  // one kernel row of one cout tile: [t 4][part 2][k-half 2][128][8] x 16 bit
-    constexpr int WV = 4;                         // 1 KB DMA pieces per wave and weight sub-stage
+    constexpr int WHALF = 16384;                  // one position pair of it = one half-stage = one ring slot
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int xbuf_bytes = 256 * p.xs;            // [t 4][part 2][k-half 2][xs][8] x 16 bit
     unsigned char* const xb0 = smem;
@@ -202,16 +214,18 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
         __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(xb + (e * 8 + wave) * 1024), 16, 0, 0);
     };
     const int ncb = p.Cin / WS_CB;
+    const int nh = ncb * 6;                             // half-stages: (channel block, kernel row, position pair)
     const unsigned char* const wglb = p.wsp + (int64_t)ct * ncb * 3 * WSLOT;
-    auto issue_w = [&](int u, int slot) {
+    // weight slab of half-stage h = (cb, ky, tp): 16 KB [2 positions][part][k-half][128][8], 2 pieces per wave
+    auto issue_w = [&](int h) {
 #ifdef SGDFR_WSPLIT_PROBE
         if (p.dbg & 16) return;
 #endif
 #pragma unroll
-        for (int v = 0; v < WV; ++v) {
+        for (int v = 0; v < 2; ++v) {
             const int piece = wave + v * 8;
-            __builtin_amdgcn_global_load_lds((glb_void*)(wglb + (int64_t)u * WSLOT + piece * 1024 + lane * 16),
-                                             (lds_void*)(wb0 + slot * WSLOT + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(wglb + (int64_t)h * WHALF + piece * 1024 + lane * 16),
+                                             (lds_void*)(wb0 + (h & 3) * WHALF + piece * 1024), 16, 0, 0);
         }
     };
 
@@ -223,10 +237,20 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][n][r] = 0.f;
 
-    // ---- prologue: channel block 0 and the first weight slab
+    // V pieces this wave really issues (xs = 144: the fifth piece exists for waves 0-3 only), per half-stage of a channel block:
+    // pieces {0, 1}, {2}, {3}, {4} in half-stages 0..3 -- all landed and published by the barrier that ends half-stage 4
+    int nvw[4];
+    {
+        auto ex = [&](int e) { return (e * 8 + wave) * 64 < 16 * p.xs ? 1 : 0; };
+        nvw[0] = ex(0) + ex(1); nvw[1] = ex(2); nvw[2] = ex(3); nvw[3] = ex(4);
+    }
+
+    // ---- prologue: channel block 0, the first three weight half-slabs
 #pragma unroll
     for (int e = 0; e < NEXV; ++e) issue_v(e, 0, xb0);
-    issue_w(0, 0);
+    issue_w(0);
+    if (nh > 1) issue_w(1);
+    if (nh > 2) issue_w(2);
     if (tid < NT) {
         const float oscale = (ET == SGDFR_SPLIT_FP16) ? WS_F16_OUT : 1.f;
         const float xsc = (ET == SGDFR_SPLIT_FP16) ? WS_F16_XSCALE : 1.f;
@@ -240,65 +264,83 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+    // K loop.  The weight half-slabs live in a FOUR-slot ring (16 KB each) and are DMA'd three half-stages ahead: the slab of
+    // h+1 is published by the barrier that ends h-1, so the first fragments of h+1 are requested in the middle of h -- BEFORE
+    // the barrier that ends h -- and no wave starts a half-stage waiting for LDS.  (With one barrier per kernel row and two
+    // 32 KB slots every wave of the block asked for its first six fragments right behind the barrier: 48 KB of LDS reads with
+    // the matrix cores idle, ~15 % of a 24-MFMA sub-stage.)  The barrier's counted wait leaves the pieces issued during h in
+    // flight and completes everything older (the slab of h+2, V pieces of the next channel block).
     const int a_off = (hi * 128 + wm * 32 + l31) * 16;
     const bool late = wave >= 4 && !(p.dbg & 4);      // the two waves of a SIMD issue their DMA pieces at different times (split.hip)
-    int xsel = 0, wsel = 0;
     const int rowstep = p.TCT * 16;
+    ws_frag a[2][2], b[2][2][NI];      // [set][part]
+    auto fetch = [&](int set, const unsigned char* wsl, const unsigned char* xr, int tl, int t) {
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            a[set][part] = *reinterpret_cast<const ws_frag*>(wsl + (tl * 2 + part) * 4096);
+#pragma unroll
+            for (int n = 0; n < NI; ++n)
+                b[set][part][n] = *reinterpret_cast<const ws_frag*>(xr + (t * 2 + part) * 32 * p.xs + boff[n]);
+        }
+    };
+    fetch(0, wb0 + a_off, xb0, 0, 0);
+    int xsel = 0, h = 0;
     for (int cb = 0; cb < ncb; ++cb) {
         const unsigned char* xcur = xb0 + xsel * xbuf_bytes;
         unsigned char* xnext = xb0 + (xsel ^ 1) * xbuf_bytes;
         const bool v_next = cb + 1 < ncb;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int u = cb * 3 + ky;
-            const bool more = u + 1 < ncb * 3;
+        for (int hh = 0; hh < 6; ++hh, ++h) {
+            const int ky = hh >> 1, tp = hh & 1;
+            int n_issued = 0;
             auto issue_all = [&]() {
-                if (more) issue_w(u + 1, wsel ^ 1);
-                if (v_next) {      // 5 pieces over the three sub-stages: 2, 2, 1
-                    if (ky == 0) { issue_v(0, cb + 1, xnext); issue_v(1, cb + 1, xnext); }
-                    if (ky == 1) { issue_v(2, cb + 1, xnext); issue_v(3, cb + 1, xnext); }
-                    if (ky == 2) issue_v(4, cb + 1, xnext);
+                if (h + 3 < nh) { issue_w(h + 3); n_issued += 2; }
+                if (v_next && hh < 4) {
+                    if (hh == 0) { issue_v(0, cb + 1, xnext); issue_v(1, cb + 1, xnext); }
+                    if (hh == 1) issue_v(2, cb + 1, xnext);
+                    if (hh == 2) issue_v(3, cb + 1, xnext);
+                    if (hh == 3) issue_v(4, cb + 1, xnext);
+                    n_issued += nvw[hh < 4 ? hh : 0];
                 }
             };
             if (!late) issue_all();
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned char* wslot = wb0 + wsel * WSLOT + a_off;
+            const unsigned char* wsl = wb0 + (h & 3) * WHALF + a_off;
             const unsigned char* xrow = xcur + ky * rowstep;
-            ws_frag a[2][2], b[2][2][NI];      // [set][part]
-            auto fetch = [&](int set, int t) {
+            // first position of the pair: fragments were requested during the previous half-stage
 #pragma unroll
-                for (int part = 0; part < 2; ++part) {
-                    a[set][part] = *reinterpret_cast<const ws_frag*>(wslot + (t * 2 + part) * 4096);
+            for (int n = 0; n < NI; ++n) acc[2 * tp][n] = ws_mfma<ET>(a[0][0], b[0][0][n], acc[2 * tp][n]);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(1, wsl, xrow, 1, 2 * tp + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int n = 0; n < NI; ++n)
-                        b[set][part][n] = *reinterpret_cast<const ws_frag*>(xrow + (t * 2 + part) * 32 * p.xs + boff[n]);
-                }
-            };
-            fetch(0, 0);
+            for (int n = 0; n < NI; ++n) acc[2 * tp][n] = ws_mfma<ET>(a[0][0], b[0][1][n], acc[2 * tp][n]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int cur = t & 1;
-                __builtin_amdgcn_sched_barrier(0);
+            for (int n = 0; n < NI; ++n) acc[2 * tp][n] = ws_mfma<ET>(a[0][1], b[0][0][n], acc[2 * tp][n]);
+            __builtin_amdgcn_sched_barrier(0);
+            // second position; the first fragments of the NEXT half-stage are requested behind its hi*hi products
 #pragma unroll
-                for (int n = 0; n < NI; ++n) acc[t][n] = ws_mfma<ET>(a[cur][0], b[cur][0][n], acc[t][n]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (t < 3) fetch(cur ^ 1, t + 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int n = 0; n < NI; ++n) acc[t][n] = ws_mfma<ET>(a[cur][0], b[cur][1][n], acc[t][n]);
-#pragma unroll
-                for (int n = 0; n < NI; ++n) acc[t][n] = ws_mfma<ET>(a[cur][1], b[cur][0][n], acc[t][n]);
-                if (t == 1 && late) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue_all();
-                }
+            for (int n = 0; n < NI; ++n) acc[2 * tp + 1][n] = ws_mfma<ET>(a[1][0], b[1][0][n], acc[2 * tp + 1][n]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (late) issue_all();
+            if (h + 1 < nh) {
+                const int hn = hh + 1;      // (6 = the first half-stage of the next channel block)
+                fetch(0, wb0 + ((h + 1) & 3) * WHALF + a_off, (hn == 6 ? xnext : xcur) + (hn == 6 ? 0 : (hn >> 1)) * rowstep, 0,
+                      hn == 6 ? 0 : 2 * (hn & 1));
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-                ws_wait_vmcnt<0>();
+#pragma unroll
+            for (int n = 0; n < NI; ++n) acc[2 * tp + 1][n] = ws_mfma<ET>(a[1][0], b[1][1][n], acc[2 * tp + 1][n]);
+#pragma unroll
+            for (int n = 0; n < NI; ++n) acc[2 * tp + 1][n] = ws_mfma<ET>(a[1][1], b[1][0][n], acc[2 * tp + 1][n]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (h + 1 < nh) {
+#ifdef SGDFR_WSPLIT_PROBE
+                if (!(p.dbg & 32))
+#endif
+                ws_wait_vmcnt_dyn(n_issued);
                 __builtin_amdgcn_s_barrier();
             }
-            wsel ^= 1;
         }
         xsel ^= 1;
     }
