@@ -3,7 +3,7 @@ committed summaries under profiles/:  python scripts/summarize_pmc.py r1e r01_e 
 import collections, csv, json, shutil, sys
 
 tag, out = sys.argv[1], sys.argv[2]
-CONV = ('modconv_mfma', 'wino_mfma', 'wino2_mfma', 'split_mfma')
+CONV = ('modconv_mfma', 'wino_mfma', 'wino2_mfma', 'split_mfma', 'wsplit_kernel')
 precision = sys.argv[3] if len(sys.argv) > 3 else 'fp16x3'
 
 
