@@ -84,6 +84,9 @@ def parse_args(argv=None):
     ap.add_argument('--layers', action='store_true', help='also print the per-layer conv table to stderr')
     ap.add_argument('--precision', choices=('fp16x3', 'fp32', 'bf16x3'), default='fp16x3')
     ap.add_argument('--no-alt', action='store_true', help='skip the extra leg that times the other arithmetic')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='synthesis config: consecutive (independent) batches alternate between this many HIP streams '
+                         '(functional.StreamPipeline; 1 = every step on one stream, also reported as `single_stream`)')
     ap.add_argument('--sustain', type=float, default=6.0,
                     help='seconds of back-to-back steps after the K-step region (synthesis; 0 = skip): the `sustained` figure')
     ap.add_argument('--no-other-configs', action='store_true',
@@ -323,7 +326,7 @@ def cpu_baseline(size, cm, budget_s=24.0):
                       'swept thread counts' % (r2, e2, r8, e8, size, cm)}
 
 
-def sustained_leg(step, units_per_step, ms_per_step, dev, seconds, probe=100):
+def sustained_leg(step, units_per_step, ms_per_step, dev, seconds, probe=100, join=None):
     """The same step back to back for >= `seconds` of wall time (the K-step region above is a sub-second burst on a chip that
     clocks to its power budget): frames/s over the whole leg and HIP-event times of its first and last `probe` steps."""
     n = max(int(seconds * 1e3 / max(ms_per_step, 1e-3)) + 1, 3 * probe)
@@ -333,11 +336,15 @@ def sustained_leg(step, units_per_step, ms_per_step, dev, seconds, probe=100):
     t0 = time.perf_counter()
     ev[0].record()
     for i in range(n):
+        if i in (probe, n - probe) and join is not None:
+            join()                       # (steps on slot streams: the probing stream waits for them before it stamps)
         if i == probe:
             ev[1].record()
         if i == n - probe:
             ev[2].record()
         step()
+    if join is not None:
+        join()
     ev[3].record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -398,30 +405,47 @@ def run_synthesis(args, rank, world, dev):
     lo, hi = D.shard_range(B * world, rank, world)
     w = S.synthetic_latents(SEED, B * world, n_latent=G.n_latent, key='bench.w')[lo:hi].contiguous().to(dev)
 
-    def step():
+    def step1():
         img, _ = G([w], input_is_latent=True)
         return img
 
+    # Steps are independent batches: they alternate between `--streams` HIP streams, so the latency-bound head of a forward
+    # (K-sliced 4x4 ... 16x16 layers, ~30 dependent launches) runs beside the big layers of the previous one.  Every kernel
+    # and every image is the same as on one stream (tests/test_gpu_generator.py); `single_stream` below is the K-step figure
+    # without it, and the per-kernel roofline pass always runs on one stream.
+    # (forwards small enough for the generator's own hipGraph replay are host-bound and share the graph's static buffers: one stream)
+    pipe = F_.StreamPipeline(args.streams, dev) if (args.streams > 1 and B * (args.size / 256.0) ** 2 > G.GRAPH_MAX_WORK) else None
+
+    def step():
+        if pipe is None:
+            return step1()
+        with pipe.next():
+            return step1()
+
     F_.set_precision(args.precision)
-    sustained = None
+    sustained = single = None
     with torch.no_grad():
+        if pipe is not None:
+            e1, _, _ = timed_region(step1, args, dev)
+            single = {'value': round(B * world * args.steps / e1, 2), 'unit': 'frames/s', 'ms_per_step': round(e1 / args.steps * 1e3, 3)}
         elapsed, mine, img = timed_region(step, args, dev)
         assert img.shape == (hi - lo, 3, args.size, args.size) and bool(torch.isfinite(img).all())
         head = {args.precision: img[:2].clone()}            # rows 0, 1 of the timed batch -> max_abs_vs_oracle
         spread = rank_spread((hi - lo) * args.steps, mine, dev, world)
         if args.sustain > 0:
-            n_s, wall_s, sustained = sustained_leg(step, B, elapsed / args.steps * 1e3, dev, args.sustain)
+            n_s, wall_s, sustained = sustained_leg(step, B, elapsed / args.steps * 1e3, dev, args.sustain,
+                                                   join=pipe.join if pipe is not None else None)
             sustained['frames_per_s'] = round(B * world * n_s / wall_s, 2)
-        roof = roofline_for(args.precision, step, args.steps, B)
+        roof = roofline_for(args.precision, step1, args.steps, B)
         roof['traffic'] = pmc_traffic(args, B)
         alt = None
         alt_mode = 'fp32' if args.precision != 'fp32' else 'fp16x3'
         if not args.no_alt:
-            exact = step()
+            exact = step1()
             F_.set_precision(alt_mode)
             try:
                 alt_elapsed, _, fast = timed_region(step, args, dev)
-                alt_roof = roofline_for(alt_mode, step, args.steps, B)
+                alt_roof = roofline_for(alt_mode, step1, args.steps, B)
             finally:
                 F_.set_precision(args.precision)
             head[alt_mode] = fast[:2].clone()
@@ -436,6 +460,9 @@ def run_synthesis(args, rank, world, dev):
                     % (world, args.size, args.cm, B),
                     {'weight_broadcast_bytes': bcast_bytes, 'weight_broadcast_ms': round(bcast_ms, 2),
                      'per_rank_frames_per_s_min_max': spread})
+    if single is not None:
+        out['config']['parallelism'] += '; consecutive batches alternate between %d HIP streams' % args.streams
+        out['single_stream'] = single
     if sustained is not None:
         sustained['vs_value'] = round(sustained['frames_per_s'] / value, 4)
         if abs(sustained['vs_value'] - 1) > 0.03:

@@ -6,7 +6,7 @@ set -u
 tag=$1
 mkdir -p gpurun_out
 python -c "import bench; print(bench.kernel_source_hash())" > gpurun_out/source_hash_$tag.txt   # what the counters were measured on
-B="python bench.py --no-cpu-baseline --no-alt --no-other-configs --no-oracle-delta --sustain 0"
+B="python bench.py --no-cpu-baseline --no-alt --no-other-configs --no-oracle-delta --sustain 0 --streams 1"   # (kernels of one forward at a time: the durations bench.py's roofline pass sees)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o bench -- $B --steps 10 --warmup 3 > gpurun_out/bench_prof_$tag.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   n=$(echo $c | tr A-Z a-z | cut -d_ -f1)

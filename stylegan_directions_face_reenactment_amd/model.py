@@ -700,7 +700,10 @@ class Generator(nn.Module):
         return (tuple(w.shape), bool(input_is_latent), bool(return_latents), float(truncation),
                 None if truncation >= 1 else tuple(truncation_latent.shape), u8, F_.PRECISION, F_.RANGE_PLAN, F_.USE_SPLIT_CHAIN,
                 F_.USE_RGB_FUSION, F_.USE_SPLITK, F_.USE_PLANE_PADDING, bool(self.overlap_rgb), w.device, F_.USE_WSPLIT,
-                F_.WSPLIT_MIN_CIN)
+                F_.WSPLIT_MIN_CIN,
+                # a graph's static input / output buffers belong to the stream that replays it: forwards queued on different
+                # streams (functional.StreamPipeline) get their own capture instead of racing on one
+                torch.cuda.current_stream(w.device).cuda_stream)
 
     def forward(self, styles, return_latents=False, return_features=False, inject_index=None, truncation=1,
                 truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=False, image_out=None,

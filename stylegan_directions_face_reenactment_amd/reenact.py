@@ -100,13 +100,16 @@ def load_latent_codes(paths, device=None):
 class ReenactmentSession:
     """One source identity, many target poses/expressions."""
 
-    def __init__(self, G, A, source_code, truncation=0.7, trunc=None, batch=32, graph=False, shifts=None):
+    def __init__(self, G, A, source_code, truncation=0.7, trunc=None, batch=32, graph=False, shifts=None, streams=2):
         """shifts: a `shift.ShiftVectors` (direction tables of the dataset) -- then `render_targets` / `frames_for_targets`
         take the 3DMM parameters of source and targets and build the shift vectors on the device too.
         graph=True captures one `batch`-sized step (DirectionMatrix -> shift -> generator) in a hipGraph the first time a
         full batch is rendered and replays it afterwards: the ~65 launches of a step become one submission, which is what a
         small batch is bound by (B=1: 1.10 -> 0.72 ms per frame).  Weights must not be replaced while the graph is alive
-        (call `reset_graph()` after loading new ones); partial last batches run eagerly."""
+        (call `reset_graph()` after loading new ones); partial last batches run eagerly.
+        streams: consecutive chunks alternate between this many HIP streams (functional.StreamPipeline: the latency-bound head
+        of chunk i+1 runs beside the big layers of chunk i; 1 = everything on the caller's stream).  Replayed graphs share
+        their static buffers and stay on the caller's stream."""
         if source_code.ndim == 2:
             source_code = source_code.unsqueeze(0)
         if source_code.shape[0] != 1 or source_code.shape[1] != G.n_latent:
@@ -119,11 +122,14 @@ class ReenactmentSession:
         self.use_graph = bool(graph)
         self.shifts = shifts
         self._graph = None          # (hipGraph, static shift-vector input, static image output)
+        self.n_streams = max(1, int(streams))
+        self.pipeline_min_work = G.GRAPH_MAX_WORK      # batch * (size/256)^2 above which chunks alternate between the streams
+        self._pipe = None
 
     def reset_graph(self):
         self._graph = None
 
-    def _step(self, sv, image_out=None):
+    def _step(self, sv, image_out=None, no_graph=False):
         shift = self.A(sv)                                              # [b, L, 512] (w_plus) or [b, 512]
         b = sv.shape[0]
         w = self.source.expand(b, -1, -1).contiguous()
@@ -132,7 +138,7 @@ class ReenactmentSession:
         # (a session with graph=True captures the whole step itself -- DirectionMatrix and latent shift included -- so the
         # generator's own per-forward graphs stay out of it)
         img, _ = self.G([latent], input_is_latent=True, truncation=self.truncation, truncation_latent=self.trunc,
-                        image_out=image_out, graph=False if self.use_graph else None)
+                        image_out=image_out, graph=False if (self.use_graph or no_graph) else None)
         return img
 
     def _graphed_step(self, sv):
@@ -166,20 +172,40 @@ class ReenactmentSession:
         functional.U8Target or None (eager chunks: the last ToRGB launch writes uint8 frames)."""
         n = shift_vectors.shape[0]
         pending = None
+        pipe = None
+        # (chunks small enough for the generator's own hipGraph replay are host-bound and share the graph's static buffers: one stream)
+        if self.n_streams > 1 and not self.use_graph and n > self.batch and \
+                self.batch * (self.G.size / 256.0) ** 2 > self.pipeline_min_work:
+            if self._pipe is None or self._pipe.streams[0].device != shift_vectors.device:
+                self._pipe = F_.StreamPipeline(self.n_streams, shift_vectors.device)
+            pipe = self._pipe
+        poisoned = [False]      # a chunk clamped operands: chunks launched in fp16x3 before the fallback took hold are suspect too
+                                # (with two streams in flight the saturation word cannot tell which of them it was)
 
         def launch(lo):
             sv = shift_vectors[lo:lo + self.batch]
             u8 = target_for(lo, sv.shape[0]) if target_for is not None else None
             if self.use_graph and sv.shape[0] == self.batch:
                 img, tok = self._graphed_step(sv)
-                return [lo, sv, u8, img, tok, True]
-            img = self._step(sv, u8)
-            return [lo, sv, u8, img, self.G.take_range_token(), False]
+                return [lo, sv, u8, img, tok, True, None, 'graph']
+            mode = self.G.range_mode()
+            if pipe is None:
+                img = self._step(sv, u8)
+                return [lo, sv, u8, img, self.G.take_range_token(), False, None, mode]
+            with pipe.next():
+                img = self._step(sv, u8, no_graph=True)
+                tok = self.G.take_range_token()
+            return [lo, sv, u8, img, tok, False, pipe.last, mode]
 
         def settle(item):
-            lo, sv, u8, img, tok, graphed = item
-            if not self.G.range_ok(tok):                                    # clamped: this chunk again, eagerly, in bf16x3
-                self._graph = None
+            lo, sv, u8, img, tok, graphed, stream, mode = item
+            ok = self.G.range_ok(tok)
+            if stream is not None:
+                pipe.join(img, stream=stream)                               # the caller's stream may now read this chunk
+            if not ok:
+                poisoned[0] = True
+            if not ok or (poisoned[0] and pipe is not None and mode == 'fp16x3'):
+                self._graph = None                                          # clamped: this chunk again, eagerly, in bf16x3
                 img, graphed = self._step(sv, u8), False
             return lo, sv, u8, img, graphed
 

@@ -259,6 +259,42 @@ def test_winograd_chain_layers_stay_within_the_per_image_bound():
     assert G.saturated_pairs() == 0 or F_.PRECISION != 'fp16x3'
 
 
+def test_independent_batches_on_alternating_streams_give_the_same_images():
+    """functional.StreamPipeline (bench.py --streams, ReenactmentSession(streams=2)): consecutive independent batches on two
+    HIP streams overlap in time; every image is bit-identical to the one-stream rendering, for raw forwards and for the
+    session's verified chunks (uint8 video frames included)."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    from stylegan_directions_face_reenactment_amd.direction_matrix import DirectionMatrix
+    from stylegan_directions_face_reenactment_amd.reenact import ReenactmentSession
+    G = hip_generator(64, 1)
+    G.use_graphs = False
+    ws = [S.synthetic_latents(SEED, 5, n_latent=G.n_latent, key='pipe.w%d' % i).cuda() for i in range(6)]
+    with torch.no_grad():
+        want = [G([w], input_is_latent=True)[0] for w in ws]
+        pipe = F_.StreamPipeline(2)
+        got = []
+        for w in ws:
+            with pipe.next():
+                got.append(G([w], input_is_latent=True)[0])
+        pipe.join(*got)
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
+    A = DirectionMatrix(512, input_dim=15, out_dim=512, w_plus=True, num_layers=8, verbose=False)
+    A.load_state_dict(S.synthetic_direction_state(SEED))
+    A = A.cuda().eval()
+    src = S.synthetic_latents(SEED, 1, n_latent=G.n_latent, key='pipe.src').cuda()
+    trunc = S.counter_tensor(SEED, 'pipe.t', (1, 512)).cuda()
+    sv = S.counter_tensor(SEED, 'pipe.sv', (23, 15), 0.0, 3.0).cuda()
+    one = ReenactmentSession(G, A, src, 0.7, trunc, batch=4, streams=1)
+    two = ReenactmentSession(G, A, src, 0.7, trunc, batch=4, streams=2)
+    two.pipeline_min_work = 0
+    assert torch.equal(one.render(sv), two.render(sv)) and two._pipe is not None and one._pipe is None
+    assert torch.equal(one.render(sv, as_uint8=True), two.render(sv, as_uint8=True))
+    src_img = S.counter_tensor(SEED, 'pipe.si', (1, 3, 64, 64), 0.0, 0.5).cuda()
+    tgt_img = S.counter_tensor(SEED, 'pipe.ti', (23, 3, 64, 64), 0.0, 0.5).cuda()
+    assert torch.equal(one.video_frames(src_img, tgt_img, sv), two.video_frames(src_img, tgt_img, sv))
+
+
 def test_generator_forward_replays_a_hipgraph_by_default():
     """from the third no-grad forward of one signature on, Generator.forward replays a captured hipGraph --
     bit-identical to the eager launches for new inputs, through generate_image too; a weight change, a different batch size,

@@ -579,9 +579,11 @@ def test_reenactment_session_rerenders_a_clamped_batch():
     A = A.cuda().eval()
     src = S.synthetic_latents(SEED, 1, n_latent=10, key='sess.src').cuda()
     sv = S.counter_tensor(SEED, 'sess.sv', (10, 15), 0.0, 3.0).cuda()
-    for graph in (False, True):
+    for graph in (False, True, 'two streams'):
         G = hip_generator(64, 1)
-        sess = ReenactmentSession(G, A, src, truncation=1.0, batch=4, graph=graph)
+        sess = ReenactmentSession(G, A, src, truncation=1.0, batch=4, graph=graph is True)
+        if graph == 'two streams':        # chunks alternate between two HIP streams: a clamping chunk also condemns the one in flight beside it
+            sess.pipeline_min_work = 0
         with torch.no_grad():
             quiet = sess.render(sv)                                   # calibrates; in range
             assert G.saturated_pairs() == 0
