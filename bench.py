@@ -515,6 +515,8 @@ def other_config_legs(args, rank, world, dev):
                           'leg_wall_s': round(time.perf_counter() - t0, 1)}
             if 'fp16_saturated_pairs' in line:
                 legs[name]['fp16_saturated_pairs'] = line['fp16_saturated_pairs']
+            if 'one_batch_at_a_time' in line:
+                legs[name]['one_batch_at_a_time'] = line['one_batch_at_a_time']
         except Exception as e:          # a neighbour leg must never take the headline line down with it
             legs[name] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
         torch.cuda.empty_cache()
@@ -564,18 +566,33 @@ def run_inference(args, rank, world, dev):
             source_code = enc(src_img)
         torch.cuda.synchronize()
         e4e_ms = (time.perf_counter() - t0) / 5 * 1e3
-        sess = ReenactmentSession(G, A, source_code, 0.7, trunc, batch=B, shifts=shifts)
+        sess = ReenactmentSession(G, A, source_code, 0.7, trunc, batch=B, shifts=shifts, streams=args.streams)
 
-        def step():
+        def step1():                       # one batch, start to finish (the roofline pass: kernels of one undisturbed step)
             frames = []
             for img in sess.frames_for_targets(ang_s, par_s, ang_t, par_t):
                 frames.append(grid_frames_uint8([src_img, tgt_img[:img.shape[0]], img], swap_rb=True))
             return frames[0]
 
+        # The frames of a video arrive batch after batch: a step queues ITS batch (shift vectors -> DirectionMatrix -> generator,
+        # on the session's other HIP stream) and finishes the previous one (range check, uint8 source|target|reenacted frames)
+        # -- ReenactmentSession.streaming(), the one-batch look-ahead `frames()` uses inside a longer video.  One batch of B
+        # frames enters and one leaves per step.
+        live = sess.streaming()
+        live.push(sess.shift_vectors_for(ang_s, par_s, ang_t, par_t))
+
+        def step():
+            img = live.push(sess.shift_vectors_for(ang_s, par_s, ang_t, par_t))
+            return grid_frames_uint8([src_img, tgt_img[:img.shape[0]], img], swap_rb=True)
+
         elapsed, mine, frames = timed_region(step, args, dev)
+        live.flush()
+        e1, _, _ = timed_region(step1, args, dev)
+        single = {'value': round(B * world * args.steps / e1, 2), 'unit': 'frames/s', 'ms_per_step': round(e1 / args.steps * 1e3, 3),
+                  'what': 'every step renders its one batch start to finish (no look-ahead across steps)'}
         assert frames.shape == (hi - lo, args.size, 3 * args.size, 3) and frames.dtype == torch.uint8
         spread = rank_spread((hi - lo) * args.steps, mine, dev, world)
-        roof = roofline_for(args.precision, step, args.steps, B)
+        roof = roofline_for(args.precision, step1, args.steps, B)
         for _ in range(2):
             enc(tgt_img)
         torch.cuda.synchronize()
@@ -589,12 +606,14 @@ def run_inference(args, rank, world, dev):
     out = base_line(args, world, 'reenacted frames/sec @%dx%d' % (args.size, args.size), 'frames/s', B * world * args.steps / elapsed, elapsed,
                     '%dxMI355X run_inference.py flow: e4e source W+ (once) + per batch of %d target frames: shift vectors from 3DMM '
                     'parameters -> DirectionMatrix -> shift + truncation psi=0.7 -> HIP Generator(%d,cm=%d) -> uint8 '
-                    'source|target|reenacted frames' % (world, B, args.size, args.cm),
+                    'source|target|reenacted frames; batches stream through ReenactmentSession.streaming() (a step queues its '
+                    'batch and finishes the previous one)' % (world, B, args.size, args.cm),
                     {'weight_broadcast_bytes': bcast_bytes, 'weight_broadcast_ms': round(bcast_ms, 2),
                      'per_rank_frames_per_s_min_max': spread, 'e4e_source_ms': round(e4e_ms, 2),
                      'e4e_batch_images_per_s': round(e4e_batch, 1),
                      'not_in_the_timed_step': 'DECA / face detection of the targets (out of scope, SURVEY.md §2); e4e of the one source image'})
     out['roofline'] = roof
+    out['one_batch_at_a_time'] = single
     if args.precision == 'fp16x3':
         out['fp16_saturated_pairs'] = G.saturated_pairs()
     return out

@@ -165,57 +165,95 @@ class ReenactmentSession:
         tok = self.G._snapshot() if mode == 'fp16x3' else None
         return static_out.clone(), tok
 
-    def _pipeline(self, shift_vectors, target_for=None):
-        """(lo, image batch) for every chunk of `shift_vectors`, each VERIFIED against the generator's fp16 range plan before
-        it is yielded: chunk i+1 is queued first, then chunk i's RangeToken is awaited (the GPU never idles for the check), and
-        a chunk that clamped operands is rendered again in the generator's fallback arithmetic.  target_for(lo, b) ->
-        functional.U8Target or None (eager chunks: the last ToRGB launch writes uint8 frames)."""
-        n = shift_vectors.shape[0]
-        pending = None
+    def _chunks(self, pipelined, device):
+        """launch(lo, sv, u8) -> item / settle(item) -> (lo, sv, u8, images, graphed) for one chunk each; see _pipeline."""
+        sess = self
         pipe = None
         # (chunks small enough for the generator's own hipGraph replay are host-bound and share the graph's static buffers: one stream)
-        if self.n_streams > 1 and not self.use_graph and n > self.batch and \
+        if pipelined and self.n_streams > 1 and not self.use_graph and \
                 self.batch * (self.G.size / 256.0) ** 2 > self.pipeline_min_work:
-            if self._pipe is None or self._pipe.streams[0].device != shift_vectors.device:
-                self._pipe = F_.StreamPipeline(self.n_streams, shift_vectors.device)
+            if self._pipe is None or self._pipe.streams[0].device != device:
+                self._pipe = F_.StreamPipeline(self.n_streams, device)
             pipe = self._pipe
-        poisoned = [False]      # a chunk clamped operands: chunks launched in fp16x3 before the fallback took hold are suspect too
+
+        class Chunks:
+            poisoned = False    # a chunk clamped operands: chunks launched in fp16x3 before the fallback took hold are suspect too
                                 # (with two streams in flight the saturation word cannot tell which of them it was)
 
-        def launch(lo):
-            sv = shift_vectors[lo:lo + self.batch]
-            u8 = target_for(lo, sv.shape[0]) if target_for is not None else None
-            if self.use_graph and sv.shape[0] == self.batch:
-                img, tok = self._graphed_step(sv)
-                return [lo, sv, u8, img, tok, True, None, 'graph']
-            mode = self.G.range_mode()
-            if pipe is None:
-                img = self._step(sv, u8)
-                return [lo, sv, u8, img, self.G.take_range_token(), False, None, mode]
-            with pipe.next():
-                img = self._step(sv, u8, no_graph=True)
-                tok = self.G.take_range_token()
-            return [lo, sv, u8, img, tok, False, pipe.last, mode]
+            def launch(self, lo, sv, u8):
+                if sess.use_graph and sv.shape[0] == sess.batch:
+                    img, tok = sess._graphed_step(sv)
+                    return [lo, sv, u8, img, tok, True, None, 'graph']
+                mode = sess.G.range_mode()
+                if pipe is None:
+                    img = sess._step(sv, u8)
+                    return [lo, sv, u8, img, sess.G.take_range_token(), False, None, mode]
+                with pipe.next():
+                    img = sess._step(sv, u8, no_graph=True)
+                    tok = sess.G.take_range_token()
+                return [lo, sv, u8, img, tok, False, pipe.last, mode]
 
-        def settle(item):
-            lo, sv, u8, img, tok, graphed, stream, mode = item
-            ok = self.G.range_ok(tok)
-            if stream is not None:
-                pipe.join(img, stream=stream)                               # the caller's stream may now read this chunk
-            if not ok:
-                poisoned[0] = True
-            if not ok or (poisoned[0] and pipe is not None and mode == 'fp16x3'):
-                self._graph = None                                          # clamped: this chunk again, eagerly, in bf16x3
-                img, graphed = self._step(sv, u8), False
-            return lo, sv, u8, img, graphed
+            def settle(self, item):
+                lo, sv, u8, img, tok, graphed, stream, mode = item
+                ok = sess.G.range_ok(tok)
+                if stream is not None:
+                    pipe.join(img, stream=stream)                           # the caller's stream may now read this chunk
+                if not ok:
+                    self.poisoned = True
+                if not ok or (self.poisoned and pipe is not None and mode == 'fp16x3'):
+                    sess._graph = None                                      # clamped: this chunk again, eagerly, in bf16x3
+                    img, graphed = sess._step(sv, u8), False
+                return lo, sv, u8, img, graphed
 
+        return Chunks()
+
+    def _pipeline(self, shift_vectors, target_for=None):
+        """(lo, image batch) for every chunk of `shift_vectors`, each VERIFIED against the generator's fp16 range plan before
+        it is yielded: chunk i+1 is queued first (on the other HIP stream when the session pipelines), then chunk i's RangeToken
+        is awaited (the GPU never idles for the check), and a chunk that clamped operands is rendered again in the generator's
+        fallback arithmetic.  target_for(lo, b) -> functional.U8Target or None (eager chunks: the last ToRGB launch writes uint8
+        frames)."""
+        n = shift_vectors.shape[0]
+        chunks = self._chunks(n > self.batch, shift_vectors.device)
+        pending = None
         for lo in range(0, n, self.batch):
-            cur = launch(lo)
+            sv = shift_vectors[lo:lo + self.batch]
+            cur = chunks.launch(lo, sv, target_for(lo, sv.shape[0]) if target_for is not None else None)
             if pending is not None:
-                yield settle(pending)
+                yield chunks.settle(pending)
             pending = cur
         if pending is not None:
-            yield settle(pending)
+            yield chunks.settle(pending)
+
+    def streaming(self, as_uint8=False):
+        """For frames that arrive chunk by chunk (a live video, bench.py's inference config): `push(shift_vectors [b, dim])`
+        queues that chunk and returns the images of the PREVIOUS one (None for the first), `flush()` returns the last -- the same
+        one-chunk look-ahead, stream alternation and range verification as `frames`, kept alive between calls."""
+        sess = self
+
+        class Streaming:
+            def __init__(self):
+                self.chunks, self.pending, self.count = None, None, 0
+
+            def _out(self, item):
+                lo, sv, u8, img, graphed = self.chunks.settle(item)
+                return images_to_uint8(img) if (as_uint8 and graphed) else img
+
+            @torch.no_grad()
+            def push(self, shift_vectors):
+                if self.chunks is None:
+                    self.chunks = sess._chunks(True, shift_vectors.device)
+                cur = self.chunks.launch(self.count, shift_vectors, F_.U8Target() if as_uint8 else None)
+                self.count += shift_vectors.shape[0]
+                prev, self.pending = self.pending, cur
+                return self._out(prev) if prev is not None else None
+
+            @torch.no_grad()
+            def flush(self):
+                prev, self.pending = self.pending, None
+                return self._out(prev) if prev is not None else None
+
+        return Streaming()
 
     @torch.no_grad()
     def frames(self, shift_vectors, as_uint8=False):

@@ -290,6 +290,14 @@ def test_independent_batches_on_alternating_streams_give_the_same_images():
     two.pipeline_min_work = 0
     assert torch.equal(one.render(sv), two.render(sv)) and two._pipe is not None and one._pipe is None
     assert torch.equal(one.render(sv, as_uint8=True), two.render(sv, as_uint8=True))
+    live, got = two.streaming(), []                       # chunk by chunk, state kept between calls
+    for lo in range(0, 23, 4):
+        prev = live.push(sv[lo:lo + 4])
+        assert (prev is None) == (lo == 0)
+        if prev is not None:
+            got.append(prev)
+    got.append(live.flush())
+    assert live.flush() is None and torch.equal(torch.cat(got, 0), one.render(sv))
     src_img = S.counter_tensor(SEED, 'pipe.si', (1, 3, 64, 64), 0.0, 0.5).cuda()
     tgt_img = S.counter_tensor(SEED, 'pipe.ti', (23, 3, 64, 64), 0.0, 0.5).cuda()
     assert torch.equal(one.video_frames(src_img, tgt_img, sv), two.video_frames(src_img, tgt_img, sv))
