@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 12
+#define SGDFR_ABI_VERSION 13
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -195,8 +195,9 @@ int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const float* noise
 
 /* sgdfr_blur_bias_act_f32 with the result multiplied by the NEXT layer's modulation s_next [B,C] and written in that layer's
  * split input form xs [B][C/8][2][2H*2W][8] (see sgdfr_to_split_f32) instead of fp32 NCHW.  plane_stride: floats between the
- * parity planes of t (0 = dense (H+1)*(W+1), see sgdfr_modconv2d_split_f32).  wino = 1 (W = 8 ... 64): xs receives the
- * Winograd input form [B][C/8][4][2][2H*W][8] of sgdfr_to_wsplit_f32 instead (twice the bytes), for sgdfr_modconv2d_wsplit_f32. */
+ * parity planes of t (0 = dense (H+1)*(W+1), see sgdfr_modconv2d_split_f32).  wino = 2 | 4 (W = 8 ... 64): xs receives the
+ * Winograd input form [B][C/8][wino+2][2][2H*2W/wino][8] of sgdfr_to_wsplit_f32(f = wino) instead (2x / 1.5x the bytes), for
+ * sgdfr_modconv2d_wsplit_f32. */
 int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, const float* noise, int64_t noise_bstride,
                                   const float* noise_w, const float* bias, const float* s_next, unsigned short* xs, int B, int C,
                                   int H, int W, int64_t plane_stride, int arith, int wino, int act, float slope, float gain,
@@ -292,34 +293,35 @@ int sgdfr_modconv2d_split_cout_tiles(int B, int Cin, int Cout, int H, int W, int
 int sgdfr_modconv2d_split_cout_tiles_xin(int B, int Cin, int Cout, int H, int W, int mode);
 int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, int mode);
 
-/* ---- The plain 3x3 modulated conv in 1-D Winograd F(2,3) form on the split-operand matrix cores (csrc/wsplit.hip; replaces the
- * same reference lines as sgdfr_modconv2d_split_f32 mode PLAIN3: ModulatedConv2d.forward model.py:232-273 + NoiseInjection
- * model.py:284-293 + FusedLeakyReLU op/fused_act.py:79-86).  Along image rows two neighbouring outputs come from four transformed
- * inputs (4 multiplies instead of 6), kernel rows stay direct: 2/3 of the MFMA work.  The transforms are applied to fp32 values
- * before the hi/lo split, so the products keep the arithmetic of `arith` (same SGDFR_SPLIT_* constants, same saturation rule;
- * |V| <= 2 max|x*s|: plan one more binade of headroom).
- *   sgdfr_to_wsplit_f32:               x [B,Cin,H,W], s [B,Cin] -> vs "WS" [B][Cin/8][t 4][hi,lo][H*W/2][8] 16-bit (8 bytes per
- *                                      input element): V = B^T (x*s) per output pair, V0 = d0-d2, V1 = d1+d2, V2 = d2-d1,
- *                                      V3 = d1-d3 with d_j = (x*s)[2*tile-1+j] (zero outside the row).  Producers may emit
- *                                      it directly (sgdfr_blur_bias_act_split_f32 with wino = 1).
+/* ---- The plain 3x3 modulated conv in 1-D Winograd form on the split-operand matrix cores (csrc/wsplit.hip; replaces the same
+ * reference lines as sgdfr_modconv2d_split_f32 mode PLAIN3: ModulatedConv2d.forward model.py:232-273 + NoiseInjection
+ * model.py:284-293 + FusedLeakyReLU op/fused_act.py:79-86).  Along image rows f neighbouring outputs come from f+2 transformed
+ * inputs, kernel rows stay direct: F(2,3) (f = 2: 4 multiplies instead of 6, 2/3 of the MFMA work) or F(4,3) (f = 4: 6 instead of
+ * 12, 1/2; interpolation points 0, +-1, +-2, inf).  The transforms are applied to fp32 values before the hi/lo split, so the
+ * products keep the arithmetic of `arith` (same SGDFR_SPLIT_* constants, same saturation rule); |V| <= 2 max|x*s| (f = 2) /
+ * 10 max|x*s| (f = 4): plan 1 / 4 more binades of headroom.
+ *   sgdfr_to_wsplit_f32:               x [B,Cin,H,W], s [B,Cin] -> vs "WS" [B][Cin/8][t f+2][hi,lo][H*W/f][8] 16-bit: V = B^T (x*s)
+ *                                      per tile of f outputs, d_j = (x*s)[f*tile-1+j] (zero outside the row); f = 2: V0 = d0-d2,
+ *                                      V1 = d1+d2, V2 = d2-d1, V3 = d1-d3.  Producers may emit it directly
+ *                                      (sgdfr_blur_bias_act_split_f32 with wino = f).
  *   sgdfr_modconv_prepack_wsplit_f32:  weight [Cout,Cin,3,3] -> U = G (weight/sqrt(9 Cin)) per kernel row, 16-bit hi/lo in
- *                                      kernel order, sgdfr_modconv_prepack_wsplit_elems() uint16 elements (= 2*12*Cin*Cout).
- *   sgdfr_modconv2d_wsplit_supported:  Cin % 16 == 0, Cout % 128 == 0, W/2 a multiple of min(16, W/2) >= 8, H a multiple of
- *                                      128 / that (16x16 ... 256x256 feature maps).
+ *                                      kernel order, sgdfr_modconv_prepack_wsplit_elems() uint16 elements (= 2*3*(f+2)*Cin*Cout).
+ *   sgdfr_modconv2d_wsplit_supported:  Cin % 16 == 0, Cout % 128 == 0, W/f a multiple of the patch width (f = 2: min(16, W/2)
+ *                                      >= 8 tiles; f = 4: min(8, W/4) >= 4), H a multiple of the patch height (256 / (f * width)).
  *   sgdfr_modconv2d_wsplit_f32:        outputs as sgdfr_modconv2d_split_f32 (PLAIN3, ksplit = 1, x_is_split = 1): y (may be
  *                                      NULL when xs_out or rgb_part is given), the next conv's split input xs_out (+ s_next),
  *                                      ToRGB partial sums rgb_part [B][(Cout/128)*3][H*W] (+ rgb_w, rgb_s). */
-int sgdfr_modconv2d_wsplit_supported(int B, int Cin, int Cout, int H, int W);
-int64_t sgdfr_modconv_prepack_wsplit_elems(int Cout, int Cin);
-int sgdfr_modconv_prepack_wsplit_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int arith, unsigned int* sat,
-                                     void* stream);
-int sgdfr_to_wsplit_f32(const float* x, const float* s, unsigned short* vs, int B, int Cin, int H, int W, int arith,
+int sgdfr_modconv2d_wsplit_supported(int B, int Cin, int Cout, int H, int W, int f);
+int64_t sgdfr_modconv_prepack_wsplit_elems(int Cout, int Cin, int f);
+int sgdfr_modconv_prepack_wsplit_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int f, int arith,
+                                     unsigned int* sat, void* stream);
+int sgdfr_to_wsplit_f32(const float* x, const float* s, unsigned short* vs, int B, int Cin, int H, int W, int f, int arith,
                         unsigned int* sat, void* stream);
 int sgdfr_modconv2d_wsplit_f32(const unsigned short* v, const unsigned short* wsp, const float* d, const float* noise,
                                int64_t noise_bstride, const float* noise_w, const float* bias, const float* zeros, float* y,
                                const float* rgb_w, const float* rgb_s, float* rgb_part, unsigned short* xs_out,
-                               const float* s_next, int B, int Cin, int Cout, int H, int W, int arith, int act, float slope,
-                               float gain, unsigned int* sat, void* stream);
+                               const float* s_next, int B, int Cin, int Cout, int H, int W, int f, int arith, int act,
+                               float slope, float gain, unsigned int* sat, void* stream);
 
 /* The rest of ToRGB.forward (model.py:350-359) when its 1x1 conv was accumulated by sgdfr_modconv2d_split_f32(rgb_part):
  *   y[b,j,p] = sum_{t<T} part[b, t*3+j, p] + bias[j] + (skip ? upfirdn2d(skip[b,j], fir[4,4], up=2, pad=(2,1))[p] : 0) */

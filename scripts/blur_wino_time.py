@@ -31,10 +31,11 @@ for C, H in ((512, 8), (512, 16), (256, 32), (128, 64)):
     nw = torch.full((1,), 0.1, device='cuda')
     bias = torch.randn(C, device='cuda')
     sn = torch.randn(B, C, device='cuda')
-    best = [1e9, 1e9]
+    best = [1e9, 1e9, 1e9]
     for _ in range(3):
-        for k, wino in enumerate((False, True)):
+        for k, wino in enumerate((0, 2, 4)):
             best[k] = min(best[k], timed(lambda: F_.blur_bias_act_split(planes, fir, H, H, sn, nz, nw, bias, True, plane_stride=ps, wino=wino)))
     mb = B * C * 4 * H * H * 4 / 1e6
-    print('blur %3d ch %3d -> %3d | split form %.0f us (%.2f TB/s) | winograd form %.0f us (%.2f TB/s) | +%.0f us'
-          % (C, H, 2 * H, best[0], 2 * mb / best[0], best[1], 3 * mb / best[1], best[1] - best[0]), flush=True)
+    print('blur %3d ch %3d -> %3d | split form %.0f us (%.2f TB/s) | F(2,3) form %.0f us (%.2f TB/s) +%.0f us | F(4,3) form %.0f us (%.2f TB/s) +%.0f us'
+          % (C, H, 2 * H, best[0], 2 * mb / best[0], best[1], 3 * mb / best[1], best[1] - best[0], best[2], 2.5 * mb / best[2],
+             best[2] - best[0]), flush=True)

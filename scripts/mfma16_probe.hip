@@ -193,6 +193,78 @@ void run_wino(const char* name, const unsigned* seed_dev, const unsigned char* s
     hipFree(out); hipFree(clk);
 }
 
+// F(4,3) pricing: 4 outputs from 6 transformed inputs (18 MFMA columns per 16 channels and output QUAD instead of 36; V is 6
+// values per 4 pixels = 1.5x the bytes, U 6/3 = 2x).  Six accumulators per wave (32 couts x 32 four-pixel tiles x 6 positions):
+// per (ky, t) step 2 + 2 fragment reads for 3 MFMAs; 128 couts x 64 tiles per block stage 36 KB of V + 144 KB of U per channel
+// block = 22.5 pieces per wave per 54 MFMAs.
+template <int WAVES, int DMA>
+__global__ __launch_bounds__(WAVES * 64, 1) void probe_f43(float* out, const unsigned* seed, int iters, unsigned long long* clk, const unsigned char* src) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 65536 / 4; i += blockDim.x) reinterpret_cast<unsigned*>(lds)[i] = seed[i];
+    __syncthreads();
+    f32x16 acc[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const unsigned char* pa = lds + ((lane >> 5) * 64 + (lane & 31)) * 16;
+    const unsigned char* pb = lds + 32768 + ((lane >> 5) * 512 + (wave & 3) * 64 + (lane & 31)) * 16;
+    frag128 a[2], b[2];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int step = 0; step < 18; ++step) {      // (ky, t)
+            const int t = step % 6;
+            if (DMA) {
+                const int n0 = step * DMA / 18, n1 = (step + 1) * DMA / 18;
+#pragma unroll
+                for (int v = n0; v < n1; ++v)
+                    __builtin_amdgcn_global_load_lds((glb_void_t*)(src + ((((size_t)blockIdx.x * 61 + it * 17 + wave * DMA + v) & 4095) << 10) + lane * 16),
+                                                     (lds_void_t*)(lds + 65536 + ((wave * DMA + v) & 63) * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                a[part] = *reinterpret_cast<const frag128*>(pa + part * 16384 + (step % 3) * 4096 + (it & 1) * 2048);
+                b[part] = *reinterpret_cast<const frag128*>(pb + part * 16384 + (step + (it & 7)) * 16);
+            }
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[term == 2]), __builtin_bit_cast(f16x8, b[term == 1]), acc[t], 0, 0, 0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[t][r];
+    out[blockIdx.x * blockDim.x + tid] = s;
+    if (blockIdx.x == 0 && tid == 0) clk[0] = t1 - t0;
+}
+
+template <int WAVES, int DMA>
+void run_f43(const char* name, const unsigned* seed_dev, const unsigned char* src) {
+    float* out; unsigned long long* clk;
+    const int blocks = 256, iters = 3000;
+    hipMalloc(&out, sizeof(float) * blocks * WAVES * 64); hipMalloc(&clk, 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipFuncSetAttribute((const void*)probe_f43<WAVES, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    probe_f43<WAVES, DMA><<<blocks, WAVES * 64, 131072>>>(out, seed_dev, 200, clk, src);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    probe_f43<WAVES, DMA><<<blocks, WAVES * 64, 131072>>>(out, seed_dev, iters, clk, src);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long c; hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
+    const double mfmas = (double)iters * 54;
+    const double flops = (double)blocks * WAVES * mfmas * 2.0 * 32 * 32 * 16;
+    const double alg = (double)blocks * WAVES * iters * 32.0 * (32 * 4) * 2.0 * 16 * 9;     // 32 couts x 32 tiles x 4 pixels, K = 16 x 9
+    printf("%-34s waves %d: %8.3f ms %7.1f TFLOP/s (16-bit issued), %6.1f algorithmic fp32 TFLOP/s, clock %.2f GHz, MFMA duty %.2f\n",
+           name, WAVES, ms, flops / ms / 1e9, alg / ms / 1e9, c / (ms * 1e6), mfmas * 32 * (WAVES / 4) / (double)c);
+    hipFree(out); hipFree(clk);
+}
+
 static unsigned short f2h(float f) { _Float16 h = (_Float16)f; unsigned short u; __builtin_memcpy(&u, &h, 2); return u; }
 
 template <int WAVES, int USE_LDS, int BARRIER, int ORDER = 0, int DMA6 = 0>
@@ -255,6 +327,9 @@ int main() {
         run_wino<8, 0, 12>("Winograd 1x2x4 + DMA 12/72", dr, src);
         run_wino<8, 0, 9>("Winograd 1x2x4 + DMA 9/72", dr, src);
         run_wino<4, 1, 24>("Winograd 2x2x4 + DMA 24/144", dr, src);
+        run_f43<8, 0>("Winograd F(4,3) 1x1x6, no DMA", dr, src);
+        run_f43<8, 23>("Winograd F(4,3) 1x1x6 + DMA 23/54", dr, src);
+        run_f43<8, 16>("Winograd F(4,3) 1x1x6 + DMA 16/54", dr, src);
     }
     return 0;
 }

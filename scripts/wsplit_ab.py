@@ -40,24 +40,29 @@ def main():
         bias = torch.randn(cout, device='cuda')
         sn = torch.randn(B, cout, device='cuda')
         rgb = (torch.randn(3, cout, device='cuda'), torch.randn(B, cout, device='cuda'))
-        wsp, wws = F_.prepack_split(w, 'fp16x3'), F_.prepack_wsplit(w, 'fp16x3')
-        xs, vs = F_.to_split(x, s, 'fp16x3'), F_.to_wsplit(x, s, 'fp16x3')
+        wsp, wws, wws4 = F_.prepack_split(w, 'fp16x3'), F_.prepack_wsplit(w, 'fp16x3'), F_.prepack_wsplit(w, 'fp16x3', f=4)
+        xs, vs, vs4 = F_.to_split(x, s, 'fp16x3'), F_.to_wsplit(x, s, 'fp16x3'), F_.to_wsplit(x, s, 'fp16x3', f=4)
         kw = dict(rgb=None, s_next=None, want_y=True) if args.y else dict(rgb=rgb, s_next=sn, want_y=False)
         plain = lambda: F_.modconv_split(xs, wsp, None, d, cout, nz, nw, bias, True, arith='fp16x3', x_split=(B, cin, h, h), batch=B, **kw)
         wino = lambda: F_.modconv_wsplit(vs, (B, cin, h, h), wws, d, cout, nz, nw, bias, True, arith='fp16x3', **kw)
+        wino4 = lambda: F_.modconv_wsplit(vs4, (B, cin, h, h), wws4, d, cout, nz, nw, bias, True, arith='fp16x3', f=4, **kw)
         ra, rb = plain(), wino()
         ra = ra if isinstance(ra, tuple) else (ra,)
         rb = rb if isinstance(rb, tuple) else (rb,)
         diff = max(float((a.float() - b.float()).abs().max()) for a, b in zip(ra, rb) if a is not None and a.dtype == torch.float32)
-        best = [1e9, 1e9]
+        rc = wino4()
+        rc = rc if isinstance(rc, tuple) else (rc,)
+        diff4 = max(float((a.float() - b.float()).abs().max()) for a, b in zip(ra, rc) if a is not None and a.dtype == torch.float32)
+        best = [1e9, 1e9, 1e9]
         for _ in range(args.rounds):
-            for k, fn in enumerate((plain, wino)):
+            for k, fn in enumerate((plain, wino, wino4)):
                 fn()
                 best[k] = min(best[k], timed(fn, args.reps))
         fl = B * F_.conv_flops(cin, cout, h, h)
-        print('plain %d->%d@%d | direct %.0f us %.0f TF | winograd %.0f us %.0f TF | %.3fx | max fp32 output diff %.2e'
-              % (cin, cout, h, best[0], fl / best[0] / 1e6, best[1], fl / best[1] / 1e6, best[0] / best[1], diff), flush=True)
-        del w, x, xs, vs
+        print('plain %d->%d@%d | direct %.0f us %.0f TF | F(2,3) %.0f us %.0f TF %.3fx diff %.2e | F(4,3) %.0f us %.0f TF %.3fx diff %.2e'
+              % (cin, cout, h, best[0], fl / best[0] / 1e6, best[1], fl / best[1] / 1e6, best[0] / best[1], diff,
+                 best[2], fl / best[2] / 1e6, best[0] / best[2], diff4), flush=True)
+        del w, x, xs, vs, vs4
 
 
 if __name__ == '__main__':

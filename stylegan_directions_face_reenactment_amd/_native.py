@@ -23,7 +23,7 @@ if os.environ.get('SGDFR_LIB'):
     else:
         import warnings as _warnings
         _warnings.warn('SGDFR_LIB is set but ignored (set SGDFR_ALLOW_LIB_OVERRIDE=1 to load a probe build)', RuntimeWarning)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -113,11 +113,11 @@ SIGNATURES['sgdfr_split_range_f32'] = [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctype
 SIGNATURES['sgdfr_absmax_f32'] = [_c_f32p, _i64, _i64, _i, ctypes.c_void_p, _i, ctypes.c_void_p]
 SIGNATURES['sgdfr_styles_batched_f32'] = [_c_f32p, _i, _i, _i, ctypes.POINTER(StyleLayer), _i, ctypes.c_void_p]
 MAX_STYLE_LAYERS = 40
-SIGNATURES['sgdfr_modconv2d_wsplit_supported'] = [_i, _i, _i, _i, _i]
-SIGNATURES['sgdfr_modconv_prepack_wsplit_f32'] = [_c_f32p, ctypes.c_void_p, _i, _i, _i, ctypes.c_void_p, ctypes.c_void_p]
-SIGNATURES['sgdfr_to_wsplit_f32'] = [_c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i, ctypes.c_void_p, ctypes.c_void_p]
+SIGNATURES['sgdfr_modconv2d_wsplit_supported'] = [_i, _i, _i, _i, _i, _i]
+SIGNATURES['sgdfr_modconv_prepack_wsplit_f32'] = [_c_f32p, ctypes.c_void_p, _i, _i, _i, _i, ctypes.c_void_p, ctypes.c_void_p]
+SIGNATURES['sgdfr_to_wsplit_f32'] = [_c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i, _i, ctypes.c_void_p, ctypes.c_void_p]
 SIGNATURES['sgdfr_modconv2d_wsplit_f32'] = [ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
-                                            _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _c_f32p, _i, _i, _i, _i, _i, _i, _i, _f, _f,
+                                            _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _c_f32p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f,
                                             ctypes.c_void_p, ctypes.c_void_p]
 # measurement-only symbols: bound when present, never required of a production library (bench.py's measured_mfma_ceiling)
 OPTIONAL_SIGNATURES = {'sgdfr_mfma_ceiling_probe': [_i, _i, _i, _i, _i, _c_f32p, ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]}
@@ -145,7 +145,7 @@ def load():
     lib.sgdfr_split_saturation_count.restype = ctypes.c_longlong
     lib.sgdfr_modconv_prepack_split_elems.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.sgdfr_modconv_prepack_split_elems.restype = ctypes.c_int64
-    lib.sgdfr_modconv_prepack_wsplit_elems.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.sgdfr_modconv_prepack_wsplit_elems.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.sgdfr_modconv_prepack_wsplit_elems.restype = ctypes.c_int64
     if lib.sgdfr_abi_version() != ABI_VERSION:
         raise RuntimeError('libsgdfr_hip.so ABI %d != expected %d: rebuild' % (lib.sgdfr_abi_version(), ABI_VERSION))

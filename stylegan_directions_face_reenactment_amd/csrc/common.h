@@ -79,6 +79,30 @@ static inline FastDiv make_fastdiv(int d) {
 }
 __device__ __forceinline__ int fdiv(int n, FastDiv f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.sh); }
 
+// Input transform B^T d of the 1-D Winograd split conv (wsplit.hip; shared with the blur's hand-over in upfirdn2d.hip, which must
+// produce the same bits as sgdfr_to_wsplit_f32).  F(2,3): d_j = in[2*tile - 1 + j], j = 0..3; F(4,3): d_j = in[4*tile - 1 + j], j = 0..5 (interpolation points
+// 0, +-1, +-2, inf: Lavin & Gray's matrices).
+template <int POS>
+__device__ __forceinline__ void ws_input_transform(const float (&d)[POS], float (&v)[POS]) {
+    if (POS == 4) {
+        v[0] = d[0] - d[2];
+        v[1] = d[1] + d[2];
+        v[2] = d[2] - d[1];
+        v[POS - 1] = d[1] - d[POS - 1];
+    } else {
+        // B^T rows: (4 0 -5 0 1 0) (0 -4 -4 1 1 0) (0 4 -4 -1 1 0) (0 -2 -1 2 1 0) (0 2 -1 -2 1 0) (0 4 0 -5 0 1)
+        const float d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[POS - 2], d5 = d[POS - 1];
+        const float a = d4 - 4.f * d2, b = d3 - 4.f * d1;         // (-4 d2 + d4), (-4 d1 + d3)
+        const float c = d4 - d2, e = 2.f * (d3 - d1);             // (-d2 + d4), (-2 d1 + 2 d3)
+        v[0] = fmaf(4.f, d[0], fmaf(-5.f, d2, d4));
+        v[1] = a + b;
+        v[2] = a - b;
+        v[3] = c + e;
+        v[POS - 2] = c - e;
+        v[POS - 1] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+    }
+}
+
 __device__ __forceinline__ float lrelu_gain(float v, float slope, float gain) {
     return (v > 0.f ? v : v * slope) * gain;
 }

@@ -193,11 +193,11 @@ __device__ __forceinline__ void blur_split2(float a, float b, unsigned& hi, unsi
 // one of two LDS tiles, 8 waves split + store the other: a wave's in-order vmcnt then holds loads OR stores) 514 -> 682 us --
 // half as many loading waves per CU.  The kernel is bound by loads in flight and DRAM locality of its 32 streams per block,
 // not by load instructions or by the shared load / store queue.
-// WINO: the hand-over writes the Winograd F(2,3) input transform of the result instead ("WS" form of wsplit.hip:
-// [B][C/8][t 4][hi,lo][2H * W][8], V = B^T (y * s_next) per output pair; bit-identical to sgdfr_to_wsplit_f32 of the fp32
-// result).  A thread takes one output pair and reads its two row neighbours from the LDS tile, so the tile must span whole
-// rows (one column tile: 2W <= 128).
-template <int ET, int QC, int NG, bool WINO = false>
+// WINO = 2 | 4: the hand-over writes the Winograd F(WINO,3) input transform of the result instead ("WS" form of wsplit.hip:
+// [B][C/8][t WINO+2][hi,lo][2H * 2W / WINO][8], V = B^T (y * s_next) per tile of WINO outputs; bit-identical to
+// sgdfr_to_wsplit_f32 of the fp32 result).  A thread takes one tile (WINO = 4: three of its six positions) and reads the
+// tile's two row neighbours from the LDS tile, so the tile must span whole rows (one column tile: 2W <= 128).
+template <int ET, int QC, int NG, int WINO = 0>
 __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(const float* __restrict__ t, const float* __restrict__ fir,
                                                         const float* __restrict__ noise, int64_t noise_bstride,
                                                         const float* __restrict__ noise_w, const float* __restrict__ bias,
@@ -329,7 +329,39 @@ __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(c
             if (sg + 1 < nseg && ms + BLUR_QV < H) load_segment(ms + BLUR_QV);
         }
         __syncthreads();
-        if (WINO) {
+        if (WINO == 4) {
+            // 8 rows x QC/2 four-pixel tiles, two threads per tile: each takes four of the eight channels through all six positions
+            // (neighbouring lanes write the two 8-byte halves of one 16-byte chunk)
+            constexpr int TPR = QC / 2;                        // tiles per row
+            const int chalf = lt & 1, item = lt >> 1;
+            const int tc = item % TPR, row = item / TPR;
+            const int oy = 2 * ms + row;
+            if (oy < 2 * H && 4 * tc < OW && valid && (NG == 1 || ms < H)) {
+                const int HT = H * W;                     // tiles per channel (2H rows x 2W/4)
+                unsigned char* dst = xs + ((((int64_t)b * G + g) * 12) * HT + (int64_t)oy * (W / 2) + tc) * 16 + 8 * chalf;
+                float v[6][4];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    float d[6], vv[6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const int px = 4 * tc - 1 + j;
+                        d[j] = (px >= 0 && px < OW) ? tile[row][px][4 * chalf + cc] * sv[4 * chalf + cc] : 0.f;
+                    }
+                    ws_input_transform<6>(d, vv);
+#pragma unroll
+                    for (int tt = 0; tt < 6; ++tt) v[tt][cc] = vv[tt];
+                }
+#pragma unroll
+                for (int tt = 0; tt < 6; ++tt) {
+                    unsigned h01, l01, h23, l23;
+                    blur_split2<ET>(v[tt][0], v[tt][1], h01, l01, sat);
+                    blur_split2<ET>(v[tt][2], v[tt][3], h23, l23, sat);
+                    *reinterpret_cast<uint2*>(dst + (int64_t)(2 * tt) * HT * 16) = make_uint2(h01, h23);
+                    *reinterpret_cast<uint2*>(dst + (int64_t)(2 * tt + 1) * HT * 16) = make_uint2(l01, l23);
+                }
+            }
+        } else if (WINO == 2) {
             // 8 rows x QC output pairs -> 8 channels each: d_j = y[2*tc - 1 + j] * s_next, V = B^T d, split, 4 x 2 chunks
             const int tc = lt % QC, row = lt / QC;
             const int oy = 2 * ms + row;
@@ -583,6 +615,7 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
                                              int B, int C, int H, int W, int64_t plane_stride, int arith, int wino, int act,
                                              float slope, float gain, unsigned int* sat, void* stream) {
     SGDFR_REQUIRE(B >= 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "blur_bias_act_split: bad shape %d %d %d %d (C %% 8)", B, C, H, W);
+    SGDFR_REQUIRE(wino == 0 || wino == 2 || wino == 4, "blur_bias_act_split: wino is 0, 2 or 4 (outputs per Winograd tile), got %d", wino);
     SGDFR_REQUIRE(!wino || (W >= 8 && W <= 64 && (W & (W - 1)) == 0), "blur_bias_act_split: the Winograd hand-over takes W = 8, 16, 32 or 64 "
                   "(output rows inside one column tile), got %d", W);
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "blur_bias_act_split: arith must be SGDFR_SPLIT_BF16/FP16");
@@ -607,13 +640,20 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
     unsigned char* out = reinterpret_cast<unsigned char*>(xs);
     void (*kern)(const float*, const float*, const float*, int64_t, const float*, const float*, const float*, unsigned char*, int,
                  int, int, int, int, int, int, float, float, unsigned*);
-    if (wino) {
+    if (wino == 2) {
         if (arith == SGDFR_SPLIT_FP16)
-            kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_FP16, 64, 1, true> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_FP16, 32, 1, true>
-                   : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_FP16, 16, 2, true> : blur_split_kernel<SGDFR_SPLIT_FP16, 8, 4, true>;
+            kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_FP16, 64, 1, 2> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_FP16, 32, 1, 2>
+                   : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_FP16, 16, 2, 2> : blur_split_kernel<SGDFR_SPLIT_FP16, 8, 4, 2>;
         else
-            kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_BF16, 64, 1, true> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_BF16, 32, 1, true>
-                   : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_BF16, 16, 2, true> : blur_split_kernel<SGDFR_SPLIT_BF16, 8, 4, true>;
+            kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_BF16, 64, 1, 2> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_BF16, 32, 1, 2>
+                   : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_BF16, 16, 2, 2> : blur_split_kernel<SGDFR_SPLIT_BF16, 8, 4, 2>;
+    } else if (wino == 4) {
+        if (arith == SGDFR_SPLIT_FP16)
+            kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_FP16, 64, 1, 4> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_FP16, 32, 1, 4>
+                   : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_FP16, 16, 2, 4> : blur_split_kernel<SGDFR_SPLIT_FP16, 8, 4, 4>;
+        else
+            kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_BF16, 64, 1, 4> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_BF16, 32, 1, 4>
+                   : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_BF16, 16, 2, 4> : blur_split_kernel<SGDFR_SPLIT_BF16, 8, 4, 4>;
     } else
     if (arith == SGDFR_SPLIT_FP16)
         kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_FP16, 64, 1> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_FP16, 32, 1>

@@ -104,27 +104,36 @@ __device__ __forceinline__ void ws_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// s_waitcnt vmcnt(n) for a wave-uniform runtime n in 0..4 (the instruction takes an immediate)
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n in 0..5 (the instruction takes an immediate)
 __device__ __forceinline__ void ws_wait_vmcnt_dyn(int n) {
     switch (n) {
         case 0: ws_wait_vmcnt<0>(); break;
         case 1: ws_wait_vmcnt<1>(); break;
         case 2: ws_wait_vmcnt<2>(); break;
         case 3: ws_wait_vmcnt<3>(); break;
-        default: ws_wait_vmcnt<4>(); break;
+        case 4: ws_wait_vmcnt<4>(); break;
+        default: ws_wait_vmcnt<5>(); break;
     }
 }
 
-template <int ET>
+// POS = transform positions of the 1-D Winograd form: 4 = F(2,3) (two outputs per tile), 6 = F(4,3) (four outputs per tile:
+// 18 instead of 36 MFMA columns per 16 channels and output quad, V 1.5x and U 2x the direct operands' bytes).
+template <int ET, int POS>
 __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
-    constexpr int NT = 128, NI = 2, NEXV = 5;
-    constexpr int WSLOT = 32768;                  // one kernel row of one cout tile: [t 4][part 2][k-half 2][128][8] x 16 bit
-    constexpr int WHALF = 16384;                  // one position pair of it = one half-stage = one ring slot
+    constexpr int NT = 128;
+    constexpr int OUTP = POS - 2;                 // output pixels per tile
+    constexpr int NI = POS == 4 ? 2 : 1;          // 32-tile MFMA column tiles per wave: POS * NI accumulators (8 / 6)
+    constexpr int TILES = 64 * NI;                // tiles per block (2 column waves): 256 pixels either way
+    constexpr int HPOS = POS / 2;                 // positions per half-stage
+    constexpr int RUNS = POS * 4;                 // (position, part, k-half) runs of the V image
+    constexpr int NEXV = POS == 4 ? 5 : 4;        // V pieces per wave and channel block (the last one may not exist for every wave)
+    constexpr int WHALF = HPOS * 8192;            // one half-stage of one cout tile: [HPOS][part 2][k-half 2][128][8] x 16 bit = one ring slot
+    constexpr int WV = HPOS;                      // 1 KB DMA pieces per wave and half-stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int xbuf_bytes = 256 * p.xs;            // [t 4][part 2][k-half 2][xs][8] x 16 bit
+    const int xbuf_bytes = RUNS * 16 * p.xs;      // [t POS][part 2][k-half 2][xs][8] x 16 bit
     unsigned char* const xb0 = smem;
     unsigned char* const wb0 = smem + 2 * xbuf_bytes;
-    float* const dl = reinterpret_cast<float*>(wb0 + 2 * WSLOT);     // [NT] d * output scale
+    float* const dl = reinterpret_cast<float*>(wb0 + 4 * WHALF);     // [NT] d * output scale (* gain)
     float* const bl = dl + NT;                                        // [NT] bias
     float* const sn = bl + NT;                                        // [NT] next layer's style * range shift
     float* const cw = sn + NT;                                        // [NT][4] ToRGB coefficients
@@ -166,9 +175,9 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
         }
     }
 
-    // this lane's two tile columns: position inside the staged patch, output pixel pair, noise
+    // this lane's tile columns: position inside the staged patch, first output pixel, noise
     int boff[NI], pix[NI];
-    float nz[NI][2];
+    float nz[NI][OUTP];
     {
         const float nw = (p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
 #pragma unroll
@@ -176,12 +185,18 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
             const int l = (wn * NI + n) * 32 + l31;
             const int r = l >> p.tct_shift, c = l & (p.TCT - 1);
             boff[n] = (hi * p.xs + l) * 16;                      // (staged row r + ky holds image row row0 - 1 + r + ky)
-            pix[n] = (row0 + r) * p.W + 2 * (col0 + c);
-            nz[n][0] = nz[n][1] = 0.f;
+            pix[n] = (row0 + r) * p.W + OUTP * (col0 + c);
+#pragma unroll
+            for (int q = 0; q < OUTP; ++q) nz[n][q] = 0.f;
             if (p.noise) {
-                const float2 t2 = *reinterpret_cast<const float2*>(p.noise + (int64_t)img0 * p.noise_bstride + pix[n]);
-                nz[n][0] = nw * t2.x;
-                nz[n][1] = nw * t2.y;
+                const float* np_ = p.noise + (int64_t)img0 * p.noise_bstride + pix[n];
+                if (OUTP == 2) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(np_);
+                    nz[n][0] = nw * t2.x; nz[n][1] = nw * t2.y;
+                } else {
+                    const float4 t4 = *reinterpret_cast<const float4*>(np_);
+                    nz[n][0] = nw * t4.x; nz[n][1] = nw * t4.y; nz[n][OUTP - 2] = nw * t4.z; nz[n][OUTP - 1] = nw * t4.w;
+                }
             }
         }
     }
@@ -192,16 +207,16 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
 #pragma unroll
     for (int e = 0; e < NEXV; ++e) {
         const int i = (e * 8 + wave) * 64 + lane;
-        if ((e * 8 + wave) * 64 >= 16 * p.xs) { vsrc[e] = -2; continue; }
+        if ((e * 8 + wave) * 64 >= RUNS * p.xs) { vsrc[e] = -2; continue; }
         const int run = fdiv(i, p.fd_xs), pos = i - run * p.xs;
         const int sr = pos >> p.tct_shift, c = pos & (p.TCT - 1);
         const int row = row0 - 1 + sr;
         const int t = run >> 2, part = (run >> 1) & 1, h = run & 1;
         vsrc[e] = (row >= 0 && row < p.H)
-                      ? ((((((int64_t)img0 * G8 + h) * 4 + t) * 2 + part) * HT) + (int64_t)row * p.TW + col0 + c) * 16
+                      ? ((((((int64_t)img0 * G8 + h) * POS + t) * 2 + part) * HT) + (int64_t)row * p.TW + col0 + c) * 16
                       : -1;
     }
-    const int64_t v_cb_stride = (int64_t)256 * HT;      // 2 eight-channel groups x [4][2][HT][16 B]
+    const int64_t v_cb_stride = (int64_t)(POS * 64) * HT;      // 2 eight-channel groups x [POS][2][HT][16 B]
 
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
@@ -214,36 +229,34 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
         __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(xb + (e * 8 + wave) * 1024), 16, 0, 0);
     };
     const int ncb = p.Cin / WS_CB;
-    const int nh = ncb * 6;                             // half-stages: (channel block, kernel row, position pair)
-    const unsigned char* const wglb = p.wsp + (int64_t)ct * ncb * 3 * WSLOT;
-    // weight slab of half-stage h = (cb, ky, tp): 16 KB [2 positions][part][k-half][128][8], 2 pieces per wave
+    const int nh = ncb * 6;                             // half-stages: (channel block, kernel row, position half)
+    const unsigned char* const wglb = p.wsp + (int64_t)ct * ncb * 6 * WHALF;
+    // weight slab of half-stage h = (cb, ky, tp): [HPOS positions][part][k-half][128][8], WV pieces per wave
     auto issue_w = [&](int h) {
 #ifdef SGDFR_WSPLIT_PROBE
         if (p.dbg & 16) return;
 #endif
 #pragma unroll
-        for (int v = 0; v < 2; ++v) {
+        for (int v = 0; v < WV; ++v) {
             const int piece = wave + v * 8;
             __builtin_amdgcn_global_load_lds((glb_void*)(wglb + (int64_t)h * WHALF + piece * 1024 + lane * 16),
                                              (lds_void*)(wb0 + (h & 3) * WHALF + piece * 1024), 16, 0, 0);
         }
     };
 
-    ws_f32x16 acc[4][NI];
+    ws_f32x16 acc[POS][NI];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < POS; ++t)
 #pragma unroll
         for (int n = 0; n < NI; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][n][r] = 0.f;
 
-    // V pieces this wave really issues (xs = 144: the fifth piece exists for waves 0-3 only), per half-stage of a channel block:
-    // pieces {0, 1}, {2}, {3}, {4} in half-stages 0..3 -- all landed and published by the barrier that ends half-stage 4
-    int nvw[4];
-    {
-        auto ex = [&](int e) { return (e * 8 + wave) * 64 < 16 * p.xs ? 1 : 0; };
-        nvw[0] = ex(0) + ex(1); nvw[1] = ex(2); nvw[2] = ex(3); nvw[3] = ex(4);
-    }
+    // V pieces this wave really issues per half-stage of a channel block (the last piece may exist for the first waves only):
+    // piece e goes out in half-stage max(0, e - (NEXV - 4)) -- all landed and published by the barrier that ends half-stage 4
+    int nvw[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < NEXV; ++e) nvw[e - (NEXV - 4) > 0 ? e - (NEXV - 4) : 0] += ((e * 8 + wave) * 64 < RUNS * p.xs) ? 1 : 0;
 
     // ---- prologue: channel block 0, the first three weight half-slabs
 #pragma unroll
@@ -264,12 +277,12 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // K loop.  The weight half-slabs live in a FOUR-slot ring (16 KB each) and are DMA'd three half-stages ahead: the slab of
-    // h+1 is published by the barrier that ends h-1, so the first fragments of h+1 are requested in the middle of h -- BEFORE
-    // the barrier that ends h -- and no wave starts a half-stage waiting for LDS.  (With one barrier per kernel row and two
-    // 32 KB slots every wave of the block asked for its first six fragments right behind the barrier: 48 KB of LDS reads with
-    // the matrix cores idle, ~15 % of a 24-MFMA sub-stage.)  The barrier's counted wait leaves the pieces issued during h in
-    // flight and completes everything older (the slab of h+2, V pieces of the next channel block).
+    // K loop.  The weight half-slabs live in a FOUR-slot ring and are DMA'd three half-stages ahead: the slab of h+1 is
+    // published by the barrier that ends h-1, so the first fragments of h+1 are requested during the last position of h --
+    // BEFORE the barrier that ends h -- and no wave starts a half-stage waiting for LDS.  (One barrier per kernel row with two
+    // slots, all eight waves asking for their first fragments right behind it, measured the same: the loop is power-bound.)
+    // The barrier's counted wait leaves the pieces issued during h in flight and completes everything older (the slab of h+2,
+    // V pieces of the next channel block).
     const int a_off = (hi * 128 + wm * 32 + l31) * 16;
     const bool late = wave >= 4 && !(p.dbg & 4);      // the two waves of a SIMD issue their DMA pieces at different times (split.hip)
     const int rowstep = p.TCT * 16;
@@ -294,12 +307,11 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
             const int ky = hh >> 1, tp = hh & 1;
             int n_issued = 0;
             auto issue_all = [&]() {
-                if (h + 3 < nh) { issue_w(h + 3); n_issued += 2; }
+                if (h + 3 < nh) { issue_w(h + 3); n_issued += WV; }
                 if (v_next && hh < 4) {
-                    if (hh == 0) { issue_v(0, cb + 1, xnext); issue_v(1, cb + 1, xnext); }
-                    if (hh == 1) issue_v(2, cb + 1, xnext);
-                    if (hh == 2) issue_v(3, cb + 1, xnext);
-                    if (hh == 3) issue_v(4, cb + 1, xnext);
+#pragma unroll
+                    for (int e = 0; e < NEXV; ++e)
+                        if ((e - (NEXV - 4) > 0 ? e - (NEXV - 4) : 0) == hh) issue_v(e, cb + 1, xnext);
                     n_issued += nvw[hh < 4 ? hh : 0];
                 }
             };
@@ -307,33 +319,30 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
             __builtin_amdgcn_sched_barrier(0);
             const unsigned char* wsl = wb0 + (h & 3) * WHALF + a_off;
             const unsigned char* xrow = xcur + ky * rowstep;
-            // first position of the pair: fragments were requested during the previous half-stage
 #pragma unroll
-            for (int n = 0; n < NI; ++n) acc[2 * tp][n] = ws_mfma<ET>(a[0][0], b[0][0][n], acc[2 * tp][n]);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch(1, wsl, xrow, 1, 2 * tp + 1);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int tl = 0; tl < HPOS; ++tl) {
+                const int t = tp * HPOS + tl;
+                const int cur = (hh * HPOS + tl) & 1;            // (6 * HPOS is even: the parity is the same in every channel block)
+                // fragments of this position were requested during the previous one (the first of a half-stage: before the
+                // barrier that precedes it)
 #pragma unroll
-            for (int n = 0; n < NI; ++n) acc[2 * tp][n] = ws_mfma<ET>(a[0][0], b[0][1][n], acc[2 * tp][n]);
+                for (int n = 0; n < NI; ++n) acc[t][n] = ws_mfma<ET>(a[cur][0], b[cur][0][n], acc[t][n]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tl == HPOS - 1 && late) issue_all();
+                if (tl + 1 < HPOS) {
+                    fetch(cur ^ 1, wsl, xrow, tl + 1, t + 1);
+                } else if (h + 1 < nh) {
+                    const int hn = hh + 1;      // (6 = the first half-stage of the next channel block)
+                    fetch(cur ^ 1, wb0 + ((h + 1) & 3) * WHALF + a_off, (hn == 6 ? xnext : xcur) + (hn == 6 ? 0 : (hn >> 1)) * rowstep, 0,
+                          hn == 6 ? 0 : HPOS * (hn & 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int n = 0; n < NI; ++n) acc[2 * tp][n] = ws_mfma<ET>(a[0][1], b[0][0][n], acc[2 * tp][n]);
-            __builtin_amdgcn_sched_barrier(0);
-            // second position; the first fragments of the NEXT half-stage are requested behind its hi*hi products
+                for (int n = 0; n < NI; ++n) acc[t][n] = ws_mfma<ET>(a[cur][0], b[cur][1][n], acc[t][n]);
 #pragma unroll
-            for (int n = 0; n < NI; ++n) acc[2 * tp + 1][n] = ws_mfma<ET>(a[1][0], b[1][0][n], acc[2 * tp + 1][n]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (late) issue_all();
-            if (h + 1 < nh) {
-                const int hn = hh + 1;      // (6 = the first half-stage of the next channel block)
-                fetch(0, wb0 + ((h + 1) & 3) * WHALF + a_off, (hn == 6 ? xnext : xcur) + (hn == 6 ? 0 : (hn >> 1)) * rowstep, 0,
-                      hn == 6 ? 0 : 2 * (hn & 1));
+                for (int n = 0; n < NI; ++n) acc[t][n] = ws_mfma<ET>(a[cur][1], b[cur][0][n], acc[t][n]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int n = 0; n < NI; ++n) acc[2 * tp + 1][n] = ws_mfma<ET>(a[1][0], b[1][1][n], acc[2 * tp + 1][n]);
-#pragma unroll
-            for (int n = 0; n < NI; ++n) acc[2 * tp + 1][n] = ws_mfma<ET>(a[1][1], b[1][0][n], acc[2 * tp + 1][n]);
-            __builtin_amdgcn_sched_barrier(0);
             if (h + 1 < nh) {
 #ifdef SGDFR_WSPLIT_PROBE
                 if (!(p.dbg & 32))
@@ -351,11 +360,11 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
     // ---- epilogue.  C/D layout of 32x32: column (tile) = lane & 31, row (cout) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
     const float e_slope = p.act ? p.slope : 1.f, e_gain = p.act ? p.gain : 1.f;
     unsigned sat = 0;
-    float rgb[NI][2][3];
+    float rgb[NI][OUTP][3];
 #pragma unroll
     for (int n = 0; n < NI; ++n)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) rgb[n][q][0] = rgb[n][q][1] = rgb[n][q][2] = 0.f;
+        for (int q = 0; q < OUTP; ++q) rgb[n][q][0] = rgb[n][q][1] = rgb[n][q][2] = 0.f;
     auto epilogue = [&](auto has_y_t, auto emit_xs_t, auto fuse_rgb_t) {
         constexpr bool HAS_Y = decltype(has_y_t)::value, EMIT_XS = decltype(emit_xs_t)::value, FUSE_RGB = decltype(fuse_rgb_t)::value;
         const int io = wm * 32 + 4 * hi;
@@ -371,42 +380,57 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
             for (int g = 0; g < 4; ++g) {
                 const float4 dq = d4p[2 * g], bq = b4p[2 * g];
                 const float dv[4] = {dq.x, dq.y, dq.z, dq.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w};
-                float v0[4], v1[4];
+                float v[OUTP][4];      // [pixel of the tile][row of the group]
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = 4 * g + j;
-                    const float m0 = acc[0][n][r], m1 = acc[1][n][r], m2 = acc[2][n][r], m3 = acc[3][n][r];
-                    const float y0 = (m0 + m1) + m2, y1 = (m1 - m2) - m3;
-                    v0[j] = lrelu_gain(y0 * dv[j] + nz[n][0] + bv[j], e_slope, e_gain);
-                    v1[j] = lrelu_gain(y1 * dv[j] + nz[n][1] + bv[j], e_slope, e_gain);
+                    float y[OUTP];
+                    if (POS == 4) {      // A^T of F(2,3)
+                        const float m0 = acc[0][n][r], m1 = acc[1][n][r], m2 = acc[2][n][r], m3 = acc[POS - 1][n][r];
+                        y[0] = (m0 + m1) + m2;
+                        y[1] = (m1 - m2) - m3;
+                    } else {             // A^T of F(4,3): rows (1 1 1 1 1 0) (0 1 -1 2 -2 0) (0 1 1 4 4 0) (0 1 -1 8 -8 1)
+                        const float m0 = acc[0][n][r], m1 = acc[1][n][r], m2 = acc[2][n][r], m3 = acc[3][n][r], m4 = acc[POS - 2][n][r],
+                                    m5 = acc[POS - 1][n][r];
+                        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                        y[0] = (m0 + s12) + s34;
+                        y[1] = fmaf(2.f, d34, d12);
+                        y[OUTP - 2] = fmaf(4.f, s34, s12);
+                        y[OUTP - 1] = fmaf(8.f, d34, d12) + m5;
+                    }
+#pragma unroll
+                    for (int q = 0; q < OUTP; ++q) v[q][j] = lrelu_gain(y[q] * dv[j] + nz[n][q] + bv[j], e_slope, e_gain);
                 }
                 if (HAS_Y) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) *reinterpret_cast<float2*>(yp + (int64_t)(8 * g + j) * HW) = make_float2(v0[j], v1[j]);
+                    for (int j = 0; j < 4; ++j) {
+                        float* dst = yp + (int64_t)(8 * g + j) * HW;
+                        if (OUTP == 2) *reinterpret_cast<float2*>(dst) = make_float2(v[0][j], v[1][j]);
+                        else *reinterpret_cast<float4*>(dst) = make_float4(v[0][j], v[1][j], v[OUTP - 2][j], v[OUTP - 1][j]);
+                    }
                 }
-                if (EMIT_XS) {      // the 4 rows are half of one 8-channel chunk of each of the two pixels
+                if (EMIT_XS) {      // the 4 rows are half of one 8-channel chunk of each pixel of the tile
                     const float4 sq = s4p[2 * g];
-                    unsigned h01, l01, h23, l23;
                     unsigned char* dst = xp + (int64_t)g * 2 * HW * 16;
-                    ws_pair<ET>(v0[0] * sq.x, v0[1] * sq.y, h01, l01, sat);
-                    ws_pair<ET>(v0[2] * sq.z, v0[3] * sq.w, h23, l23, sat);
-                    *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
-                    *reinterpret_cast<uint2*>(dst + (int64_t)HW * 16) = make_uint2(l01, l23);
-                    ws_pair<ET>(v1[0] * sq.x, v1[1] * sq.y, h01, l01, sat);
-                    ws_pair<ET>(v1[2] * sq.z, v1[3] * sq.w, h23, l23, sat);
-                    *reinterpret_cast<uint2*>(dst + 16) = make_uint2(h01, h23);
-                    *reinterpret_cast<uint2*>(dst + (int64_t)HW * 16 + 16) = make_uint2(l01, l23);
+#pragma unroll
+                    for (int q = 0; q < OUTP; ++q) {
+                        unsigned h01, l01, h23, l23;
+                        ws_pair<ET>(v[q][0] * sq.x, v[q][1] * sq.y, h01, l01, sat);
+                        ws_pair<ET>(v[q][2] * sq.z, v[q][3] * sq.w, h23, l23, sat);
+                        *reinterpret_cast<uint2*>(dst + 16 * q) = make_uint2(h01, h23);
+                        *reinterpret_cast<uint2*>(dst + (int64_t)HW * 16 + 16 * q) = make_uint2(l01, l23);
+                    }
                 }
                 if (FUSE_RGB) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float4 q = cwp[8 * g + j];
-                        rgb[n][0][0] = fmaf(v0[j], q.x, rgb[n][0][0]);
-                        rgb[n][0][1] = fmaf(v0[j], q.y, rgb[n][0][1]);
-                        rgb[n][0][2] = fmaf(v0[j], q.z, rgb[n][0][2]);
-                        rgb[n][1][0] = fmaf(v1[j], q.x, rgb[n][1][0]);
-                        rgb[n][1][1] = fmaf(v1[j], q.y, rgb[n][1][1]);
-                        rgb[n][1][2] = fmaf(v1[j], q.z, rgb[n][1][2]);
+                        const float4 q4 = cwp[8 * g + j];
+#pragma unroll
+                        for (int q = 0; q < OUTP; ++q) {
+                            rgb[n][q][0] = fmaf(v[q][j], q4.x, rgb[n][q][0]);
+                            rgb[n][q][1] = fmaf(v[q][j], q4.y, rgb[n][q][1]);
+                            rgb[n][q][2] = fmaf(v[q][j], q4.z, rgb[n][q][2]);
+                        }
                     }
                 }
             }
@@ -431,11 +455,11 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
 #pragma unroll
         for (int n = 0; n < NI; ++n)
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < OUTP; ++q)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const float v = rgb[n][q][j] + __shfl_xor(rgb[n][q][j], 32, 64);
-                    if (hi == 0) red[(wm * 256 + ((wn * NI + n) * 32 + l31) * 2 + q) * 3 + j] = v;
+                    const float vv = rgb[n][q][j] + __shfl_xor(rgb[n][q][j], 32, 64);
+                    if (hi == 0) red[(wm * 256 + ((wn * NI + n) * 32 + l31) * OUTP + q) * 3 + j] = vv;
                 }
         __syncthreads();
         if (wm == 0 && hi == 0) {
@@ -443,29 +467,50 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
             for (int n = 0; n < NI; ++n)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    float t2[2];
+                    float tq[OUTP];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
+                    for (int q = 0; q < OUTP; ++q) {
                         float t = 0.f;
 #pragma unroll
-                        for (int w2 = 0; w2 < 4; ++w2) t += red[(w2 * 256 + ((wn * NI + n) * 32 + l31) * 2 + q) * 3 + j];
-                        t2[q] = t;
+                        for (int w2 = 0; w2 < 4; ++w2) t += red[(w2 * 256 + ((wn * NI + n) * 32 + l31) * OUTP + q) * 3 + j];
+                        tq[q] = t;
                     }
-                    *reinterpret_cast<float2*>(p.rgb_part + (((int64_t)img0 * p.n_cout_tiles + ct) * 3 + j) * HW + pix[n]) =
-                        make_float2(t2[0], t2[1]);
+                    float* dst = p.rgb_part + (((int64_t)img0 * p.n_cout_tiles + ct) * 3 + j) * HW + pix[n];
+                    if (OUTP == 2) *reinterpret_cast<float2*>(dst) = make_float2(tq[0], tq[1]);
+                    else *reinterpret_cast<float4*>(dst) = make_float4(tq[0], tq[1], tq[OUTP - 2], tq[OUTP - 1]);
                 }
         }
     }
     if (ET == SGDFR_SPLIT_FP16 && __builtin_expect(sat != 0, 0)) atomicAdd(p.sat ? p.sat : &g_wsplit_saturated, sat);
 }
 
-// x [B,Cin,H,W] fp32 and s [B,Cin] -> WS [B][Cin/8][t 4][hi,lo][H * W/2][8]: B^T (x*s) per row pair, split.
+template <int POS>
+__device__ __forceinline__ void ws_weight_transform(float g0, float g1, float g2, float (&u)[POS]) {
+    if (POS == 4) {
+        u[0] = g0;
+        u[1] = 0.5f * ((g0 + g2) + g1);
+        u[2] = 0.5f * ((g0 + g2) - g1);
+        u[POS - 1] = g2;
+    } else {
+        // G rows: (1/4 0 0) (-1/6 -1/6 -1/6) (-1/6 1/6 -1/6) (1/24 1/12 1/6) (1/24 -1/12 1/6) (0 0 1)
+        const float s02 = g0 + g2, q = fmaf(4.f, g2, g0);          // g0 + 4 g2
+        u[0] = 0.25f * g0;
+        u[1] = (-1.f / 6.f) * (s02 + g1);
+        u[2] = (-1.f / 6.f) * (s02 - g1);
+        u[3] = (1.f / 24.f) * fmaf(2.f, g1, q);
+        u[POS - 2] = (1.f / 24.f) * fmaf(-2.f, g1, q);
+        u[POS - 1] = g2;
+    }
+}
+
+// x [B,Cin,H,W] fp32 and s [B,Cin] -> WS [B][Cin/8][t POS][hi,lo][H * W/(POS-2)][8]: B^T (x*s) per output tile, split.
 // One thread = one tile of one 8-channel group.
-template <int ET>
+template <int ET, int POS>
 __global__ __launch_bounds__(256) void to_wsplit_kernel(const float* __restrict__ x, const float* __restrict__ s,
                                                        unsigned char* __restrict__ vs, int B, int Cin, int H, int W,
                                                        unsigned* __restrict__ sat_word) {
-    const int G = Cin / 8, TW = W / 2, HT = H * TW;
+    constexpr int OUTP = POS - 2;
+    const int G = Cin / 8, TW = W / OUTP, HT = H * TW;
     const int64_t n = (int64_t)B * G * HT;
     const float sc = (ET == SGDFR_SPLIT_FP16) ? WS_F16_XSCALE : 1.f;
     unsigned sat = 0;
@@ -474,25 +519,29 @@ __global__ __launch_bounds__(256) void to_wsplit_kernel(const float* __restrict_
         const int64_t bg = idx / HT;
         const int g = (int)(bg % G), b = (int)(bg / G);
         const int row = pos / TW, tc = pos - row * TW;
-        float v[4][8];
+        float v[POS][8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const float* xp = x + (((int64_t)b * Cin + g * 8 + c) * H + row) * W + 2 * tc;
+            const float* xp = x + (((int64_t)b * Cin + g * 8 + c) * H + row) * W + OUTP * tc;
             const float sv = s[(int64_t)b * Cin + g * 8 + c] * sc;
-            const float d0 = tc > 0 ? xp[-1] * sv : 0.f, d1 = xp[0] * sv, d2 = xp[1] * sv, d3 = tc + 1 < TW ? xp[2] * sv : 0.f;
-            v[0][c] = d0 - d2;
-            v[1][c] = d1 + d2;
-            v[2][c] = d2 - d1;
-            v[3][c] = d1 - d3;
+            float d[POS], vv[POS];
+#pragma unroll
+            for (int j = 0; j < POS; ++j) {
+                const int col = OUTP * tc - 1 + j;
+                d[j] = (col >= 0 && col < W) ? xp[j - 1] * sv : 0.f;
+            }
+            ws_input_transform<POS>(d, vv);
+#pragma unroll
+            for (int t = 0; t < POS; ++t) v[t][c] = vv[t];
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < POS; ++t) {
             uint4 vh, vl;
             unsigned* ph = reinterpret_cast<unsigned*>(&vh);
             unsigned* pl = reinterpret_cast<unsigned*>(&vl);
 #pragma unroll
             for (int c = 0; c < 4; ++c) ws_pair<ET>(v[t][2 * c], v[t][2 * c + 1], ph[c], pl[c], sat);
-            unsigned char* dst = vs + (((bg * 4 + t) * 2) * HT + pos) * 16;
+            unsigned char* dst = vs + (((bg * POS + t) * 2) * HT + pos) * 16;
             *reinterpret_cast<uint4*>(dst) = vh;
             *reinterpret_cast<uint4*>(dst + (int64_t)HT * 16) = vl;
         }
@@ -501,7 +550,8 @@ __global__ __launch_bounds__(256) void to_wsplit_kernel(const float* __restrict_
 }
 
 // weight [Cout,Cin,3,3] fp32 -> 16-bit hi/lo of U = G (weight/sqrt(9 Cin)) per kernel row, in the kernel's LDS order:
-//   [cout tile 128][cin block][ky][t][part][k-half][128 couts][8 cin]
+//   [cout tile 128][cin block][ky][t POS][part][k-half][128 couts][8 cin]
+template <int POS>
 __global__ __launch_bounds__(256) void prepack_wsplit_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
                                                             int Cout, int Cin, float scale, int et, unsigned* __restrict__ sat_word) {
     const int64_t n = (int64_t)Cout * Cin * 3;
@@ -512,15 +562,15 @@ __global__ __launch_bounds__(256) void prepack_wsplit_kernel(const float* __rest
         const int ci = (int)((idx / 3) % Cin);
         const int co = (int)(idx / (3 * (int64_t)Cin));
         const float* g = w + ((int64_t)co * Cin + ci) * 9 + ky * 3;
-        const float g0 = g[0] * scale, g1 = g[1] * scale, g2 = g[2] * scale;
-        const float U[4] = {g0, 0.5f * ((g0 + g2) + g1), 0.5f * ((g0 + g2) - g1), g2};
+        float U[POS];
+        ws_weight_transform<POS>(g[0] * scale, g[1] * scale, g[2] * scale, U);
         const int ctile = co / 128, col = co - ctile * 128, cb = ci / WS_CB, h = (ci % WS_CB) / 8, c8 = ci % 8;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < POS; ++t) {
             unsigned hp, lp;
             if (et == SGDFR_SPLIT_FP16) ws_pair<SGDFR_SPLIT_FP16>(U[t], 0.f, hp, lp, sat);
             else ws_pair<SGDFR_SPLIT_BF16>(U[t], 0.f, hp, lp, sat);
-            const int64_t base = ((((int64_t)ctile * ncb + cb) * 3 + ky) * 4 + t) * 2;      // -> [part]
+            const int64_t base = ((((int64_t)ctile * ncb + cb) * 3 + ky) * POS + t) * 2;      // -> [part]
             out[(((base + 0) * 2 + h) * 128 + col) * 8 + c8] = (unsigned short)(hp & 0xffffu);
             out[(((base + 1) * 2 + h) * 128 + col) * 8 + c8] = (unsigned short)(lp & 0xffffu);
         }
@@ -542,20 +592,22 @@ unsigned int wsplit_saturation_count(int reset) {
 
 using namespace sgdfr;
 
-// geometry; returns 0 when the shape cannot use the kernel
-static int wsplit_geometry(int B, int Cin, int Cout, int H, int W, WsParams* out) {
-    if (B < 1 || Cin % WS_CB != 0 || Cout % 128 != 0 || W % 2 != 0 || W < 16 || H < 1) return 0;
+// geometry for F(f,3), f = 2 | 4 outputs per tile; returns 0 when the shape cannot use the kernel
+static int wsplit_geometry(int B, int Cin, int Cout, int H, int W, int f, WsParams* out) {
+    if ((f != 2 && f != 4) || B < 1 || Cin % WS_CB != 0 || Cout % 128 != 0 || W % f != 0 || W < 16 || H < 1) return 0;
     WsParams p{};
     p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
-    p.TW = W / 2;
-    p.TCT = p.TW >= 16 ? 16 : 8;
-    p.tct_shift = p.TCT == 16 ? 4 : 3;
-    p.TR = 128 / p.TCT;
+    p.TW = W / f;
+    const int tiles = f == 2 ? 128 : 64, runs = (f + 2) * 4;          // tiles per block; (position, part, k-half) runs
+    const int tct_max = f == 2 ? 16 : 8;
+    p.TCT = p.TW >= tct_max ? tct_max : tct_max / 2;
+    p.tct_shift = p.TCT == 16 ? 4 : p.TCT == 8 ? 3 : 2;
+    p.TR = tiles / p.TCT;
     if (p.TW % p.TCT != 0 || H % p.TR != 0) return 0;
     p.tiles_x = p.TW / p.TCT;
     p.tiles_y = H / p.TR;
     p.xs = (p.TR + 2) * p.TCT;
-    if ((16 * p.xs) % 64 != 0 || 16 * p.xs > 5 * 512) return 0;
+    if ((runs * p.xs) % 64 != 0 || runs * p.xs > (f == 2 ? 5 : 4) * 512) return 0;
     p.n_pix_tiles = B * p.tiles_x * p.tiles_y;
     p.n_cout_tiles = Cout / 128;
     if ((int64_t)p.n_pix_tiles * p.n_cout_tiles >= (1ll << 30) || (int64_t)B * Cout * H * W >= (1ll << 40)) return 0;
@@ -567,39 +619,43 @@ static int wsplit_geometry(int B, int Cin, int Cout, int H, int W, WsParams* out
     return 1;
 }
 
-extern "C" int sgdfr_modconv2d_wsplit_supported(int B, int Cin, int Cout, int H, int W) {
-    return wsplit_geometry(B, Cin, Cout, H, W, nullptr);
+extern "C" int sgdfr_modconv2d_wsplit_supported(int B, int Cin, int Cout, int H, int W, int f) {
+    return wsplit_geometry(B, Cin, Cout, H, W, f, nullptr);
 }
 
-extern "C" int64_t sgdfr_modconv_prepack_wsplit_elems(int Cout, int Cin) { return (int64_t)Cout * Cin * 12 * 2; }
+extern "C" int64_t sgdfr_modconv_prepack_wsplit_elems(int Cout, int Cin, int f) { return (int64_t)Cout * Cin * 3 * (f + 2) * 2; }
 
-extern "C" int sgdfr_modconv_prepack_wsplit_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int arith,
+extern "C" int sgdfr_modconv_prepack_wsplit_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int f, int arith,
                                                 unsigned int* sat, void* stream) {
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "prepack_wsplit: arith must be SGDFR_SPLIT_BF16/FP16");
+    SGDFR_REQUIRE(f == 2 || f == 4, "prepack_wsplit: f (outputs per Winograd tile) must be 2 or 4, got %d", f);
     SGDFR_REQUIRE(Cout > 0 && Cin > 0 && Cin % WS_CB == 0 && Cout % 128 == 0,
                   "prepack_wsplit: needs Cin %% 16 == 0 and Cout %% 128 == 0, got Cin=%d Cout=%d", Cin, Cout);
     SGDFR_REQUIRE(weight && wsp, "prepack_wsplit: null pointer");
     int64_t g = ((int64_t)Cout * Cin * 3 + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(prepack_wsplit_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), weight, wsp, Cout, Cin,
-                       (arith == SGDFR_SPLIT_FP16 ? WS_F16_WSCALE : 1.f) / sqrtf((float)Cin * 9), arith, sat);
+    const float scale = (arith == SGDFR_SPLIT_FP16 ? WS_F16_WSCALE : 1.f) / sqrtf((float)Cin * 9);
+    if (f == 2)
+        hipLaunchKernelGGL(prepack_wsplit_kernel<4>, dim3((int)g), dim3(256), 0, as_stream(stream), weight, wsp, Cout, Cin, scale, arith, sat);
+    else
+        hipLaunchKernelGGL(prepack_wsplit_kernel<6>, dim3((int)g), dim3(256), 0, as_stream(stream), weight, wsp, Cout, Cin, scale, arith, sat);
     return check_launch("modconv_prepack_wsplit");
 }
 
-extern "C" int sgdfr_to_wsplit_f32(const float* x, const float* s, unsigned short* vs, int B, int Cin, int H, int W, int arith,
+extern "C" int sgdfr_to_wsplit_f32(const float* x, const float* s, unsigned short* vs, int B, int Cin, int H, int W, int f, int arith,
                                    unsigned int* sat, void* stream) {
-    SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cin % 8 == 0 && H > 0 && W > 0 && W % 2 == 0, "to_wsplit: bad shape B=%d Cin=%d H=%d W=%d (Cin %% 8, even W)", B, Cin, H, W);
+    SGDFR_REQUIRE(f == 2 || f == 4, "to_wsplit: f (outputs per Winograd tile) must be 2 or 4, got %d", f);
+    SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cin % 8 == 0 && H > 0 && W > 0 && W % f == 0, "to_wsplit: bad shape B=%d Cin=%d H=%d W=%d (Cin %% 8, W %% f)", B, Cin, H, W);
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "to_wsplit: arith must be SGDFR_SPLIT_BF16/FP16");
     if (B == 0) return 0;
     SGDFR_REQUIRE(x && s && vs && (reinterpret_cast<uintptr_t>(vs) & 15) == 0, "to_wsplit: null or misaligned pointer");
-    int64_t g = ((int64_t)B * (Cin / 8) * H * (W / 2) + 255) / 256;
+    int64_t g = ((int64_t)B * (Cin / 8) * H * (W / f) + 255) / 256;
     if (g > 256 * 32) g = 256 * 32;
-    if (arith == SGDFR_SPLIT_FP16)
-        hipLaunchKernelGGL(to_wsplit_kernel<SGDFR_SPLIT_FP16>, dim3((int)g), dim3(256), 0, as_stream(stream), x, s,
-                           reinterpret_cast<unsigned char*>(vs), B, Cin, H, W, sat);
-    else
-        hipLaunchKernelGGL(to_wsplit_kernel<SGDFR_SPLIT_BF16>, dim3((int)g), dim3(256), 0, as_stream(stream), x, s,
-                           reinterpret_cast<unsigned char*>(vs), B, Cin, H, W, sat);
+    unsigned char* out = reinterpret_cast<unsigned char*>(vs);
+    void (*kern)(const float*, const float*, unsigned char*, int, int, int, int, unsigned*) =
+        arith == SGDFR_SPLIT_FP16 ? (f == 2 ? to_wsplit_kernel<SGDFR_SPLIT_FP16, 4> : to_wsplit_kernel<SGDFR_SPLIT_FP16, 6>)
+                                  : (f == 2 ? to_wsplit_kernel<SGDFR_SPLIT_BF16, 4> : to_wsplit_kernel<SGDFR_SPLIT_BF16, 6>);
+    hipLaunchKernelGGL(kern, dim3((int)g), dim3(256), 0, as_stream(stream), x, s, out, B, Cin, H, W, sat);
     return check_launch("to_wsplit");
 }
 
@@ -607,23 +663,24 @@ extern "C" int sgdfr_modconv2d_wsplit_f32(const unsigned short* v, const unsigne
                                           int64_t noise_bstride, const float* noise_w, const float* bias, const float* zeros,
                                           float* y, const float* rgb_w, const float* rgb_s, float* rgb_part,
                                           unsigned short* xs_out, const float* s_next, int B, int Cin, int Cout, int H, int W,
-                                          int arith, int act, float slope, float gain, unsigned int* sat, void* stream) {
+                                          int f, int arith, int act, float slope, float gain, unsigned int* sat, void* stream) {
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "modconv_wsplit: arith must be SGDFR_SPLIT_BF16/FP16");
     SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "modconv_wsplit: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin,
                   Cout, H, W);
     if (B == 0) return 0;
     WsParams p;
-    SGDFR_REQUIRE(wsplit_geometry(B, Cin, Cout, H, W, &p),
-                  "modconv_wsplit: shape B=%d Cin=%d Cout=%d H=%d W=%d not supported (Cin %% 16, Cout %% 128, W/2 %% min(16, W/2), "
-                  "H %% (128 / tile columns)); use sgdfr_modconv2d_split_f32", B, Cin, Cout, H, W);
+    SGDFR_REQUIRE(wsplit_geometry(B, Cin, Cout, H, W, f, &p),
+                  "modconv_wsplit: shape B=%d Cin=%d Cout=%d H=%d W=%d f=%d not supported (f = 2 | 4, Cin %% 16, Cout %% 128, W/f a "
+                  "multiple of the patch width, H of the patch height); use sgdfr_modconv2d_split_f32", B, Cin, Cout, H, W, f);
     SGDFR_REQUIRE(v && wsp && zeros && (y || rgb_part || xs_out), "modconv_wsplit: null pointer");
     SGDFR_REQUIRE(((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(wsp)) & 15) == 0,
                   "modconv_wsplit: v and wsp must be 16-byte aligned");
-    SGDFR_REQUIRE(!noise || (noise_w && (reinterpret_cast<uintptr_t>(noise) & 7) == 0 && noise_bstride % 2 == 0),
-                  "modconv_wsplit: noise needs noise_w and 8-byte alignment");
-    SGDFR_REQUIRE(!y || (reinterpret_cast<uintptr_t>(y) & 7) == 0, "modconv_wsplit: y must be 8-byte aligned");
+    const uintptr_t amask = (uintptr_t)(4 * f - 1);      // a lane stores / loads f consecutive floats
+    SGDFR_REQUIRE(!noise || (noise_w && (reinterpret_cast<uintptr_t>(noise) & amask) == 0 && noise_bstride % f == 0),
+                  "modconv_wsplit: noise needs noise_w and %d-byte alignment", 4 * f);
+    SGDFR_REQUIRE(!y || (reinterpret_cast<uintptr_t>(y) & amask) == 0, "modconv_wsplit: y must be %d-byte aligned", 4 * f);
     SGDFR_REQUIRE(!xs_out || (s_next && (reinterpret_cast<uintptr_t>(xs_out) & 15) == 0), "modconv_wsplit: xs_out needs s_next and a 16-byte aligned buffer");
-    SGDFR_REQUIRE(!rgb_part || (rgb_w && rgb_s && (reinterpret_cast<uintptr_t>(rgb_part) & 7) == 0), "modconv_wsplit: the fused ToRGB needs rgb_w and rgb_s");
+    SGDFR_REQUIRE(!rgb_part || (rgb_w && rgb_s && (reinterpret_cast<uintptr_t>(rgb_part) & amask) == 0), "modconv_wsplit: the fused ToRGB needs rgb_w and rgb_s");
     p.v = reinterpret_cast<const unsigned char*>(v);
     p.wsp = reinterpret_cast<const unsigned char*>(wsp);
     p.zeros = reinterpret_cast<const unsigned char*>(zeros);
@@ -632,8 +689,10 @@ extern "C" int sgdfr_modconv2d_wsplit_f32(const unsigned short* v, const unsigne
     p.xs_out = reinterpret_cast<unsigned char*>(xs_out); p.s_next = s_next; p.sat = sat;
     p.act = act; p.slope = slope; p.gain = gain;
     p.dbg = getenv("SGDFR_WSPLIT_DBG") ? atoi(getenv("SGDFR_WSPLIT_DBG")) : 0;
-    const size_t lds = 2 * (size_t)256 * p.xs + 2 * 32768 + 7 * 128 * sizeof(float);
-    void (*kern)(WsParams) = arith == SGDFR_SPLIT_FP16 ? wsplit_kernel<SGDFR_SPLIT_FP16> : wsplit_kernel<SGDFR_SPLIT_BF16>;
+    // V double buffer + four weight half-slabs + tables: f = 2: 80 + 64 + 3.5 KB, f = 4: 60 + 96 + 3.5 KB (of 160)
+    const size_t lds = 2 * (size_t)(f + 2) * 64 * p.xs + 4 * (size_t)((f + 2) / 2) * 8192 + 7 * 128 * sizeof(float);
+    void (*kern)(WsParams) = arith == SGDFR_SPLIT_FP16 ? (f == 2 ? wsplit_kernel<SGDFR_SPLIT_FP16, 4> : wsplit_kernel<SGDFR_SPLIT_FP16, 6>)
+                                                        : (f == 2 ? wsplit_kernel<SGDFR_SPLIT_BF16, 4> : wsplit_kernel<SGDFR_SPLIT_BF16, 6>);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
         set_error("modconv_wsplit: LDS request %zu B refused", lds);

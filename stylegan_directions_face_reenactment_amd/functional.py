@@ -269,11 +269,13 @@ USE_RGB_FUSION = True        # ToRGB partial sums in the epilogue of the split c
 BACKWARD_ARITH = os.environ.get('SGDFR_BWD_ARITH', 'fp16x3')      # dL/dx convs of the split kernels: 'bf16x3' | 'fp16x3' (ranged per image, autograd.py)
 USE_SPLITK = True            # K-sliced launches for convs that cannot fill the chip (small batch / 4x4, 8x8 layers)
 USE_WINOGRAD = True          # plain 3x3 layers: Winograd F(2x2,3x3) MFMA kernel when the shape allows it
-# Inference chain, plain layers fed by a transposed conv + blur: 1-D Winograd F(2,3) form of the split conv (csrc/wsplit.hip).
-# The blur then writes 8 instead of 4 bytes per element, so it pays where the conv's K loop dominates: layers with at least
-# WSPLIT_MIN_CIN input channels (same-box A/B at B=64, scripts/wsplit_ab.py; 0 = never).
+# Inference chain, plain layers fed by a transposed conv + blur: 1-D Winograd form of the split conv (csrc/wsplit.hip), F(4,3)
+# by default (half the MFMA work; F(2,3): 2/3).  The blur then writes 6 (F(2,3): 8) instead of 4 bytes per element, so it pays
+# where the conv's K loop dominates: layers with at least WSPLIT_MIN_CIN input channels (same-box A/B at B=64,
+# scripts/wsplit_ab.py + scripts/blur_wino_time.py; 0 = never).
 USE_WSPLIT = os.environ.get('SGDFR_WSPLIT', '1') != '0'
-WSPLIT_MIN_CIN = int(os.environ.get('SGDFR_WSPLIT_MIN_CIN', '256'))
+WSPLIT_F = int(os.environ.get('SGDFR_WSPLIT_F', '4'))      # outputs per Winograd tile the chain prefers: 2 = F(2,3), 4 = F(4,3)
+WSPLIT_MIN_CIN = int(os.environ.get('SGDFR_WSPLIT_MIN_CIN', '128'))
 WINOGRAD_MIN_BLOCKS = 256    # below this many (64 cout x 64 tile) blocks the direct kernel's smaller tiles win
 # Arithmetic of the 3x3 modulated convs (inference path, autograd forward, and dL/dx of the plain convs; the strided dL/dx of
 # the transposed convs and the weight gradients always use the fp32 MFMA kernels):
@@ -549,44 +551,56 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
 
 
 # ---- 1-D Winograd F(2,3) form of the plain split conv (csrc/wsplit.hip): 2/3 of the MFMA work of the direct split kernel
-def prepack_wsplit(weight, arith=None):
+def prepack_wsplit(weight, arith=None, f=2):
     """weight [1,Cout,Cin,3,3] -> int16 buffer of the hi/lo terms of U = G (weight/sqrt(9 Cin)) per kernel row in wsplit.hip's
-    LDS order (Cout % 128 == 0)."""
+    LDS order (Cout % 128 == 0); f = outputs per Winograd tile (2: F(2,3), 4: F(4,3))."""
     arith = _SPLIT_ARITH[arith or PRECISION]
     N.require_device(weight)
     w = N.f32c(weight)
     _, cout, cin, k, _ = w.shape
-    wsp = torch.empty(N.load().sgdfr_modconv_prepack_wsplit_elems(cout, cin), device=w.device, dtype=torch.int16)
-    N.call('sgdfr_modconv_prepack_wsplit_f32', N.ptr(w), N.ptr(wsp), cout, cin, arith, _sat(), N.stream())
+    wsp = torch.empty(N.load().sgdfr_modconv_prepack_wsplit_elems(cout, cin, f), device=w.device, dtype=torch.int16)
+    N.call('sgdfr_modconv_prepack_wsplit_f32', N.ptr(w), N.ptr(wsp), cout, cin, f, arith, _sat(), N.stream())
     return wsp
 
 
-def wsplit_ok(B, cin, cout, H, W):
-    return PRECISION in _SPLIT_ARITH and bool(_shape_query('sgdfr_modconv2d_wsplit_supported', B, cin, cout, H, W))
+def wsplit_ok(B, cin, cout, H, W, f=2):
+    return PRECISION in _SPLIT_ARITH and bool(_shape_query('sgdfr_modconv2d_wsplit_supported', B, cin, cout, H, W, f))
+
+
+def wsplit_chain_f(B, cin, cout, H, W):
+    """Winograd form the inference chain runs this plain layer (fed by a transposed conv + blur) in: 0 (direct), 2 or 4 outputs
+    per tile."""
+    if not (USE_WSPLIT and USE_SPLIT_CHAIN and WSPLIT_MIN_CIN > 0 and cin >= WSPLIT_MIN_CIN and W <= 128):
+        return 0
+    for f in ((4, 2) if WSPLIT_F == 4 else (2,)):
+        if wsplit_ok(B, cin, cout, H, W, f):
+            return f
+    return 0
 
 
 def wsplit_chain_ok(B, cin, cout, H, W):
-    """Should the inference chain run this plain layer (fed by a transposed conv + blur) in Winograd form?"""
-    return USE_WSPLIT and USE_SPLIT_CHAIN and WSPLIT_MIN_CIN > 0 and cin >= WSPLIT_MIN_CIN and W <= 128 and \
-        wsplit_ok(B, cin, cout, H, W)
+    return wsplit_chain_f(B, cin, cout, H, W) != 0
 
 
-def to_wsplit(x, s, arith=None):
-    """x [B,Cin,H,W], s [B,Cin] -> int16 buffer [B, Cin/8, 4, 2, H*W/2, 8]: the Winograd input transform of x*s per output pair,
-    split (the "WS" form modconv_wsplit stages by DMA)."""
+WSPLIT_GROWTH_LOG2 = {2: 1, 4: 4}      # |B^T d| <= 2 max|d| (F(2,3)) / 10 max|d| (F(4,3)): binades the range plan adds
+
+
+def to_wsplit(x, s, arith=None, f=2):
+    """x [B,Cin,H,W], s [B,Cin] -> int16 buffer [B, Cin/8, f+2, 2, H*W/f, 8]: the Winograd input transform of x*s per tile of f
+    outputs, split (the "WS" form modconv_wsplit stages by DMA)."""
     arith = _SPLIT_ARITH[arith or PRECISION]
     N.require_device(x, s)
     x, s = N.f32c(x), N.f32c(s)
     B, cin, H, W = x.shape
-    vs = torch.empty(B, cin // 8, 4, 2, H * W // 2, 8, device=x.device, dtype=torch.int16)
-    N.call('sgdfr_to_wsplit_f32', N.ptr(x), N.ptr(s), N.ptr(vs), B, cin, H, W, arith, _sat(), N.stream())
+    vs = torch.empty(B, cin // 8, f + 2, 2, H * W // f, 8, device=x.device, dtype=torch.int16)
+    N.call('sgdfr_to_wsplit_f32', N.ptr(x), N.ptr(s), N.ptr(vs), B, cin, H, W, f, arith, _sat(), N.stream())
     return vs
 
 
 def modconv_wsplit(vs, shape, wsp, d, cout, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2,
-                   arith=None, rgb=None, want_y=True, s_next=None, desc=None):
+                   arith=None, rgb=None, want_y=True, s_next=None, desc=None, f=2):
     """Plain 3x3 modulated conv of a WS input (to_wsplit / the blur's Winograd hand-over; shape = (B, Cin, H, W)) with the pack of
-    prepack_wsplit.  Outputs as modconv_split with a pre-split input: y | (y, part) | (y, part, xs_out)."""
+    prepack_wsplit (same f).  Outputs as modconv_split with a pre-split input: y | (y, part) | (y, part, xs_out)."""
     arith = _SPLIT_ARITH[arith or PRECISION]
     N.require_device(d, bias, noise_weight)
     if not vs.is_cuda or vs.dtype != torch.int16 or not wsp.is_cuda or wsp.dtype != torch.int16:
@@ -605,10 +619,10 @@ def modconv_wsplit(vs, shape, wsp, d, cout, noise=None, noise_weight=None, bias=
         rgb_w, rgb_s = N.f32c(rgb[0]), N.f32c(rgb[1])
         N.require_device(rgb_w, rgb_s)
         part = torch.empty(B, (cout // 128) * 3, H, W, device=vs.device, dtype=torch.float32)
-    _timed_conv(desc or ('wsplit %d->%d @%dx%d' % (cin, cout, H, W)), B * conv_flops(cin, cout, H, W), lambda: N.call(
+    _timed_conv(desc or ('wsplit F(%d,3) %d->%d @%dx%d' % (f, cin, cout, H, W)), B * conv_flops(cin, cout, H, W), lambda: N.call(
         'sgdfr_modconv2d_wsplit_f32', N.ptr(vs), N.ptr(wsp), N.ptr(d), N.ptr(nz), nzb,
         N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(_zero_words(vs.device)), N.ptr(y), N.ptr(rgb_w),
-        N.ptr(rgb_s), N.ptr(part), N.ptr(xs_out), N.ptr(s_next) if s_next is not None else None, B, cin, cout, H, W, arith,
+        N.ptr(rgb_s), N.ptr(part), N.ptr(xs_out), N.ptr(s_next) if s_next is not None else None, B, cin, cout, H, W, f, arith,
         int(activate), float(slope), float(gain), _sat(), N.stream()))
     if s_next is not None:
         return y, part, xs_out
@@ -646,8 +660,8 @@ class SplitAct:
     Winograd input form of that conv instead ([B, C/8, 4, 2, H*W/2, 8], see to_wsplit / modconv_wsplit)."""
     __slots__ = ('xs', 'shape', 'wino')
 
-    def __init__(self, xs, shape, wino=False):
-        self.xs, self.shape, self.wino = xs, tuple(shape), bool(wino)
+    def __init__(self, xs, shape, wino=0):
+        self.xs, self.shape, self.wino = xs, tuple(shape), (2 if wino is True else int(wino or 0))
 
 
 def xin_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
@@ -668,7 +682,7 @@ def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, 
             raise RuntimeError('styled_conv_split: the Winograd input form feeds plain convs only')
         B, cin, H, W = x.shape
         res = modconv_wsplit(x.xs, x.shape, wsp, d, cout, noise, noise_weight, bias, True, rgb=rgb,
-                             want_y=want_y and s_next is None, s_next=s_next)
+                             want_y=want_y and s_next is None, s_next=s_next, f=x.wino)
         if s_next is not None:
             _, part, xs = res
             return SplitAct(xs, (B, cout, H, W)), part
@@ -831,19 +845,20 @@ def blur_bias_act_split(planes, fir, H, W, s_next, noise=None, noise_weight=None
                         gain=SQRT2, arith=None, plane_stride=0, wino=False):
     """blur_bias_act whose result goes out as the next layer's split input (x * s_next as 16-bit hi/lo pairs,
     [B, C/8, 2, 2H*2W, 8] int16) instead of fp32 NCHW.  plane_stride: floats between the parity planes when `planes` is the
-    padded [B, C, 4, plane_stride] buffer of modconv_split(mode=UP3, plane_stride=...).  wino=True: the Winograd input form of
-    to_wsplit instead ([B, C/8, 4, 2, 2H*W, 8], for modconv_wsplit)."""
+    padded [B, C, 4, plane_stride] buffer of modconv_split(mode=UP3, plane_stride=...).  wino = 2 | 4: the Winograd input form
+    of to_wsplit(f=wino) instead ([B, C/8, wino+2, 2, 4HW/wino, 8], for modconv_wsplit)."""
     arith = _SPLIT_ARITH[arith or PRECISION]
     N.require_device(planes, fir, bias, noise_weight, s_next)
     B, C = planes.shape[0], planes.shape[1]
     nz, nzb = _noise_args(noise, B, 2 * H, 2 * W)
+    wino = 2 if wino is True else int(wino or 0)
     if wino:
-        xs = torch.empty(B, C // 8, 4, 2, 2 * H * W, 8, device=planes.device, dtype=torch.int16)
+        xs = torch.empty(B, C // 8, wino + 2, 2, 4 * H * W // wino, 8, device=planes.device, dtype=torch.int16)
     else:
         xs = torch.empty(B, C // 8, 2, 4 * H * W, 8, device=planes.device, dtype=torch.int16)
     N.call('sgdfr_blur_bias_act_split_f32', N.ptr(planes), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
            N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(N.f32c(s_next)), N.ptr(xs), B, C, H, W,
-           int(plane_stride), arith, int(bool(wino)), int(activate), float(slope), float(gain), _sat(), N.stream())
+           int(plane_stride), arith, wino, int(activate), float(slope), float(gain), _sat(), N.stream())
     return xs
 
 

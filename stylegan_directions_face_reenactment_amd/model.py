@@ -233,17 +233,17 @@ class ModulatedConv2d(nn.Module):
                 cache[1][slot] = F_.prepack_split(self.weight.detach(), arith=arith, adjoint=adjoint)
         return cache[1][slot]
 
-    def packed_wsplit(self, arith=None):
-        """Weight pack of the 1-D Winograd form of the plain split conv (functional.prepack_wsplit), cached like packed_split."""
+    def packed_wsplit(self, arith=None, f=2):
+        """Weight pack of the 1-D Winograd form F(f,3) of the plain split conv (functional.prepack_wsplit), cached like packed_split."""
         arith = arith or F_.PRECISION
         key = self._key()
         cache = getattr(self, '_pack_s', None)
         if cache is None or cache[0] != key:
             cache = self._pack_s = [key, {}]
-        slot = (arith, 'wino')
+        slot = (arith, 'wino', f)
         if slot not in cache[1]:
             with torch.no_grad():
-                cache[1][slot] = F_.prepack_wsplit(self.weight.detach(), arith=arith)
+                cache[1][slot] = F_.prepack_wsplit(self.weight.detach(), arith=arith, f=f)
         return cache[1][slot]
 
     def style_spec(self, latent_index):
@@ -632,30 +632,30 @@ class Generator(nn.Module):
         if st['mode'] != 'fp16x3':
             return None, st['mode']
         conv_layer = {id(l.conv): i for i, l in enumerate(layers)}
-        # (layers that take their input in Winograd form: |B^T (x*s)| <= 2 max|x*s| -- one more binade)
+        # (layers that take their input in Winograd form: |B^T (x*s)| <= 2 (F(2,3)) / 10 (F(4,3)) max|x*s| -- 1 / 4 more binades)
         wino = self._wino_inputs(latent.shape[0], layers)
-        plans = [(st['x_log2'][conv_layer[id(m)]] + int(conv_layer[id(m)] in wino), F_.CALIBRATION_HEADROOM)
-                 if id(m) in conv_layer else None for m, _ in order]
+        plans = [(st['x_log2'][conv_layer[id(m)]] + F_.WSPLIT_GROWTH_LOG2.get(wino.get(conv_layer[id(m)], 0), 0),
+                  F_.CALIBRATION_HEADROOM) if id(m) in conv_layer else None for m, _ in order]
         return plans, 'fp16x3'
 
     def _wino_inputs(self, batch, layers):
-        """Indices of the plain layers that the inference chain runs in 1-D Winograd form (functional.wsplit_chain_ok: fed by a
-        transposed conv + blur that can hand over the transformed input, enough input channels for the smaller MFMA count to
-        outweigh the doubled hand-over bytes).  A pure function of (batch, layer shapes, switches): the range plan and the
-        launch plan both ask it."""
+        """{index of a plain layer the inference chain runs in 1-D Winograd form: outputs per tile (2 | 4)} (functional.
+        wsplit_chain_f: fed by a transposed conv + blur that can hand over the transformed input, enough input channels for the
+        smaller MFMA count to outweigh the larger hand-over).  A pure function of (batch, layer shapes, switches): the range plan
+        and the launch plan both ask it."""
         key = (batch, F_.PRECISION, F_.USE_WSPLIT, F_.WSPLIT_MIN_CIN, F_.USE_SPLIT_CHAIN, F_.USE_RGB_FUSION, F_.USE_SPLITK,
-               F_.USE_PLANE_PADDING)
+               F_.USE_PLANE_PADDING, F_.WSPLIT_F)
         cache = self.__dict__.setdefault('_wino_cache', {})
         if key not in cache:
-            out, res = set(), self.input.input.shape[2]
+            out, res = {}, self.input.input.shape[2]
             for li, layer in enumerate(layers):
                 c = layer.conv
                 if c.upsample:
                     res *= 2
-                elif li >= 2 and layers[li - 1].conv.upsample and \
-                        F_.wsplit_chain_ok(batch, c.in_channel, c.out_channel, res, res) and \
-                        F_.rgb_fusable(batch, c.in_channel, c.out_channel, res, res):
-                    out.add(li)
+                elif li >= 2 and layers[li - 1].conv.upsample and F_.rgb_fusable(batch, c.in_channel, c.out_channel, res, res):
+                    f = F_.wsplit_chain_f(batch, c.in_channel, c.out_channel, res, res)
+                    if f:
+                        out[li] = f
             cache[key] = out
         return cache[key]
 
@@ -700,7 +700,7 @@ class Generator(nn.Module):
         return (tuple(w.shape), bool(input_is_latent), bool(return_latents), float(truncation),
                 None if truncation >= 1 else tuple(truncation_latent.shape), u8, F_.PRECISION, F_.RANGE_PLAN, F_.USE_SPLIT_CHAIN,
                 F_.USE_RGB_FUSION, F_.USE_SPLITK, F_.USE_PLANE_PADDING, bool(self.overlap_rgb), w.device, F_.USE_WSPLIT,
-                F_.WSPLIT_MIN_CIN,
+                F_.WSPLIT_MIN_CIN, F_.WSPLIT_F,
                 # a graph's static input / output buffers belong to the stream that replays it: forwards queued on different
                 # streams (functional.StreamPipeline) get their own capture instead of racing on one
                 torch.cuda.current_stream(w.device).cuda_stream)
@@ -900,7 +900,7 @@ class Generator(nn.Module):
         # Per-layer launch decisions depend only on (batch, arithmetic, which noises are given): cached, so a forward does
         # not query the library 40 times (it matters for the launch-bound small batches).
         key = (batch, chain, F_.PRECISION, F_.USE_SPLIT_CHAIN, F_.USE_RGB_FUSION, F_.USE_SPLITK, tuple(n is None for n in noise),
-               F_.USE_WSPLIT, F_.WSPLIT_MIN_CIN)
+               F_.USE_WSPLIT, F_.WSPLIT_MIN_CIN, F_.WSPLIT_F)
         plan = self._chain_plans.get(key) if hasattr(self, '_chain_plans') else None
         if plan is None:
             plan, res = [], self.input.input.shape[2]
@@ -919,12 +919,12 @@ class Generator(nn.Module):
                     F_.xin_ok(batch, nxt.in_channel, nxt.out_channel, res_out, res_out,
                               F_.N.MODE_UP3 if nxt.upsample else F_.N.MODE_PLAIN3)
                 want_y = not (fuse and (nxt is None or to_next))
-                plan.append([use_chain, fuse, to_next, want_y, False])
+                plan.append([use_chain, fuse, to_next, want_y, 0])
                 res = res_out
             # plain layers in Winograd form: the producing transposed conv's blur hands over the transformed input
-            for li in self._wino_inputs(batch, layers) if chain else ():
+            for li, f in (self._wino_inputs(batch, layers).items() if chain else ()):
                 if plan[li][0] and plan[li][1] and plan[li - 1][0] and plan[li - 1][2]:
-                    plan[li - 1][4] = True
+                    plan[li - 1][4] = f
             if not hasattr(self, '_chain_plans'):
                 self._chain_plans = {}
             self._chain_plans[key] = plan
@@ -945,9 +945,9 @@ class Generator(nn.Module):
                 out, part = layer(x, None, noise=nz, batch=batch if first else None, sd=sdl, ranged=ranged), None
             else:
                 rgb_arg = (to_rgbs[k].conv.weight.view(3, c.out_channel), sd[sd_of_rgb[k]][0]) if fuse else None
-                wino_in = isinstance(x, F_.SplitAct) and x.wino
+                wino_in = x.wino if isinstance(x, F_.SplitAct) else 0
                 out, part = F_.styled_conv_split(
-                    x, c.packed_wsplit() if wino_in else c.packed_split(), sdl[0], sdl[1], c.out_channel, upsample=up,
+                    x, c.packed_wsplit(f=wino_in) if wino_in else c.packed_split(), sdl[0], sdl[1], c.out_channel, upsample=up,
                     fir=c.blur.kernel if up else None, noise=nz, noise_weight=layer.noise.weight, bias=layer.activate.bias,
                     batch=batch if first else None, s_next=sd[sd_of_layer[li + 1]][0] if to_next else None, rgb=rgb_arg,
                     want_y=want_y, wino_next=wino_next)

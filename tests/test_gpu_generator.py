@@ -230,9 +230,9 @@ def test_split_chain_is_bit_identical_to_layer_by_layer():
 
 
 def test_winograd_chain_layers_stay_within_the_per_image_bound():
-    """The wide plain layers of the chain run in 1-D Winograd F(2,3) form (csrc/wsplit.hip, fed by the blur's transformed
-    hand-over): a different summation order, so not bit-identical to the direct split kernels -- held to the fp64 oracle with
-    the same image bound, and to the direct chain within twice the arithmetic's noise."""
+    """The wide plain layers of the chain run in 1-D Winograd form (F(4,3) by default, F(2,3) with functional.WSPLIT_F = 2;
+    csrc/wsplit.hip, fed by the blur's transformed hand-over): a different summation order, so not bit-identical to the direct
+    split kernels -- both forms are held to the fp64 oracle with the direct chain's image bound."""
     from stylegan_directions_face_reenactment_amd import functional as F_
     if F_.PRECISION == 'fp32':
         pytest.skip('the chain exists only for the split arithmetics')
@@ -242,20 +242,27 @@ def test_winograd_chain_layers_stay_within_the_per_image_bound():
     P64 = O.cast_state(synthetic_state(size, 1), torch.float64)
     with torch.no_grad():
         ref, _ = O.generator_forward(P64, [w[:2].double().cpu()], input_is_latent=True)
-        assert F_.USE_WSPLIT
+        assert F_.USE_WSPLIT and F_.WSPLIT_F == 4
         a, _ = G([w], input_is_latent=True)
         used = sorted(G._wino_inputs(B, [G.conv1] + list(G.convs)))
+        assert set(G._wino_inputs(B, [G.conv1] + list(G.convs)).values()) == {4}
+        F_.WSPLIT_F = 2
+        try:
+            a2, _ = G([w], input_is_latent=True)
+            assert set(G._wino_inputs(B, [G.conv1] + list(G.convs)).values()) == {2}
+        finally:
+            F_.WSPLIT_F = 4
         F_.USE_WSPLIT = False
         try:
             b, _ = G([w], input_is_latent=True)
         finally:
             F_.USE_WSPLIT = True
-    assert used == [6, 8], used                          # 512 @ 32^2, 256 @ 64^2 (512 @ 16^2 joins from B = 48)
+    assert used == [6, 8, 10], used                      # 512 @ 32^2, 256 @ 64^2, 128 @ 128^2 (512 @ 16^2 joins from B = 48)
     assert not torch.equal(a, b)
     bound = 2e-4 if F_.PRECISION == 'fp16x3' else 5e-4
-    ea, eb = maxabs(a[:2], ref), maxabs(b[:2], ref)
-    print('256^2 images vs fp64 oracle: winograd chain %.2e, direct chain %.2e' % (ea, eb))
-    assert ea <= bound and eb <= bound
+    ea, ea2, eb = maxabs(a[:2], ref), maxabs(a2[:2], ref), maxabs(b[:2], ref)
+    print('256^2 images vs fp64 oracle: F(4,3) chain %.2e, F(2,3) chain %.2e, direct chain %.2e' % (ea, ea2, eb))
+    assert ea <= bound and ea2 <= bound and eb <= bound and not torch.equal(a, a2)
     assert G.saturated_pairs() == 0 or F_.PRECISION != 'fp16x3'
 
 
