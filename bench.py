@@ -235,8 +235,8 @@ def _layer_entry(desc, sec, fl, n, peak):
     e = {'layer': desc, 'us': round(sec / n * 1e6, 1), 'tflops': round(fl / sec / 1e12, 1), 'frac': round(fl / sec / 1e12 / peak, 3)}
     if desc.startswith('wino'):
         e['mfma_frac'] = round(e['frac'] * 16 / 36, 3)
-    if desc.startswith('wsplit'):      # 1-D Winograd F(2,3) form of the split conv: 12 of the direct conv's 18 MFMA columns per output pair
-        e['mfma_frac'] = round(e['frac'] * 2 / 3, 3)
+    if desc.startswith('wsplit'):      # 1-D Winograd form of the split conv: F(2,3) issues 12 of the direct conv's 18 MFMA columns per
+        e['mfma_frac'] = round(e['frac'] * (0.5 if 'F(4,3)' in desc else 2 / 3), 3)     # output pair, F(4,3) 18 of 36 per output quad
     return e
 
 
@@ -246,7 +246,7 @@ def roofline_for(precision, step, steps, units_per_step):
                              'wino_mfma_kernel (large plain 3x3 layers) + modconv_mfma_kernel (small plain, transposed)',
                              units_per_step)
     r = conv_roofline(step, steps, SPLIT_PEAK_TFLOPS, 'split_mfma_kernel (plain + transposed 3x3 conv launches, %s) + wsplit_kernel '
-                      '(its 1-D Winograd F(2,3) form on the wide plain layers: 2/3 of the MFMA work, see mfma_frac)' % precision,
+                      '(its 1-D Winograd F(4,3) form on the plain layers with Cin >= 128: half the MFMA work, see mfma_frac)' % precision,
                       units_per_step)
     r['peak_note'] = ('dense 16-bit MFMA peak 2500 TFLOP/s / 3 products per fp32 product; the same achieved figure is %.2fx '
                       'the 157.3 TFLOP/s fp32-MFMA peak' % (r['achieved'] / FP32_MFMA_PEAK_TFLOPS))

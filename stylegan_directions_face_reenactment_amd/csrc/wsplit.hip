@@ -1,5 +1,8 @@
-// Plain 3x3 modulated convolution in 1-D Winograd F(2,3) form on the split-operand 16-bit matrix cores (the arithmetic of
-// split.hip: every fp32 operand as two 16-bit terms hi + lo, three MFMA products, fp32 accumulation).
+// Plain 3x3 modulated convolution in 1-D Winograd form -- F(2,3) or F(4,3) along image rows, kernel rows direct -- on the
+// split-operand 16-bit matrix cores (the arithmetic of split.hip: every fp32 operand as two 16-bit terms hi + lo, three MFMA
+// products, fp32 accumulation).  The text below describes F(2,3) (POS = 4 transform positions); F(4,3) (POS = 6: four outputs
+// from six transformed inputs, HALF the MFMA work, V 1.5x and U 2x the direct operands' bytes, six accumulators per wave, block
+// 128 couts x 64 four-pixel tiles) is the same kernel with three positions per half-stage -- see the kernel's template comment.
 //
 // Why: the split conv kernels run at the chip's power budget inside their K loop -- the only way past that roof is
 // fewer MFMAs per output.  Along image rows the 3-tap correlation of two neighbouring outputs is computed from four
