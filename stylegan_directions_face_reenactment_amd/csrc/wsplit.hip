@@ -99,6 +99,7 @@ struct WsParams {
     int act;
     float slope, gain;
     int dbg;
+    int desync;                  // first-round start spread: estimated block time in 4096-clock units (0 = off)
     FastDiv fd_xs, fd_tiles_x, fd_per_img, fd_npt;
 };
 
@@ -161,6 +162,14 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
     const int ty = fdiv(prem, p.fd_tiles_x), tx = prem - ty * p.tiles_x;
     const int row0 = ty * p.TR, col0 = tx * p.TCT, n0 = ct * NT;
 
+    // First-round desynchronisation (split.hip's transposed conv): equal blocks started together reach their store phase
+    // together; spreading the starts of the first round over a fraction of a block time lets later rounds store while other CUs
+    // compute.
+    if (p.desync > 0 && blockIdx.x < 256) {
+        const int slot = (int)((blockIdx.x * 2654435761u) >> 24);          // 0..255, scrambled
+        const int n_sleep = (slot * p.desync) >> 8;
+        for (int i = 0; i < n_sleep; ++i) __builtin_amdgcn_s_sleep(64);
+    }
     const bool fuse_rgb = p.rgb_part != nullptr, emit_xs = p.xs_out != nullptr;
     // epilogue coefficients: global loads at the top of the tile, LDS writes in the prologue (one exposed latency, hidden
     // behind the descriptor arithmetic); they go through LDS because loads between stores would serialise on vmcnt
@@ -180,9 +189,11 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
 
     // this lane's tile columns: position inside the staged patch, first output pixel, noise
     int boff[NI], pix[NI];
+    // (the activation gain is folded into d, bias and noise: lrelu(t) * gain = max(g t, slope * g t) for gain > 0, 0 < slope <= 1)
+    const float e_slope = p.act ? p.slope : 1.f, e_gain = p.act ? p.gain : 1.f;
     float nz[NI][OUTP];
     {
-        const float nw = (p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
+        const float nw = ((p.noise && p.noise_w) ? p.noise_w[0] : 0.f) * e_gain;
 #pragma unroll
         for (int n = 0; n < NI; ++n) {
             const int l = (wn * NI + n) * 32 + l31;
@@ -271,8 +282,8 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
         const float oscale = (ET == SGDFR_SPLIT_FP16) ? WS_F16_OUT : 1.f;
         const float xsc = (ET == SGDFR_SPLIT_FP16) ? WS_F16_XSCALE : 1.f;
         const float rs = rsqrtf((float)p.Cout);
-        dl[tid] = t_d * oscale;
-        bl[tid] = t_b;
+        dl[tid] = t_d * oscale * e_gain;
+        bl[tid] = t_b * e_gain;
         sn[tid] = t_s * xsc;
         *reinterpret_cast<float4*>(cw + 4 * tid) = make_float4(t_w0 * (t_r * rs), t_w1 * (t_r * rs), t_w2 * (t_r * rs), 0.f);
     }
@@ -287,7 +298,9 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
     // The barrier's counted wait leaves the pieces issued during h in flight and completes everything older (the slab of h+2,
     // V pieces of the next channel block).
     const int a_off = (hi * 128 + wm * 32 + l31) * 16;
-    const bool late = wave >= 4 && !(p.dbg & 4);      // the two waves of a SIMD issue their DMA pieces at different times (split.hip)
+    // the two waves of a SIMD issue their DMA pieces at different times, waves 4-7 behind the first MFMAs of the half-stage's last
+    // position (split.hip's finding holds here: 2.5-3 % on every F(4,3) layer in a same-process A/B, SGDFR_WSPLIT_DBG=4 switches it off)
+    const bool late = wave >= 4 && !(p.dbg & 4);
     const int rowstep = p.TCT * 16;
     ws_frag a[2][2], b[2][2][NI];      // [set][part]
     auto fetch = [&](int set, const unsigned char* wsl, const unsigned char* xr, int tl, int t) {
@@ -361,13 +374,16 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
     if (p.dbg & 2) return;
 #endif
     // ---- epilogue.  C/D layout of 32x32: column (tile) = lane & 31, row (cout) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-    const float e_slope = p.act ? p.slope : 1.f, e_gain = p.act ? p.gain : 1.f;
+    // The element loop works on PAIRS of neighbouring pixels as two-float vectors: scale + noise + bias, the leaky-ReLU product,
+    // the next layer's style and the ToRGB sums are v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (one instruction per pair; no MFMA
+    // is in flight here, so the packed forms cost nothing extra) -- 13 instead of 18 VALU instructions per output in chain form.
+    constexpr int NP = OUTP / 2;
     unsigned sat = 0;
-    float rgb[NI][OUTP][3];
+    ws_f32x2 rgb2[NI][NP][3];
 #pragma unroll
     for (int n = 0; n < NI; ++n)
 #pragma unroll
-        for (int q = 0; q < OUTP; ++q) rgb[n][q][0] = rgb[n][q][1] = rgb[n][q][2] = 0.f;
+        for (int pp = 0; pp < NP; ++pp) rgb2[n][pp][0] = rgb2[n][pp][1] = rgb2[n][pp][2] = (ws_f32x2){0.f, 0.f};
     auto epilogue = [&](auto has_y_t, auto emit_xs_t, auto fuse_rgb_t) {
         constexpr bool HAS_Y = decltype(has_y_t)::value, EMIT_XS = decltype(emit_xs_t)::value, FUSE_RGB = decltype(fuse_rgb_t)::value;
         const int io = wm * 32 + 4 * hi;
@@ -383,7 +399,7 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
             for (int g = 0; g < 4; ++g) {
                 const float4 dq = d4p[2 * g], bq = b4p[2 * g];
                 const float dv[4] = {dq.x, dq.y, dq.z, dq.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w};
-                float v[OUTP][4];      // [pixel of the tile][row of the group]
+                ws_f32x2 v2[NP][4];      // [pixel pair of the tile][row of the group]
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = 4 * g + j;
@@ -402,26 +418,38 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
                         y[OUTP - 1] = fmaf(8.f, d34, d12) + m5;
                     }
 #pragma unroll
-                    for (int q = 0; q < OUTP; ++q) v[q][j] = lrelu_gain(y[q] * dv[j] + nz[n][q] + bv[j], e_slope, e_gain);
+                    for (int pp = 0; pp < NP; ++pp) {
+                        const ws_f32x2 yy = {y[2 * pp], y[2 * pp + 1]}, nn = {nz[n][2 * pp], nz[n][2 * pp + 1]};
+                        const ws_f32x2 t = yy * dv[j] + (nn + bv[j]);
+                        const ws_f32x2 ts = t * e_slope;
+                        v2[pp][j] = (ws_f32x2){fmaxf(t[0], ts[0]), fmaxf(t[1], ts[1])};
+                    }
                 }
                 if (HAS_Y) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float* dst = yp + (int64_t)(8 * g + j) * HW;
-                        if (OUTP == 2) *reinterpret_cast<float2*>(dst) = make_float2(v[0][j], v[1][j]);
-                        else *reinterpret_cast<float4*>(dst) = make_float4(v[0][j], v[1][j], v[OUTP - 2][j], v[OUTP - 1][j]);
+                        if (OUTP == 2) *reinterpret_cast<float2*>(dst) = make_float2(v2[0][j][0], v2[0][j][1]);
+                        else *reinterpret_cast<float4*>(dst) = make_float4(v2[0][j][0], v2[0][j][1], v2[NP - 1][j][0], v2[NP - 1][j][1]);
                     }
                 }
                 if (EMIT_XS) {      // the 4 rows are half of one 8-channel chunk of each pixel of the tile
                     const float4 sq = s4p[2 * g];
+                    const float sv[4] = {sq.x, sq.y, sq.z, sq.w};
                     unsigned char* dst = xp + (int64_t)g * 2 * HW * 16;
 #pragma unroll
-                    for (int q = 0; q < OUTP; ++q) {
-                        unsigned h01, l01, h23, l23;
-                        ws_pair<ET>(v[q][0] * sq.x, v[q][1] * sq.y, h01, l01, sat);
-                        ws_pair<ET>(v[q][2] * sq.z, v[q][3] * sq.w, h23, l23, sat);
-                        *reinterpret_cast<uint2*>(dst + 16 * q) = make_uint2(h01, h23);
-                        *reinterpret_cast<uint2*>(dst + (int64_t)HW * 16 + 16 * q) = make_uint2(l01, l23);
+                    for (int pp = 0; pp < NP; ++pp) {
+                        ws_f32x2 pr[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pr[j] = v2[pp][j] * sv[j];
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            unsigned h01, l01, h23, l23;
+                            ws_pair<ET>(pr[0][k], pr[1][k], h01, l01, sat);
+                            ws_pair<ET>(pr[2][k], pr[3][k], h23, l23, sat);
+                            *reinterpret_cast<uint2*>(dst + 16 * (2 * pp + k)) = make_uint2(h01, h23);
+                            *reinterpret_cast<uint2*>(dst + (int64_t)HW * 16 + 16 * (2 * pp + k)) = make_uint2(l01, l23);
+                        }
                     }
                 }
                 if (FUSE_RGB) {
@@ -429,10 +457,10 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
                     for (int j = 0; j < 4; ++j) {
                         const float4 q4 = cwp[8 * g + j];
 #pragma unroll
-                        for (int q = 0; q < OUTP; ++q) {
-                            rgb[n][q][0] = fmaf(v[q][j], q4.x, rgb[n][q][0]);
-                            rgb[n][q][1] = fmaf(v[q][j], q4.y, rgb[n][q][1]);
-                            rgb[n][q][2] = fmaf(v[q][j], q4.z, rgb[n][q][2]);
+                        for (int pp = 0; pp < NP; ++pp) {
+                            rgb2[n][pp][0] = v2[pp][j] * q4.x + rgb2[n][pp][0];
+                            rgb2[n][pp][1] = v2[pp][j] * q4.y + rgb2[n][pp][1];
+                            rgb2[n][pp][2] = v2[pp][j] * q4.z + rgb2[n][pp][2];
                         }
                     }
                 }
@@ -461,7 +489,8 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
             for (int q = 0; q < OUTP; ++q)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const float vv = rgb[n][q][j] + __shfl_xor(rgb[n][q][j], 32, 64);
+                    const float mine = rgb2[n][q >> 1][j][q & 1];
+                    const float vv = mine + __shfl_xor(mine, 32, 64);
                     if (hi == 0) red[(wm * 256 + ((wn * NI + n) * 32 + l31) * OUTP + q) * 3 + j] = vv;
                 }
         __syncthreads();
@@ -692,6 +721,14 @@ extern "C" int sgdfr_modconv2d_wsplit_f32(const unsigned short* v, const unsigne
     p.xs_out = reinterpret_cast<unsigned char*>(xs_out); p.s_next = s_next; p.sat = sat;
     p.act = act; p.slope = slope; p.gain = gain;
     p.dbg = getenv("SGDFR_WSPLIT_DBG") ? atoi(getenv("SGDFR_WSPLIT_DBG")) : 0;
+    {
+        // same-process A/B at B=64 (scripts/wsplit_env_ab.py, 60 % of the block-time estimate): 256@64^2 (8 rounds of blocks) 618 ->
+        // 607 us, 128@128^2 (16 rounds) 733 -> 713 us, 512@32^2 (4 rounds: the spread costs part of a round) 557 -> 568 us
+        const int pct = getenv("SGDFR_WSPLIT_DESYNC") ? atoi(getenv("SGDFR_WSPLIT_DESYNC")) : 60;
+        const double block_clk = (double)(Cin / WS_CB) * (f == 2 ? 72 : 54) * 32 * 2 / 0.7 + 12000.0;
+        const int blocks = p.n_pix_tiles * p.n_cout_tiles;
+        p.desync = (pct > 0 && blocks >= 2048) ? (int)(block_clk * pct / 100 / 4096) : 0;
+    }
     // V double buffer + four weight half-slabs + tables: f = 2: 80 + 64 + 3.5 KB, f = 4: 60 + 96 + 3.5 KB (of 160)
     const size_t lds = 2 * (size_t)(f + 2) * 64 * p.xs + 4 * (size_t)((f + 2) / 2) * 8192 + 7 * 128 * sizeof(float);
     void (*kern)(WsParams) = arith == SGDFR_SPLIT_FP16 ? (f == 2 ? wsplit_kernel<SGDFR_SPLIT_FP16, 4> : wsplit_kernel<SGDFR_SPLIT_FP16, 6>)
