@@ -190,3 +190,28 @@ def test_direction_tables_on_cpu_match_reference_coefficients():
         SH.ShiftVectors('voxceleb', 15, 6, ranges=g['ranges_voxceleb']).make_shift(
             torch.zeros(1, 3), torch.zeros(2, 3), {'pose': torch.zeros(1, 6), 'alpha_exp': torch.zeros(1, 50)},
             {'pose': torch.zeros(2, 6), 'alpha_exp': torch.zeros(2, 50)})      # CPU tensors: refused, no fallback
+
+
+def test_winograd_layer_plan_of_the_bench_configs():
+    """Which plain layers the no-grad chain runs in 1-D Winograd form is a pure function of (batch, layer shapes, switches) answered
+    by host-only shape queries of the library: pinned here for the BASELINE configs (no GPU needed)."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    from stylegan_directions_face_reenactment_amd.model import Generator
+    G = Generator(256, 512, 8, channel_multiplier=1)
+    layers = [G.conv1] + list(G.convs)
+    assert F_.USE_WSPLIT and F_.WSPLIT_F == 4 and F_.WSPLIT_MIN_CIN == 128
+    # B=64 (configs[1]): 512 @ 16^2, 512 @ 32^2, 256 @ 64^2, 128 @ 128^2 in F(4,3); the 64 -> 64 @ 256^2 layer stays direct
+    assert G._wino_inputs(64, layers) == {4: 4, 6: 4, 8: 4, 10: 4}
+    # B=32 (configs[2]): the 16^2 layer is K-sliced (too few tiles to fill the chip), so it cannot fuse its ToRGB and stays direct
+    assert G._wino_inputs(32, layers) == {6: 4, 8: 4, 10: 4}
+    assert G._wino_inputs(2, layers) == {}
+    old = F_.WSPLIT_F
+    try:
+        F_.WSPLIT_F = 2
+        assert G._wino_inputs(64, layers) == {4: 2, 6: 2, 8: 2, 10: 2}
+    finally:
+        F_.WSPLIT_F = old
+    lib = F_.N.load()
+    assert lib.sgdfr_modconv_prepack_wsplit_elems(512, 512, 4) == 512 * 512 * 3 * 6 * 2
+    assert lib.sgdfr_modconv_prepack_wsplit_elems(512, 512, 2) == 512 * 512 * 3 * 4 * 2
+    assert not lib.sgdfr_modconv2d_wsplit_supported(64, 64, 64, 256, 256, 4)          # Cout = 64: no 128-cout tile

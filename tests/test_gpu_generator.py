@@ -266,6 +266,22 @@ def test_winograd_chain_layers_stay_within_the_per_image_bound():
     assert G.saturated_pairs() == 0 or F_.PRECISION != 'fp16x3'
 
 
+def test_graph_replay_with_winograd_layers_is_bit_identical():
+    """A captured forward that contains wsplit launches (B=16 at 256^2: the 32^2 ... 128^2 plain layers) replays the same bits."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    if F_.PRECISION == 'fp32':
+        pytest.skip('the chain exists only for the split arithmetics')
+    G = hip_generator(256, 1)
+    ws = [S.synthetic_latents(SEED, 16, n_latent=G.n_latent, key='wgraph.w%d' % i).cuda() for i in range(4)]
+    with torch.no_grad():
+        assert G._wino_inputs(16, [G.conv1] + list(G.convs))
+        eager = [G([w], input_is_latent=True, graph=False)[0] for w in ws]
+        got = [G([w], input_is_latent=True, graph=True)[0] for w in ws]
+        assert len(G._graphs) == 1
+        for a, b in zip(eager, got):
+            assert torch.equal(a, b)
+
+
 def test_independent_batches_on_alternating_streams_give_the_same_images():
     """functional.StreamPipeline (bench.py --streams, ReenactmentSession(streams=2)): consecutive independent batches on two
     HIP streams overlap in time; every image is bit-identical to the one-stream rendering, for raw forwards and for the
