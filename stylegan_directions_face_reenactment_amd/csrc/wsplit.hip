@@ -96,6 +96,7 @@ struct WsParams {
     int tiles_x, tiles_y;
     int xs;                      // staged positions per (t, part, k-half) run: (TR + 2) * TCT
     int n_pix_tiles, n_cout_tiles;
+    int total_blocks;            // tiles x cout tiles; the grid may be smaller (persistent blocks)
     int act;
     float slope, gain;
     int dbg;
@@ -108,7 +109,7 @@ __device__ __forceinline__ void ws_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// s_waitcnt vmcnt(n) for a wave-uniform runtime n in 0..5 (the instruction takes an immediate)
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n in 0..12 (the instruction takes an immediate; larger n wait for 12: stricter)
 __device__ __forceinline__ void ws_wait_vmcnt_dyn(int n) {
     switch (n) {
         case 0: ws_wait_vmcnt<0>(); break;
@@ -116,7 +117,14 @@ __device__ __forceinline__ void ws_wait_vmcnt_dyn(int n) {
         case 2: ws_wait_vmcnt<2>(); break;
         case 3: ws_wait_vmcnt<3>(); break;
         case 4: ws_wait_vmcnt<4>(); break;
-        default: ws_wait_vmcnt<5>(); break;
+        case 5: ws_wait_vmcnt<5>(); break;
+        case 6: ws_wait_vmcnt<6>(); break;
+        case 7: ws_wait_vmcnt<7>(); break;
+        case 8: ws_wait_vmcnt<8>(); break;
+        case 9: ws_wait_vmcnt<9>(); break;
+        case 10: ws_wait_vmcnt<10>(); break;
+        case 11: ws_wait_vmcnt<11>(); break;
+        default: ws_wait_vmcnt<12>(); break;
     }
 }
 
@@ -141,26 +149,115 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
     float* const bl = dl + NT;                                        // [NT] bias
     float* const sn = bl + NT;                                        // [NT] next layer's style * range shift
     float* const cw = sn + NT;                                        // [NT][4] ToRGB coefficients
-    float* const red = reinterpret_cast<float*>(smem);                // [4][256 px][3] after the K loop (dead staging buffers)
+    float* const red = reinterpret_cast<float*>(wb0 + 3 * WHALF);    // [4][256 px][3] after the K loop: the ring slot of the last half-stage
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
     const int HW = p.H * p.W, HT = p.H * p.TW, G8 = p.Cin / 8;
 
-    // XCD-aware tile order: the blocks resident on one XCD (blockIdx & 7) walk neighbouring patches of one cout tile
-    int lid;
-    {
-        const int nblk = (int)gridDim.x, q8 = nblk >> 3, r8 = nblk & 7;
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    }
-    const int ct = fdiv(lid, p.fd_npt), pt = lid - ct * p.n_pix_tiles;
+    // Persistent blocks: the grid is one block per CU (or fewer).  The tiles are dealt to the XCDs (blockIdx & 7) in eight contiguous
+    // ranges -- the blocks resident on one XCD walk neighbouring patches of one cout tile (weights and halo rows shared in that
+    // XCD's L2), and the XCDs work on DIFFERENT cout tiles of the same patches at the same time (the second reader of a V patch
+    // finds it in the Infinity Cache; with round-robin rounds over all tiles it came back 4 rounds later: 256@64^2 +1.4 %) -- and
+    // a block takes every (blocks of its XCD)-th tile of its XCD's range.  With one block per tile this is the plain XCD-aware
+    // order.  The last channel block of a tile stages the first channel block and the first three weight half-slabs of the
+    // block's NEXT tile (and loads its epilogue coefficients), so a tile does not start with ~100 KB of exposed DMA latency.
+    struct Tile { int ct, img0, row0, col0; };
     const int per_img = p.tiles_x * p.tiles_y;
-    const int img0 = fdiv(pt, p.fd_per_img);
-    const int prem = pt - img0 * per_img;
-    const int ty = fdiv(prem, p.fd_tiles_x), tx = prem - ty * p.tiles_x;
-    const int row0 = ty * p.TR, col0 = tx * p.TCT, n0 = ct * NT;
+    auto lid_of = [&](int j) -> int {          // j-th tile of this block, -1: none
+        const int nblk = (int)gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int bk = (nblk >> 3) + (xcd < (nblk & 7) ? 1 : 0);                              // blocks on this XCD
+        const int tq = p.total_blocks >> 3, tr = p.total_blocks & 7;
+        const int nk = tq + (xcd < tr ? 1 : 0), sk = xcd * tq + min(xcd, tr);                // this XCD's tiles: [sk, sk + nk)
+        const int local = idx + j * bk;
+        return local < nk ? sk + local : -1;
+    };
+    auto tile_of = [&](int lid) -> Tile {
+        Tile t;
+        t.ct = fdiv(lid, p.fd_npt);
+        const int pt = lid - t.ct * p.n_pix_tiles;
+        t.img0 = fdiv(pt, p.fd_per_img);
+        const int prem = pt - t.img0 * per_img;
+        const int ty = fdiv(prem, p.fd_tiles_x), tx = prem - ty * p.tiles_x;
+        t.row0 = ty * p.TR;
+        t.col0 = tx * p.TCT;
+        return t;
+    };
+    // staging descriptor of V piece e of a tile: item i = (run (t, part, k-half), position) -> one 16-byte chunk; a wave's piece is
+    // 64 consecutive items, so the LDS image is simply item order.  -1: zero page (rows outside the image), -2: no item.
+    auto vsrc_of = [&](const Tile& T, int e) -> int64_t {
+        const int i = (e * 8 + wave) * 64 + lane;
+        if ((e * 8 + wave) * 64 >= RUNS * p.xs) return -2;
+        const int run = fdiv(i, p.fd_xs), pos = i - run * p.xs;
+        const int sr = pos >> p.tct_shift, c = pos & (p.TCT - 1);
+        const int row = T.row0 - 1 + sr;
+        const int t = run >> 2, part = (run >> 1) & 1, h = run & 1;
+        return (row >= 0 && row < p.H)
+                   ? ((((((int64_t)T.img0 * G8 + h) * POS + t) * 2 + part) * HT) + (int64_t)row * p.TW + T.col0 + c) * 16
+                   : -1;
+    };
+    const bool fuse_rgb = p.rgb_part != nullptr, emit_xs = p.xs_out != nullptr;
+    // epilogue coefficients of a tile: global loads early (top of a tile / first half-stage of the previous tile's last channel
+    // block), LDS writes in the prologue; they go through LDS because loads between stores would serialise on vmcnt
+    struct TabVals { float d, b, s, r, w0, w1, w2; };
+    auto tables_load = [&](const Tile& T) -> TabVals {
+        TabVals t{1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (tid < NT) {
+            const int n0 = T.ct * NT;
+            const int64_t bc = (int64_t)T.img0 * p.Cout + n0 + tid;
+            t.d = p.d ? p.d[bc] : 1.f;
+            t.b = p.bias ? p.bias[n0 + tid] : 0.f;
+            if (emit_xs) t.s = p.s_next[bc];
+            if (fuse_rgb) {
+                t.r = p.rgb_s[bc];
+                t.w0 = p.rgb_w[n0 + tid];
+                t.w1 = p.rgb_w[p.Cout + n0 + tid];
+                t.w2 = p.rgb_w[2 * p.Cout + n0 + tid];
+            }
+        }
+        return t;
+    };
+    const int ntab = wave < 2 ? ((p.d ? 1 : 0) + (p.bias ? 1 : 0) + (emit_xs ? 1 : 0) + (fuse_rgb ? 4 : 0)) : 0;   // loads tables_load issues
+    // (the activation gain is folded into d, bias and noise: lrelu(t) * gain = max(g t, slope * g t) for gain > 0, 0 < slope <= 1)
+    const float e_slope = p.act ? p.slope : 1.f, e_gain = p.act ? p.gain : 1.f;
+    const int64_t v_cb_stride = (int64_t)(POS * 64) * HT;      // 2 eight-channel groups x [POS][2][HT][16 B]
+    const int ncb = p.Cin / WS_CB;
+    const int nh = ncb * 6;                             // half-stages: (channel block, kernel row, position half)
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    auto issue_v_at = [&](int64_t src_off, int e, int cb, unsigned char* xb) {
+        if (src_off == -2) return;                       // wave-uniform
+#ifdef SGDFR_WSPLIT_PROBE
+        if (p.dbg & 8) return;
+#endif
+        const unsigned char* src = src_off >= 0 ? p.v + src_off + cb * v_cb_stride : p.zeros;
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(xb + (e * 8 + wave) * 1024), 16, 0, 0);
+    };
+    // weight slab of half-stage h = (cb, ky, tp) of a cout tile: [HPOS positions][part][k-half][128][8], WV pieces per wave
+    auto issue_w_of = [&](const unsigned char* wg, int h) {
+#ifdef SGDFR_WSPLIT_PROBE
+        if (p.dbg & 16) return;
+#endif
+#pragma unroll
+        for (int v = 0; v < WV; ++v) {
+            const int piece = wave + v * 8;
+            __builtin_amdgcn_global_load_lds((glb_void*)(wg + (int64_t)h * WHALF + piece * 1024 + lane * 16),
+                                             (lds_void*)(wb0 + (h & 3) * WHALF + piece * 1024), 16, 0, 0);
+        }
+    };
+    // V pieces this wave really issues per half-stage of a channel block (the last piece may exist for the first waves only):
+    // piece e goes out in half-stage max(0, e - (NEXV - 4)) -- all landed and published by the barrier that ends half-stage 4
+    int nvw[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < NEXV; ++e) nvw[e - (NEXV - 4) > 0 ? e - (NEXV - 4) : 0] += ((e * 8 + wave) * 64 < RUNS * p.xs) ? 1 : 0;
+    const int a_off = (hi * 128 + wm * 32 + l31) * 16;
+    // the two waves of a SIMD issue their DMA pieces at different times, waves 4-7 behind the first MFMAs of the half-stage's last
+    // position (split.hip's finding holds here: 2.5-3 % on every F(4,3) layer in a same-process A/B, SGDFR_WSPLIT_DBG=4 switches it off)
+    const bool late = wave >= 4 && !(p.dbg & 4);
+    const int rowstep = p.TCT * 16;
+    // a tile may stage its successor only when the ring and the V buffers come round: an even number of channel blocks
+    const bool can_prefetch = (ncb & 1) == 0 && !(p.dbg & 128);
 
     // First-round desynchronisation (split.hip's transposed conv): equal blocks started together reach their store phase
     // together; spreading the starts of the first round over a fraction of a block time lets later rounds store while other CUs
@@ -170,27 +267,21 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
         const int n_sleep = (slot * p.desync) >> 8;
         for (int i = 0; i < n_sleep; ++i) __builtin_amdgcn_s_sleep(64);
     }
-    const bool fuse_rgb = p.rgb_part != nullptr, emit_xs = p.xs_out != nullptr;
-    // epilogue coefficients: global loads at the top of the tile, LDS writes in the prologue (one exposed latency, hidden
-    // behind the descriptor arithmetic); they go through LDS because loads between stores would serialise on vmcnt
-    float t_d = 1.f, t_b = 0.f, t_s = 0.f, t_r = 0.f, t_w0 = 0.f, t_w1 = 0.f, t_w2 = 0.f;
-    if (tid < NT) {
-        const int64_t bc = (int64_t)img0 * p.Cout + n0 + tid;
-        t_d = p.d ? p.d[bc] : 1.f;
-        t_b = p.bias ? p.bias[n0 + tid] : 0.f;
-        if (emit_xs) t_s = p.s_next[bc];
-        if (fuse_rgb) {
-            t_r = p.rgb_s[bc];
-            t_w0 = p.rgb_w[n0 + tid];
-            t_w1 = p.rgb_w[p.Cout + n0 + tid];
-            t_w2 = p.rgb_w[2 * p.Cout + n0 + tid];
-        }
-    }
+
+    unsigned sat = 0;
+    bool prefetched = false;       // this tile's first channel block, weight half-slabs and coefficients were staged by the previous tile
+    TabVals tvn{};
+    for (int jt = 0;; ++jt) {
+    const int lid = lid_of(jt);
+    if (lid < 0) break;
+    const int lid_n = lid_of(jt + 1);
+    const bool has_next = can_prefetch && lid_n >= 0;
+    const Tile T = tile_of(lid), Tn = has_next ? tile_of(lid_n) : T;
+    const int ct = T.ct, img0 = T.img0, row0 = T.row0, col0 = T.col0, n0 = ct * NT;
+    const TabVals tv = prefetched ? tvn : tables_load(T);
 
     // this lane's tile columns: position inside the staged patch, first output pixel, noise
     int boff[NI], pix[NI];
-    // (the activation gain is folded into d, bias and noise: lrelu(t) * gain = max(g t, slope * g t) for gain > 0, 0 < slope <= 1)
-    const float e_slope = p.act ? p.slope : 1.f, e_gain = p.act ? p.gain : 1.f;
     float nz[NI][OUTP];
     {
         const float nw = ((p.noise && p.noise_w) ? p.noise_w[0] : 0.f) * e_gain;
@@ -214,49 +305,11 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
             }
         }
     }
-
-    // staging descriptors of the V patch: item i = (run (t, part, k-half), position) -> one 16-byte chunk; a wave's piece is
-    // 64 consecutive items, so the LDS image is simply item order.  -1: zero page (rows outside the image), -2: no item.
     int64_t vsrc[NEXV];
 #pragma unroll
-    for (int e = 0; e < NEXV; ++e) {
-        const int i = (e * 8 + wave) * 64 + lane;
-        if ((e * 8 + wave) * 64 >= RUNS * p.xs) { vsrc[e] = -2; continue; }
-        const int run = fdiv(i, p.fd_xs), pos = i - run * p.xs;
-        const int sr = pos >> p.tct_shift, c = pos & (p.TCT - 1);
-        const int row = row0 - 1 + sr;
-        const int t = run >> 2, part = (run >> 1) & 1, h = run & 1;
-        vsrc[e] = (row >= 0 && row < p.H)
-                      ? ((((((int64_t)img0 * G8 + h) * POS + t) * 2 + part) * HT) + (int64_t)row * p.TW + col0 + c) * 16
-                      : -1;
-    }
-    const int64_t v_cb_stride = (int64_t)(POS * 64) * HT;      // 2 eight-channel groups x [POS][2][HT][16 B]
-
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef const __attribute__((address_space(1))) void glb_void;
-    auto issue_v = [&](int e, int cb, unsigned char* xb) {
-        if (vsrc[e] == -2) return;                       // wave-uniform
-#ifdef SGDFR_WSPLIT_PROBE
-        if (p.dbg & 8) return;
-#endif
-        const unsigned char* src = vsrc[e] >= 0 ? p.v + vsrc[e] + cb * v_cb_stride : p.zeros;
-        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(xb + (e * 8 + wave) * 1024), 16, 0, 0);
-    };
-    const int ncb = p.Cin / WS_CB;
-    const int nh = ncb * 6;                             // half-stages: (channel block, kernel row, position half)
+    for (int e = 0; e < NEXV; ++e) vsrc[e] = vsrc_of(T, e);
     const unsigned char* const wglb = p.wsp + (int64_t)ct * ncb * 6 * WHALF;
-    // weight slab of half-stage h = (cb, ky, tp): [HPOS positions][part][k-half][128][8], WV pieces per wave
-    auto issue_w = [&](int h) {
-#ifdef SGDFR_WSPLIT_PROBE
-        if (p.dbg & 16) return;
-#endif
-#pragma unroll
-        for (int v = 0; v < WV; ++v) {
-            const int piece = wave + v * 8;
-            __builtin_amdgcn_global_load_lds((glb_void*)(wglb + (int64_t)h * WHALF + piece * 1024 + lane * 16),
-                                             (lds_void*)(wb0 + (h & 3) * WHALF + piece * 1024), 16, 0, 0);
-        }
-    };
+    const unsigned char* const wglb_n = p.wsp + (int64_t)Tn.ct * ncb * 6 * WHALF;
 
     ws_f32x16 acc[POS][NI];
 #pragma unroll
@@ -266,30 +319,29 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][n][r] = 0.f;
 
-    // V pieces this wave really issues per half-stage of a channel block (the last piece may exist for the first waves only):
-    // piece e goes out in half-stage max(0, e - (NEXV - 4)) -- all landed and published by the barrier that ends half-stage 4
-    int nvw[4] = {0, 0, 0, 0};
+    // ---- prologue: channel block 0 and the first three weight half-slabs (unless the previous tile staged them); tables
+    if (!prefetched) {
 #pragma unroll
-    for (int e = 0; e < NEXV; ++e) nvw[e - (NEXV - 4) > 0 ? e - (NEXV - 4) : 0] += ((e * 8 + wave) * 64 < RUNS * p.xs) ? 1 : 0;
-
-    // ---- prologue: channel block 0, the first three weight half-slabs
-#pragma unroll
-    for (int e = 0; e < NEXV; ++e) issue_v(e, 0, xb0);
-    issue_w(0);
-    if (nh > 1) issue_w(1);
-    if (nh > 2) issue_w(2);
+        for (int e = 0; e < NEXV; ++e) issue_v_at(vsrc[e], e, 0, xb0);
+        issue_w_of(wglb, 0);
+        if (nh > 1) issue_w_of(wglb, 1);
+        if (nh > 2) issue_w_of(wglb, 2);
+    }
     if (tid < NT) {
         const float oscale = (ET == SGDFR_SPLIT_FP16) ? WS_F16_OUT : 1.f;
         const float xsc = (ET == SGDFR_SPLIT_FP16) ? WS_F16_XSCALE : 1.f;
         const float rs = rsqrtf((float)p.Cout);
-        dl[tid] = t_d * oscale * e_gain;
-        bl[tid] = t_b * e_gain;
-        sn[tid] = t_s * xsc;
-        *reinterpret_cast<float4*>(cw + 4 * tid) = make_float4(t_w0 * (t_r * rs), t_w1 * (t_r * rs), t_w2 * (t_r * rs), 0.f);
+        dl[tid] = tv.d * oscale * e_gain;
+        bl[tid] = tv.b * e_gain;
+        sn[tid] = tv.s * xsc;
+        *reinterpret_cast<float4*>(cw + 4 * tid) = make_float4(tv.w0 * (tv.r * rs), tv.w1 * (tv.r * rs), tv.w2 * (tv.r * rs), 0.f);
     }
-    ws_wait_vmcnt<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!prefetched) {
+        ws_wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // (a staged tile starts behind the barrier that ended the previous one: every wave had waited for its pieces before it)
 
     // K loop.  The weight half-slabs live in a FOUR-slot ring and are DMA'd three half-stages ahead: the slab of h+1 is
     // published by the barrier that ends h-1, so the first fragments of h+1 are requested during the last position of h --
@@ -297,11 +349,6 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
     // slots, all eight waves asking for their first fragments right behind it, measured the same: the loop is power-bound.)
     // The barrier's counted wait leaves the pieces issued during h in flight and completes everything older (the slab of h+2,
     // V pieces of the next channel block).
-    const int a_off = (hi * 128 + wm * 32 + l31) * 16;
-    // the two waves of a SIMD issue their DMA pieces at different times, waves 4-7 behind the first MFMAs of the half-stage's last
-    // position (split.hip's finding holds here: 2.5-3 % on every F(4,3) layer in a same-process A/B, SGDFR_WSPLIT_DBG=4 switches it off)
-    const bool late = wave >= 4 && !(p.dbg & 4);
-    const int rowstep = p.TCT * 16;
     ws_frag a[2][2], b[2][2][NI];      // [set][part]
     auto fetch = [&](int set, const unsigned char* wsl, const unsigned char* xr, int tl, int t) {
 #pragma unroll
@@ -318,17 +365,26 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
         const unsigned char* xcur = xb0 + xsel * xbuf_bytes;
         unsigned char* xnext = xb0 + (xsel ^ 1) * xbuf_bytes;
         const bool v_next = cb + 1 < ncb;
+        const bool pre_next = !v_next && has_next;      // the last channel block stages the next tile's first one
 #pragma unroll
         for (int hh = 0; hh < 6; ++hh, ++h) {
             const int ky = hh >> 1, tp = hh & 1;
             int n_issued = 0;
             auto issue_all = [&]() {
-                if (h + 3 < nh) { issue_w(h + 3); n_issued += WV; }
-                if (v_next && hh < 4) {
+                if (h + 3 < nh) { issue_w_of(wglb, h + 3); n_issued += WV; }
+                else if (has_next) { issue_w_of(wglb_n, h + 3 - nh); n_issued += WV; }      // (nh % 4 == 0: the ring comes round)
+                if ((v_next || pre_next) && hh < 4) {
 #pragma unroll
                     for (int e = 0; e < NEXV; ++e)
-                        if ((e - (NEXV - 4) > 0 ? e - (NEXV - 4) : 0) == hh) issue_v(e, cb + 1, xnext);
+                        if ((e - (NEXV - 4) > 0 ? e - (NEXV - 4) : 0) == hh) {
+                            if (v_next) issue_v_at(vsrc[e], e, cb + 1, xnext);
+                            else issue_v_at(vsrc_of(Tn, e), e, 0, xnext);
+                        }
                     n_issued += nvw[hh < 4 ? hh : 0];
+                }
+                if (pre_next && hh == 0) {      // the next tile's coefficients: in flight with this half-stage's pieces
+                    tvn = tables_load(Tn);
+                    n_issued += ntab;
                 }
             };
             if (!late) issue_all();
@@ -360,25 +416,34 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (h + 1 < nh) {
+                // (the first half-stage of a staged tile waits for nothing: what it publishes landed before the previous tile's
+                // epilogue, and what is in flight now are that epilogue's stores -- loads and stores retire through one in-order counter)
+                if (!(prefetched && h == 0)) {
 #ifdef SGDFR_WSPLIT_PROBE
-                if (!(p.dbg & 32))
+                    if (!(p.dbg & 32))
 #endif
-                ws_wait_vmcnt_dyn(n_issued);
+                    ws_wait_vmcnt_dyn(n_issued);
+                }
                 __builtin_amdgcn_s_barrier();
+            } else if (has_next) {
+                ws_wait_vmcnt<0>();      // the next tile's first stages have landed before this tile's stores join the queue
+                // (its coefficients too: "use" them here, so the compiler's own wait for these loads sits at this point and not
+                //  behind the epilogue's stores at the top of the next tile)
+                asm volatile("" : "+v"(tvn.d), "+v"(tvn.b), "+v"(tvn.s), "+v"(tvn.r), "+v"(tvn.w0), "+v"(tvn.w1), "+v"(tvn.w2));
             }
         }
         xsel ^= 1;
     }
+    prefetched = has_next;
 
 #ifdef SGDFR_WSPLIT_PROBE
-    if (p.dbg & 2) return;
+    if (p.dbg & 2) { __syncthreads(); continue; }
 #endif
     // ---- epilogue.  C/D layout of 32x32: column (tile) = lane & 31, row (cout) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
     // The element loop works on PAIRS of neighbouring pixels as two-float vectors: scale + noise + bias, the leaky-ReLU product,
     // the next layer's style and the ToRGB sums are v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (one instruction per pair; no MFMA
     // is in flight here, so the packed forms cost nothing extra) -- 13 instead of 18 VALU instructions per output in chain form.
     constexpr int NP = OUTP / 2;
-    unsigned sat = 0;
     ws_f32x2 rgb2[NI][NP][3];
 #pragma unroll
     for (int n = 0; n < NI; ++n)
@@ -512,6 +577,8 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
                     else *reinterpret_cast<float4*>(dst) = make_float4(tq[0], tq[1], tq[OUTP - 2], tq[OUTP - 1]);
                 }
         }
+    }
+    __syncthreads();      // the next tile refills the tables; every wave has left the staging buffers and `red`
     }
     if (ET == SGDFR_SPLIT_FP16 && __builtin_expect(sat != 0, 0)) atomicAdd(p.sat ? p.sat : &g_wsplit_saturated, sat);
 }
@@ -738,6 +805,11 @@ extern "C" int sgdfr_modconv2d_wsplit_f32(const unsigned short* v, const unsigne
         set_error("modconv_wsplit: LDS request %zu B refused", lds);
         return 2;
     }
-    hipLaunchKernelGGL(kern, dim3(p.n_pix_tiles * p.n_cout_tiles), dim3(512), lds, as_stream(stream), p);
+    // Persistent blocks, one per CU, from two tiles per CU on: a block's tile stages the first channel block, the first three
+    // weight half-slabs and the epilogue coefficients of the block's next tile (see the kernel).
+    const int persist = getenv("SGDFR_WSPLIT_PERSIST") ? atoi(getenv("SGDFR_WSPLIT_PERSIST")) : 256;      // (read per launch: scripts/wsplit_env_ab.py)
+    p.total_blocks = p.n_pix_tiles * p.n_cout_tiles;
+    const int grid = (persist > 0 && p.total_blocks >= 2 * persist) ? persist : p.total_blocks;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, as_stream(stream), p);
     return check_launch("modconv2d_wsplit");
 }

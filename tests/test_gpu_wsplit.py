@@ -15,6 +15,9 @@ CASES = [  # cin, cout, H, B
     (16, 128, 128, 2),     # 4 patches across
     (16, 128, 256, 1),
     (128, 384, 32, 5),
+    (32, 256, 64, 40),     # 1280 blocks: persistent blocks, 5 tiles each, every tile but the last stages its successor
+    (48, 128, 64, 40),     # odd number of channel blocks: persistent without staging ahead (the ring does not come round)
+    (16, 128, 128, 36),    # 2304 blocks: 9 tiles per block, first-round start spread
 ]
 TOL = {'fp16x3': 2e-5, 'bf16x3': 1e-4}
 
