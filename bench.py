@@ -413,8 +413,8 @@ def run_synthesis(args, rank, world, dev):
     # (K-sliced 4x4 ... 16x16 layers, ~30 dependent launches) runs beside the big layers of the previous one.  Every kernel
     # and every image is the same as on one stream (tests/test_gpu_generator.py); `single_stream` below is the K-step figure
     # without it, and the per-kernel roofline pass always runs on one stream.
-    # (forwards small enough for the generator's own hipGraph replay are host-bound and share the graph's static buffers: one stream)
-    pipe = F_.StreamPipeline(args.streams, dev) if (args.streams > 1 and B * (args.size / 256.0) ** 2 > G.GRAPH_MAX_WORK) else None
+    # (forwards small enough for the generator's own hipGraph replay get one capture per stream: Generator._graph_key)
+    pipe = F_.StreamPipeline(args.streams, dev) if args.streams > 1 else None
 
     def step():
         if pipe is None:
