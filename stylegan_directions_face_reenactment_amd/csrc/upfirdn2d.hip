@@ -197,6 +197,9 @@ __device__ __forceinline__ void blur_split2(float a, float b, unsigned& hi, unsi
 // [B][C/8][t WINO+2][hi,lo][2H * 2W / WINO][8], V = B^T (y * s_next) per tile of WINO outputs; bit-identical to
 // sgdfr_to_wsplit_f32 of the fp32 result).  A thread takes one tile (WINO = 4: three of its six positions) and reads the
 // tile's two row neighbours from the LDS tile, so the tile must span whole rows (one column tile: 2W <= 128).
+// (WINO variants: 3 waves per SIMD = 168 registers -- at 128 the sliding window spills.  The 8-wave blocks of the 64 -> 128 level then
+// fit a CU only once; tried for that level: requesting the next segment's plane rows after the hand-over instead of before it, to
+// get back under 128 registers and two blocks per CU: 88 bytes of scratch remained and the level went from 367 to 513 us.)
 template <int ET, int QC, int NG, int WINO = 0>
 __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(const float* __restrict__ t, const float* __restrict__ fir,
                                                         const float* __restrict__ noise, int64_t noise_bstride,
