@@ -573,7 +573,8 @@ def wsplit_chain_f(B, cin, cout, H, W):
     if not (USE_WSPLIT and USE_SPLIT_CHAIN and WSPLIT_MIN_CIN > 0 and cin >= WSPLIT_MIN_CIN and W <= 128):
         return 0
     for f in ((4, 2) if WSPLIT_F == 4 else (2,)):
-        if wsplit_ok(B, cin, cout, H, W, f):
+        # (F(2,3) hands over 8 bytes per element and saves a third of the MFMAs: it only pays from 256 input channels on)
+        if wsplit_ok(B, cin, cout, H, W, f) and (f == 4 or cin >= max(WSPLIT_MIN_CIN, 256)):
             return f
     return 0
 
