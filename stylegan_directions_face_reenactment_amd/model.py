@@ -703,7 +703,7 @@ class Generator(nn.Module):
                 F_.WSPLIT_MIN_CIN, F_.WSPLIT_F,
                 # a graph's static input / output buffers belong to the stream that replays it: forwards queued on different
                 # streams (functional.StreamPipeline) get their own capture instead of racing on one
-                torch.cuda.current_stream(w.device).cuda_stream)
+                F_.N.stream().value)
 
     def forward(self, styles, return_latents=False, return_features=False, inject_index=None, truncation=1,
                 truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=False, image_out=None,
