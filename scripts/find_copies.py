@@ -1,5 +1,7 @@
 """Which host-side op issues device-to-device copies inside a no-grad forward?  (4 __amd_rocclr_copyBuffer per
 forward.)  python scripts/find_copies.py"""
+import os
+os.environ.setdefault('SGDFR_VERIFY_RANGE', '0')      # timing script: raw forwards return at once (the product default verifies)
 import os, sys
 import torch
 from torch.profiler import profile, ProfilerActivity

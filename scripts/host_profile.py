@@ -1,4 +1,6 @@
 """Where does the host time of one eager no-grad forward go (B=1: the forward is host-bound)?  python scripts/host_profile.py"""
+import os
+os.environ.setdefault('SGDFR_VERIFY_RANGE', '0')      # timing script: raw forwards return at once (the product default verifies)
 import cProfile, pstats, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stylegan_directions_face_reenactment_amd import synthetic as S

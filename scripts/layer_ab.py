@@ -5,6 +5,8 @@ loops, so both variants run on the same box in the same thermal state, interleav
 
     python scripts/layer_ab.py [--batch 64] [--reps 20] [--rounds 3] VAR=a,b [VAR2=a,b ...]
 """
+import os
+os.environ.setdefault('SGDFR_VERIFY_RANGE', '0')      # timing script: raw forwards return at once (the product default verifies)
 import argparse
 import os
 import sys

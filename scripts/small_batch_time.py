@@ -1,5 +1,7 @@
 """Per-forward time of the no-grad generator at small batches (launch-bound regime), eager launches vs the default hipGraph
 replay of Generator.forward, raw and through generate_image (verified forwards): python scripts/small_batch_time.py"""
+import os
+os.environ.setdefault('SGDFR_VERIFY_RANGE', '0')      # timing script: raw forwards return at once (the product default verifies)
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stylegan_directions_face_reenactment_amd import synthetic as S, functional as F_

@@ -1,4 +1,6 @@
 """Does splitting one batch over several HIP streams fill the wave-quantisation tails?  python scripts/stream_split_probe.py"""
+import os
+os.environ.setdefault('SGDFR_VERIFY_RANGE', '0')      # timing script: raw forwards return at once (the product default verifies)
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,8 @@
 """Do consecutive independent forwards overlap usefully when they alternate between two HIP streams (the head of a forward --
 4x4 ... 16x16 layers, K-sliced, under-filling the chip, and ~200 us of launch gaps -- against the big layers of the previous
 one)?  python scripts/two_stream_probe.py [--batch 64] [--streams 2]"""
+import os
+os.environ.setdefault('SGDFR_VERIFY_RANGE', '0')      # timing script: raw forwards return at once (the product default verifies)
 import argparse, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,7 @@
 """Same-process A/B of the plain split conv against its 1-D Winograd F(2,3) form (csrc/wsplit.hip) on the generator's plain layer
 shapes in their chain form (pre-split / pre-transformed input, xs_out + fused ToRGB, no y):  python scripts/wsplit_ab.py [--batch 64]"""
+import os
+os.environ.setdefault('SGDFR_VERIFY_RANGE', '0')      # timing script: raw forwards return at once (the product default verifies)
 import argparse
 import os
 import sys

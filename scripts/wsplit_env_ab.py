@@ -1,5 +1,7 @@
 """A/B of environment switches of wsplit.hip (read per launch) on the generator's F(4,3) layer shapes, chain form, same process:
     python scripts/wsplit_env_ab.py SGDFR_WSPLIT_DESYNC=0,50,100"""
+import os
+os.environ.setdefault('SGDFR_VERIFY_RANGE', '0')      # timing script: raw forwards return at once (the product default verifies)
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stylegan_directions_face_reenactment_amd import functional as F_      # noqa: E402

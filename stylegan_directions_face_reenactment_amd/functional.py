@@ -30,6 +30,21 @@ def _timed_conv(desc, flops, launch):
     CONV_TIMING.append((e0, e1, flops, desc))
 
 
+# bench.py sets this to a list to time the HBM-bound launches of the path (FIR blur after the transposed conv, ToRGB / its
+# finish): entries are (start_event, end_event, algorithmic_bytes, description)
+HBM_TIMING = None
+
+
+def _timed_hbm(desc, nbytes, launch):
+    if HBM_TIMING is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    HBM_TIMING.append((e0, e1, nbytes, desc))
+
+
 # ------------------------------------------------------------------ small dense ops
 
 def pixel_norm(x, eps=1e-8):
@@ -703,6 +718,9 @@ def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, 
             _, part, xs = res
             return SplitAct(xs, (B, cout, H, W)), part
         return res if rgb is not None else (res, None)
+    if s_next is not None and not wino_next and x_split is not None and upfir_chain_ok(B, x_split[1], cout, H, W):
+        xs = modconv_upfir_split(xin, x_split, wsp, d, cout, fir, s_next, noise, noise_weight, bias, True)
+        return SplitAct(xs, (B, cout, 2 * H, 2 * W)), None
     if s_next is not None and USE_PLANE_PADDING and \
             _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, x_split[1] if x_split else x.shape[1], cout, H, W, N.MODE_UP3) == 1:
         # parity planes padded to whole 128-byte lines: the odd-sized dense planes make every store run straddle two lines
@@ -715,6 +733,44 @@ def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, 
         xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, wino=wino_next)
         return SplitAct(xs, (B, cout, 2 * H, 2 * W), wino_next), None
     return blur_bias_act(planes, fir, H, W, noise, noise_weight, bias, True), None
+
+
+# Upsampling layers of the inference chain whose FIR blur runs in the transposed conv's epilogue (csrc/upfir.hip): the parity planes
+# (8 bytes of HBM traffic per output element between the two launches) never leave the CU, for a recomputed one-super-pixel halo
+# ring per patch (1.35x the layer's MFMA work at 128 x 128 inputs).  It pays where the blur launch was large against the conv's K loop:
+# inputs at least UPFIR_MIN_W wide (same-box A/B at B=64; 0 = never).  Needs the direct split hand-over (a Winograd consumer
+# takes its input from the two-pass form's blur).
+USE_UPFIR = os.environ.get('SGDFR_UPFIR', '1') != '0'
+UPFIR_MIN_W = int(os.environ.get('SGDFR_UPFIR_MIN_W', '128'))
+
+
+def upfir_ok(B, cin, cout, H, W):
+    return PRECISION in _SPLIT_ARITH and bool(_shape_query('sgdfr_modconv2d_upfir_supported', B, cin, cout, H, W))
+
+
+def upfir_chain_ok(B, cin, cout, H, W):
+    """Does the inference chain run this upsampling layer as ONE launch (transposed conv + blur fused)?"""
+    return USE_UPFIR and USE_SPLIT_CHAIN and UPFIR_MIN_W > 0 and W >= UPFIR_MIN_W and upfir_ok(B, cin, cout, H, W)
+
+
+def modconv_upfir_split(xs_in, shape, wsp, d, cout, fir, s_next, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2,
+                        gain=SQRT2, arith=None, desc=None):
+    """Upsampling StyledConv in one launch: xs_in = the split form of x*s (shape = (B, Cin, H, W)) -> the split form of
+    act(blur(conv_transpose(x*s) * d) + noise + bias) * s_next, [B, cout/8, 2, 2H*2W, 8] int16 (same bits as
+    modconv_split(mode=UP3) + blur_bias_act_split)."""
+    arith = _SPLIT_ARITH[arith or PRECISION]
+    N.require_device(d, fir, bias, noise_weight, s_next)
+    if not xs_in.is_cuda or xs_in.dtype != torch.int16 or not wsp.is_cuda or wsp.dtype != torch.int16:
+        raise RuntimeError('modconv_upfir_split: xs_in / wsp are the int16 device buffers made by to_split / prepack_split')
+    B, cin, H, W = shape
+    nz, nzb = _noise_args(noise, B, 2 * H, 2 * W)
+    xs = torch.empty(B, cout // 8, 2, 4 * H * W, 8, device=xs_in.device, dtype=torch.int16)
+    st, sat = N.stream(), _sat()
+    _timed_conv(desc or ('upfir split %d->%d @%dx%d' % (cin, cout, H, W)), B * conv_flops(cin, cout, H, W), lambda: N.call(
+        'sgdfr_modconv2d_upfir_split_f32', N.ptr(xs_in), N.ptr(wsp), N.ptr(N.f32c(d)), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
+        N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(N.f32c(s_next)), N.ptr(_zero_words(xs_in.device)),
+        N.ptr(xs), B, cin, cout, H, W, arith, int(activate), float(slope), float(gain), sat, st))
+    return xs
 
 
 def rgb_fusable(B, cin, cout, H, W):
@@ -777,6 +833,7 @@ def torgb_finish(part, bias=None, skip=None, fir=None, u8=None):
     B, c3, H, W = part.shape
     if skip is not None and tuple(skip.shape) != (B, 3, H // 2, W // 2):
         raise RuntimeError('skip shape %s does not match output [%d,3,%d,%d]/2' % (tuple(skip.shape), B, H, W))
+    skip_bytes = 3 * (H // 2) * (W // 2) * 4 if skip is not None else 0
     if u8 is not None:
         frames = u8.frames
         if frames is None:
@@ -784,14 +841,17 @@ def torgb_finish(part, bias=None, skip=None, fir=None, u8=None):
         if frames.dtype != torch.uint8 or not frames.is_cuda or not frames.is_contiguous() or frames.ndim != 4 or \
                 frames.shape[0] != B or frames.shape[1] != H or frames.shape[3] != 3 or frames.shape[2] < (u8.panel + 1) * W:
             raise RuntimeError('uint8 target %s cannot hold panel %d of [%d,%d,%d,3] frames' % (tuple(frames.shape), u8.panel, B, H, W))
-        N.call('sgdfr_torgb_finish_u8_f32', N.ptr(part), c3 // 3, N.ptr(N.f32c(bias)) if bias is not None else None,
-               N.ptr(N.f32c(skip)) if skip is not None else None, N.ptr(N.f32c(fir)) if fir is not None else None, N.ptr(frames),
-               frames.shape[2] * 3, u8.panel * W, int(u8.swap_rb), B, H, W, N.stream())
+        # algorithmic bytes: the partial sums once, the skip once, one byte per output channel and pixel
+        _timed_hbm('torgb_finish_u8 T=%d @%dx%d' % (c3 // 3, H, W), B * (c3 * H * W * 4 + skip_bytes + 3 * H * W), lambda: N.call(
+            'sgdfr_torgb_finish_u8_f32', N.ptr(part), c3 // 3, N.ptr(N.f32c(bias)) if bias is not None else None,
+            N.ptr(N.f32c(skip)) if skip is not None else None, N.ptr(N.f32c(fir)) if fir is not None else None, N.ptr(frames),
+            frames.shape[2] * 3, u8.panel * W, int(u8.swap_rb), B, H, W, N.stream()))
         return frames
     y = torch.empty(B, 3, H, W, device=part.device, dtype=torch.float32)
-    N.call('sgdfr_torgb_finish_f32', N.ptr(part), c3 // 3, N.ptr(N.f32c(bias)) if bias is not None else None,
-           N.ptr(N.f32c(skip)) if skip is not None else None, N.ptr(N.f32c(fir)) if fir is not None else None, N.ptr(y), B, H, W,
-           N.stream())
+    _timed_hbm('torgb_finish T=%d @%dx%d' % (c3 // 3, H, W), B * (c3 * H * W * 4 + skip_bytes + 3 * H * W * 4), lambda: N.call(
+        'sgdfr_torgb_finish_f32', N.ptr(part), c3 // 3, N.ptr(N.f32c(bias)) if bias is not None else None,
+        N.ptr(N.f32c(skip)) if skip is not None else None, N.ptr(N.f32c(fir)) if fir is not None else None, N.ptr(y), B, H, W,
+        N.stream()))
     return y
 
 
@@ -836,9 +896,11 @@ def blur_bias_act(planes, fir, H, W, noise=None, noise_weight=None, bias=None, a
     y = out if out is not None else torch.empty(B, C, 2 * H, 2 * W, device=planes.device, dtype=torch.float32)
     if tuple(y.shape) != (B, C, 2 * H, 2 * W) or not y.is_contiguous():
         raise RuntimeError('blur_bias_act: out must be a contiguous [B,C,2H,2W] tensor')
-    N.call('sgdfr_blur_bias_act_f32', N.ptr(planes), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
-           N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(y), B, C, H, W, int(activate),
-           float(slope), float(gain), N.stream())
+    # algorithmic bytes: every parity plane read once (4 (H+1)(W+1) floats per channel), every output element written once
+    _timed_hbm('blur %d ch %dx%d -> %dx%d fp32' % (C, H, W, 2 * H, 2 * W), B * C * (16 * (H + 1) * (W + 1) + 16 * H * W), lambda: N.call(
+        'sgdfr_blur_bias_act_f32', N.ptr(planes), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
+        N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(y), B, C, H, W, int(activate),
+        float(slope), float(gain), N.stream()))
     return y
 
 
@@ -857,9 +919,13 @@ def blur_bias_act_split(planes, fir, H, W, s_next, noise=None, noise_weight=None
         xs = torch.empty(B, C // 8, wino + 2, 2, 4 * H * W // wino, 8, device=planes.device, dtype=torch.int16)
     else:
         xs = torch.empty(B, C // 8, 2, 4 * H * W, 8, device=planes.device, dtype=torch.int16)
-    N.call('sgdfr_blur_bias_act_split_f32', N.ptr(planes), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
-           N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(N.f32c(s_next)), N.ptr(xs), B, C, H, W,
-           int(plane_stride), arith, wino, int(activate), float(slope), float(gain), _sat(), N.stream())
+    # algorithmic bytes: the planes once + the hand-over (4 bytes per element in the direct split form, 4 (f+2)/f in Winograd form)
+    out_b = 4 * H * W * (4 * (wino + 2) // wino if wino else 4)
+    _timed_hbm('blur %d ch %dx%d -> %dx%d %s' % (C, H, W, 2 * H, 2 * W, 'WS F(%d,3)' % wino if wino else 'XS'),
+               B * C * (16 * (H + 1) * (W + 1) + out_b), lambda: N.call(
+        'sgdfr_blur_bias_act_split_f32', N.ptr(planes), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
+        N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(N.f32c(s_next)), N.ptr(xs), B, C, H, W,
+        int(plane_stride), arith, wino, int(activate), float(slope), float(gain), _sat(), N.stream()))
     return xs
 
 
@@ -909,9 +975,11 @@ def torgb(x, w_rgb, s, bias=None, skip=None, fir=None):
     if skip is not None and tuple(skip.shape) != (B, 3, H // 2, W // 2):
         raise RuntimeError('skip shape %s does not match output [%d,3,%d,%d]/2' % (tuple(skip.shape), B, H, W))
     y = torch.empty(B, 3, H, W, device=x.device, dtype=torch.float32)
-    N.call('sgdfr_torgb_fwd_f32', N.ptr(x), N.ptr(N.f32c(w_rgb)), N.ptr(s), N.ptr(N.f32c(bias)) if bias is not None else None,
-           N.ptr(N.f32c(skip)) if skip is not None else None, N.ptr(N.f32c(fir)) if fir is not None else None,
-           N.ptr(y), B, cin, H, W, N.stream())
+    _timed_hbm('torgb %d ch @%dx%d' % (cin, H, W), B * ((cin + 3) * H * W * 4 + (3 * (H // 2) * (W // 2) * 4 if skip is not None else 0)),
+               lambda: N.call(
+        'sgdfr_torgb_fwd_f32', N.ptr(x), N.ptr(N.f32c(w_rgb)), N.ptr(s), N.ptr(N.f32c(bias)) if bias is not None else None,
+        N.ptr(N.f32c(skip)) if skip is not None else None, N.ptr(N.f32c(fir)) if fir is not None else None,
+        N.ptr(y), B, cin, H, W, N.stream()))
     return y
 
 

@@ -37,7 +37,7 @@ VERIFY_RANGE = os.environ.get('SGDFR_VERIFY_RANGE', '1') != '0'
 def generate_image(G, latent_code, truncation, trunc, w_plus=True, num_layers_shift=8, shift_code=None,
                    input_is_latent=False, return_latents=False):
     """generic.py:137-151."""
-    extra = {'verify_range': True} if (VERIFY_RANGE and hasattr(G, 'range_ok')) else {}
+    extra = {'verify_range': bool(VERIFY_RANGE)} if hasattr(G, 'range_ok') else {}
     if shift_code is None:
         imgs = G([latent_code], return_latents=return_latents, truncation=truncation, truncation_latent=trunc,
                  input_is_latent=input_is_latent, **extra)

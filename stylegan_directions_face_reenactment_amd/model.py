@@ -53,11 +53,13 @@ def _side_stream(device):
 class RangeToken:
     """One no-grad fp16x3 forward's claim on its generator's saturation word: `snap` (pinned host int32) receives the word's
     value right after the forward's last launch, `event` marks that copy; `delta` = pairs clamped by THIS forward, filled in
-    when the token is checked (Generator.range_ok / the non-blocking poll of the next forward)."""
-    __slots__ = ('event', 'snap', 'delta')
+    when the token is checked (Generator.range_ok / the non-blocking poll of the next forward).  `stamp` = the weights the forward
+    ran on (a saturation of OLD weights must not switch the arithmetic of new ones); `suspect`: another forward that was in flight
+    beside this one (other HIP stream) clamped operands and the shared word cannot tell the two apart -- range_ok() says False."""
+    __slots__ = ('event', 'snap', 'delta', 'stamp', 'suspect')
 
-    def __init__(self, event, snap):
-        self.event, self.snap, self.delta = event, snap, None
+    def __init__(self, event, snap, stamp=None):
+        self.event, self.snap, self.delta, self.stamp, self.suspect = event, snap, None, stamp, False
 
 
 _PINNED_WORDS = []      # free list of pinned int32 [1] host tensors (a fresh pin_memory() per forward would cost ~20 us)
@@ -512,7 +514,8 @@ class Generator(nn.Module):
         snap.copy_(word, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        tok = RangeToken(ev, snap)
+        st = getattr(self, '_range_state', None)
+        tok = RangeToken(ev, snap, st['stamp'] if st is not None else None)
         self._sat_tokens.append(tok)
         return tok
 
@@ -529,14 +532,34 @@ class Generator(nn.Module):
                 break
             toks.pop(0)
             val = int(tok.snap[0]) & 0xffffffff
-            tok.delta = (val - self._sat_seen) & 0xffffffff
-            self.__dict__['_sat_seen'] = val
+            # Snapshots of forwards on DIFFERENT streams (functional.StreamPipeline) may be taken out of queue order: a later
+            # token can hold a smaller value.  The running maximum (as a signed 32-bit distance: the word may wrap) keeps the
+            # deltas non-negative; whoever was still in flight when a non-zero delta shows up is marked suspect, because the
+            # shared word cannot say which of the overlapping forwards clamped.
+            dist = (val - self._sat_seen) & 0xffffffff
+            tok.delta = dist if dist < 0x80000000 else 0
+            if tok.delta:
+                self.__dict__['_sat_seen'] = val
+                for other in toks:
+                    other.suspect = True
+            if tok.suspect and not tok.delta:
+                tok.delta = 1
             new += tok.delta
             _PINNED_WORDS.append(tok.snap)
             tok.snap = None
             if tok is upto:
                 break
         return new
+
+    def _settle_oldest_if_full(self):
+        """Every fp16x3 forward leaves a token -- no forward goes unchecked.  When MAX_PENDING_TOKENS are already queued (the host
+        runs that far ahead of the device) the OLDEST one is awaited first: the host then trails the device by at most that
+        many forwards, and a saturation in the awaited forward switches the arithmetic at once."""
+        toks = self.__dict__.get('_sat_tokens')
+        if toks and len(toks) >= self.MAX_PENDING_TOKENS and not torch.cuda.is_current_stream_capturing():
+            seen = self._check_tokens(upto=toks[0])
+            if seen:
+                self._fall_back(seen, 'in earlier forwards')
 
     def saturated_pairs(self):
         """fp16 operand pairs this generator's launches (forward and backward) clamped or found non-finite so far
@@ -559,7 +582,10 @@ class Generator(nn.Module):
         if token.delta is None:
             self._check_tokens(upto=token)
         if token.delta:
-            self._fall_back(token.delta, 'in the forward just checked')
+            st = getattr(self, '_range_state', None)
+            # (a token of weights that have since been replaced: re-render, but leave the NEW weights' calibrated plan alone)
+            if st is not None and (token.stamp is None or token.stamp == st['stamp']):
+                self._fall_back(token.delta, 'in the forward just checked')
             return False
         return True
 
@@ -675,7 +701,7 @@ class Generator(nn.Module):
         style mixing, caller-supplied or fresh noise, a caller-owned uint8 target, hooks, an enclosing capture, bench timing --
         and, unless graph=True, forwards that are neither host-bound nor verified (see forward)."""
         if graph is False or not USE_GRAPHS or not getattr(self, 'use_graphs', True) or torch.is_grad_enabled() or \
-                F_.CONV_TIMING is not None:
+                F_.CONV_TIMING is not None or F_.HBM_TIMING is not None:
             return None
         if len(styles) != 1 or inject_index is not None or noise is not None or randomize_noise:
             return None
@@ -705,11 +731,19 @@ class Generator(nn.Module):
                 # streams (functional.StreamPipeline) get their own capture instead of racing on one
                 F_.N.stream().value)
 
+    # A raw `G([w])` -- what the reference's scripts call (run_inference.py:125, utils_inference.py:88, optimization.py:50,
+    # invert_images.py:103, extract_statistics.py:85) -- hands back VERIFIED frames: the forward is awaited and, had any fp16
+    # operand left the range plan, re-rendered in bf16x3 first.  Throughput callers that check tokens themselves
+    # (ReenactmentSession, functional.StreamPipeline loops, bench.py) pass verify_range=False; `G.verify_range_default = False`
+    # or SGDFR_VERIFY_RANGE=0 changes the default for a generator / the process.
+    verify_range_default = os.environ.get('SGDFR_VERIFY_RANGE', '1') != '0'
+
     def forward(self, styles, return_latents=False, return_features=False, inject_index=None, truncation=1,
                 truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=False, image_out=None,
-                verify_range=False, graph=None):
+                verify_range=None, graph=None):
         """Reference signature (model.py:471-482) plus optional extensions (no-grad forwards only): image_out / verify_range
-        (see _forward_impl) and graph (None: the default policy below, True: replay whenever possible, False: always eager).
+        (see _forward_impl; None = this generator's default, which is to verify) and graph (None: the default policy below,
+        True: replay whenever possible, False: always eager).
 
         hipGraph replay.  A no-grad forward is ~65 dependent launches = ~1 ms of Python at any batch size.  From the third
         forward of one signature (input shape, flags, arithmetic) on, the launch sequence is captured once and REPLAYED: the
@@ -721,6 +755,8 @@ class Generator(nn.Module):
         batch size (generate_image at B=32: 7.8 k -> 8.3 k frames/s).  Weight changes (tracked like the weight packs; after
         `.data` edits call invalidate_packs()), a change of arithmetic / range plan, hooks, style mixing, caller-supplied
         noise and randomize_noise run eagerly.  Switch off: `G.use_graphs = False` or SGDFR_GRAPHS=0."""
+        if verify_range is None:
+            verify_range = bool(self.verify_range_default)
         key = self._graph_key(styles, return_latents, inject_index, truncation, truncation_latent, input_is_latent, noise,
                               randomize_noise, image_out, verify_range, graph)
         if key is None:
@@ -737,6 +773,15 @@ class Generator(nn.Module):
             entry = None
         w = styles[0]
         trunc = truncation_latent if truncation < 1 else None
+        if entry is not None and entry['mode'] == 'fp16x3' and self.__dict__.get('_sat_tokens'):
+            # the non-blocking poll of the eager path (_range_plans), which a replay never reaches: tokens of finished forwards are
+            # resolved here, and a saturation seen in any of them switches this generator to bf16x3 before the next replay
+            seen = self._check_tokens()
+            if seen:
+                self._fall_back(seen, 'in earlier forwards')
+                self._drop_graphs()
+                return self._forward_impl(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
+                                          input_is_latent, None, False, image_out, verify_range)
         if entry is None:
             n = calls.get(key, 0)
             if n < self.GRAPH_AFTER:                       # not yet: packs, launch plans and the range calibration settle eagerly
@@ -768,14 +813,14 @@ class Generator(nn.Module):
         self.__dict__['_last_token'] = None
         if entry['mode'] == 'fp16x3' and F_.PRECISION == 'fp16x3' and F_.RANGE_PLAN is True:
             # the captured launches add to this generator's saturation word like eager ones: snapshot it behind the replay
-            if verify_range or len(self._sat_tokens) < self.MAX_PENDING_TOKENS:
-                tok = self._snapshot()
-                if not verify_range:
-                    self.__dict__['_last_token'] = tok
-                elif not self.range_ok(tok):               # this batch clamped operands: render it again (eagerly, now in bf16x3)
-                    self._drop_graphs()
-                    return self._forward_impl(styles, return_latents, return_features, inject_index, truncation,
-                                              truncation_latent, input_is_latent, None, False, image_out, False)
+            self._settle_oldest_if_full()
+            tok = self._snapshot()
+            if not verify_range:
+                self.__dict__['_last_token'] = tok
+            elif not self.range_ok(tok):                   # this batch clamped operands: render it again (eagerly, now in bf16x3)
+                self._drop_graphs()
+                return self._forward_impl(styles, return_latents, return_features, inject_index, truncation,
+                                          truncation_latent, input_is_latent, None, False, image_out, False)
         return res
 
     def _forward_impl(self, styles, return_latents=False, return_features=False, inject_index=None, truncation=1,
@@ -842,9 +887,7 @@ class Generator(nn.Module):
                                   plans is not None, return_latents, image_out)
             if plans is None:
                 return out
-            toks = self._sat_tokens
-            if not verify_range and len(toks) >= self.MAX_PENDING_TOKENS:
-                return out                                 # the host is far ahead of the device: the next poll catches up
+            self._settle_oldest_if_full()
             tok = self._snapshot()
             if not verify_range or tok is None:
                 self.__dict__['_last_token'] = tok

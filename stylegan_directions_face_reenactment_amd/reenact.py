@@ -137,8 +137,9 @@ class ReenactmentSession:
         latent = F_.latent_prepare(w, self.G.n_latent, shift=shift, shift_layers=layers)
         # (a session with graph=True captures the whole step itself -- DirectionMatrix and latent shift included -- so the
         # generator's own per-forward graphs stay out of it)
+        # (verify_range=False: the session checks every chunk's RangeToken itself, one chunk behind the launches)
         img, _ = self.G([latent], input_is_latent=True, truncation=self.truncation, truncation_latent=self.trunc,
-                        image_out=image_out, graph=False if (self.use_graph or no_graph) else None)
+                        image_out=image_out, graph=False if (self.use_graph or no_graph) else None, verify_range=False)
         return img
 
     def _graphed_step(self, sv):
@@ -178,7 +179,9 @@ class ReenactmentSession:
 
         class Chunks:
             poisoned = False    # a chunk clamped operands: chunks launched in fp16x3 before the fallback took hold are suspect too
-                                # (with two streams in flight the saturation word cannot tell which of them it was)
+                                # (with two streams in flight the saturation word cannot tell which of them it was); cleared
+                                # once a chunk launched in the fallback arithmetic has settled, or when the weights changed
+            stamp = None        # weights (Generator._range_state stamp) the flag belongs to
 
             def launch(self, lo, sv, u8):
                 if sess.use_graph and sv.shape[0] == sess.batch:
@@ -198,11 +201,20 @@ class ReenactmentSession:
                 ok = sess.G.range_ok(tok)
                 if stream is not None:
                     pipe.join(img, stream=stream)                           # the caller's stream may now read this chunk
+                st = getattr(sess.G, '_range_state', None)
+                stamp = st['stamp'] if st is not None else None
+                if self.poisoned and stamp != self.stamp:                   # new weights, fresh plan: old suspicions do not apply
+                    self.poisoned = False
+                    sess.reset_graph()
                 if not ok:
-                    self.poisoned = True
+                    self.poisoned, self.stamp = True, stamp
                 if not ok or (self.poisoned and pipe is not None and mode == 'fp16x3'):
                     sess._graph = None                                      # clamped: this chunk again, eagerly, in bf16x3
                     img, graphed = sess._step(sv, u8), False
+                elif self.poisoned and mode not in ('fp16x3', 'graph'):
+                    # every chunk launched before the fallback took hold has been re-rendered: nothing in flight is suspect now
+                    self.poisoned = False
+                    sess.reset_graph()
                 return lo, sv, u8, img, graphed
 
         return Chunks()

@@ -476,14 +476,14 @@ def test_saturation_is_counted_and_generator_falls_back():
         ok, _ = G([w], input_is_latent=True)
         assert G._range_state['mode'] == 'fp16x3' and G.saturated_pairs() == 0
         loud = [n * 1e9 if i == 4 else n for i, n in enumerate(noises)]
-        G([w], input_is_latent=True, noise=loud)
+        G([w], input_is_latent=True, noise=loud, verify_range=False)
         tok = G.take_range_token()
         assert tok is not None and G.saturated_pairs() > 0
         assert F_.split_saturation_count(reset=False) == 0          # a generator's launches never touch the device-wide counter
         torch.cuda.synchronize()                                    # (the poll below is non-blocking: let the forward finish)
         with warnings.catch_warnings(record=True) as rec:
             warnings.simplefilter('always')
-            again, _ = G([w], input_is_latent=True)
+            again, _ = G([w], input_is_latent=True, verify_range=False)
         assert G._range_state['mode'] == 'bf16x3' and any('bf16x3' in str(r.message) for r in rec)
         assert tok.delta and not G.range_ok(tok)
         with F_.precision('bf16x3'):
@@ -547,7 +547,7 @@ def test_a_clamped_batch_is_never_returned_and_neighbours_are_unaffected():
         # what an unverified fp16x3 forward of the same batch would have handed back is NOT within the bar: the test bites
         G3 = hip_generator(64, 1)
         G3([wd], input_is_latent=True)
-        bad, _ = G3([wd], input_is_latent=True, noise=loud)
+        bad, _ = G3([wd], input_is_latent=True, noise=loud, verify_range=False)
         assert maxabs(bad, ref) > 1e-3 * max(1.0, scale)
         # the neighbour: own word untouched, still fp16x3, same bits as before
         after, _ = G2([wd], input_is_latent=True, verify_range=True)
@@ -563,6 +563,59 @@ def test_a_clamped_batch_is_never_returned_and_neighbours_are_unaffected():
             warnings.simplefilter('ignore')
             img = generate_image(G4, wd, 1.0, None, input_is_latent=True)
         assert G4.saturated_pairs() > 0 and maxabs(img, ref) <= 1e-3 * max(1.0, scale)
+
+
+def test_raw_generator_call_never_returns_a_clamped_frame():
+    """VERDICT r3 #5.  The reference's scripts call `G([w], ...)` directly (run_inference.py:125, invert_images.py:103,
+    extract_statistics.py:85, utils_inference.py:88): that call -- no extra keyword -- must hand back verified frames.  Calibrate
+    on a tame batch, then the FIRST raw call on a batch whose activations sit 2^8 beyond the plan's headroom is within 1e-3 of the
+    oracle, eager and hipGraph-replayed alike; and a stream of unverified forwards (verify_range=False) notices the saturation
+    by itself even when every forward is a graph replay and the caller never asks (the replay branch polls too)."""
+    import warnings
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    if F_.PRECISION != 'fp16x3':
+        pytest.skip('range plan / saturation are fp16x3 matters')
+    state = synthetic_state(64, 1)
+    w = S.synthetic_latents(SEED, 6, n_latent=10, key='clamp.w')
+    wd = w.cuda()
+    with torch.no_grad():
+        for replay in (False, True):
+            G = hip_generator(64, 1)
+            n_warm = 4 if replay else 1                              # (the third call of a signature captures, the fourth replays)
+            for _ in range(n_warm):
+                quiet, _ = G([wd], input_is_latent=True)
+            assert G.saturated_pairs() == 0 and G.range_mode() == 'fp16x3'
+            assert bool(G.__dict__.get('_graphs')) == replay         # verified forwards replay a graph from the third call on
+            G.noises.noise_4.mul_(2.0 ** 14)
+            G._range_state = dict(G._range_state, stamp=G._weights_stamp())       # keep the tame plan: the buffers changed under it
+            for e in (G.__dict__.get('_graphs') or {}).values():
+                e['stamp'] = G._weights_stamp()
+            ref, _ = O.generator_forward(O.cast_state(state, torch.float64), [w.double()], input_is_latent=True,
+                                         noise=[getattr(G.noises, 'noise_%d' % i).cpu().double() for i in range(G.num_layers)])
+            scale = float(ref.abs().max())
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                got, _ = G([wd], input_is_latent=True)               # the raw call, first time on the loud data
+            err = maxabs(got, ref)
+            print('raw call (%s): max|ref| %.1f, returned vs fp64 oracle %.2e' % ('replay' if replay else 'eager', scale, err))
+            assert G.saturated_pairs() > 0 and G.range_mode() == 'bf16x3' and err <= 1e-3 * max(1.0, scale)
+        # unverified replays: nobody asks for tokens, the generator still falls back within MAX_PENDING_TOKENS forwards
+        G = hip_generator(64, 1)
+        for _ in range(4):
+            G([wd], input_is_latent=True, verify_range=False, graph=True)
+        assert G.__dict__.get('_graphs') and G.range_mode() == 'fp16x3'
+        G.noises.noise_4.mul_(2.0 ** 14)
+        G._range_state = dict(G._range_state, stamp=G._weights_stamp())
+        for e in G.__dict__['_graphs'].values():
+            e['stamp'] = G._weights_stamp()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            for i in range(G.MAX_PENDING_TOKENS + 2):
+                G([wd], input_is_latent=True, verify_range=False, graph=True)
+                G.take_range_token()                                  # dropped on the floor, like a caller that never checks
+        assert G.range_mode() == 'bf16x3'
+        late, _ = G([wd], input_is_latent=True, verify_range=False, graph=True)
+        assert maxabs(late, ref) <= 1e-3 * max(1.0, scale)
 
 
 def test_reenactment_session_rerenders_a_clamped_batch():
