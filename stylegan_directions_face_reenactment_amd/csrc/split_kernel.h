@@ -943,13 +943,17 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         float* const tb = reinterpret_cast<float*>(smem);
         const int TPOS = p.tpos, TCs = p.TC, OW = 2 * p.W;
         const int64_t OHW = (int64_t)4 * p.H * p.W;
+        // flipped taps, as the blur kernel; pinned in SGPRs (the compiler otherwise re-loads them from memory inside every
+        // output's FMA chain: 16 live VGPRs are more than this epilogue has to spare)
         float kf[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) kf[i] = p.fir[15 - i];      // flipped, as the blur kernel (uniform -> SGPRs)
+        for (int i = 0; i < 16; ++i)
+            kf[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.fir[15 - i])));
         const float nw = (p.noise && p.noise_w) ? p.noise_w[0] : 0.f;
         const float f_slope = p.act ? p.slope : 1.f, f_gain = p.act ? p.gain : 1.f;
         int lpos[NI], opix[NI];
         bool lok[NI];
+        float lokf[NI];                        // 1 for lanes that own an output quad, 0 for the halo ring / out-of-image lanes
         float nzq[NI][2][2];
 #pragma unroll
         for (int n = 0; n < NI; ++n) {
@@ -958,6 +962,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             const int r = fdiv(lc, p.fd_TC), c = lc - r * p.TC;
             const int a = row0 + r, b = col0 + c;
             lok[n] = l < p.TR * p.TC && r >= 1 && r <= p.TR - 2 && c >= 1 && c <= p.TC - 2 && a < p.H && b < p.W && img0 < p.B;
+            lokf[n] = lok[n] ? 1.f : 0.f;
             lpos[n] = l + p.TC + 1;
             opix[n] = lok[n] ? (2 * a) * OW + 2 * b : 0;
 #pragma unroll
@@ -968,6 +973,14 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                     nzq[n][rr][0] = t2.x; nzq[n][rr][1] = t2.y;
                 }
             }
+        }
+        // The margins of the exchange buffer (TC + 1 positions either side of the 256) are only ever read by lanes that produce
+        // no output; they are zeroed once so those lanes compute on finite values and can be masked by a multiplication
+        // (a select on the result makes the compiler wrap every output's FMA chain in its own divergent branch).
+        for (int i = tid; i < 16 * 2 * (p.TC + 1); i += NTHR) {
+            const int c16 = i / (2 * (p.TC + 1)), m = i - c16 * 2 * (p.TC + 1);
+            const int pos = m < p.TC + 1 ? m : PT + m;
+            *reinterpret_cast<float4*>(tb + (c16 * TPOS + pos) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const int cc = wm * 8 + hi * 4;        // this lane's first cout inside a 16-cout chunk (chunk g = rows 4g .. 4g+3 of every wave)
         const float4* const d4p = reinterpret_cast<const float4*>(dl + wm * 32 + 4 * hi);
@@ -1028,8 +1041,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 #pragma unroll
                             for (int xo = 0; xo < 2; ++xo) {
                                 const float x = lrelu_gain(fmaf(nw, nzq[n][rr][xo], o[rr][xo] + bv[j]), f_slope, f_gain);
-                                // (halo / out-of-image lanes computed on whatever the margins hold: zero them before they are counted)
-                                v[j2][rr][xo] = lok[n] ? x * sv[j] : 0.f;
+                                v[j2][rr][xo] = x * (sv[j] * lokf[n]);      // (x * (s * 1) == x * s; lanes without a quad: finite * 0)
                             }
                     }
 #pragma unroll

@@ -735,12 +735,14 @@ def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, 
     return blur_bias_act(planes, fir, H, W, noise, noise_weight, bias, True), None
 
 
-# Upsampling layers of the inference chain whose FIR blur runs in the transposed conv's epilogue (csrc/upfir.hip): the parity planes
-# (8 bytes of HBM traffic per output element between the two launches) never leave the CU, for a recomputed one-super-pixel halo
-# ring per patch (1.35x the layer's MFMA work at 128 x 128 inputs).  It pays where the blur launch was large against the conv's K loop:
-# inputs at least UPFIR_MIN_W wide (same-box A/B at B=64; 0 = never).  Needs the direct split hand-over (a Winograd consumer
-# takes its input from the two-pass form's blur).
-USE_UPFIR = os.environ.get('SGDFR_UPFIR', '1') != '0'
+# Upsampling layers as ONE launch: the FIR blur (+ noise, bias, leaky-ReLU, split hand-over) in the transposed conv's epilogue
+# (csrc/upfir.hip), so the parity planes -- 8 bytes of HBM traffic per output element between the two launches -- never leave the CU,
+# for a recomputed one-super-pixel halo ring per patch.  Bit-identical to the two-pass form (tests/test_gpu_upfir.py).  OFF by
+# default: measured at B=64 (scripts/upfir_ab.sh, scripts/upfir_probe.py) the fused launch of the 128 -> 256 level takes
+# 1.2-1.37 ms against 0.97 ms for conv + blur -- its FIR / conversion epilogue (0.9 ms alone) is as long as the blur launch it
+# replaces and, one block per CU, overlaps nothing, and the halo costs the K loop 1.35x the tiles.  SGDFR_UPFIR=1 takes it for
+# inputs at least UPFIR_MIN_W wide whose consumer takes the direct split hand-over.
+USE_UPFIR = os.environ.get('SGDFR_UPFIR', '0') != '0'
 UPFIR_MIN_W = int(os.environ.get('SGDFR_UPFIR_MIN_W', '128'))
 
 

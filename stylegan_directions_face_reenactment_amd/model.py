@@ -726,7 +726,7 @@ class Generator(nn.Module):
         return (tuple(w.shape), bool(input_is_latent), bool(return_latents), float(truncation),
                 None if truncation >= 1 else tuple(truncation_latent.shape), u8, F_.PRECISION, F_.RANGE_PLAN, F_.USE_SPLIT_CHAIN,
                 F_.USE_RGB_FUSION, F_.USE_SPLITK, F_.USE_PLANE_PADDING, bool(self.overlap_rgb), w.device, F_.USE_WSPLIT,
-                F_.WSPLIT_MIN_CIN, F_.WSPLIT_F,
+                F_.WSPLIT_MIN_CIN, F_.WSPLIT_F, F_.USE_UPFIR, F_.UPFIR_MIN_W,
                 # a graph's static input / output buffers belong to the stream that replays it: forwards queued on different
                 # streams (functional.StreamPipeline) get their own capture instead of racing on one
                 F_.N.stream().value)
