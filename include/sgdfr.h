@@ -194,8 +194,9 @@ int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const float* noise
                             float slope, float gain, void* stream);
 
 /* sgdfr_blur_bias_act_f32 with the result multiplied by the NEXT layer's modulation s_next [B,C] and written in that layer's
- * split input form xs [B][C/8][2][2H*2W][8] (see sgdfr_to_split_f32) instead of fp32 NCHW.  plane_stride: floats between the
- * parity planes of t (0 = dense (H+1)*(W+1), see sgdfr_modconv2d_split_f32).  wino = 2 | 4 (W = 8 ... 64): xs receives the
+ * split input form xs [B][C/8][2][2H*2W][8] (see sgdfr_to_split_f32) instead of fp32 NCHW.  plane_stride: 0 = t is the dense
+ * planar [B*C][4][(H+1)*(W+1)]; otherwise t is the interleaved [B*C][plane_stride][px][py] form of sgdfr_modconv2d_split_f32
+ * (16-byte aligned).  wino = 2 | 4 (W = 8 ... 64): xs receives the
  * Winograd input form [B][C/8][wino+2][2][2H*2W/wino][8] of sgdfr_to_wsplit_f32(f = wino) instead (2x / 1.5x the bytes), for
  * sgdfr_modconv2d_wsplit_f32. */
 int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, const float* noise, int64_t noise_bstride,
@@ -280,9 +281,11 @@ int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned 
                               const float* rgb_s, float* rgb_part, int x_is_split, unsigned short* xs_out, const float* s_next,
                               int B, int Cin, int Cout, int H, int W, int mode, int64_t plane_stride, int arith, int act,
                               float slope, float gain, unsigned int* sat, void* stream);
-/* plane_stride (UP3, ksplit <= 1; 0 = dense): floats between the parity planes of y, >= (H+1)*(W+1).  A multiple of 32 makes
- * every 32-position store run of the kernel one whole 128-byte line (dense planes are odd-sized, their stores run at half the
- * write bandwidth); sgdfr_blur_bias_act_split_f32 takes the same stride. */
+/* plane_stride (UP3, ksplit <= 1; 0 = dense planar planes y [B][Cout][4][(H+1)*(W+1)]): positions per (image, cout) of the
+ * INTERLEAVED form y [B][Cout][plane_stride][px][py] -- the four parity phases of a super-pixel are one 16-byte quad (element
+ * 2*px + py), >= (H+1)*(W+1) positions, the same bytes in total.  A multiple of 32 positions keeps every store run of the kernel
+ * on whole 128-byte lines (dense planes are odd-sized: their stores run at half the write bandwidth), a lane stores one quad
+ * instead of four dwords, and sgdfr_blur_bias_act_split_f32 (same stride) fetches a super-pixel with one 16-byte load. */
 /* x [B,Cin,H,W], s [B,Cin] -> xs [B][Cin/8][2][H*W][8] 16-bit: x*s already split (and range-shifted) the way the kernel
  * stages it; sgdfr_modconv2d_split_f32(x = xs, s = NULL, x_is_split = 1) then fills LDS by DMA only.  Producers can emit
  * that form directly: sgdfr_modconv2d_split_f32(xs_out, s_next = the NEXT layer's modulation [B,Cout]) (y may then be NULL)

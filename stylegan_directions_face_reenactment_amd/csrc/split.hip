@@ -503,6 +503,8 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
         SGDFR_REQUIRE(mode == SGDFR_MODE_UP3 && plane_stride >= (int64_t)p.R * p.P && plane_stride < (1 << 30) && ksplit <= 1,
                       "modconv_split: plane_stride is for UP3 launches without K slices, >= (H+1)*(W+1)");
         p.rps = (int)plane_stride;
+        static const int il_env = getenv("SGDFR_PLANE_IL") ? atoi(getenv("SGDFR_PLANE_IL")) : 1;      // (0: padded PLANAR planes, A/B only)
+        p.plane_il = il_env;
         p.total_pix = (int64_t)B * p.rps;
         SGDFR_REQUIRE(p.total_pix + 4ll * p.P + 8 < (1ll << 31), "modconv_split: padded position space too large");
         p.n_pix_tiles = (int)((p.total_pix + plan->pt - 1) / plan->pt);

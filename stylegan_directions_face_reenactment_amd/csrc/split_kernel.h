@@ -87,6 +87,7 @@ struct SplitParams {
     int dbg;
     int total_blocks;            // tiles x cout tiles x K slices; the grid may be smaller (persistent blocks)
     int rps;                     // UP3: positions per image of the flat space = stride of one parity plane, >= R*P (see plane_stride)
+    int plane_il;                // UP3 with plane_stride: the four parity phases of a position are stored together, y [B][Cout][rps][px][py]
     int tstep_r, tstep_c, torg;  // patch tiles: tile (ty, tx) starts at (ty*tstep_r + torg, tx*tstep_c + torg) (plain conv: TR, TC, 0)
     int tpos;                    // UPF: positions per cout of the epilogue's exchange buffer (256 + a margin of TC + 1 either side)
     const float* fir;            // UPF: the 4x4 FIR taps on the device (row-major, as Blur.kernel)
@@ -1093,6 +1094,24 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                 // the base pointer, the per-row / per-plane increments are wave-uniform)
                 const float4* const d4p = reinterpret_cast<const float4*>(dl + io);
                 float* const yp = yout + ybase[n] + (int64_t)(n0 + wm * (MI * 32) + 4 * hi) * 4 * p.rps;
+                if (p.plane_il) {      // (block-uniform) one 16-byte store per cout and position: [position][px][py], 512-byte runs per half-wave
+                    float* const yq = yp + 3 * (ybase[n] - (int64_t)dimg[n] * p.Cout * 4 * p.rps);
+#pragma unroll
+                    for (int m = 0; m < MI; ++m) {
+                        if (n0 + wm * (MI * 32) + m * 32 >= p.Cout) continue;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 d4 = d4p[m * 8 + 2 * g];
+                            const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                *reinterpret_cast<float4*>(yq + (int64_t)(m * 32 + 8 * g + j) * 4 * p.rps) =
+                                    make_float4(acc[0][m][n][4 * g + j] * dv[j], acc[PH > 2 ? 2 : 0][m][n][4 * g + j] * dv[j],
+                                                acc[PH > 1 ? 1 : 0][m][n][4 * g + j] * dv[j], acc[PH > 3 ? 3 : 0][m][n][4 * g + j] * dv[j]);
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int m = 0; m < MI; ++m) {
                     if (n0 + wm * (MI * 32) + m * 32 >= p.Cout) continue;     // padding rows of a half-filled cout tile (wave-uniform)

@@ -200,7 +200,11 @@ __device__ __forceinline__ void blur_split2(float a, float b, unsigned& hi, unsi
 // (WINO variants: 3 waves per SIMD = 168 registers -- at 128 the sliding window spills.  The 8-wave blocks of the 64 -> 128 level then
 // fit a CU only once; tried for that level: requesting the next segment's plane rows after the hand-over instead of before it, to
 // get back under 128 registers and two blocks per CU: 88 bytes of scratch remained and the level went from 367 to 513 us.)
-template <int ET, int QC, int NG, int WINO = 0>
+// IL: the planes arrive interleaved, t [planes][pstride positions][px][py] (what split.hip's MODE_UP3 writes when it is given a
+// plane_stride): a super-pixel's four phases are one 16-byte load, so a new super row of the sliding window costs three vector
+// loads (8 + 16 + 16 bytes: left neighbour's px = 1 pair, own position, right neighbour) instead of ten dword loads from four
+// planes -- four times the bytes in flight per load instruction on a kernel that is bound by loads in flight.
+template <int ET, int QC, int NG, int WINO = 0, bool IL = false>
 __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(const float* __restrict__ t, const float* __restrict__ fir,
                                                         const float* __restrict__ noise, int64_t noise_bstride,
                                                         const float* __restrict__ noise_w, const float* __restrict__ bias,
@@ -274,15 +278,38 @@ __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(c
         // segment's arithmetic -- before its hand-over -- so a block's plane reads run under its own stores (measured on the
         // 128 -> 256 level: loads alone 250 us, compute + stores alone 276 us, both in sequence 524 us).
         float rows[2 * BLUR_QV][5];
+        // IL: super row a -> T rows 2a (d0) and 2a+1 (d1), window columns 2n-1 .. 2n+3
+        const bool c_ok = n < W && valid, l_ok = c_ok && n >= 1;
+        auto load_srow = [&](int a, float (&d0)[5], float (&d1)[5]) {
+            const float* q = tp + ((int64_t)a * GW + n) * 4;
+            const bool rok = a >= 0;
+            const float2 lf = (rok && l_ok) ? *reinterpret_cast<const float2*>(q - 2) : make_float2(0.f, 0.f);        // (n-1: px 1, py 0 | 1)
+            const float4 cf = (rok && c_ok) ? *reinterpret_cast<const float4*>(q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 rf = (rok && c_ok) ? *reinterpret_cast<const float4*>(q + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            d0[0] = lf.x; d0[1] = cf.x; d0[2] = cf.z; d0[3] = rf.x; d0[4] = rf.z;
+            d1[0] = lf.y; d1[1] = cf.y; d1[2] = cf.w; d1[3] = rf.y; d1[4] = rf.w;
+        };
         auto load_segment = [&](int ms) {
+            if (IL) {
+#pragma unroll
+                for (int i = 0; i < BLUR_QV; ++i)
+                    if (ms + i < H) load_srow(ms + i + 1, rows[2 * i], rows[2 * i + 1]);
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < 2 * BLUR_QV; ++i)
                 if (ms + (i >> 1) < H) load_row(2 * ms + 2 + i, rows[i]);
         };
         {
             const int ms0 = rt * BLUR_QV * nseg;
+            if (IL) {
+                float drop[5];
+                load_srow(ms0 - 1, drop, win[0]);
+                load_srow(ms0, win[1], win[2]);
+            } else {
 #pragma unroll
-            for (int u = 0; u < 3; ++u) load_row(2 * ms0 - 1 + u, win[u]);
+                for (int u = 0; u < 3; ++u) load_row(2 * ms0 - 1 + u, win[u]);
+            }
             if (n < W) load_segment(ms0);
         }
         for (int sg = 0; sg < nseg; ++sg) {
@@ -625,8 +652,11 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
     if (B == 0) return 0;
     SGDFR_REQUIRE(t && fir && s_next && xs && (reinterpret_cast<uintptr_t>(xs) & 15) == 0, "blur_bias_act_split: null / misaligned pointer");
     SGDFR_REQUIRE(!noise || noise_w, "blur_bias_act_split: noise without noise_w");
+    static const int il_env = getenv("SGDFR_PLANE_IL") ? atoi(getenv("SGDFR_PLANE_IL")) : 1;      // (0: padded PLANAR planes, A/B only)
+    const bool il = plane_stride != 0 && il_env != 0;       // padded planes are interleaved planes (see sgdfr.h)
     if (plane_stride == 0) plane_stride = (int64_t)(H + 1) * (W + 1);
     SGDFR_REQUIRE(plane_stride >= (int64_t)(H + 1) * (W + 1) && plane_stride < (1 << 30), "blur_bias_act_split: plane_stride < (H+1)*(W+1)");
+    SGDFR_REQUIRE(!il || (reinterpret_cast<uintptr_t>(t) & 15) == 0, "blur_bias_act_split: interleaved planes must be 16-byte aligned");
     const int QC = W >= 64 ? 64 : W > 16 ? 32 : W > 8 ? 16 : W > 4 ? 8 : 4;
     const int NG = QC < 32 ? 256 / (8 * QC) : 1;
     // row segments per block: as many as keep >= 8 blocks per CU (the window slides across them: each plane row is read once)
@@ -643,29 +673,18 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
     unsigned char* out = reinterpret_cast<unsigned char*>(xs);
     void (*kern)(const float*, const float*, const float*, int64_t, const float*, const float*, const float*, unsigned char*, int,
                  int, int, int, int, int, int, float, float, unsigned*);
-    if (wino == 2) {
-        if (arith == SGDFR_SPLIT_FP16)
-            kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_FP16, 64, 1, 2> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_FP16, 32, 1, 2>
-                   : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_FP16, 16, 2, 2> : blur_split_kernel<SGDFR_SPLIT_FP16, 8, 4, 2>;
-        else
-            kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_BF16, 64, 1, 2> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_BF16, 32, 1, 2>
-                   : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_BF16, 16, 2, 2> : blur_split_kernel<SGDFR_SPLIT_BF16, 8, 4, 2>;
-    } else if (wino == 4) {
-        if (arith == SGDFR_SPLIT_FP16)
-            kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_FP16, 64, 1, 4> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_FP16, 32, 1, 4>
-                   : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_FP16, 16, 2, 4> : blur_split_kernel<SGDFR_SPLIT_FP16, 8, 4, 4>;
-        else
-            kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_BF16, 64, 1, 4> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_BF16, 32, 1, 4>
-                   : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_BF16, 16, 2, 4> : blur_split_kernel<SGDFR_SPLIT_BF16, 8, 4, 4>;
-    } else
-    if (arith == SGDFR_SPLIT_FP16)
-        kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_FP16, 64, 1> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_FP16, 32, 1>
-               : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_FP16, 16, 2> : QC == 8 ? blur_split_kernel<SGDFR_SPLIT_FP16, 8, 4>
-                                                                                  : blur_split_kernel<SGDFR_SPLIT_FP16, 4, 8>;
-    else
-        kern = QC == 64 ? blur_split_kernel<SGDFR_SPLIT_BF16, 64, 1> : QC == 32 ? blur_split_kernel<SGDFR_SPLIT_BF16, 32, 1>
-               : QC == 16 ? blur_split_kernel<SGDFR_SPLIT_BF16, 16, 2> : QC == 8 ? blur_split_kernel<SGDFR_SPLIT_BF16, 8, 4>
-                                                                                  : blur_split_kernel<SGDFR_SPLIT_BF16, 4, 8>;
+    // (ET, WINO, IL) -> the QC / NG variant of this launch
+#define SGDFR_BLUR_PICK(ET_, WINO_, IL_)                                                                                          \
+    (QC == 64   ? blur_split_kernel<ET_, 64, 1, WINO_, IL_>                                                                       \
+     : QC == 32 ? blur_split_kernel<ET_, 32, 1, WINO_, IL_>                                                                       \
+     : QC == 16 ? blur_split_kernel<ET_, 16, 2, WINO_, IL_>                                                                       \
+     : (QC == 8 || WINO_ != 0) ? blur_split_kernel<ET_, 8, 4, WINO_, IL_>                                                         \
+                : blur_split_kernel<ET_, 4, (WINO_ != 0 ? 4 : 8), WINO_, IL_>)
+#define SGDFR_BLUR_PICK_W(ET_, IL_) (wino == 2 ? SGDFR_BLUR_PICK(ET_, 2, IL_) : wino == 4 ? SGDFR_BLUR_PICK(ET_, 4, IL_) : SGDFR_BLUR_PICK(ET_, 0, IL_))
+    if (arith == SGDFR_SPLIT_FP16) kern = il ? SGDFR_BLUR_PICK_W(SGDFR_SPLIT_FP16, true) : SGDFR_BLUR_PICK_W(SGDFR_SPLIT_FP16, false);
+    else kern = il ? SGDFR_BLUR_PICK_W(SGDFR_SPLIT_BF16, true) : SGDFR_BLUR_PICK_W(SGDFR_SPLIT_BF16, false);
+#undef SGDFR_BLUR_PICK_W
+#undef SGDFR_BLUR_PICK
     hipLaunchKernelGGL(kern, dim3((int)g), dim3(8 * QC * NG), 0, as_stream(stream), t, fir, noise, noise_bstride, noise_w, bias, s_next,
                        out, B, C, H, W, (int)plane_stride, nseg, act, slope, gain, sat);
     return check_launch("blur_bias_act_split");

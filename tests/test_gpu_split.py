@@ -280,9 +280,10 @@ def test_blur_adjoint_split_equals_the_two_pass_form(C, H, B):
 
 @pytest.mark.parametrize('cin,cout,H,B', [(64, 64, 32, 64), (32, 128, 64, 5), (128, 64, 16, 200), (16, 64, 128, 2)])
 def test_padded_parity_planes_equal_dense_planes(cin, cout, H, B):
-    """plane_stride (parity planes padded to whole 128-byte lines, the inference chain's layout): same values as the dense
-    [B,Cout,4,H+1,W+1] planes, bit for bit, from the fp32-input and the pre-split-input kernel, and the blur that reads them
-    hands over the same split activation."""
+    """plane_stride (the inference chain's layout: positions padded to whole 128-byte lines AND the four parity phases of a position
+    stored together, [B,Cout,plane_stride,(px,py)]): same values as the dense [B,Cout,4,H+1,W+1] planes, bit for bit, from the
+    fp32-input and the pre-split-input kernel, and the blur that reads them hands over the same split activation (direct and both
+    Winograd forms)."""
     from stylegan_directions_face_reenactment_amd import functional as F_
     N = F_.N
     x = S.counter_tensor(11, 'pp.x', (B, cin, H, H)).cuda()
@@ -296,20 +297,24 @@ def test_padded_parity_planes_equal_dense_planes(cin, cout, H, B):
     rp = (H + 1) * (H + 1)
     ps = (rp + 31) // 32 * 32
     dense = F_.modconv_split(x, wsp, s, d, cout, arith='fp16x3', mode=N.MODE_UP3)
+
+    def planar(il):       # [B, cout, ps, px, py] -> [B, cout, phase 2*py+px, position]
+        return il.view(B, cout, ps, 2, 2).permute(0, 1, 4, 3, 2).reshape(B, cout, 4, ps)[..., :rp]
     pad_a = F_.modconv_split(x, wsp, s, d, cout, arith='fp16x3', mode=N.MODE_UP3, plane_stride=ps)
-    assert pad_a.shape == (B, cout, 4, ps) and torch.equal(pad_a[..., :rp], dense.view(B, cout, 4, rp))
+    assert pad_a.shape == (B, cout, 4, ps) and torch.equal(planar(pad_a), dense.view(B, cout, 4, rp))
     if F_.xin_ok(B, cin, cout, H, H, N.MODE_UP3):
         xs = F_.to_split(x, s, 'fp16x3')
         pad_b = F_.modconv_split(xs, wsp, None, d, cout, arith='fp16x3', mode=N.MODE_UP3, x_split=tuple(x.shape), batch=B,
                                  plane_stride=ps)
-        assert torch.equal(pad_b[..., :rp], dense.view(B, cout, 4, rp))
+        assert torch.equal(planar(pad_b), dense.view(B, cout, 4, rp))
     fir = torch.tensor(O.make_fir([1, 3, 3, 1], gain=4.0).numpy()).cuda()
     nz = S.counter_tensor(11, 'pp.n', (1, 1, 2 * H, 2 * H)).cuda()
     nw = torch.full((1,), 0.1).cuda()
     bias = S.counter_tensor(11, 'pp.b', (cout,), 0.0, 0.1).cuda()
-    a = F_.blur_bias_act_split(dense, fir, H, H, sn, nz, nw, bias, True, arith='fp16x3')
-    b = F_.blur_bias_act_split(pad_a, fir, H, H, sn, nz, nw, bias, True, arith='fp16x3', plane_stride=ps)
-    assert torch.equal(a, b)
+    for wino in ((0, 2, 4) if H <= 64 else (0,)):
+        a = F_.blur_bias_act_split(dense, fir, H, H, sn, nz, nw, bias, True, arith='fp16x3', wino=wino)
+        b = F_.blur_bias_act_split(pad_a, fir, H, H, sn, nz, nw, bias, True, arith='fp16x3', plane_stride=ps, wino=wino)
+        assert torch.equal(a, b), wino
 
 
 def test_fp16_split_saturates_instead_of_overflowing():
