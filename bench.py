@@ -854,7 +854,7 @@ def run_trainer(args, rank, world, dev):
                      'losses_finite': finite, 'loss_first_last': [round(float(losses[0]), 5), round(float(losses[-1]), 5)],
                      'fp16_saturated_pairs_fwd_and_bwd': G.saturated_pairs() if args.precision == 'fp16x3' else None,
                      'forward_arithmetic': args.precision,
-                     'backward_arithmetic': 'fp32' if args.precision == 'fp32' else F_.BACKWARD_ARITH})
+                     'backward_arithmetic': 'fp32' if args.precision == 'fp32' else F_.config().backward_arith})
     out['dtype'] = DTYPE[args.precision] + ('; backward: dL/dx convs in the same fp16 hi+lo arithmetic, range-planned per image from max|g| (bf16 hi+lo with '
                                             'SGDFR_BWD_ARITH=bf16x3), no weight gradients (G frozen), everything else f32' if args.precision != 'fp32' else '')
     out['roofline'] = roof

@@ -206,11 +206,12 @@ class StyledConvFn(Function):
         ctx.save_for_backward(x, s, d, out, noise_w, bias, noise, planes)
         ctx.mod, ctx.activate = mod, activate
         ctx.sat = F_.current_sink()         # the owning generator's saturation word: the backward's launches count there too
+        ctx.cfg = F_.config()               # ... and run under the configuration of the forward (its generator's), not the caller's
         return out
 
     @staticmethod
     def backward(ctx, g):
-        with F_.saturation_sink(ctx.sat):
+        with F_.using(ctx.cfg), F_.saturation_sink(ctx.sat):
             return StyledConvFn._backward(ctx, g)
 
     @staticmethod
@@ -220,7 +221,7 @@ class StyledConvFn(Function):
         B, cout = out.shape[0], out.shape[1]
         cin, H, W = x.shape[1], x.shape[2], x.shape[3]
         slope, gain = (0.2, 2 ** 0.5) if ctx.activate else (1.0, 1.0)
-        bw_arith = F_.BACKWARD_ARITH if F_.PRECISION != 'fp32' else 'bf16x3'
+        bw_arith = F_.config().backward_arith if F_.config().precision != 'fp32' else 'bf16x3'
         if bw_arith == 'fp16x3':
             g_pre, sums, g_max = F_.act_grad_reduce(g, out, noise, noise_w, bias, want_y=(not up) and d is not None,
                                                     slope=slope, gain=gain, want_absmax=True)
@@ -239,7 +240,7 @@ class StyledConvFn(Function):
             # two binades of headroom; with the true maximum and that headroom finite gradients cannot saturate)
             d_in, d_out = F_.split_range(ones_d, F_.ones_like_rows(B, cin, out.device), g_max, headroom=2 if up else 0)
         if up:
-            split_down = F_.PRECISION != 'fp32' and F_.split_ok(B, cout, cin, H, W, N.MODE_DOWN3)
+            split_down = F_.config().precision != 'fp32' and F_.split_ok(B, cout, cin, H, W, N.MODE_DOWN3)
             gT = None
             if split_down and not ctx.needs_input_grad[3]:
                 # frozen weights: only the conv below reads the plane gradient -> the blur adjoint writes it directly in the

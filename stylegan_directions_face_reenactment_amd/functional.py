@@ -4,6 +4,7 @@ Each function is one (or a fixed short sequence of) native launch(es) on torch's
 nothing here computes with torch ops.  Reference lines each function stands for are cited inline
 (paths relative to the reference's libs/gan/StyleGAN2/).
 """
+import dataclasses
 import functools
 import os
 import threading
@@ -14,6 +15,103 @@ from torch.autograd import Function
 from . import _native as N
 
 SQRT2 = 2 ** 0.5
+
+# ------------------------------------------------------------------ configuration
+# Every switch of the path lives in ONE frozen object.  `config()` is the configuration in force for the calling thread: the
+# innermost `with using(cfg):` block, else the process default DEFAULT (seeded from SGDFR_* environment variables once, at import).
+# A Generator holds its own (`G.config`, None = follow the ambient one) and runs its forward -- and, through the autograd
+# Functions, its backward -- under it, so two generators with different arithmetics interleave in one process; launch plans, range
+# plans and hipGraph captures are keyed on the object itself (hashable), not on an enumeration of switches.
+@dataclasses.dataclass(frozen=True)
+class Config:
+    # Arithmetic of the 3x3 modulated convs (inference path, autograd forward, dL/dx of the plain convs): 'fp16x3' | 'fp32' | 'bf16x3'
+    # (see the PRECISION comment below)
+    precision: str = 'fp16x3'
+    # Range plan of the fp16-split conv: True (calibrated per weight version) | 'exact' (measured per layer and image) | False
+    range_plan: object = True
+    backward_arith: str = 'fp16x3'      # dL/dx convs of the split kernels: 'bf16x3' | 'fp16x3' (ranged per image, autograd.py)
+    use_plane_padding: bool = True      # inference chain: parity planes of the transposed conv padded to whole lines + interleaved
+    use_split_chain: bool = True        # activations between split convs only in split form
+    use_rgb_fusion: bool = True         # ToRGB partial sums in the epilogue of the split conv that feeds it (no-grad path)
+    use_splitk: bool = True             # K-sliced launches for convs that cannot fill the chip (small batch / 4x4, 8x8 layers)
+    use_winograd: bool = True           # fp32 path, plain 3x3 layers: Winograd F(2x2,3x3) MFMA kernel when the shape allows it
+    winograd_min_blocks: int = 256      # below this many (64 cout x 64 tile) blocks the direct kernel's smaller tiles win
+    use_wsplit: bool = True             # inference chain, plain layers fed by a transposed conv + blur: 1-D Winograd form (wsplit.hip)
+    wsplit_f: int = 4                   # outputs per Winograd tile the chain prefers: 2 = F(2,3), 4 = F(4,3)
+    wsplit_min_cin: int = 128           # ... for layers with at least this many input channels (0 = never)
+    use_upfir: bool = False             # upsampling layers as one launch (csrc/upfir.hip); off: slower than conv + blur
+    upfir_min_w: int = 128              # ... for inputs at least this wide
+
+    def replace(self, **changes):
+        return dataclasses.replace(self, **changes)
+
+    @classmethod
+    def from_env(cls, env=None):
+        e = os.environ if env is None else env
+        rp = e.get('SGDFR_RANGE_PLAN', '1')
+        return cls(precision=e.get('SGDFR_PRECISION', 'fp16x3'),
+                   range_plan=False if rp == '0' else ('exact' if rp == 'exact' else True),
+                   backward_arith=e.get('SGDFR_BWD_ARITH', 'fp16x3'),
+                   use_plane_padding=e.get('SGDFR_PLANE_PADDING', '1') != '0',
+                   use_split_chain=e.get('SGDFR_SPLIT_CHAIN', '1') != '0',
+                   use_wsplit=e.get('SGDFR_WSPLIT', '1') != '0', wsplit_f=int(e.get('SGDFR_WSPLIT_F', '4')),
+                   wsplit_min_cin=int(e.get('SGDFR_WSPLIT_MIN_CIN', '128')),
+                   use_upfir=e.get('SGDFR_UPFIR', '0') != '0', upfir_min_w=int(e.get('SGDFR_UPFIR_MIN_W', '128')))
+
+    def __post_init__(self):
+        if self.precision not in ('fp32', 'fp16x3', 'bf16x3'):
+            raise ValueError("precision must be 'fp32', 'fp16x3' or 'bf16x3', got %r" % (self.precision,))
+        if self.backward_arith not in ('fp16x3', 'bf16x3'):
+            raise ValueError("backward_arith must be 'fp16x3' or 'bf16x3', got %r" % (self.backward_arith,))
+        if self.wsplit_f not in (2, 4):
+            raise ValueError('wsplit_f must be 2 or 4')
+
+
+DEFAULT = Config.from_env()
+_ambient = threading.local()
+
+
+def config():
+    """The Config in force for this thread (innermost `using` block, else DEFAULT)."""
+    return getattr(_ambient, 'cfg', None) or DEFAULT
+
+
+def set_default(cfg):
+    """Replace the process default (what bench.py --precision does); `using` blocks and generator-held configs are unaffected."""
+    global DEFAULT
+    if not isinstance(cfg, Config):
+        raise TypeError('set_default takes a functional.Config')
+    DEFAULT = cfg
+
+
+class using:
+    """`with functional.using(cfg):` -- cfg is the configuration of every launch issued by this thread inside the block."""
+
+    def __init__(self, cfg):
+        self.cfg, self.prev = cfg, None
+
+    def __enter__(self):
+        self.prev = getattr(_ambient, 'cfg', None)
+        _ambient.cfg = self.cfg
+        return self.cfg
+
+    def __exit__(self, *exc):
+        _ambient.cfg = self.prev
+
+
+_LEGACY = {n: n.lower() for n in ('PRECISION', 'RANGE_PLAN', 'USE_PLANE_PADDING', 'USE_SPLIT_CHAIN', 'USE_RGB_FUSION', 'BACKWARD_ARITH',
+                                  'USE_SPLITK', 'USE_WINOGRAD', 'USE_WSPLIT', 'WSPLIT_F', 'WSPLIT_MIN_CIN', 'WINOGRAD_MIN_BLOCKS',
+                                  'USE_UPFIR', 'UPFIR_MIN_W')}
+
+
+def __getattr__(name):
+    """Read-only views of the ambient config under the old module-level names (functional.PRECISION ...).  They cannot be
+    assigned any more: use `with using(config().replace(...))`, `set_default`, or a Generator's `config`."""
+    if name in _LEGACY:
+        return getattr(config(), _LEGACY[name])
+    raise AttributeError('module %r has no attribute %r' % (__name__, name))
+
+
 
 # bench.py sets this to a list to time the MFMA conv launches: entries are
 # (start_event, end_event, algorithmic_flops, description) recorded on the launch stream
@@ -202,8 +300,7 @@ def styles_batched(latent, specs, plans=None):
 #                         read -- at the price of fp32 hand-over between layers (no split chain, no fused ToRGB) and one extra
 #                         read of every activation
 #   False ('0')           off: the fixed 2^-4 pre-scale of round 1
-_rp = os.environ.get('SGDFR_RANGE_PLAN', '1')
-RANGE_PLAN = False if _rp == '0' else ('exact' if _rp == 'exact' else True)
+# (Config.range_plan)
 DESIGN_X_LOG2 = 10          # uncalibrated bound taken on trust for a conv input: |x| < 2^10
 CALIBRATION_HEADROOM = 6    # binades kept free above a calibrated activation maximum before the fp16 terms saturate
 
@@ -278,20 +375,10 @@ def _noise_args(noise, B, H, W):
     raise RuntimeError('noise of shape %s does not broadcast to [%d,1,%d,%d]' % (tuple(noise.shape), B, H, W))
 
 
-USE_PLANE_PADDING = os.environ.get('SGDFR_PLANE_PADDING', '1') != '0'     # inference chain: parity planes of the transposed conv padded to whole 128-byte lines
-USE_SPLIT_CHAIN = os.environ.get('SGDFR_SPLIT_CHAIN', '1') != '0'   # activations between split convs only in split form
-USE_RGB_FUSION = True        # ToRGB partial sums in the epilogue of the split conv that feeds it (no-grad path)
-BACKWARD_ARITH = os.environ.get('SGDFR_BWD_ARITH', 'fp16x3')      # dL/dx convs of the split kernels: 'bf16x3' | 'fp16x3' (ranged per image, autograd.py)
-USE_SPLITK = True            # K-sliced launches for convs that cannot fill the chip (small batch / 4x4, 8x8 layers)
-USE_WINOGRAD = True          # plain 3x3 layers: Winograd F(2x2,3x3) MFMA kernel when the shape allows it
 # Inference chain, plain layers fed by a transposed conv + blur: 1-D Winograd form of the split conv (csrc/wsplit.hip), F(4,3)
 # by default (half the MFMA work; F(2,3): 2/3).  The blur then writes 6 (F(2,3): 8) instead of 4 bytes per element, so it pays
 # where the conv's K loop dominates: layers with at least WSPLIT_MIN_CIN input channels (same-box A/B at B=64,
 # scripts/wsplit_ab.py + scripts/blur_wino_time.py; 0 = never).
-USE_WSPLIT = os.environ.get('SGDFR_WSPLIT', '1') != '0'
-WSPLIT_F = int(os.environ.get('SGDFR_WSPLIT_F', '4'))      # outputs per Winograd tile the chain prefers: 2 = F(2,3), 4 = F(4,3)
-WSPLIT_MIN_CIN = int(os.environ.get('SGDFR_WSPLIT_MIN_CIN', '128'))
-WINOGRAD_MIN_BLOCKS = 256    # below this many (64 cout x 64 tile) blocks the direct kernel's smaller tiles win
 # Arithmetic of the 3x3 modulated convs (inference path, autograd forward, and dL/dx of the plain convs; the strided dL/dx of
 # the transposed convs and the weight gradients always use the fp32 MFMA kernels):
 #   'fp16x3' (default)  fp32 operands split into fp16 hi + lo (11+11 significant bits), hi*hi + hi*lo + lo*hi on
@@ -306,7 +393,6 @@ WINOGRAD_MIN_BLOCKS = 256    # below this many (64 cout x 64 tile) blocks the di
 #                       per-layer bound RELATIVE to max|y| for inputs scaled by 2^-20 ... 2^15 and styles in [1e-3, 1e3].
 #   'fp32'              fp32 MFMA kernels (direct + Winograd) everywhere.
 #   'bf16x3'            as fp16x3 with bf16 terms: full fp32 range, 8+8 bits (~1e-4 on images; contract 1e-3).
-PRECISION = os.environ.get('SGDFR_PRECISION', 'fp16x3')
 _zeros = {}
 
 
@@ -402,24 +488,24 @@ class capture_graph:
 
 
 def set_precision(mode):
-    global PRECISION
+    """Process default arithmetic of the 3x3 convs (bench.py --precision): replaces the DEFAULT config's `precision`."""
     if mode not in ('fp32', 'fp16x3', 'bf16x3'):
         raise ValueError("precision must be 'fp32', 'fp16x3' or 'bf16x3', got %r" % (mode,))
-    PRECISION = mode
+    set_default(DEFAULT.replace(precision=mode))
 
 
-class precision:
-    """`with functional.precision('fp32'):` -- the arithmetic of the 3x3 convs inside the block."""
+class precision(using):
+    """`with functional.precision('fp32'):` -- the arithmetic of the 3x3 convs inside the block (the ambient config otherwise)."""
 
     def __init__(self, mode):
-        self.mode, self.prev = mode, None
+        if mode not in ('fp32', 'fp16x3', 'bf16x3'):
+            raise ValueError("precision must be 'fp32', 'fp16x3' or 'bf16x3', got %r" % (mode,))
+        self.mode = mode
+        super().__init__(None)
 
     def __enter__(self):
-        self.prev = PRECISION
-        set_precision(self.mode)
-
-    def __exit__(self, *exc):
-        set_precision(self.prev)
+        self.cfg = config().replace(precision=self.mode)
+        return super().__enter__()
 
 
 def _zero_words(device):
@@ -441,11 +527,11 @@ def prepack_wino(weight, adjoint=False):
 
 
 def wino_ok(B, cin, cout, H, W):
-    if not USE_WINOGRAD:
+    if not config().use_winograd:
         return False
     if not N.load().sgdfr_modconv2d_wino_supported(B, cin, cout, H, W):
         return False
-    return ((B * (H // 2) * (W // 2) + 63) // 64) * (cout // 64) >= WINOGRAD_MIN_BLOCKS
+    return ((B * (H // 2) * (W // 2) + 63) // 64) * (cout // 64) >= config().winograd_min_blocks
 
 
 def modconv_wino(x, u, s, d, cout, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2,
@@ -473,7 +559,7 @@ def prepack_split(weight, arith=None, adjoint=False):
     """weight [1,Cout,Cin,3,3] -> uint16 buffer of 16-bit hi/lo terms of weight/sqrt(9 Cin) in split.hip's LDS order
     (arith: 'bf16x3' or 'fp16x3', default = the current PRECISION; adjoint: True = the pack of dL/dx of the plain conv,
     'down' = of dL/dx of the transposed conv, mode DOWN3)."""
-    arith = _SPLIT_ARITH[arith or PRECISION]
+    arith = _SPLIT_ARITH[arith or config().precision]
     N.require_device(weight)
     w = N.f32c(weight)
     _, cout, cin, k, _ = w.shape
@@ -491,7 +577,7 @@ def _shape_query(name, *shape):
 
 
 def split_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
-    return PRECISION in _SPLIT_ARITH and bool(_shape_query('sgdfr_modconv2d_split_supported', B, cin, cout, H, W, mode))
+    return config().precision in _SPLIT_ARITH and bool(_shape_query('sgdfr_modconv2d_split_supported', B, cin, cout, H, W, mode))
 
 
 def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2,
@@ -500,7 +586,7 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
     """3x3 modulated conv in a split arithmetic (same contract as modconv_raw, modes PLAIN3 and UP3); `wsp` must have
     been packed for the same `arith`.  rgb = (w_rgb [3,Cout], s_rgb [B,Cout]) also returns the per-cout-tile partial sums
     [B, T*3, H, W] of the ToRGB 1x1 conv that follows the layer (see rgb_fusable / torgb_finish)."""
-    arith = _SPLIT_ARITH[arith or PRECISION]
+    arith = _SPLIT_ARITH[arith or config().precision]
     N.require_device(s, d, bias, noise_weight)
     if not wsp.is_cuda or wsp.dtype != torch.int16:
         raise RuntimeError('modconv_split: wsp must be the int16 device buffer made by prepack_split')
@@ -534,7 +620,7 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
             raise RuntimeError('modconv_split: want_y=False only makes sense with the fused ToRGB (rgb=...) or s_next')
         y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32) if want_y else None
     st, sat = N.stream(), _sat()
-    ks = _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cin, cout, H, W, mode) if USE_SPLITK else 1
+    ks = _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cin, cout, H, W, mode) if config().use_splitk else 1
     if ks > 1 and y is None:
         raise RuntimeError('modconv_split: this launch is K-sliced and cannot fuse ToRGB (check rgb_fusable first)')
     partials = torch.empty((ks,) + tuple(y.shape), device=x.device, dtype=torch.float32) if ks > 1 else None
@@ -569,7 +655,7 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
 def prepack_wsplit(weight, arith=None, f=2):
     """weight [1,Cout,Cin,3,3] -> int16 buffer of the hi/lo terms of U = G (weight/sqrt(9 Cin)) per kernel row in wsplit.hip's
     LDS order (Cout % 128 == 0); f = outputs per Winograd tile (2: F(2,3), 4: F(4,3))."""
-    arith = _SPLIT_ARITH[arith or PRECISION]
+    arith = _SPLIT_ARITH[arith or config().precision]
     N.require_device(weight)
     w = N.f32c(weight)
     _, cout, cin, k, _ = w.shape
@@ -579,17 +665,17 @@ def prepack_wsplit(weight, arith=None, f=2):
 
 
 def wsplit_ok(B, cin, cout, H, W, f=2):
-    return PRECISION in _SPLIT_ARITH and bool(_shape_query('sgdfr_modconv2d_wsplit_supported', B, cin, cout, H, W, f))
+    return config().precision in _SPLIT_ARITH and bool(_shape_query('sgdfr_modconv2d_wsplit_supported', B, cin, cout, H, W, f))
 
 
 def wsplit_chain_f(B, cin, cout, H, W):
     """Winograd form the inference chain runs this plain layer (fed by a transposed conv + blur) in: 0 (direct), 2 or 4 outputs
     per tile."""
-    if not (USE_WSPLIT and USE_SPLIT_CHAIN and WSPLIT_MIN_CIN > 0 and cin >= WSPLIT_MIN_CIN and W <= 128):
+    if not (config().use_wsplit and config().use_split_chain and config().wsplit_min_cin > 0 and cin >= config().wsplit_min_cin and W <= 128):
         return 0
-    for f in ((4, 2) if WSPLIT_F == 4 else (2,)):
+    for f in ((4, 2) if config().wsplit_f == 4 else (2,)):
         # (F(2,3) hands over 8 bytes per element and saves a third of the MFMAs: it only pays from 256 input channels on)
-        if wsplit_ok(B, cin, cout, H, W, f) and (f == 4 or cin >= max(WSPLIT_MIN_CIN, 256)):
+        if wsplit_ok(B, cin, cout, H, W, f) and (f == 4 or cin >= max(config().wsplit_min_cin, 256)):
             return f
     return 0
 
@@ -604,7 +690,7 @@ WSPLIT_GROWTH_LOG2 = {2: 1, 4: 4}      # |B^T d| <= 2 max|d| (F(2,3)) / 10 max|d
 def to_wsplit(x, s, arith=None, f=2):
     """x [B,Cin,H,W], s [B,Cin] -> int16 buffer [B, Cin/8, f+2, 2, H*W/f, 8]: the Winograd input transform of x*s per tile of f
     outputs, split (the "WS" form modconv_wsplit stages by DMA)."""
-    arith = _SPLIT_ARITH[arith or PRECISION]
+    arith = _SPLIT_ARITH[arith or config().precision]
     N.require_device(x, s)
     x, s = N.f32c(x), N.f32c(s)
     B, cin, H, W = x.shape
@@ -617,7 +703,7 @@ def modconv_wsplit(vs, shape, wsp, d, cout, noise=None, noise_weight=None, bias=
                    arith=None, rgb=None, want_y=True, s_next=None, desc=None, f=2):
     """Plain 3x3 modulated conv of a WS input (to_wsplit / the blur's Winograd hand-over; shape = (B, Cin, H, W)) with the pack of
     prepack_wsplit (same f).  Outputs as modconv_split with a pre-split input: y | (y, part) | (y, part, xs_out)."""
-    arith = _SPLIT_ARITH[arith or PRECISION]
+    arith = _SPLIT_ARITH[arith or config().precision]
     N.require_device(d, bias, noise_weight)
     if not vs.is_cuda or vs.dtype != torch.int16 or not wsp.is_cuda or wsp.dtype != torch.int16:
         raise RuntimeError('modconv_wsplit: vs / wsp are the int16 device buffers made by to_wsplit / prepack_wsplit')
@@ -648,7 +734,7 @@ def modconv_wsplit(vs, shape, wsp, d, cout, noise=None, noise_weight=None, bias=
 def planes_to_split(gt, d, arith=None):
     """gt [B,C,4,H+1,W+1] (gradient of the transposed conv's parity planes), d [B,C] or None -> int16 buffer
     [B, 4*C/8, 2, (H+1)*(W+1), 8]: gt*d in the phase-major split form that modconv_split(mode=DOWN3) stages."""
-    arith = _SPLIT_ARITH[arith or PRECISION]
+    arith = _SPLIT_ARITH[arith or config().precision]
     N.require_device(gt, d)
     gt = N.f32c(gt)
     B, C, _, R, P = gt.shape
@@ -661,7 +747,7 @@ def planes_to_split(gt, d, arith=None):
 def to_split(x, s, arith=None):
     """x [B,Cin,H,W], s [B,Cin] -> int16 buffer [B, Cin/8, 2, H*W, 8]: x*s in the split form the kernels stage
     (modconv_split(x=that, s=None, x_split=(B,Cin,H,W)) then fills LDS by DMA)."""
-    arith = _SPLIT_ARITH[arith or PRECISION]
+    arith = _SPLIT_ARITH[arith or config().precision]
     N.require_device(x, s)
     x, s = N.f32c(x), N.f32c(s)
     B, cin, H, W = x.shape
@@ -682,7 +768,7 @@ class SplitAct:
 
 def xin_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
     """Can the split conv of this shape take its input as a SplitAct?"""
-    return USE_SPLIT_CHAIN and split_ok(B, cin, cout, H, W, mode) and \
+    return config().use_split_chain and split_ok(B, cin, cout, H, W, mode) and \
         bool(_shape_query('sgdfr_modconv2d_split_xin_supported', B, cin, cout, H, W, mode))
 
 
@@ -721,7 +807,7 @@ def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, 
     if s_next is not None and not wino_next and x_split is not None and upfir_chain_ok(B, x_split[1], cout, H, W):
         xs = modconv_upfir_split(xin, x_split, wsp, d, cout, fir, s_next, noise, noise_weight, bias, True)
         return SplitAct(xs, (B, cout, 2 * H, 2 * W)), None
-    if s_next is not None and USE_PLANE_PADDING and \
+    if s_next is not None and config().use_plane_padding and \
             _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, x_split[1] if x_split else x.shape[1], cout, H, W, N.MODE_UP3) == 1:
         # parity planes padded to whole 128-byte lines: the odd-sized dense planes make every store run straddle two lines
         ps = ((H + 1) * (W + 1) + 31) // 32 * 32
@@ -742,17 +828,15 @@ def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, 
 # 1.2-1.37 ms against 0.97 ms for conv + blur -- its FIR / conversion epilogue (0.9 ms alone) is as long as the blur launch it
 # replaces and, one block per CU, overlaps nothing, and the halo costs the K loop 1.35x the tiles.  SGDFR_UPFIR=1 takes it for
 # inputs at least UPFIR_MIN_W wide whose consumer takes the direct split hand-over.
-USE_UPFIR = os.environ.get('SGDFR_UPFIR', '0') != '0'
-UPFIR_MIN_W = int(os.environ.get('SGDFR_UPFIR_MIN_W', '128'))
 
 
 def upfir_ok(B, cin, cout, H, W):
-    return PRECISION in _SPLIT_ARITH and bool(_shape_query('sgdfr_modconv2d_upfir_supported', B, cin, cout, H, W))
+    return config().precision in _SPLIT_ARITH and bool(_shape_query('sgdfr_modconv2d_upfir_supported', B, cin, cout, H, W))
 
 
 def upfir_chain_ok(B, cin, cout, H, W):
     """Does the inference chain run this upsampling layer as ONE launch (transposed conv + blur fused)?"""
-    return USE_UPFIR and USE_SPLIT_CHAIN and UPFIR_MIN_W > 0 and W >= UPFIR_MIN_W and upfir_ok(B, cin, cout, H, W)
+    return config().use_upfir and config().use_split_chain and config().upfir_min_w > 0 and W >= config().upfir_min_w and upfir_ok(B, cin, cout, H, W)
 
 
 def modconv_upfir_split(xs_in, shape, wsp, d, cout, fir, s_next, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2,
@@ -760,7 +844,7 @@ def modconv_upfir_split(xs_in, shape, wsp, d, cout, fir, s_next, noise=None, noi
     """Upsampling StyledConv in one launch: xs_in = the split form of x*s (shape = (B, Cin, H, W)) -> the split form of
     act(blur(conv_transpose(x*s) * d) + noise + bias) * s_next, [B, cout/8, 2, 2H*2W, 8] int16 (same bits as
     modconv_split(mode=UP3) + blur_bias_act_split)."""
-    arith = _SPLIT_ARITH[arith or PRECISION]
+    arith = _SPLIT_ARITH[arith or config().precision]
     N.require_device(d, fir, bias, noise_weight, s_next)
     if not xs_in.is_cuda or xs_in.dtype != torch.int16 or not wsp.is_cuda or wsp.dtype != torch.int16:
         raise RuntimeError('modconv_upfir_split: xs_in / wsp are the int16 device buffers made by to_split / prepack_split')
@@ -778,8 +862,8 @@ def modconv_upfir_split(xs_in, shape, wsp, d, cout, fir, s_next, noise=None, noi
 def rgb_fusable(B, cin, cout, H, W):
     """True when the plain 3x3 conv of this shape runs on the split kernel in one pass, so the ToRGB that follows it can be
     accumulated in its epilogue instead of re-reading the activation."""
-    return USE_RGB_FUSION and split_ok(B, cin, cout, H, W) and \
-        (not USE_SPLITK or _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cin, cout, H, W, N.MODE_PLAIN3) == 1)
+    return config().use_rgb_fusion and split_ok(B, cin, cout, H, W) and \
+        (not config().use_splitk or _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cin, cout, H, W, N.MODE_PLAIN3) == 1)
 
 
 class StreamPipeline:
@@ -875,7 +959,7 @@ def modconv_raw(x, wp, s, d, cout, mode, H, W, noise=None, noise_weight=None, bi
         y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
     nz, nzb = _noise_args(noise, B, H, W) if mode == N.MODE_PLAIN3 else (None, 0)
     st = N.stream()
-    splits = N.load().sgdfr_modconv2d_splitk_hint(B, cin, cout, H, W, mode) if USE_SPLITK else 1
+    splits = N.load().sgdfr_modconv2d_splitk_hint(B, cin, cout, H, W, mode) if config().use_splitk else 1
     if splits > 1:      # too few tiles to fill the chip: slice K across extra blocks, reduce deterministically
         partials = torch.empty((splits,) + tuple(y.shape), device=x.device, dtype=torch.float32)
         _timed_conv((desc or 'conv') + ' splitK%d' % splits, B * conv_flops(cin, cout, H, W), lambda: N.call(
@@ -912,7 +996,7 @@ def blur_bias_act_split(planes, fir, H, W, s_next, noise=None, noise_weight=None
     [B, C/8, 2, 2H*2W, 8] int16) instead of fp32 NCHW.  plane_stride: floats between the parity planes when `planes` is the
     padded [B, C, 4, plane_stride] buffer of modconv_split(mode=UP3, plane_stride=...).  wino = 2 | 4: the Winograd input form
     of to_wsplit(f=wino) instead ([B, C/8, wino+2, 2, 4HW/wino, 8], for modconv_wsplit)."""
-    arith = _SPLIT_ARITH[arith or PRECISION]
+    arith = _SPLIT_ARITH[arith or config().precision]
     N.require_device(planes, fir, bias, noise_weight, s_next)
     B, C = planes.shape[0], planes.shape[1]
     nz, nzb = _noise_args(noise, B, 2 * H, 2 * W)
@@ -944,7 +1028,7 @@ def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_we
     if not upsample:
         B = s.shape[0] if batch is None else batch
         if split is not None and split_ok(B, cin, cout, H, W):
-            if RANGE_PLAN and not ranged and PRECISION == 'fp16x3' and d is not None:
+            if config().range_plan and not ranged and config().precision == 'fp16x3' and d is not None:
                 s, d = _exact_range(x, s, d, batch)       # (ranged: the caller's s, d already carry a plan)
             return modconv_split(x, split() if callable(split) else split, s, d, cout, noise, noise_weight, bias,
                                  activate, slope, gain, batch, rgb=rgb, want_y=want_y)
@@ -960,7 +1044,7 @@ def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_we
     Bu = s.shape[0] if batch is None else batch
     use_split = split is not None and split_ok(Bu, cin, cout, H, W, N.MODE_UP3)
     if use_split:
-        if RANGE_PLAN and not ranged and PRECISION == 'fp16x3' and d is not None:
+        if config().range_plan and not ranged and config().precision == 'fp16x3' and d is not None:
             s, d = _exact_range(x, s, d, batch)
         planes = modconv_split(x, split() if callable(split) else split, s, d, cout, batch=batch, mode=N.MODE_UP3)
     else:
@@ -1059,7 +1143,7 @@ def blur_adjoint(g, fir, planes=None):
 def blur_adjoint_split(g, fir, planes=None, d=None, arith=None):
     """blur_adjoint + planes_to_split in one pass: g [B,C,2H,2W] -> (the int16 phase-major split form of gT*d that
     modconv_split(mode=DOWN3) stages, asum [B,C] = sum gT*T when the forward planes are given)."""
-    arith = _SPLIT_ARITH[arith or PRECISION]
+    arith = _SPLIT_ARITH[arith or config().precision]
     N.require_device(g, fir, planes, d)
     g = N.f32c(g)
     B, C, H2, W2 = g.shape

@@ -1,0 +1,119 @@
+"""hipGraph replay of repeated no-grad forwards: which calls may be replayed (_graph_key), the capture at the third call
+of a signature, the replay with its range-token bookkeeping.  Mixed into model.Generator."""
+import os
+
+import torch
+
+from . import functional as F_
+
+USE_GRAPHS = os.environ.get('SGDFR_GRAPHS', '1') != '0'      # hipGraph replay of repeated no-grad forwards (Generator.forward)
+
+
+class GraphReplayMixin:
+    """Methods of model.Generator (which provides _forward_impl, _weights_stamp, range_mode, the RangePlanMixin)."""
+    GRAPH_AFTER = 2                 # eager no-grad forwards of one signature before the next one is captured as a hipGraph
+    MAX_GRAPHS = 4                  # captured signatures kept per generator (each holds its intermediates in a private pool)
+
+    def _drop_graphs(self):
+        self.__dict__.pop('_graphs', None)
+        self.__dict__.pop('_graph_calls', None)
+
+    GRAPH_MAX_WORK = 6              # default policy: replay when batch * (size / 256)^2 <= this (host-bound forwards), or when verified
+
+    def _graph_key(self, styles, return_latents, inject_index, truncation, truncation_latent, input_is_latent, noise,
+                   randomize_noise, image_out, verify_range, graph):
+        """Signature under which a no-grad forward may be replayed as a hipGraph, or None when it must run eagerly: gradients,
+        style mixing, caller-supplied or fresh noise, a caller-owned uint8 target, hooks, an enclosing capture, bench timing --
+        and, unless graph=True, forwards that are neither host-bound nor verified (see forward)."""
+        if graph is False or not USE_GRAPHS or not getattr(self, 'use_graphs', True) or torch.is_grad_enabled() or \
+                F_.CONV_TIMING is not None or F_.HBM_TIMING is not None:
+            return None
+        if len(styles) != 1 or inject_index is not None or noise is not None or randomize_noise:
+            return None
+        w = styles[0]
+        if not isinstance(w, torch.Tensor) or not w.is_cuda or w.dtype != torch.float32 or w.requires_grad:
+            return None
+        if graph is None and not verify_range and w.shape[0] * (self.size / 256.0) ** 2 > self.GRAPH_MAX_WORK:
+            return None
+        if image_out is not None and image_out.frames is not None:
+            return None
+        if truncation < 1 and truncation_latent is None:
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        mods = self.__dict__.get('_all_mods')
+        if mods is None:
+            mods = self.__dict__['_all_mods'] = list(self.modules())
+        for m in mods:
+            if m._forward_hooks or m._forward_pre_hooks:
+                return None
+        u8 = None if image_out is None else ('u8', image_out.swap_rb)
+        return (tuple(w.shape), bool(input_is_latent), bool(return_latents), float(truncation),
+                None if truncation >= 1 else tuple(truncation_latent.shape), u8, F_.config(), bool(self.overlap_rgb), w.device,
+                # a graph's static input / output buffers belong to the stream that replays it: forwards queued on different
+                # streams (functional.StreamPipeline) get their own capture instead of racing on one
+                F_.N.stream().value)
+
+    def _replay_or_run(self, key, styles, return_latents, return_features, inject_index, truncation, truncation_latent, input_is_latent,
+                       image_out, verify_range):
+        """forward() for a call that has a graph signature: eager until the signature has settled, then capture once, then replay."""
+        graphs = self.__dict__.setdefault('_graphs', {})
+        calls = self.__dict__.setdefault('_graph_calls', {})
+        stamp, mode = self._weights_stamp(), self.range_mode()
+        entry = graphs.get(key)
+        if entry is not None and (entry['stamp'] != stamp or entry['mode'] != mode):
+            self._drop_graphs()                            # new weights / the generator changed arithmetic: every graph is stale
+            graphs = self.__dict__.setdefault('_graphs', {})
+            calls = self.__dict__.setdefault('_graph_calls', {})
+            entry = None
+        w = styles[0]
+        trunc = truncation_latent if truncation < 1 else None
+        if entry is not None and entry['mode'] == 'fp16x3' and self.__dict__.get('_sat_tokens'):
+            # the non-blocking poll of the eager path (_range_plans), which a replay never reaches: tokens of finished forwards are
+            # resolved here, and a saturation seen in any of them switches this generator to bf16x3 before the next replay
+            seen = self._check_tokens()
+            if seen:
+                self._fall_back(seen, 'in earlier forwards')
+                self._drop_graphs()
+                return self._forward_impl(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
+                                          input_is_latent, None, False, image_out, verify_range)
+        if entry is None:
+            n = calls.get(key, 0)
+            if n < self.GRAPH_AFTER:                       # not yet: packs, launch plans and the range calibration settle eagerly
+                calls[key] = n + 1
+                return self._forward_impl(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
+                                          input_is_latent, None, False, image_out, verify_range)
+            st = getattr(self, '_range_state', None)
+            if F_.config().precision == 'fp16x3' and F_.config().range_plan is True and (st is None or st['stamp'] != stamp):
+                return self._forward_impl(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
+                                          input_is_latent, None, False, image_out, verify_range)       # calibrate first (host read)
+            s_in = w.detach().clone()
+            s_tr = trunc.detach().clone() if trunc is not None else None
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with F_.capture_graph(g):
+                out = self._forward_impl([s_in], return_latents, False, None, truncation, s_tr, input_is_latent, None, False,
+                                         None if image_out is None else F_.U8Target(None, 0, image_out.swap_rb), False)
+            mode = self.range_mode()
+            entry = {'graph': g, 'in': s_in, 'trunc': s_tr, 'out': out, 'stamp': stamp, 'mode': mode}
+            while len(graphs) >= self.MAX_GRAPHS:
+                graphs.pop(next(iter(graphs)))
+            graphs[key] = entry
+        entry['in'].copy_(w)
+        if entry['trunc'] is not None:
+            entry['trunc'].copy_(trunc)
+        entry['graph'].replay()
+        img, lat = entry['out']
+        res = (img.clone(), lat.clone() if lat is not None else None)
+        self.__dict__['_last_token'] = None
+        if entry['mode'] == 'fp16x3' and F_.config().precision == 'fp16x3' and F_.config().range_plan is True:
+            # the captured launches add to this generator's saturation word like eager ones: snapshot it behind the replay
+            self._settle_oldest_if_full()
+            tok = self._snapshot()
+            if not verify_range:
+                self.__dict__['_last_token'] = tok
+            elif not self.range_ok(tok):                   # this batch clamped operands: render it again (eagerly, now in bf16x3)
+                self._drop_graphs()
+                return self._forward_impl(styles, return_latents, return_features, inject_index, truncation,
+                                          truncation_latent, input_is_latent, None, False, image_out, False)
+        return res

@@ -27,6 +27,9 @@ from torch import nn
 
 from . import autograd as AG
 from . import functional as F_
+from .graph_runner import GraphReplayMixin
+from .planner import PlannerMixin
+from .range_plan import RangePlanMixin, RangeToken  # noqa: F401  (RangeToken re-exported: callers hold tokens)
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d  # noqa: F401  (re-exported like model.py:8)
 
 
@@ -39,7 +42,6 @@ def make_kernel(k):
 
 
 _SIDE_STREAMS = {}
-USE_GRAPHS = os.environ.get('SGDFR_GRAPHS', '1') != '0'      # hipGraph replay of repeated no-grad forwards (Generator.forward)
 
 
 def _side_stream(device):
@@ -48,25 +50,6 @@ def _side_stream(device):
     if st is None:
         st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
     return st
-
-
-class RangeToken:
-    """One no-grad fp16x3 forward's claim on its generator's saturation word: `snap` (pinned host int32) receives the word's
-    value right after the forward's last launch, `event` marks that copy; `delta` = pairs clamped by THIS forward, filled in
-    when the token is checked (Generator.range_ok / the non-blocking poll of the next forward).  `stamp` = the weights the forward
-    ran on (a saturation of OLD weights must not switch the arithmetic of new ones); `suspect`: another forward that was in flight
-    beside this one (other HIP stream) clamped operands and the shared word cannot tell the two apart -- range_ok() says False."""
-    __slots__ = ('event', 'snap', 'delta', 'stamp', 'suspect')
-
-    def __init__(self, event, snap, stamp=None):
-        self.event, self.snap, self.delta, self.stamp, self.suspect = event, snap, None, stamp, False
-
-
-_PINNED_WORDS = []      # free list of pinned int32 [1] host tensors (a fresh pin_memory() per forward would cost ~20 us)
-
-
-def _pinned_word():
-    return _PINNED_WORDS.pop() if _PINNED_WORDS else torch.zeros(1, dtype=torch.int32).pin_memory()
 
 
 def _needs_grad(*tensors):
@@ -224,7 +207,7 @@ class ModulatedConv2d(nn.Module):
     def packed_split(self, adjoint=False, arith=None):
         """16-bit hi/lo weight pack of the split precision modes (default arith = functional.PRECISION), cached per weight
         version (adjoint=True: the pack of the plain conv's dL/dx conv; 'down': of the transposed conv's, mode DOWN3)."""
-        arith = arith or F_.PRECISION
+        arith = arith or F_.config().precision
         key = self._key()
         cache = getattr(self, '_pack_s', None)
         if cache is None or cache[0] != key:
@@ -237,7 +220,7 @@ class ModulatedConv2d(nn.Module):
 
     def packed_wsplit(self, arith=None, f=2):
         """Weight pack of the 1-D Winograd form F(f,3) of the plain split conv (functional.prepack_wsplit), cached like packed_split."""
-        arith = arith or F_.PRECISION
+        arith = arith or F_.config().precision
         key = self._key()
         cache = getattr(self, '_pack_s', None)
         if cache is None or cache[0] != key:
@@ -374,7 +357,7 @@ class ToRGB(nn.Module):
         return F_.torgb_finish(part, bias=self.bias.view(3), skip=skip, fir=fir, u8=u8)
 
 
-class Generator(nn.Module):
+class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
     def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01):
         super().__init__()
         self.size = size
@@ -409,6 +392,9 @@ class Generator(nn.Module):
             in_channel = out_channel
         self.n_latent = self.log_size * 2 - 2
         self.overlap_rgb = True     # run the ToRGB chain on a side stream in no-grad forwards
+        # functional.Config this generator runs under (arithmetic, range plan, chain / Winograd / fusion switches); None = whatever
+        # is in force where it is called (functional.config(): a `using` block, else the process default)
+        self.config = None
 
     def invalidate_packs(self):
         """Forget every cached weight re-pack and launch plan.  Needed only after in-place edits through `.data`
@@ -452,8 +438,6 @@ class Generator(nn.Module):
     def get_latent(self, input):
         return self.style(input)
 
-    # ---- range plan of the fp16-split arithmetic (functional.PRECISION == 'fp16x3') and this generator's saturation word
-    MAX_PENDING_TOKENS = 8          # unchecked forwards in flight before a forward stops adding snapshots (host far ahead)
 
     def _params(self):
         """The parameter list, walked once and cached (nn.Module.parameters() costs ~0.15 ms per call on this module tree:
@@ -475,17 +459,6 @@ class Generator(nn.Module):
             v += p._version
         return (w.data_ptr(), w.device, v)
 
-    def _sat_word(self):
-        """This generator's saturation word (functional.saturation_sink): one int32 on the weights' device, owned by the
-        instance -- not a buffer (never in the state_dict), deep-copied with the module, re-made after .to(device)."""
-        dev = self.input.input.device
-        w = self.__dict__.get('_sat')
-        if w is None or w.device != dev:
-            w = self.__dict__['_sat'] = F_.new_saturation_word(dev)
-            self.__dict__['_sat_seen'] = 0
-            self.__dict__['_sat_tokens'] = []
-        return w
-
     def __deepcopy__(self, memo):
         # (optimization.py:28 deep-copies G) the copy gets its own word and no tokens of the original
         import copy
@@ -504,233 +477,7 @@ class Generator(nn.Module):
             st.pop(k, None)
         return st
 
-    def _snapshot(self):
-        """Queue an async copy of the saturation word into pinned host memory behind everything launched so far on the current
-        stream; returns the RangeToken (None while capturing a graph)."""
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        word = self._sat_word()
-        snap = _pinned_word()
-        snap.copy_(word, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        st = getattr(self, '_range_state', None)
-        tok = RangeToken(ev, snap, st['stamp'] if st is not None else None)
-        self._sat_tokens.append(tok)
-        return tok
-
-    def _check_tokens(self, upto=None):
-        """Resolve queued tokens in order: all that are complete (upto=None, never blocks) or everything up to and including
-        `upto` (blocks on its event).  Returns the number of newly seen saturated pairs."""
-        toks = self.__dict__.get('_sat_tokens')
-        new = 0
-        while toks:
-            tok = toks[0]
-            if upto is not None:
-                tok.event.synchronize()
-            elif not tok.event.query():
-                break
-            toks.pop(0)
-            val = int(tok.snap[0]) & 0xffffffff
-            # Snapshots of forwards on DIFFERENT streams (functional.StreamPipeline) may be taken out of queue order: a later
-            # token can hold a smaller value.  The running maximum (as a signed 32-bit distance: the word may wrap) keeps the
-            # deltas non-negative; whoever was still in flight when a non-zero delta shows up is marked suspect, because the
-            # shared word cannot say which of the overlapping forwards clamped.
-            dist = (val - self._sat_seen) & 0xffffffff
-            tok.delta = dist if dist < 0x80000000 else 0
-            if tok.delta:
-                self.__dict__['_sat_seen'] = val
-                for other in toks:
-                    other.suspect = True
-            if tok.suspect and not tok.delta:
-                tok.delta = 1
-            new += tok.delta
-            _PINNED_WORDS.append(tok.snap)
-            tok.snap = None
-            if tok is upto:
-                break
-        return new
-
-    def _settle_oldest_if_full(self):
-        """Every fp16x3 forward leaves a token -- no forward goes unchecked.  When MAX_PENDING_TOKENS are already queued (the host
-        runs that far ahead of the device) the OLDEST one is awaited first: the host then trails the device by at most that
-        many forwards, and a saturation in the awaited forward switches the arithmetic at once."""
-        toks = self.__dict__.get('_sat_tokens')
-        if toks and len(toks) >= self.MAX_PENDING_TOKENS and not torch.cuda.is_current_stream_capturing():
-            seen = self._check_tokens(upto=toks[0])
-            if seen:
-                self._fall_back(seen, 'in earlier forwards')
-
-    def saturated_pairs(self):
-        """fp16 operand pairs this generator's launches (forward and backward) clamped or found non-finite so far
-        (synchronises the device).  0 = the fp32-grade claim of the fp16x3 arithmetic held for everything it produced."""
-        return int(self._sat_word().item()) & 0xffffffff
-
-    def _fall_back(self, pairs, where):
-        st = getattr(self, '_range_state', None)
-        if st is not None and st['mode'] == 'fp16x3':
-            st['mode'] = 'bf16x3'
-            warnings.warn('Generator: %d fp16 operand pairs left the planned range (or were NaN/Inf) %s; this generator now runs '
-                          'the bf16x3 arithmetic (fp32 exponent range) until its weights change' % (pairs, where),
-                          RuntimeWarning, stacklevel=4)
-
-    def range_ok(self, token):
-        """Did the forward behind `token` stay inside the fp16 range plan?  Blocks until that forward has finished (and only that
-        far).  False: it clamped operands -- the generator has switched itself to bf16x3, re-render the batch."""
-        if token is None:
-            return True
-        if token.delta is None:
-            self._check_tokens(upto=token)
-        if token.delta:
-            st = getattr(self, '_range_state', None)
-            # (a token of weights that have since been replaced: re-render, but leave the NEW weights' calibrated plan alone)
-            if st is not None and (token.stamp is None or token.stamp == st['stamp']):
-                self._fall_back(token.delta, 'in the forward just checked')
-            return False
-        return True
-
-    def range_mode(self):
-        """Arithmetic the next no-grad forward of this generator will run in ('fp16x3' with a live range plan, its fallback, or
-        functional.PRECISION when no plan applies)."""
-        st = getattr(self, '_range_state', None)
-        if F_.PRECISION == 'fp16x3' and F_.RANGE_PLAN is True and st is not None:
-            return st['mode']
-        return F_.PRECISION
-
-    def take_range_token(self):
-        """The RangeToken of the latest no-grad forward (None when that forward did not run in fp16x3)."""
-        tok = self.__dict__.get('_last_token')
-        self.__dict__['_last_token'] = None
-        return tok
-
-    def _calibrate_ranges(self, latent, noise, specs, layers):
-        """One forward of (at most 8 rows of) this batch on the fp32 kernels, recording max |x| of every 3x3 conv's input:
-        x_log2[l] = floor(log2 max)+1 feeds the range plan of functional.styles_batched.  Runs once per weight version
-        (tracked like the weight packs; after `.data` edits call invalidate_packs()).  One device->host read."""
-        n = min(latent.shape[0], 8)
-        lat = latent[:n].contiguous()
-        words = torch.zeros(len(layers), device=latent.device, dtype=torch.int32)
-        with F_.precision('fp32'):
-            sd = F_.styles_batched(lat, specs)
-            sd_of_layer = [0] + [2 + 3 * (i // 2) + (i % 2) for i in range(len(self.convs))]
-            x = self.input.input
-            for li, layer in enumerate(layers):
-                F_.absmax(x, per_image=False, out=words[li:li + 1])
-                nz = noise[li]
-                if nz is not None and nz.shape[0] not in (1, n):
-                    nz = nz[:n]
-                x = layer(x, None, noise=nz, batch=n if li == 0 else None, sd=sd[sd_of_layer[li]], ranged=True)
-        bits = words.cpu().tolist()
-        x_log2, bad = [], False
-        for b in bits:
-            v = struct.unpack('f', struct.pack('I', b & 0xffffffff))[0]
-            if not math.isfinite(v):
-                bad = True
-                x_log2.append(F_.DESIGN_X_LOG2)
-            else:
-                x_log2.append(0 if v == 0.0 else int(math.floor(math.log2(v))) + 1)
-        return x_log2, bad
-
-    def _range_plans(self, latent, noise, specs, order, layers):
-        """(plans for styles_batched, arithmetic to run this forward in).  fp16x3 only."""
-        st = getattr(self, '_range_state', None)
-        stamp = self._weights_stamp()
-        capturing = torch.cuda.is_current_stream_capturing()
-        self._sat_word()
-        if st is None or st['stamp'] != stamp:
-            if capturing:
-                raise RuntimeError('Generator: the first forward after a weight change calibrates activation ranges (one host '
-                                   'read) and cannot run inside a graph capture: run one forward before capturing')
-            x_log2, bad = self._calibrate_ranges(latent, noise, specs, layers)
-            if self._sat_tokens:                        # forwards of the previous weights: settle them (the calibration synced anyway)
-                self._check_tokens(upto=self._sat_tokens[-1])
-            st = self._range_state = {'stamp': stamp, 'x_log2': x_log2, 'mode': 'fp16x3'}
-            if bad:
-                st['mode'] = 'fp32'
-                warnings.warn('Generator: non-finite activations during range calibration; this generator runs on the fp32 '
-                              'kernels until its weights change', RuntimeWarning, stacklevel=3)
-        elif st['mode'] == 'fp16x3' and not capturing and self._sat_tokens:
-            # every earlier forward left a token; the ones already finished are checked here WITHOUT blocking, so a
-            # saturating batch is noticed one or two forwards later even by callers that never ask (verify_range=False)
-            seen = self._check_tokens()
-            if seen:
-                self._fall_back(seen, 'in earlier forwards')
-        if st['mode'] != 'fp16x3':
-            return None, st['mode']
-        conv_layer = {id(l.conv): i for i, l in enumerate(layers)}
-        # (layers that take their input in Winograd form: |B^T (x*s)| <= 2 (F(2,3)) / 10 (F(4,3)) max|x*s| -- 1 / 4 more binades)
-        wino = self._wino_inputs(latent.shape[0], layers)
-        plans = [(st['x_log2'][conv_layer[id(m)]] + F_.WSPLIT_GROWTH_LOG2.get(wino.get(conv_layer[id(m)], 0), 0),
-                  F_.CALIBRATION_HEADROOM) if id(m) in conv_layer else None for m, _ in order]
-        return plans, 'fp16x3'
-
-    def _wino_inputs(self, batch, layers):
-        """{index of a plain layer the inference chain runs in 1-D Winograd form: outputs per tile (2 | 4)} (functional.
-        wsplit_chain_f: fed by a transposed conv + blur that can hand over the transformed input, enough input channels for the
-        smaller MFMA count to outweigh the larger hand-over).  A pure function of (batch, layer shapes, switches): the range plan
-        and the launch plan both ask it."""
-        key = (batch, F_.PRECISION, F_.USE_WSPLIT, F_.WSPLIT_MIN_CIN, F_.USE_SPLIT_CHAIN, F_.USE_RGB_FUSION, F_.USE_SPLITK,
-               F_.USE_PLANE_PADDING, F_.WSPLIT_F)
-        cache = self.__dict__.setdefault('_wino_cache', {})
-        if key not in cache:
-            out, res = {}, self.input.input.shape[2]
-            for li, layer in enumerate(layers):
-                c = layer.conv
-                if c.upsample:
-                    res *= 2
-                elif li >= 2 and layers[li - 1].conv.upsample and F_.rgb_fusable(batch, c.in_channel, c.out_channel, res, res):
-                    f = F_.wsplit_chain_f(batch, c.in_channel, c.out_channel, res, res)
-                    if f:
-                        out[li] = f
-            cache[key] = out
-        return cache[key]
-
     # ---- the path itself (model.py:471-539)
-    GRAPH_AFTER = 2                 # eager no-grad forwards of one signature before the next one is captured as a hipGraph
-    MAX_GRAPHS = 4                  # captured signatures kept per generator (each holds its intermediates in a private pool)
-
-    def _drop_graphs(self):
-        self.__dict__.pop('_graphs', None)
-        self.__dict__.pop('_graph_calls', None)
-
-    GRAPH_MAX_WORK = 6              # default policy: replay when batch * (size / 256)^2 <= this (host-bound forwards), or when verified
-
-    def _graph_key(self, styles, return_latents, inject_index, truncation, truncation_latent, input_is_latent, noise,
-                   randomize_noise, image_out, verify_range, graph):
-        """Signature under which a no-grad forward may be replayed as a hipGraph, or None when it must run eagerly: gradients,
-        style mixing, caller-supplied or fresh noise, a caller-owned uint8 target, hooks, an enclosing capture, bench timing --
-        and, unless graph=True, forwards that are neither host-bound nor verified (see forward)."""
-        if graph is False or not USE_GRAPHS or not getattr(self, 'use_graphs', True) or torch.is_grad_enabled() or \
-                F_.CONV_TIMING is not None or F_.HBM_TIMING is not None:
-            return None
-        if len(styles) != 1 or inject_index is not None or noise is not None or randomize_noise:
-            return None
-        w = styles[0]
-        if not isinstance(w, torch.Tensor) or not w.is_cuda or w.dtype != torch.float32 or w.requires_grad:
-            return None
-        if graph is None and not verify_range and w.shape[0] * (self.size / 256.0) ** 2 > self.GRAPH_MAX_WORK:
-            return None
-        if image_out is not None and image_out.frames is not None:
-            return None
-        if truncation < 1 and truncation_latent is None:
-            return None
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        mods = self.__dict__.get('_all_mods')
-        if mods is None:
-            mods = self.__dict__['_all_mods'] = list(self.modules())
-        for m in mods:
-            if m._forward_hooks or m._forward_pre_hooks:
-                return None
-        u8 = None if image_out is None else ('u8', image_out.swap_rb)
-        return (tuple(w.shape), bool(input_is_latent), bool(return_latents), float(truncation),
-                None if truncation >= 1 else tuple(truncation_latent.shape), u8, F_.PRECISION, F_.RANGE_PLAN, F_.USE_SPLIT_CHAIN,
-                F_.USE_RGB_FUSION, F_.USE_SPLITK, F_.USE_PLANE_PADDING, bool(self.overlap_rgb), w.device, F_.USE_WSPLIT,
-                F_.WSPLIT_MIN_CIN, F_.WSPLIT_F, F_.USE_UPFIR, F_.UPFIR_MIN_W,
-                # a graph's static input / output buffers belong to the stream that replays it: forwards queued on different
-                # streams (functional.StreamPipeline) get their own capture instead of racing on one
-                F_.N.stream().value)
-
     # A raw `G([w])` -- what the reference's scripts call (run_inference.py:125, utils_inference.py:88, optimization.py:50,
     # invert_images.py:103, extract_statistics.py:85) -- hands back VERIFIED frames: the forward is awaited and, had any fp16
     # operand left the range plan, re-rendered in bf16x3 first.  Throughput callers that check tokens themselves
@@ -755,6 +502,11 @@ class Generator(nn.Module):
         batch size (generate_image at B=32: 7.8 k -> 8.3 k frames/s).  Weight changes (tracked like the weight packs; after
         `.data` edits call invalidate_packs()), a change of arithmetic / range plan, hooks, style mixing, caller-supplied
         noise and randomize_noise run eagerly.  Switch off: `G.use_graphs = False` or SGDFR_GRAPHS=0."""
+        cfg = getattr(self, 'config', None)
+        if cfg is not None and cfg is not F_.config():      # this generator's own configuration: forward (and, through the autograd
+            with F_.using(cfg):                             # Functions, backward) run under it whatever the caller's ambient one is
+                return self.forward(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
+                                    input_is_latent, noise, randomize_noise, image_out, verify_range, graph)
         if verify_range is None:
             verify_range = bool(self.verify_range_default)
         key = self._graph_key(styles, return_latents, inject_index, truncation, truncation_latent, input_is_latent, noise,
@@ -762,66 +514,8 @@ class Generator(nn.Module):
         if key is None:
             return self._forward_impl(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
                                       input_is_latent, noise, randomize_noise, image_out, verify_range)
-        graphs = self.__dict__.setdefault('_graphs', {})
-        calls = self.__dict__.setdefault('_graph_calls', {})
-        stamp, mode = self._weights_stamp(), self.range_mode()
-        entry = graphs.get(key)
-        if entry is not None and (entry['stamp'] != stamp or entry['mode'] != mode):
-            self._drop_graphs()                            # new weights / the generator changed arithmetic: every graph is stale
-            graphs = self.__dict__.setdefault('_graphs', {})
-            calls = self.__dict__.setdefault('_graph_calls', {})
-            entry = None
-        w = styles[0]
-        trunc = truncation_latent if truncation < 1 else None
-        if entry is not None and entry['mode'] == 'fp16x3' and self.__dict__.get('_sat_tokens'):
-            # the non-blocking poll of the eager path (_range_plans), which a replay never reaches: tokens of finished forwards are
-            # resolved here, and a saturation seen in any of them switches this generator to bf16x3 before the next replay
-            seen = self._check_tokens()
-            if seen:
-                self._fall_back(seen, 'in earlier forwards')
-                self._drop_graphs()
-                return self._forward_impl(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
-                                          input_is_latent, None, False, image_out, verify_range)
-        if entry is None:
-            n = calls.get(key, 0)
-            if n < self.GRAPH_AFTER:                       # not yet: packs, launch plans and the range calibration settle eagerly
-                calls[key] = n + 1
-                return self._forward_impl(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
-                                          input_is_latent, None, False, image_out, verify_range)
-            st = getattr(self, '_range_state', None)
-            if F_.PRECISION == 'fp16x3' and F_.RANGE_PLAN is True and (st is None or st['stamp'] != stamp):
-                return self._forward_impl(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
-                                          input_is_latent, None, False, image_out, verify_range)       # calibrate first (host read)
-            s_in = w.detach().clone()
-            s_tr = trunc.detach().clone() if trunc is not None else None
-            torch.cuda.current_stream().synchronize()
-            g = torch.cuda.CUDAGraph()
-            with F_.capture_graph(g):
-                out = self._forward_impl([s_in], return_latents, False, None, truncation, s_tr, input_is_latent, None, False,
-                                         None if image_out is None else F_.U8Target(None, 0, image_out.swap_rb), False)
-            mode = self.range_mode()
-            entry = {'graph': g, 'in': s_in, 'trunc': s_tr, 'out': out, 'stamp': stamp, 'mode': mode}
-            while len(graphs) >= self.MAX_GRAPHS:
-                graphs.pop(next(iter(graphs)))
-            graphs[key] = entry
-        entry['in'].copy_(w)
-        if entry['trunc'] is not None:
-            entry['trunc'].copy_(trunc)
-        entry['graph'].replay()
-        img, lat = entry['out']
-        res = (img.clone(), lat.clone() if lat is not None else None)
-        self.__dict__['_last_token'] = None
-        if entry['mode'] == 'fp16x3' and F_.PRECISION == 'fp16x3' and F_.RANGE_PLAN is True:
-            # the captured launches add to this generator's saturation word like eager ones: snapshot it behind the replay
-            self._settle_oldest_if_full()
-            tok = self._snapshot()
-            if not verify_range:
-                self.__dict__['_last_token'] = tok
-            elif not self.range_ok(tok):                   # this batch clamped operands: render it again (eagerly, now in bf16x3)
-                self._drop_graphs()
-                return self._forward_impl(styles, return_latents, return_features, inject_index, truncation,
-                                          truncation_latent, input_is_latent, None, False, image_out, False)
-        return res
+        return self._replay_or_run(key, styles, return_latents, return_features, inject_index, truncation, truncation_latent,
+                                   input_is_latent, image_out, verify_range)
 
     def _forward_impl(self, styles, return_latents=False, return_features=False, inject_index=None, truncation=1,
                       truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=False, image_out=None,
@@ -877,9 +571,9 @@ class Generator(nn.Module):
             # no-grad: every layer's s = A_l(w_l) and demodulation d_l in two launches (instead of 33)
             specs = [m.style_spec(li) for m, li in order]
             plans, arith = None, None                      # arith: this generator's fallback arithmetic, when it has one
-            if F_.PRECISION == 'fp16x3' and F_.RANGE_PLAN is True:
+            if F_.config().precision == 'fp16x3' and F_.config().range_plan is True:
                 plans, arith = self._range_plans(latent, noise, specs, order, layers)
-            if arith is not None and arith != F_.PRECISION:    # saturation / non-finite fallback: run this forward in `arith`
+            if arith is not None and arith != F_.config().precision:    # saturation / non-finite fallback: run this forward in `arith`
                 with F_.precision(arith):
                     return self._synthesis(latent, F_.styles_batched(latent, specs), layers, to_rgbs, noise, False, False,
                                            return_latents, image_out)
@@ -906,8 +600,8 @@ class Generator(nn.Module):
         # inference on the split kernels: layers are launched through functional.styled_conv_split, not through their
         # modules -- unless somebody hooked a layer's forward (per-layer probes), then every module really runs
         hooked = any(m._forward_hooks or m._forward_pre_hooks for m in layers + to_rgbs)
-        chain = (not grad) and (not hooked) and F_.PRECISION in ('fp16x3', 'bf16x3') and \
-            not (F_.PRECISION == 'fp16x3' and F_.RANGE_PLAN == 'exact')       # 'exact': fp32 hand-over, max |x| measured per layer
+        chain = (not grad) and (not hooked) and F_.config().precision in ('fp16x3', 'bf16x3') and \
+            not (F_.config().precision == 'fp16x3' and F_.config().range_plan == 'exact')       # 'exact': fp32 hand-over, max |x| measured per layer
 
         # The RGB branch: a fused ToRGB (partial sums from the conv epilogue) is finished by a small launch on the main
         # stream; an unfused one (HBM-bound kernel re-reading the activation) runs on a side HIP stream next to the conv chain.
@@ -940,37 +634,7 @@ class Generator(nn.Module):
             with torch.cuda.stream(side):
                 return run()
 
-        # Per-layer launch decisions depend only on (batch, arithmetic, which noises are given): cached, so a forward does
-        # not query the library 40 times (it matters for the launch-bound small batches).
-        key = (batch, chain, F_.PRECISION, F_.USE_SPLIT_CHAIN, F_.USE_RGB_FUSION, F_.USE_SPLITK, tuple(n is None for n in noise),
-               F_.USE_WSPLIT, F_.WSPLIT_MIN_CIN, F_.WSPLIT_F)
-        plan = self._chain_plans.get(key) if hasattr(self, '_chain_plans') else None
-        if plan is None:
-            plan, res = [], self.input.input.shape[2]
-            for li, layer in enumerate(layers):
-                c = layer.conv
-                up = c.upsample
-                res_out = 2 * res if up else res
-                nxt = layers[li + 1].conv if li + 1 < len(layers) else None
-                mode = F_.N.MODE_UP3 if up else F_.N.MODE_PLAIN3
-                use_chain = chain and noise[li] is not None and F_.split_ok(batch, c.in_channel, c.out_channel, res, res, mode)
-                fuse = use_chain and (not up) and F_.rgb_fusable(batch, c.in_channel, c.out_channel, res, res)
-                # hand the activation to the next conv in its own split input form when it can stage that by DMA (and,
-                # for a plain conv, when nothing else needs the fp32 tensor: its ToRGB is fused into this launch)
-                to_next = use_chain and nxt is not None and (up or fuse) and nxt.kernel_size == 3 and \
-                    noise[li + 1] is not None and \
-                    F_.xin_ok(batch, nxt.in_channel, nxt.out_channel, res_out, res_out,
-                              F_.N.MODE_UP3 if nxt.upsample else F_.N.MODE_PLAIN3)
-                want_y = not (fuse and (nxt is None or to_next))
-                plan.append([use_chain, fuse, to_next, want_y, 0])
-                res = res_out
-            # plain layers in Winograd form: the producing transposed conv's blur hands over the transformed input
-            for li, f in (self._wino_inputs(batch, layers).items() if chain else ()):
-                if plan[li][0] and plan[li][1] and plan[li - 1][0] and plan[li - 1][2]:
-                    plan[li - 1][4] = f
-            if not hasattr(self, '_chain_plans'):
-                self._chain_plans = {}
-            self._chain_plans[key] = plan
+        plan = self._chain_plan(batch, chain, noise, layers)
 
         # ConstantInput is broadcast inside the kernel (batch stride 0) instead of repeated
         x, skip = self.input.input, None

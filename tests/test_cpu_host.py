@@ -205,12 +205,8 @@ def test_winograd_layer_plan_of_the_bench_configs():
     # B=32 (configs[2]): the 16^2 layer is K-sliced (too few tiles to fill the chip), so it cannot fuse its ToRGB and stays direct
     assert G._wino_inputs(32, layers) == {6: 4, 8: 4, 10: 4}
     assert G._wino_inputs(2, layers) == {}
-    old = F_.WSPLIT_F
-    try:
-        F_.WSPLIT_F = 2
+    with F_.using(F_.config().replace(wsplit_f=2)):
         assert G._wino_inputs(64, layers) == {4: 2, 6: 2, 8: 2}         # (F(2,3) pays from 256 input channels on)
-    finally:
-        F_.WSPLIT_F = old
     lib = F_.N.load()
     assert lib.sgdfr_modconv_prepack_wsplit_elems(512, 512, 4) == 512 * 512 * 3 * 6 * 2
     assert lib.sgdfr_modconv_prepack_wsplit_elems(512, 512, 2) == 512 * 512 * 3 * 4 * 2

@@ -9,10 +9,8 @@ from util import O, S, SEED, golden, hip_generator, maxabs, synthetic_state, t
 def _both_arithmetics(request):
     """Gradients are checked with the split-fp16 conv kernels (forward + plain-conv dL/dx) and with the fp32 MFMA kernels."""
     from stylegan_directions_face_reenactment_amd import functional as F_
-    default = F_.PRECISION
-    F_.set_precision(request.param)
-    yield
-    F_.set_precision(default)
+    with F_.precision(request.param):
+        yield
 
 
 pytestmark = pytest.mark.gpu
@@ -360,17 +358,13 @@ def test_backward_arithmetics_of_the_split_dx_convs(cin, cout, h, up, capsys):
     for p_ in m.parameters():
         p_.requires_grad_(False)
     errs = {}
-    saved = F_.BACKWARD_ARITH
-    try:
-        for arith in ('bf16x3', 'fp16x3'):
-            F_.BACKWARD_ARITH = arith
-            for scale in (1.0, 2.0 ** -30, 2.0 ** 20):
-                xh = x.cuda().requires_grad_(True)
+    for arith in ('bf16x3', 'fp16x3'):
+        for scale in (1.0, 2.0 ** -30, 2.0 ** 20):
+            xh = x.cuda().requires_grad_(True)
+            with F_.using(F_.config().replace(backward_arith=arith)):      # the Function remembers the forward's config for its backward
                 out = m(xh, st.cuda(), noise=nz.cuda())
-                (out * (g.cuda() * scale)).sum().backward()
-                errs[(arith, scale)] = _rel(xh.grad / scale, xr.grad)
-    finally:
-        F_.BACKWARD_ARITH = saved
+            (out * (g.cuda() * scale)).sum().backward()
+            errs[(arith, scale)] = _rel(xh.grad / scale, xr.grad)
     with capsys.disabled():
         print('\n  dx rel err %s: ' % key + ', '.join('%s@2^%d %.1e' % (a, round(__import__('math').log2(sc)), e) for (a, sc), e in errs.items()))
     assert F_.split_saturation_count(reset=True) == 0

@@ -12,10 +12,8 @@ from util import O, S, SEED, golden, hip_generator, image_digest, maxabs, synthe
 def _both_arithmetics(request):
     """Every generator-level check runs twice: default split-fp16 conv kernels and the fp32 MFMA / Winograd kernels."""
     from stylegan_directions_face_reenactment_amd import functional as F_
-    default = F_.PRECISION
-    F_.set_precision(request.param)
-    yield
-    F_.set_precision(default)
+    with F_.precision(request.param):
+        yield
 
 pytestmark = pytest.mark.gpu
 
@@ -214,17 +212,11 @@ def test_split_chain_is_bit_identical_to_layer_by_layer():
         G = hip_generator(size, 1)
         w = S.synthetic_latents(SEED, B, n_latent=G.n_latent, key='chain.w').cuda()
         tr = S.counter_tensor(SEED, 'chain.t', (1, 512)).cuda()
-        F_.USE_WSPLIT = False
-        try:
-            with torch.no_grad():
-                a, _ = G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr)
-                F_.USE_SPLIT_CHAIN = False
-                try:
-                    b, _ = G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr)
-                finally:
-                    F_.USE_SPLIT_CHAIN = True
-        finally:
-            F_.USE_WSPLIT = True
+        with torch.no_grad():
+            G.config = F_.config().replace(use_wsplit=False)
+            a, _ = G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr)
+            G.config = F_.config().replace(use_wsplit=False, use_split_chain=False)
+            b, _ = G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr)
         assert torch.equal(a, b)
         assert G.saturated_pairs() == 0 or F_.PRECISION != 'fp16x3'     # nothing of this generator hit the fp16 clamp
 
@@ -246,17 +238,11 @@ def test_winograd_chain_layers_stay_within_the_per_image_bound():
         a, _ = G([w], input_is_latent=True)
         used = sorted(G._wino_inputs(B, [G.conv1] + list(G.convs)))
         assert set(G._wino_inputs(B, [G.conv1] + list(G.convs)).values()) == {4}
-        F_.WSPLIT_F = 2
-        try:
+        with F_.using(F_.config().replace(wsplit_f=2)):
             a2, _ = G([w], input_is_latent=True)
             assert G._wino_inputs(B, [G.conv1] + list(G.convs)) == {6: 2, 8: 2}
-        finally:
-            F_.WSPLIT_F = 4
-        F_.USE_WSPLIT = False
-        try:
+        with F_.using(F_.config().replace(use_wsplit=False)):
             b, _ = G([w], input_is_latent=True)
-        finally:
-            F_.USE_WSPLIT = True
     assert used == [6, 8, 10], used                      # 512 @ 32^2, 256 @ 64^2, 128 @ 128^2 (512 @ 16^2 joins from B = 48)
     assert not torch.equal(a, b)
     bound = 2e-4 if F_.PRECISION == 'fp16x3' else 5e-4

@@ -97,13 +97,9 @@ def test_split_generator_within_contract():
         with torch.no_grad():
             ref, _ = O.generator_forward(P64, [w.double().cpu()], input_is_latent=True)
             outs = {}
-            default = F_.PRECISION
             for mode in ('fp32', 'fp16x3', 'bf16x3'):
-                F_.set_precision(mode)
-                try:
+                with F_.precision(mode):
                     outs[mode], _ = G([w], input_is_latent=True)
-                finally:
-                    F_.set_precision(default)
             exact = outs['fp32']
         e_exact = maxabs(exact, ref)
         e16, eb = maxabs(outs['fp16x3'], ref), maxabs(outs['bf16x3'], ref)
@@ -621,6 +617,47 @@ def test_raw_generator_call_never_returns_a_clamped_frame():
         assert G.range_mode() == 'bf16x3'
         late, _ = G([wd], input_is_latent=True, verify_range=False, graph=True)
         assert maxabs(late, ref) <= 1e-3 * max(1.0, scale)
+
+
+def test_two_generators_with_their_own_configs_interleave():
+    """the switches are a frozen functional.Config held by the generator, not module globals.  Three generators of
+    the same weights -- fp16x3 chain, fp32 kernels, bf16x3 without the Winograd form -- called alternately in one process each
+    produce exactly what they produce alone under the same configuration as the ambient one, hipGraph replays included, and a
+    backward started outside any `using` block runs in the arithmetic of its forward."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    base = F_.config()
+    cfgs = [base.replace(precision='fp16x3'), base.replace(precision='fp32'), base.replace(precision='bf16x3', use_wsplit=False)]
+    w = S.synthetic_latents(SEED, 4, n_latent=10, key='cfg.w').cuda()
+    with torch.no_grad():
+        alone = []
+        for cfg in cfgs:
+            G = hip_generator(64, 1)
+            with F_.using(cfg):
+                alone.append(G([w], input_is_latent=True)[0])
+        gens = [hip_generator(64, 1) for _ in cfgs]
+        for G, cfg in zip(gens, cfgs):
+            G.config = cfg
+        for rnd in range(5):                                       # (round 3 on: verified forwards replay their hipGraph)
+            for G, want in zip(gens, alone):
+                assert torch.equal(G([w], input_is_latent=True)[0], want), (rnd, G.config.precision)
+        assert [G.range_mode() for G in gens] == ['fp16x3', 'fp32', 'bf16x3'] and F_.config() is base
+        assert not torch.equal(alone[0], alone[1]) and not torch.equal(alone[0], alone[2])
+    # backward under the forward's config: the ambient backward_arith differs from the generator's
+    G = hip_generator(64, 1)
+    for p_ in G.parameters():
+        p_.requires_grad_(False)
+    grads = {}
+    for arith in ('fp16x3', 'bf16x3'):
+        G.config = base.replace(backward_arith=arith)
+        wl = w.clone().requires_grad_(True)
+        img, _ = G([wl], input_is_latent=True)
+        with F_.using(base.replace(backward_arith='bf16x3' if arith == 'fp16x3' else 'fp16x3')):
+            img.square().mean().backward()
+        grads[arith] = wl.grad.clone()
+    G.config = base.replace(backward_arith='fp16x3')
+    wl = w.clone().requires_grad_(True)
+    G([wl], input_is_latent=True)[0].square().mean().backward()
+    assert torch.equal(grads['fp16x3'], wl.grad) and not torch.equal(grads['fp16x3'], grads['bf16x3'])
 
 
 def test_reenactment_session_rerenders_a_clamped_batch():

@@ -41,14 +41,11 @@ def test_fused_up_conv_equals_the_two_pass_form_bit_for_bit(B, cin, cout, H, W, 
         x, w, s, d, sn, nz, nw, bias = _inputs('uf%d' % per_sample, B, cin, cout, H, W, per_sample)
         wsp = F_.prepack_split(w, arith)
         xs = F_.to_split(x, s, arith)
-        keep, F_.USE_SPLITK = F_.USE_SPLITK, False          # (K slices add their partial sums in another order)
-        try:
+        with F_.using(F_.config().replace(use_splitk=False)):          # (K slices add their partial sums in another order)
             if F_.xin_ok(B, cin, cout, H, W, F_.N.MODE_UP3):
                 planes = F_.modconv_split(xs, wsp, None, d, cout, mode=F_.N.MODE_UP3, x_split=(B, cin, H, W), arith=arith)
             else:           # tiling plans without a pre-split variant convert x*s in the kernel: the same bits
                 planes = F_.modconv_split(x, wsp, s, d, cout, mode=F_.N.MODE_UP3, arith=arith)
-        finally:
-            F_.USE_SPLITK = keep
         want = F_.blur_bias_act_split(planes, _fir(), H, W, sn, nz, nw, bias, True, arith=arith)
         word = F_.new_saturation_word(x.device)
         with F_.saturation_sink(word):
@@ -98,21 +95,18 @@ def test_generator_with_the_fused_level_equals_the_two_pass_chain():
         pytest.skip('split arithmetics only')
     G = hip_generator(256, 1)
     w = S.synthetic_latents(SEED, 3, n_latent=G.n_latent, key='upfir.w')
-    keep = F_.USE_UPFIR
     try:
         with torch.no_grad():
-            F_.USE_UPFIR = True
-            G.invalidate_packs()
+            G.config = F_.config().replace(use_upfir=True)
             F_.CONV_TIMING = []
             fused, _ = G([w.cuda()], input_is_latent=True)
             descs = [r[3] for r in F_.CONV_TIMING]
             F_.CONV_TIMING = None
             assert any(dsc.startswith('upfir') for dsc in descs), descs
-            F_.USE_UPFIR = False
-            G.invalidate_packs()
+            G.config = F_.config().replace(use_upfir=False)
             two, _ = G([w.cuda()], input_is_latent=True)
     finally:
-        F_.USE_UPFIR, F_.CONV_TIMING = keep, None
+        F_.CONV_TIMING = None
     assert torch.equal(fused, two)
     ref, _ = O.generator_forward(synthetic_state(256, 1), [w], input_is_latent=True)
     assert maxabs(fused, ref) <= 2e-4

@@ -134,7 +134,9 @@ def test_blur_winograd_handover_is_bit_identical_to_transforming_the_fp32_result
     got = F_.blur_bias_act_split(planes, fir, H, H, sn, noise, nw, bias, True, arith=arith, wino=f)
     assert got.shape == want.shape and torch.equal(got, want)
     ps = ((H + 1) * (H + 1) + 31) // 32 * 32
-    padded = torch.zeros(B, C, 4, ps, device='cuda')
-    padded[..., :(H + 1) * (H + 1)] = planes.view(B, C, 4, -1)
+    # the padded form is interleaved: [B, C, positions, px, py] (include/sgdfr.h, plane_stride)
+    il = torch.zeros(B, C, ps, 2, 2, device='cuda')
+    il[:, :, :(H + 1) * (H + 1)] = planes.view(B, C, 2, 2, -1).permute(0, 1, 4, 3, 2)      # [.., py, px, pos] -> [.., pos, px, py]
+    padded = il.view(B, C, 4, ps)
     got2 = F_.blur_bias_act_split(padded, fir, H, H, sn, noise, nw, bias, True, arith=arith, plane_stride=ps, wino=f)
     assert torch.equal(got2, want)
