@@ -657,6 +657,8 @@ def other_config_legs(args, rank, world, dev):
                                      if k in ('e4e_source_ms', 'e4e_batch_images_per_s', 'generator_only_ms_per_step',
                                               'loss_heads_and_optimizer_ms_per_step', 'losses_finite', 'backward_arithmetic')},
                           'conv_roofline': {k: line['roofline'][k] for k in ('achieved', 'peak', 'unit', 'frac', 'conv_ms_per_step')},
+                          # every conv instantiation of the leg (forward rows, and for the trainer the `bwd ...` dL/dx rows)
+                          'conv_per_layer': line['roofline']['per_layer'],
                           'leg_wall_s': round(time.perf_counter() - t0, 1)}
             if 'fp16_saturated_pairs' in line:
                 legs[name]['fp16_saturated_pairs'] = line['fp16_saturated_pairs']

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 14
+#define SGDFR_ABI_VERSION 15
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -69,6 +69,17 @@ int sgdfr_fused_bias_act_f32(const float* x, const float* bias, const float* ref
 int sgdfr_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int in_h, int in_w, int minor,
                         int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
                         int pad_y0, int pad_y1, void* stream);
+
+/* The two natives for every dtype the reference dispatches (AT_DISPATCH_FLOATING_TYPES_AND_HALF: fused_bias_act_kernel.cu:79,
+ * upfirdn2d_kernel.cu:225): x / bias / ref / k / y all of `dtype`; half is computed in float and rounded once, double in double.
+ * SGDFR_DTYPE_F32 forwards to the _f32 entry points above. */
+#define SGDFR_DTYPE_F32 0
+#define SGDFR_DTYPE_F16 1
+#define SGDFR_DTYPE_F64 2
+int sgdfr_fused_bias_act(const void* x, const void* bias, const void* ref, void* y, int64_t n, int step_b, int size_b, int act,
+                         int grad, float alpha, float scale, int dtype, void* stream);
+int sgdfr_upfirdn2d(const void* x, const void* k, void* y, int major, int in_h, int in_w, int minor, int kh, int kw, int up_x,
+                    int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, int dtype, void* stream);
 
 /* y[m, n] = act( (sum_k x[m*ldx + k] * w[n*K + k]) * wscale + bias[n] * bscale ), m<M, n<N.
  * bias may be NULL.  act: SGDFR_ACT_*. */

@@ -23,7 +23,7 @@ if os.environ.get('SGDFR_LIB'):
     else:
         import warnings as _warnings
         _warnings.warn('SGDFR_LIB is set but ignored (set SGDFR_ALLOW_LIB_OVERRIDE=1 to load a probe build)', RuntimeWarning)
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -124,6 +124,10 @@ SIGNATURES['sgdfr_modconv2d_upfir_tiles'] = [_i, _i, _i, _i, _i, ctypes.POINTER(
 SIGNATURES['sgdfr_modconv2d_upfir_split_f32'] = [ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
                                                  _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i, _i, _i, _f, _f, ctypes.c_void_p,
                                                  ctypes.c_void_p]
+SIGNATURES['sgdfr_fused_bias_act'] = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _i64, _i, _i, _i, _i, _f, _f, _i,
+                                      ctypes.c_void_p]
+SIGNATURES['sgdfr_upfirdn2d'] = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [_i] * 15 + [ctypes.c_void_p]
+DTYPES = {torch.float32: 0, torch.float16: 1, torch.float64: 2}      # SGDFR_DTYPE_* of the two reference natives
 # measurement-only symbols: bound when present, never required of a production library (bench.py's measured_mfma_ceiling)
 OPTIONAL_SIGNATURES = {'sgdfr_mfma_ceiling_probe': [_i, _i, _i, _i, _i, _c_f32p, ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]}
 
@@ -192,7 +196,7 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def require_device(*tensors):
+def require_device(*tensors, dtype=torch.float32):
     """The reference's natives raise RuntimeError for non-CUDA tensors (CHECK_CUDA in
     op/fused_bias_act.cpp, op/upfirdn2d.cpp); same contract here -- and no silent CPU path."""
     for t in tensors:
@@ -200,8 +204,16 @@ def require_device(*tensors):
             continue
         if not t.is_cuda:
             raise RuntimeError('expected a GPU (HIP) tensor, got device %s: this package has no CPU path' % t.device)
-        if t.dtype != torch.float32:
-            raise RuntimeError('expected float32, got %s' % t.dtype)
+        if t.dtype != dtype:
+            raise RuntimeError('expected %s, got %s' % (str(dtype).replace('torch.', ''), t.dtype))
+
+
+def native_dtype(t):
+    """SGDFR_DTYPE_* of a tensor for the two natives the reference dispatches over float / double / half
+    (AT_DISPATCH_FLOATING_TYPES_AND_HALF, fused_bias_act_kernel.cu:79, upfirdn2d_kernel.cu:225)."""
+    if t.dtype not in DTYPES:
+        raise RuntimeError('expected float32, float16 or float64, got %s' % t.dtype)
+    return DTYPES[t.dtype]
 
 
 def f32c(t):

@@ -76,6 +76,30 @@ __global__ __launch_bounds__(256) void fused_bias_act_kernel(const float* __rest
     }
 }
 
+// The other two dtypes the reference's native dispatches (AT_DISPATCH_FLOATING_TYPES_AND_HALF, fused_bias_act_kernel.cu:79): one
+// element per thread, arithmetic in float (half) / double (double), result rounded once.
+template <typename T, typename A>
+__global__ __launch_bounds__(256) void fused_bias_act_typed_kernel(const T* __restrict__ x, const T* __restrict__ bias,
+                                                                  const T* __restrict__ ref, T* __restrict__ y, int64_t n,
+                                                                  int step_b, int size_b, int grad, A alpha, A scale) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        A v = (A)x[i];
+        const A b = bias ? (A)bias[(i / step_b) % size_b] : (A)0;
+        const A r = ref ? (A)ref[i] : (A)0;
+        A o;
+        if (grad == 0) {
+            v += b;
+            o = (v > (A)0 ? v : v * alpha) * scale;
+        } else if (grad == 1) {
+            o = (r > (A)0 ? v : v * alpha) * scale;
+        } else {
+            o = (A)0;
+        }
+        y[i] = (T)o;
+    }
+}
+
 // ---------------------------------------------------------------- pixelnorm
 // one wave per row: wave-shuffle reduction over D
 __global__ __launch_bounds__(256) void pixelnorm_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int D,
@@ -216,6 +240,29 @@ extern "C" int sgdfr_fused_bias_act_f32(const float* x, const float* bias, const
     else
         hipLaunchKernelGGL(fused_bias_act_kernel<false>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, bias,
                            ref, y, n, step_b, size_b, grad, alpha, scale);
+    return check_launch("fused_bias_act");
+}
+
+extern "C" int sgdfr_fused_bias_act(const void* x, const void* bias, const void* ref, void* y, int64_t n, int step_b, int size_b,
+                                    int act, int grad, float alpha, float scale, int dtype, void* stream) {
+    if (dtype == SGDFR_DTYPE_F32)
+        return sgdfr_fused_bias_act_f32(static_cast<const float*>(x), static_cast<const float*>(bias), static_cast<const float*>(ref),
+                                        static_cast<float*>(y), n, step_b, size_b, act, grad, alpha, scale, stream);
+    SGDFR_REQUIRE(dtype == SGDFR_DTYPE_F16 || dtype == SGDFR_DTYPE_F64, "fused_bias_act: dtype must be SGDFR_DTYPE_F32/F16/F64, got %d", dtype);
+    SGDFR_REQUIRE(act == 3, "fused_bias_act: only act=3 (leaky relu) is implemented, got %d", act);
+    SGDFR_REQUIRE(grad >= 0 && grad <= 2, "fused_bias_act: grad must be 0,1,2, got %d", grad);
+    SGDFR_REQUIRE(n >= 0, "fused_bias_act: negative n");
+    if (n == 0) return 0;
+    SGDFR_REQUIRE(x && y, "fused_bias_act: null x/y");
+    SGDFR_REQUIRE(!bias || (step_b > 0 && size_b > 0), "fused_bias_act: bad bias geometry %d %d", step_b, size_b);
+    if (dtype == SGDFR_DTYPE_F16)
+        hipLaunchKernelGGL((fused_bias_act_typed_kernel<_Float16, float>), dim3(grid_for(n)), dim3(256), 0, as_stream(stream),
+                           static_cast<const _Float16*>(x), static_cast<const _Float16*>(bias), static_cast<const _Float16*>(ref),
+                           static_cast<_Float16*>(y), n, step_b, size_b, grad, alpha, scale);
+    else
+        hipLaunchKernelGGL((fused_bias_act_typed_kernel<double, double>), dim3(grid_for(n)), dim3(256), 0, as_stream(stream),
+                           static_cast<const double*>(x), static_cast<const double*>(bias), static_cast<const double*>(ref),
+                           static_cast<double*>(y), n, step_b, size_b, grad, (double)alpha, (double)scale);
     return check_launch("fused_bias_act");
 }
 

@@ -56,6 +56,43 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UpfirdnParams p) {
     }
 }
 
+// The same generic path for the other dtypes of the reference's dispatch (AT_DISPATCH_FLOATING_TYPES_AND_HALF, upfirdn2d_kernel.cu:225):
+// T = storage type, A = accumulator (float for half, double for double); taps straight from global memory (L1-resident).
+template <typename T, typename A>
+__global__ __launch_bounds__(256) void upfirdn2d_typed_kernel(const T* __restrict__ x, const T* __restrict__ k, T* __restrict__ y,
+                                                             UpfirdnParams p) {
+    const int64_t total = (int64_t)p.major * p.out_h * p.out_w * p.minor;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int mi = (int)(idx % p.minor);
+        int64_t r = idx / p.minor;
+        const int ox = (int)(r % p.out_w);
+        r /= p.out_w;
+        const int oy = (int)(r % p.out_h);
+        const int mj = (int)(r / p.out_h);
+        const int by = oy * p.down_y - p.pad_y0, bx = ox * p.down_x - p.pad_x0;
+        int ky0 = (-by) % p.up_y;
+        if (ky0 < 0) ky0 += p.up_y;
+        int kx0 = (-bx) % p.up_x;
+        if (kx0 < 0) kx0 += p.up_x;
+        const T* xp = x + (int64_t)mj * p.in_h * p.in_w * p.minor + mi;
+        A acc = (A)0;
+        for (int ky = ky0; ky < p.kh; ky += p.up_y) {
+            const int uy = by + ky;
+            if (uy < 0) continue;
+            const int iy = uy / p.up_y;
+            if (iy >= p.in_h) break;
+            for (int kx = kx0; kx < p.kw; kx += p.up_x) {
+                const int ux = bx + kx;
+                if (ux < 0) continue;
+                const int ix = ux / p.up_x;
+                if (ix >= p.in_w) break;
+                acc += (A)xp[((int64_t)iy * p.in_w + ix) * p.minor] * (A)k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+            }
+        }
+        y[idx] = (T)acc;
+    }
+}
+
 // Blur after the stride-2 transposed conv, reading the parity planes written by MODE_UP3.
 //   t: [planes, 4, H+1, W+1], plane ph = 2*(row&1)+(col&1) holds T[row,col] at [row>>1, col>>1]
 //   y: [planes, 2H, 2W];  y[oy,ox] = sum_{ky,kx} Tpad[oy+ky, ox+kx] * K[3-ky][3-kx],  Tpad[i,j] = T[i-1,j-1]
@@ -622,6 +659,33 @@ extern "C" int sgdfr_upfirdn2d_f32(const float* x, const float* k, float* y, int
     int64_t g = (total + 255) / 256;
     if (g > 256 * 16) g = 256 * 16;
     hipLaunchKernelGGL(upfirdn2d_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), p);
+    return check_launch("upfirdn2d");
+}
+
+extern "C" int sgdfr_upfirdn2d(const void* x, const void* k, void* y, int major, int in_h, int in_w, int minor, int kh, int kw, int up_x,
+                               int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, int dtype, void* stream) {
+    if (dtype == SGDFR_DTYPE_F32)
+        return sgdfr_upfirdn2d_f32(static_cast<const float*>(x), static_cast<const float*>(k), static_cast<float*>(y), major, in_h, in_w,
+                                   minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, stream);
+    SGDFR_REQUIRE(dtype == SGDFR_DTYPE_F16 || dtype == SGDFR_DTYPE_F64, "upfirdn2d: dtype must be SGDFR_DTYPE_F32/F16/F64, got %d", dtype);
+    SGDFR_REQUIRE(major >= 0 && in_h > 0 && in_w > 0 && minor > 0, "upfirdn2d: bad input shape [%d,%d,%d,%d]", major, in_h, in_w, minor);
+    SGDFR_REQUIRE(kh > 0 && kw > 0 && kh <= kMaxTaps && kw <= kMaxTaps, "upfirdn2d: kernel %dx%d unsupported (max %d)", kh, kw, kMaxTaps);
+    SGDFR_REQUIRE(up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0, "upfirdn2d: up/down factors must be positive");
+    const int out_h = (in_h * up_y + pad_y0 + pad_y1 - kh + down_y) / down_y;
+    const int out_w = (in_w * up_x + pad_x0 + pad_x1 - kw + down_x) / down_x;
+    SGDFR_REQUIRE(out_h > 0 && out_w > 0, "upfirdn2d: empty output %dx%d", out_h, out_w);
+    if (major == 0) return 0;
+    SGDFR_REQUIRE(x && k && y, "upfirdn2d: null pointer");
+    UpfirdnParams p{nullptr, nullptr, nullptr, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, out_h, out_w};
+    const int64_t total = (int64_t)major * out_h * out_w * minor;
+    int64_t g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (dtype == SGDFR_DTYPE_F16)
+        hipLaunchKernelGGL((upfirdn2d_typed_kernel<_Float16, float>), dim3((int)g), dim3(256), 0, as_stream(stream),
+                           static_cast<const _Float16*>(x), static_cast<const _Float16*>(k), static_cast<_Float16*>(y), p);
+    else
+        hipLaunchKernelGGL((upfirdn2d_typed_kernel<double, double>), dim3((int)g), dim3(256), 0, as_stream(stream),
+                           static_cast<const double*>(x), static_cast<const double*>(k), static_cast<double*>(y), p);
     return check_launch("upfirdn2d");
 }
 

@@ -22,7 +22,13 @@ def _bias_geometry(x):
 
 
 def _launch(x, bias, ref, grad_order, slope, scale):
-    N.require_device(x, bias, ref)
+    """fp32, fp16 or fp64 (the dtypes of the reference's dispatch, fused_bias_act_kernel.cu:79); bias / ref follow x's dtype."""
+    dt = N.native_dtype(x)
+    if bias is not None and bias.dtype != x.dtype:        # (a module's fp32 bias Parameter under a half / double input)
+        bias = bias.to(x.dtype)
+    if ref is not None and ref.dtype != x.dtype:
+        ref = ref.to(x.dtype)
+    N.require_device(x, bias, ref, dtype=x.dtype)
     x = N.f32c(x)
     bias = N.f32c(bias) if bias is not None else None
     ref = N.f32c(ref) if ref is not None else None
@@ -30,8 +36,12 @@ def _launch(x, bias, ref, grad_order, slope, scale):
     if bias is not None and bias.numel() != channels:
         raise RuntimeError('bias has %d elements but input has %d channels' % (bias.numel(), channels))
     y = torch.empty_like(x)
-    N.call('sgdfr_fused_bias_act_f32', N.ptr(x), N.ptr(bias), N.ptr(ref), N.ptr(y), x.numel(), inner, channels,
-           3, grad_order, float(slope), float(scale), N.stream())
+    if dt == 0:
+        N.call('sgdfr_fused_bias_act_f32', N.ptr(x), N.ptr(bias), N.ptr(ref), N.ptr(y), x.numel(), inner, channels,
+               3, grad_order, float(slope), float(scale), N.stream())
+    else:
+        N.call('sgdfr_fused_bias_act', N.ptr(x), N.ptr(bias), N.ptr(ref), N.ptr(y), x.numel(), inner, channels,
+               3, grad_order, float(slope), float(scale), dt, N.stream())
     return y
 
 

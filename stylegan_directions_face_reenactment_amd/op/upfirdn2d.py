@@ -32,7 +32,10 @@ def out_size(g, in_h, in_w, kh, kw):
 
 def upfirdn2d_native_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
     """Call-compatible with the reference's native ``upfirdn2d_op.upfirdn2d``: input [major, H, W, minor]."""
-    N.require_device(input, kernel)
+    dt = N.native_dtype(input)                    # fp32 | fp16 | fp64 (upfirdn2d_kernel.cu:225); the taps follow the input's dtype
+    if kernel.dtype != input.dtype:
+        kernel = kernel.to(input.dtype)
+    N.require_device(input, kernel, dtype=input.dtype)
     g = Geometry(up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
     x, k = N.f32c(input), N.f32c(kernel)
     major, in_h, in_w, minor = x.shape
@@ -40,8 +43,12 @@ def upfirdn2d_native_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x
     if oh <= 0 or ow <= 0:
         raise RuntimeError('upfirdn2d: empty output %dx%d' % (oh, ow))
     y = torch.empty(major, oh, ow, minor, device=x.device, dtype=x.dtype)
-    N.call('sgdfr_upfirdn2d_f32', N.ptr(x), N.ptr(k), N.ptr(y), major, in_h, in_w, minor, k.shape[0], k.shape[1],
-           *g, N.stream())
+    if dt == 0:
+        N.call('sgdfr_upfirdn2d_f32', N.ptr(x), N.ptr(k), N.ptr(y), major, in_h, in_w, minor, k.shape[0], k.shape[1],
+               *g, N.stream())
+    else:
+        N.call('sgdfr_upfirdn2d', N.ptr(x), N.ptr(k), N.ptr(y), major, in_h, in_w, minor, k.shape[0], k.shape[1],
+               *g, dt, N.stream())
     return y
 
 
@@ -77,5 +84,6 @@ def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
     up, down = _pair(up), _pair(down)
     if len(pad) == 2:
         pad = (pad[0], pad[1], pad[0], pad[1])
-    N.require_device(input, kernel)
+    N.native_dtype(input)
+    N.require_device(input, dtype=input.dtype)
     return _UpFirDn.apply(input, kernel, Geometry(up[0], up[1], down[0], down[1], *pad))

@@ -657,7 +657,11 @@ def test_two_generators_with_their_own_configs_interleave():
     G.config = base.replace(backward_arith='fp16x3')
     wl = w.clone().requires_grad_(True)
     G([wl], input_is_latent=True)[0].square().mean().backward()
-    assert torch.equal(grads['fp16x3'], wl.grad) and not torch.equal(grads['fp16x3'], grads['bf16x3'])
+    # (the backward's plane reductions use fp32 atomics: two runs of one arithmetic agree to rounding noise, the two arithmetics differ
+    # by the bf16 terms' 16 operand bits)
+    same, other = maxabs(grads['fp16x3'], wl.grad), maxabs(grads['fp16x3'], grads['bf16x3'])
+    print('dL/dw: fp16x3 run to run %.2e, fp16x3 vs bf16x3 %.2e' % (same, other))
+    assert other > 0 and same * 4 < other
 
 
 def test_reenactment_session_rerenders_a_clamped_batch():
