@@ -507,13 +507,25 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
                         ws_f32x2 pr[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) pr[j] = v2[pp][j] * sv[j];
+                        unsigned h01[2], l01[2], h23[2], l23[2];      // [pixel of the pair]
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
-                            unsigned h01, l01, h23, l23;
-                            ws_pair<ET>(pr[0][k], pr[1][k], h01, l01, sat);
-                            ws_pair<ET>(pr[2][k], pr[3][k], h23, l23, sat);
-                            *reinterpret_cast<uint2*>(dst + 16 * (2 * pp + k)) = make_uint2(h01, h23);
-                            *reinterpret_cast<uint2*>(dst + (int64_t)HW * 16 + 16 * (2 * pp + k)) = make_uint2(l01, l23);
+                            ws_pair<ET>(pr[0][k], pr[1][k], h01[k], l01[k], sat);
+                            ws_pair<ET>(pr[2][k], pr[3][k], h23[k], l23[k], sat);
+                        }
+                        {
+                            // The two lane halves hold channels 4*hi .. 4*hi+3 of the same pixels.  One v_permlane32_swap per
+                            // register (lanes 32..63 of the first pixel's <-> lanes 0..31 of the second's) gives the lower half
+                            // the first pixel's whole 8-channel chunk and the upper half the second's: 16-byte stores, neighbouring
+                            // chunks from the two halves in one instruction (32 contiguous bytes per tile instead of 2 x 8).
+                            auto swap32 = [](unsigned& x0, unsigned& x1) {
+                                const auto r2 = __builtin_amdgcn_permlane32_swap(x0, x1, false, false);
+                                x0 = r2[0]; x1 = r2[1];
+                            };
+                            swap32(h01[0], h01[1]); swap32(h23[0], h23[1]); swap32(l01[0], l01[1]); swap32(l23[0], l23[1]);
+                            unsigned char* const d16 = dst - 8 * hi + 16 * (2 * pp + hi);
+                            *reinterpret_cast<uint4*>(d16) = make_uint4(h01[0], h23[0], h01[1], h23[1]);
+                            *reinterpret_cast<uint4*>(d16 + (int64_t)HW * 16) = make_uint4(l01[0], l23[0], l01[1], l23[1]);
                         }
                     }
                 }
