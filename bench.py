@@ -737,6 +737,17 @@ def run_inference(args, rank, world, dev):
         e1, _, _ = timed_region(step1, args, dev)
         single = {'value': round(B * world * args.steps / e1, 2), 'unit': 'frames/s', 'ms_per_step': round(e1 / args.steps * 1e3, 3),
                   'what': 'every step renders its one batch start to finish (no look-ahead across steps)'}
+        # the same with the session's whole step (DirectionMatrix -> shift -> generator) replayed as ONE hipGraph (graph=True)
+        sess_g = ReenactmentSession(G, A, source_code, 0.7, trunc, batch=B, shifts=shifts, streams=1, graph=True)
+
+        def step1g():
+            for img in sess_g.frames_for_targets(ang_s, par_s, ang_t, par_t):
+                out = grid_frames_uint8([src_img, tgt_img[:img.shape[0]], img], swap_rb=True)
+            return out
+        eg, _, _ = timed_region(step1g, args, dev)
+        single['session_graph'] = {'value': round(B * world * args.steps / eg, 2), 'ms_per_step': round(eg / args.steps * 1e3, 3),
+                                   'what': 'ReenactmentSession(graph=True): the step as one hipGraph replay'}
+        del sess_g
         assert frames.shape == (hi - lo, args.size, 3 * args.size, 3) and frames.dtype == torch.uint8
         spread = rank_spread((hi - lo) * args.steps, mine, dev, world)
         roof = roofline_for(args.precision, step1, args.steps, B)

@@ -129,7 +129,7 @@ class ReenactmentSession:
     def reset_graph(self):
         self._graph = None
 
-    def _step(self, sv, image_out=None, no_graph=False):
+    def _step(self, sv, image_out=None, no_graph=False, prefer_graph=False):
         shift = self.A(sv)                                              # [b, L, 512] (w_plus) or [b, 512]
         b = sv.shape[0]
         w = self.source.expand(b, -1, -1).contiguous()
@@ -139,7 +139,8 @@ class ReenactmentSession:
         # generator's own per-forward graphs stay out of it)
         # (verify_range=False: the session checks every chunk's RangeToken itself, one chunk behind the launches)
         img, _ = self.G([latent], input_is_latent=True, truncation=self.truncation, truncation_latent=self.trunc,
-                        image_out=image_out, graph=False if (self.use_graph or no_graph) else None, verify_range=False)
+                        image_out=image_out, graph=False if (self.use_graph or no_graph) else (True if prefer_graph else None),
+                        verify_range=False)
         return img
 
     def _graphed_step(self, sv):
@@ -189,7 +190,9 @@ class ReenactmentSession:
                     return [lo, sv, u8, img, tok, True, None, 'graph']
                 mode = sess.G.range_mode()
                 if pipe is None:
-                    img = sess._step(sv, u8)
+                    # (one stream: the chunk's token is awaited right behind its launches, which exposes the ~0.5 ms of host enqueue
+                    # time of an eager forward -- the generator replays its hipGraph for these, as a verified forward does)
+                    img = sess._step(sv, u8, prefer_graph=True)
                     return [lo, sv, u8, img, sess.G.take_range_token(), False, None, mode]
                 with pipe.next():
                     img = sess._step(sv, u8, no_graph=True)
