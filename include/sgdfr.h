@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 15
+#define SGDFR_ABI_VERSION 16
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -233,6 +233,14 @@ int sgdfr_modconv2d_upfir_split_f32(const unsigned short* xs_in, const unsigned 
                                     const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
                                     const float* s_next, const float* zeros, unsigned short* xs_out, int B, int Cin, int Cout,
                                     int H, int W, int arith, int act, float slope, float gain, unsigned int* sat, void* stream);
+
+/* sgdfr_modconv2d_split_f32(mode = SGDFR_MODE_UP3, x_is_split = 1, plane_stride != 0) as a role-swapping kernel (csrc/uppp.hip): two wave
+ * groups per block, one running a tile's MFMAs while the other DMAs its next operands and stores its own finished tile's planes, so
+ * the plane stores leave the matrix cores' critical path.  Same arguments' meaning, same bits in y [B][Cout][plane_stride][px][py].
+ *   supported: Cin % 16 == 0, Cout % 64 == 0, plane_stride >= (H+1)*(W+1) and > 129 + W (a 128-position tile touches <= 2 images) */
+int sgdfr_modconv2d_up_pp_supported(int B, int Cin, int Cout, int H, int W, int64_t plane_stride);
+int sgdfr_modconv2d_up_pp_f32(const unsigned short* xs_in, const unsigned short* wsp, const float* d, const float* zeros, float* y,
+                              int B, int Cin, int Cout, int H, int W, int64_t plane_stride, int arith, void* stream);
 
 /* y[b,j,p] = sum_i w_rgb[j*Cin+i]/sqrt(Cin) * s[b,i] * x[b,i,p] + bias[j]
  *          + (skip ? upfirdn2d(skip[b,j] (H/2 x W/2), fir[4,4], up=2, pad=(2,1))[p] : 0),  j<3 */

@@ -39,6 +39,7 @@ class Config:
     use_wsplit: bool = True             # inference chain, plain layers fed by a transposed conv + blur: 1-D Winograd form (wsplit.hip)
     wsplit_f: int = 4                   # outputs per Winograd tile the chain prefers: 2 = F(2,3), 4 = F(4,3)
     wsplit_min_cin: int = 128           # ... for layers with at least this many input channels (0 = never)
+    use_up_pp: bool = False             # transposed conv of the chain on the role-swapping kernel (csrc/uppp.hip)
     use_upfir: bool = False             # upsampling layers as one launch (csrc/upfir.hip); off: slower than conv + blur
     upfir_min_w: int = 128              # ... for inputs at least this wide
 
@@ -56,6 +57,7 @@ class Config:
                    use_split_chain=e.get('SGDFR_SPLIT_CHAIN', '1') != '0',
                    use_wsplit=e.get('SGDFR_WSPLIT', '1') != '0', wsplit_f=int(e.get('SGDFR_WSPLIT_F', '4')),
                    wsplit_min_cin=int(e.get('SGDFR_WSPLIT_MIN_CIN', '128')),
+                   use_up_pp=e.get('SGDFR_UPPP', '0') != '0',
                    use_upfir=e.get('SGDFR_UPFIR', '0') != '0', upfir_min_w=int(e.get('SGDFR_UPFIR_MIN_W', '128')))
 
     def __post_init__(self):
@@ -619,6 +621,13 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
         if not want_y and rgb is None and s_next is None:
             raise RuntimeError('modconv_split: want_y=False only makes sense with the fused ToRGB (rgb=...) or s_next')
         y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32) if want_y else None
+    if mode == N.MODE_UP3 and x_split is not None and plane_stride and config().use_up_pp and d is not None and \
+            _shape_query('sgdfr_modconv2d_up_pp_supported', B, cin, cout, H, W, int(plane_stride)):
+        # two wave groups per block swapping roles (MFMA | DMA + plane stores): csrc/uppp.hip, same planes bit for bit
+        _timed_conv(desc or ('up-pp %d->%d @%dx%d' % (cin, cout, H, W)), B * conv_flops(cin, cout, H, W), lambda: N.call(
+            'sgdfr_modconv2d_up_pp_f32', N.ptr(x), N.ptr(wsp), N.ptr(N.f32c(d)), N.ptr(_zero_words(x.device)), N.ptr(y), B, cin, cout,
+            H, W, int(plane_stride), arith, N.stream()))
+        return y
     st, sat = N.stream(), _sat()
     ks = _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cin, cout, H, W, mode) if config().use_splitk else 1
     if ks > 1 and y is None:

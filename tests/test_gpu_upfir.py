@@ -110,3 +110,36 @@ def test_generator_with_the_fused_level_equals_the_two_pass_chain():
     assert torch.equal(fused, two)
     ref, _ = O.generator_forward(synthetic_state(256, 1), [w], input_is_latent=True)
     assert maxabs(fused, ref) <= 2e-4
+
+
+@pytest.mark.parametrize('B,cin,cout,H,W', [(2, 32, 64, 16, 16), (3, 64, 128, 20, 12), (1, 128, 64, 128, 128), (5, 32, 64, 8, 64),
+                                            (7, 48, 192, 33, 17), (64, 64, 64, 32, 32)])
+@pytest.mark.parametrize('arith', ['fp16x3', 'bf16x3'])
+def test_role_swapping_transposed_conv_writes_the_same_planes(B, cin, cout, H, W, arith):
+    """csrc/uppp.hip (two wave groups per block: one runs a tile's MFMAs while the other DMAs its next operands and stores its own
+    finished tile) against split.hip's transposed conv on the same pre-split input: identical interleaved planes, for tiles that
+    straddle images, ragged last tiles, blocks with an odd number of tiles and grids smaller than the tile count."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    ps = ((H + 1) * (W + 1) + 31) // 32 * 32
+    if not F_._shape_query('sgdfr_modconv2d_up_pp_supported', B, cin, cout, H, W, ps) or not F_.xin_ok(B, cin, cout, H, W, F_.N.MODE_UP3):
+        pytest.skip('shape outside one of the two kernels')
+    x, w, s, d, sn, nz, nw, bias = _inputs('pp', B, cin, cout, H, W)
+    wsp = F_.prepack_split(w, arith)
+    xs = F_.to_split(x, s, arith)
+    with F_.using(F_.config().replace(use_splitk=False, use_up_pp=False)):
+        want = F_.modconv_split(xs, wsp, None, d, cout, mode=F_.N.MODE_UP3, x_split=(B, cin, H, W), arith=arith, plane_stride=ps)
+    with F_.using(F_.config().replace(use_splitk=False, use_up_pp=True)):
+        F_.CONV_TIMING = []
+        try:
+            got = F_.modconv_split(xs, wsp, None, d, cout, mode=F_.N.MODE_UP3, x_split=(B, cin, H, W), arith=arith, plane_stride=ps)
+            assert F_.CONV_TIMING[0][3].startswith('up-pp')
+        finally:
+            F_.CONV_TIMING = None
+    torch.cuda.synchronize()
+    rp = (H + 1) * (W + 1)
+    a, b = got.view(B, cout, ps, 4)[:, :, :rp], want.view(B, cout, ps, 4)[:, :, :rp]
+    same = torch.equal(a, b)
+    if not same:
+        bad = (a != b).nonzero()
+        print('mismatches (b, cout, pos, phase):', bad[:8].tolist(), bad.shape[0], 'of', a.numel())
+    assert same
