@@ -211,3 +211,31 @@ def test_winograd_layer_plan_of_the_bench_configs():
     assert lib.sgdfr_modconv_prepack_wsplit_elems(512, 512, 4) == 512 * 512 * 3 * 6 * 2
     assert lib.sgdfr_modconv_prepack_wsplit_elems(512, 512, 2) == 512 * 512 * 3 * 4 * 2
     assert not lib.sgdfr_modconv2d_wsplit_supported(64, 64, 64, 256, 256, 4)          # Cout = 64: no 128-cout tile
+
+
+def test_config_object_is_frozen_scoped_and_seeded_from_the_environment():
+    """functional.Config: frozen and hashable (launch plans / hipGraph keys hash it), `using` blocks nest and restore, the module-level
+    names are read-only views, environment variables only seed the default."""
+    import dataclasses
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    base = F_.config()
+    assert base is F_.DEFAULT and hash(base) == hash(base.replace())
+    with pytest.raises(dataclasses.FrozenInstanceError):
+        base.precision = 'fp32'
+    with pytest.raises(ValueError):
+        base.replace(precision='fp8')
+    with F_.using(base.replace(precision='fp32', use_wsplit=False)) as c1:
+        assert F_.config() is c1 and F_.PRECISION == 'fp32' and F_.USE_WSPLIT is False
+        with F_.precision('bf16x3'):
+            assert F_.config().precision == 'bf16x3' and F_.config().use_wsplit is False
+        assert F_.config() is c1
+    assert F_.config() is base and F_.PRECISION == base.precision
+    env = F_.Config.from_env({'SGDFR_PRECISION': 'bf16x3', 'SGDFR_RANGE_PLAN': 'exact', 'SGDFR_WSPLIT_F': '2', 'SGDFR_UPFIR': '1'})
+    assert (env.precision, env.range_plan, env.wsplit_f, env.use_upfir, env.use_up_pp) == ('bf16x3', 'exact', 2, True, False)
+    from stylegan_directions_face_reenactment_amd.model import Generator
+    G = Generator(32, 512, 8, channel_multiplier=1)
+    assert G.config is None and G.range_mode() == base.precision
+    G.config = base.replace(precision='fp32')
+    assert G.range_mode() == 'fp32'
+    import copy
+    assert copy.deepcopy(G).config == G.config
