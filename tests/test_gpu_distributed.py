@@ -33,6 +33,17 @@ assert all(torch.equal(G.state_dict()[k].cpu(), ref[k]) for k in ref)
 t = torch.arange(1024, device='cuda', dtype=torch.float32)
 dist.all_reduce(t)
 assert torch.equal(t.cpu(), torch.arange(1024, dtype=torch.float32))
+# the other collectives of bench.py's N > 1 flow, on RCCL: MAX all-reduce of a float64 (max_over_ranks), all_gather of float64
+# tensors (rank_spread), all_gather_object (gather_objects: rank affinity, the last rank's oracle check)
+t64 = torch.tensor([3.25], dtype=torch.float64, device='cuda')
+dist.all_reduce(t64, op=dist.ReduceOp.MAX)
+assert float(t64) == 3.25
+got = [torch.zeros_like(t64)]
+dist.all_gather(got, t64)
+assert float(got[0]) == 3.25
+objs = [None]
+dist.all_gather_object(objs, {'rank': 0, 'within_bar': True, 'fp16x3': 1.5e-5})
+assert objs[0]['within_bar'] is True and objs[0]['fp16x3'] == 1.5e-5
 dist.barrier()
 torch.cuda.synchronize()
 print('rccl-ok backend=%%s bytes=%%d' %% (dist.get_backend(), n))
