@@ -320,9 +320,25 @@ __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(c
         auto load_srow = [&](int a, float (&d0)[5], float (&d1)[5]) {
             const float* q = tp + ((int64_t)a * GW + n) * 4;
             const bool rok = a >= 0;
+#if defined(SGDFR_BLUR_PROBE) && SGDFR_BLUR_PROBE == 2      // ablation: no plane loads
+            for (int v = 0; v < 5; ++v) { d0[v] = (float)(a + v); d1[v] = (float)(n - v); }
+            if (rok) return;
+#endif
+#if defined(SGDFR_BLUR_PROBE) && (SGDFR_BLUR_PROBE == 4 || SGDFR_BLUR_PROBE == 6)      // A/B: non-temporal plane loads
+            typedef float bl_f4 __attribute__((ext_vector_type(4)));
+            typedef float bl_f2 __attribute__((ext_vector_type(2)));
+            float2 lf = make_float2(0.f, 0.f);
+            float4 cf = make_float4(0.f, 0.f, 0.f, 0.f), rf = cf;
+            if (rok && l_ok) { const bl_f2 t2 = __builtin_nontemporal_load(reinterpret_cast<const bl_f2*>(q - 2)); lf = make_float2(t2[0], t2[1]); }
+            if (rok && c_ok) {
+                const bl_f4 t4 = __builtin_nontemporal_load(reinterpret_cast<const bl_f4*>(q)), u4 = __builtin_nontemporal_load(reinterpret_cast<const bl_f4*>(q + 4));
+                cf = make_float4(t4[0], t4[1], t4[2], t4[3]); rf = make_float4(u4[0], u4[1], u4[2], u4[3]);
+            }
+#else
             const float2 lf = (rok && l_ok) ? *reinterpret_cast<const float2*>(q - 2) : make_float2(0.f, 0.f);        // (n-1: px 1, py 0 | 1)
             const float4 cf = (rok && c_ok) ? *reinterpret_cast<const float4*>(q) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 rf = (rok && c_ok) ? *reinterpret_cast<const float4*>(q + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
             d0[0] = lf.x; d0[1] = cf.x; d0[2] = cf.z; d0[3] = rf.x; d0[4] = rf.z;
             d1[0] = lf.y; d1[1] = cf.y; d1[2] = cf.w; d1[3] = rf.y; d1[4] = rf.w;
         };
@@ -373,6 +389,12 @@ __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(c
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
                     float o0 = 0.f, o1 = 0.f;
+#if defined(SGDFR_BLUR_PROBE) && SGDFR_BLUR_PROBE == 3      // ablation: 5 adds per output instead of 16 FMAs (is the kernel VALU-bound?)
+#pragma unroll
+                    for (int ky = 0; ky < 4; ++ky) { o0 += win[rr + ky][ky]; o1 += win[rr + ky][1 + ky]; }
+                    o0 += win[rr][3]; o1 += win[rr + 3][1];
+                    for (int v = 0; v < 5; ++v) o0 += win[4 - rr][v] * 1e-9f;      // (keep every window entry alive)
+#else
 #pragma unroll
                     for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
@@ -380,6 +402,7 @@ __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(c
                             o0 = fmaf(win[rr + ky][kx], kf[ky * 4 + kx], o0);
                             o1 = fmaf(win[rr + ky][1 + kx], kf[ky * 4 + kx], o1);
                         }
+#endif
                     float v0 = fmaf(nw, nzq[rr][0], o0 + bv), v1 = fmaf(nw, nzq[rr][1], o1 + bv);
                     if (act) {
                         v0 = lrelu_gain(v0, slope, gain);
@@ -486,8 +509,14 @@ __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(c
                 if (vh.x == 0x7fc07fc0u)
 #endif
                 {
+#if defined(SGDFR_BLUR_PROBE) && (SGDFR_BLUR_PROBE == 5 || SGDFR_BLUR_PROBE == 6)      // A/B: non-temporal hand-over stores
+                    typedef unsigned bl_u4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store((bl_u4){vh.x, vh.y, vh.z, vh.w}, reinterpret_cast<bl_u4*>(dst));
+                    __builtin_nontemporal_store((bl_u4){vl.x, vl.y, vl.z, vl.w}, reinterpret_cast<bl_u4*>(dst + (int64_t)OHW * 16));
+#else
                     *reinterpret_cast<uint4*>(dst) = vh;
                     *reinterpret_cast<uint4*>(dst + (int64_t)OHW * 16) = vl;
+#endif
                 }
             }
         }
