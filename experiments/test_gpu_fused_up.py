@@ -1,10 +1,17 @@
-"""GPU: the upsampling StyledConv as ONE launch (csrc/upfir.hip: transposed conv with the FIR blur, noise, bias, leaky-ReLU and the
+"""GPU (run explicitly: `python experiments/build.py && python -m pytest experiments -m gpu`): the two shelved kernels against the
+product path.  The upsampling StyledConv as ONE launch (experiments/csrc/upfir.hip: transposed conv with the FIR blur, noise, bias, leaky-ReLU and the
 split hand-over in its epilogue; reference model.py:246-257 + 303-337) against the two-pass form it replaces and against the
 fp64 oracle."""
+import os
+import sys
+
 import pytest
 import torch
 
-from util import O, S, hip_generator, maxabs, synthetic_state, SEED
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from util import O, S, maxabs      # noqa: E402
+import fused_up as X               # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -35,7 +42,7 @@ def test_fused_up_conv_equals_the_two_pass_form_bit_for_bit(B, cin, cout, H, W, 
     arithmetic: the int16 hand-over buffers must be identical, for square / ragged shapes, shared and per-sample noise, and
     patches that hang over the right and bottom edges."""
     from stylegan_directions_face_reenactment_amd import functional as F_
-    if not F_.upfir_ok(B, cin, cout, H, W) or not F_.split_ok(B, cin, cout, H, W, F_.N.MODE_UP3):
+    if not X.upfir_ok(B, cin, cout, H, W) or not F_.split_ok(B, cin, cout, H, W, F_.N.MODE_UP3):
         pytest.skip('shape not supported by one of the two forms')
     for per_sample in (False, True):
         x, w, s, d, sn, nz, nw, bias = _inputs('uf%d' % per_sample, B, cin, cout, H, W, per_sample)
@@ -49,7 +56,7 @@ def test_fused_up_conv_equals_the_two_pass_form_bit_for_bit(B, cin, cout, H, W, 
         want = F_.blur_bias_act_split(planes, _fir(), H, W, sn, nz, nw, bias, True, arith=arith)
         word = F_.new_saturation_word(x.device)
         with F_.saturation_sink(word):
-            got = F_.modconv_upfir_split(xs, (B, cin, H, W), wsp, d, cout, _fir(), sn, nz, nw, bias, True, arith=arith)
+            got = X.modconv_upfir_split(xs, (B, cin, H, W), wsp, d, cout, _fir(), sn, nz, nw, bias, True, arith=arith)
         torch.cuda.synchronize()
         assert got.shape == want.shape and int(word.item()) == 0
         same = torch.equal(got, want)
@@ -76,7 +83,7 @@ def test_fused_up_conv_matches_fp64_oracle():
         s_r, d_r = (F_.split_range(s, dd.float().cuda(), F_.absmax(x)) if arith == 'fp16x3' else (s, dd.float().cuda()))
         xs = F_.to_split(x, s_r, arith)
         ones = torch.ones(B, cout).cuda()
-        got = F_.modconv_upfir_split(xs, (B, cin, H, H), wsp, d_r, cout, _fir(), ones, nz, nw, bias, True, arith=arith)
+        got = X.modconv_upfir_split(xs, (B, cin, H, H), wsp, d_r, cout, _fir(), ones, nz, nw, bias, True, arith=arith)
         # decode the hand-over: hi + lo terms (fp16: times 2^4, the static activation pre-scale of the split form)
         dt = torch.float16 if arith == 'fp16x3' else torch.bfloat16
         val = got.view(dt).float()
@@ -87,54 +94,23 @@ def test_fused_up_conv_matches_fp64_oracle():
         assert err <= tol
 
 
-def test_generator_with_the_fused_level_equals_the_two_pass_chain():
-    """Generator(256) images with the 128 -> 256 level fused are the SAME BITS as with the two-pass form, and within 2e-4 of the
-    oracle; the chain really took the fused launch (conv timing descriptions)."""
-    from stylegan_directions_face_reenactment_amd import functional as F_
-    if F_.PRECISION not in ('fp16x3', 'bf16x3'):
-        pytest.skip('split arithmetics only')
-    G = hip_generator(256, 1)
-    w = S.synthetic_latents(SEED, 3, n_latent=G.n_latent, key='upfir.w')
-    try:
-        with torch.no_grad():
-            G.config = F_.config().replace(use_upfir=True)
-            F_.CONV_TIMING = []
-            fused, _ = G([w.cuda()], input_is_latent=True)
-            descs = [r[3] for r in F_.CONV_TIMING]
-            F_.CONV_TIMING = None
-            assert any(dsc.startswith('upfir') for dsc in descs), descs
-            G.config = F_.config().replace(use_upfir=False)
-            two, _ = G([w.cuda()], input_is_latent=True)
-    finally:
-        F_.CONV_TIMING = None
-    assert torch.equal(fused, two)
-    ref, _ = O.generator_forward(synthetic_state(256, 1), [w], input_is_latent=True)
-    assert maxabs(fused, ref) <= 2e-4
-
-
 @pytest.mark.parametrize('B,cin,cout,H,W', [(2, 32, 64, 16, 16), (3, 64, 128, 20, 12), (1, 128, 64, 128, 128), (5, 32, 64, 8, 64),
                                             (7, 48, 192, 33, 17), (64, 64, 64, 32, 32)])
 @pytest.mark.parametrize('arith', ['fp16x3', 'bf16x3'])
 def test_role_swapping_transposed_conv_writes_the_same_planes(B, cin, cout, H, W, arith):
-    """csrc/uppp.hip (two wave groups per block: one runs a tile's MFMAs while the other DMAs its next operands and stores its own
+    """experiments/csrc/uppp.hip (two wave groups per block: one runs a tile's MFMAs while the other DMAs its next operands and stores its own
     finished tile) against split.hip's transposed conv on the same pre-split input: identical interleaved planes, for tiles that
     straddle images, ragged last tiles, blocks with an odd number of tiles and grids smaller than the tile count."""
     from stylegan_directions_face_reenactment_amd import functional as F_
     ps = ((H + 1) * (W + 1) + 31) // 32 * 32
-    if not F_._shape_query('sgdfr_modconv2d_up_pp_supported', B, cin, cout, H, W, ps) or not F_.xin_ok(B, cin, cout, H, W, F_.N.MODE_UP3):
+    if not X.up_pp_ok(B, cin, cout, H, W, ps) or not F_.xin_ok(B, cin, cout, H, W, F_.N.MODE_UP3):
         pytest.skip('shape outside one of the two kernels')
     x, w, s, d, sn, nz, nw, bias = _inputs('pp', B, cin, cout, H, W)
     wsp = F_.prepack_split(w, arith)
     xs = F_.to_split(x, s, arith)
-    with F_.using(F_.config().replace(use_splitk=False, use_up_pp=False)):
+    with F_.using(F_.config().replace(use_splitk=False)):
         want = F_.modconv_split(xs, wsp, None, d, cout, mode=F_.N.MODE_UP3, x_split=(B, cin, H, W), arith=arith, plane_stride=ps)
-    with F_.using(F_.config().replace(use_splitk=False, use_up_pp=True)):
-        F_.CONV_TIMING = []
-        try:
-            got = F_.modconv_split(xs, wsp, None, d, cout, mode=F_.N.MODE_UP3, x_split=(B, cin, H, W), arith=arith, plane_stride=ps)
-            assert F_.CONV_TIMING[0][3].startswith('up-pp')
-        finally:
-            F_.CONV_TIMING = None
+    got = X.modconv_up_pp(xs, (B, cin, H, W), wsp, d, cout, ps, arith=arith)
     torch.cuda.synchronize()
     rp = (H + 1) * (W + 1)
     a, b = got.view(B, cout, ps, 4)[:, :, :rp], want.view(B, cout, ps, 4)[:, :, :rp]

@@ -23,7 +23,7 @@ if os.environ.get('SGDFR_LIB'):
     else:
         import warnings as _warnings
         _warnings.warn('SGDFR_LIB is set but ignored (set SGDFR_ALLOW_LIB_OVERRIDE=1 to load a probe build)', RuntimeWarning)
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -119,17 +119,10 @@ SIGNATURES['sgdfr_to_wsplit_f32'] = [_c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, 
 SIGNATURES['sgdfr_modconv2d_wsplit_f32'] = [ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
                                             _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p, _c_f32p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f,
                                             ctypes.c_void_p, ctypes.c_void_p]
-SIGNATURES['sgdfr_modconv2d_upfir_supported'] = [_i, _i, _i, _i, _i]
-SIGNATURES['sgdfr_modconv2d_upfir_tiles'] = [_i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
-SIGNATURES['sgdfr_modconv2d_upfir_split_f32'] = [ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,
-                                                 _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i, _i, _i, _f, _f, ctypes.c_void_p,
-                                                 ctypes.c_void_p]
 SIGNATURES['sgdfr_fused_bias_act'] = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _i64, _i, _i, _i, _i, _f, _f, _i,
                                       ctypes.c_void_p]
 SIGNATURES['sgdfr_upfirdn2d'] = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [_i] * 15 + [ctypes.c_void_p]
 DTYPES = {torch.float32: 0, torch.float16: 1, torch.float64: 2}      # SGDFR_DTYPE_* of the two reference natives
-SIGNATURES['sgdfr_modconv2d_up_pp_supported'] = [_i, _i, _i, _i, _i, _i64]
-SIGNATURES['sgdfr_modconv2d_up_pp_f32'] = [ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, _i, _i, _i64, _i, ctypes.c_void_p]
 # measurement-only symbols: bound when present, never required of a production library (bench.py's measured_mfma_ceiling)
 OPTIONAL_SIGNATURES = {'sgdfr_mfma_ceiling_probe': [_i, _i, _i, _i, _i, _c_f32p, ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]}
 

@@ -1,0 +1,131 @@
+"""The inference dataflow between split convs ("split chain"): which hand-over form each layer of the no-grad
+forward takes, the StyledConv that runs it, and the two-stream pipeline of independent batches.  Launch wrappers live in
+functional.py; nothing here touches the C ABI directly except shape queries.
+"""
+import torch
+
+from . import _native as N
+from .config import config
+from .functional import (_shape_query, blur_bias_act, blur_bias_act_split, modconv_split, modconv_wsplit, split_ok, wsplit_ok)
+
+
+class SplitAct:
+    """An activation that only exists in the NEXT conv's split input form (x * s_next as 16-bit hi/lo pairs,
+    [B, C/8, 2, H*W, 8] int16): written by the producing kernel's epilogue, staged by DMA in the consumer.  wino=True: the
+    Winograd input form of that conv instead ([B, C/8, 4, 2, H*W/2, 8], see to_wsplit / modconv_wsplit)."""
+    __slots__ = ('xs', 'shape', 'wino')
+
+    def __init__(self, xs, shape, wino=0):
+        self.xs, self.shape, self.wino = xs, tuple(shape), (2 if wino is True else int(wino or 0))
+
+
+def xin_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
+    """Can the split conv of this shape take its input as a SplitAct?"""
+    return config().use_split_chain and split_ok(B, cin, cout, H, W, mode) and \
+        bool(_shape_query('sgdfr_modconv2d_split_xin_supported', B, cin, cout, H, W, mode))
+
+
+def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, noise_weight=None, bias=None, batch=None,
+                      s_next=None, rgb=None, want_y=True, wino_next=False):
+    """One StyledConv on the split kernels with the inference-only dataflow options: x may be a SplitAct (then `s` is
+    already applied), s_next asks for the output as a SplitAct for the next conv, rgb for the fused ToRGB partial sums.
+    A SplitAct in Winograd form (x.wino) runs on modconv_wsplit with `wsp` = the prepack_wsplit pack; wino_next (transposed
+    conv + blur only) asks for the output in that form.
+    Returns (activation: fp32 tensor | SplitAct | None, ToRGB partials | None)."""
+    if isinstance(x, SplitAct) and x.wino:
+        if upsample:
+            raise RuntimeError('styled_conv_split: the Winograd input form feeds plain convs only')
+        B, cin, H, W = x.shape
+        res = modconv_wsplit(x.xs, x.shape, wsp, d, cout, noise, noise_weight, bias, True, rgb=rgb,
+                             want_y=want_y and s_next is None, s_next=s_next, f=x.wino)
+        if s_next is not None:
+            _, part, xs = res
+            return SplitAct(xs, (B, cout, H, W)), part
+        return res if rgb is not None else (res, None)
+    if isinstance(x, SplitAct):
+        B, cin, H, W = x.shape
+        xin, x_split, s_arg = x.xs, x.shape, None
+        batch = B
+    else:
+        xin, x_split, s_arg = x, None, s
+        B = s.shape[0] if batch is None else batch
+        H, W = x.shape[2], x.shape[3]
+    if not upsample:
+        res = modconv_split(xin, wsp, s_arg, d, cout, noise, noise_weight, bias, True, batch=batch, rgb=rgb,
+                            want_y=want_y and s_next is None, x_split=x_split, s_next=s_next)
+        if s_next is not None:          # the activation leaves only as the next conv's split input
+            _, part, xs = res
+            return SplitAct(xs, (B, cout, H, W)), part
+        return res if rgb is not None else (res, None)
+    if s_next is not None and config().use_plane_padding and \
+            _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, x_split[1] if x_split else x.shape[1], cout, H, W, N.MODE_UP3) == 1:
+        # parity planes padded to whole 128-byte lines: the odd-sized dense planes make every store run straddle two lines
+        ps = ((H + 1) * (W + 1) + 31) // 32 * 32
+        planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split, plane_stride=ps)
+        xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, plane_stride=ps, wino=wino_next)
+        return SplitAct(xs, (B, cout, 2 * H, 2 * W), wino_next), None
+    planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split)
+    if s_next is not None:
+        xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, wino=wino_next)
+        return SplitAct(xs, (B, cout, 2 * H, 2 * W), wino_next), None
+    return blur_bias_act(planes, fir, H, W, noise, noise_weight, bias, True), None
+
+
+def wsplit_chain_f(B, cin, cout, H, W):
+    """Winograd form the inference chain runs this plain layer (fed by a transposed conv + blur) in: 0 (direct), 2 or 4 outputs
+    per tile."""
+    if not (config().use_wsplit and config().use_split_chain and config().wsplit_min_cin > 0 and cin >= config().wsplit_min_cin and W <= 128):
+        return 0
+    for f in ((4, 2) if config().wsplit_f == 4 else (2,)):
+        # (F(2,3) hands over 8 bytes per element and saves a third of the MFMAs: it only pays from 256 input channels on)
+        if wsplit_ok(B, cin, cout, H, W, f) and (f == 4 or cin >= max(config().wsplit_min_cin, 256)):
+            return f
+    return 0
+
+
+def wsplit_chain_ok(B, cin, cout, H, W):
+    return wsplit_chain_f(B, cin, cout, H, W) != 0
+
+
+def rgb_fusable(B, cin, cout, H, W):
+    """True when the plain 3x3 conv of this shape runs on the split kernel in one pass, so the ToRGB that follows it can be
+    accumulated in its epilogue instead of re-reading the activation."""
+    return config().use_rgb_fusion and split_ok(B, cin, cout, H, W) and \
+        (not config().use_splitk or _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cin, cout, H, W, N.MODE_PLAIN3) == 1)
+
+
+class StreamPipeline:
+    """Consecutive INDEPENDENT batches on alternating HIP streams.  The head of a generator forward (4x4 ... 16x16 layers:
+    K-sliced launches that under-fill the chip, ~30 dependent launches with ~6 us of gap each) then runs beside the big layers
+    of the previous batch instead of in front of its own: 9.69 k -> 10.08 k frames/s at B=64 with two streams (three: 9.91 k),
+    bit-identical images (scripts/two_stream_probe.py).
+
+        pipe = StreamPipeline(2)
+        for w in batches:
+            with pipe.next():                 # the slot's stream first waits for what the caller's stream has queued so far
+                img, _ = G([w], input_is_latent=True, verify_range=False)      # (the default verifies: it would WAIT per call
+                out.append(img); tokens.append(G.last_range_token)             #  and serialise the two streams)
+        pipe.join(*out)                       # the caller's stream now waits for every slot; tensors are handed over to it
+        bad = [i for i, t in enumerate(tokens) if t is not None and not G.range_ok(t)]      # re-render those (ReenactmentSession does)
+    """
+
+    def __init__(self, n=2, device=None):
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, int(n)))]
+        self._i = 0
+        self.last = None                      # stream of the latest slot
+
+    def next(self):
+        s = self.streams[self._i % len(self.streams)]
+        self._i += 1
+        s.wait_stream(torch.cuda.current_stream(s.device))
+        self.last = s
+        return torch.cuda.stream(s)
+
+    def join(self, *tensors, stream=None):
+        """The current stream waits for `stream` (default: every slot); `tensors` (made on slot streams) may then be used on it."""
+        cur = torch.cuda.current_stream(self.streams[0].device)
+        for s in ([stream] if stream is not None else self.streams):
+            cur.wait_stream(s)
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(cur)

@@ -332,7 +332,6 @@ extern "C" int sgdfr_planes_to_split_f32(const float* gt, const float* d, unsign
 
 unsigned int blur_split_saturation_count(int reset);     // upfirdn2d.hip's counter
 namespace sgdfr { unsigned int wsplit_saturation_count(int reset); }     // wsplit.hip's
-namespace sgdfr { unsigned int upfir_saturation_count(int reset); }      // upfir.hip's
 
 // Number of fp16-split operand pairs that hit the +-65504 clamp (|x*s| > 1.04e6) since the last reset, over all split
 // kernels on the current device; synchronises the device.  Negative: HIP error.
@@ -343,8 +342,7 @@ extern "C" long long sgdfr_split_saturation_count(int reset) {
         const unsigned int z = 0;
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_split_saturated), &z, sizeof(z)) != hipSuccess) return -1;
     }
-    return (long long)v + (long long)blur_split_saturation_count(reset) + (long long)sgdfr::wsplit_saturation_count(reset) +
-           (long long)sgdfr::upfir_saturation_count(reset);
+    return (long long)v + (long long)blur_split_saturation_count(reset) + (long long)sgdfr::wsplit_saturation_count(reset);
 }
 
 #ifdef SGDFR_SPLIT_PROBE

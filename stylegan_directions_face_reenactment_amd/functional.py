@@ -3,147 +3,56 @@
 Each function is one (or a fixed short sequence of) native launch(es) on torch's current HIP stream;
 nothing here computes with torch ops.  Reference lines each function stands for are cited inline
 (paths relative to the reference's libs/gan/StyleGAN2/).
+
+The package's host layer is four modules; this one is the launch wrappers and the facade the rest of the package (and the
+tests) import as `F_`:
+    config.py    the frozen Config, `config()`, `using`, `precision`, `set_default`        (re-exported here)
+    timing.py    per-launch HIP-event timing for bench.py: `timing.collect()`             (used here)
+    chain.py     the split-chain dataflow: SplitAct, styled_conv_split, wsplit_chain_f,
+                 rgb_fusable, xin_ok, StreamPipeline                                       (served lazily as F_.<name>)
 """
-import dataclasses
 import functools
-import os
+import sys
 import threading
+import types
 
 import torch
 from torch.autograd import Function
 
 from . import _native as N
+from . import config as _config
+from .config import Config, config, precision, set_default, set_precision, using      # noqa: F401  (the facade's exports)
+from .timing import timed_conv as _timed_conv, timed_hbm as _timed_hbm
 
 SQRT2 = 2 ** 0.5
 
-# ------------------------------------------------------------------ configuration
-# Every switch of the path lives in ONE frozen object.  `config()` is the configuration in force for the calling thread: the
-# innermost `with using(cfg):` block, else the process default DEFAULT (seeded from SGDFR_* environment variables once, at import).
-# A Generator holds its own (`G.config`, None = follow the ambient one) and runs its forward -- and, through the autograd
-# Functions, its backward -- under it, so two generators with different arithmetics interleave in one process; launch plans, range
-# plans and hipGraph captures are keyed on the object itself (hashable), not on an enumeration of switches.
-@dataclasses.dataclass(frozen=True)
-class Config:
-    # Arithmetic of the 3x3 modulated convs (inference path, autograd forward, dL/dx of the plain convs): 'fp16x3' | 'fp32' | 'bf16x3'
-    # (see the PRECISION comment below)
-    precision: str = 'fp16x3'
-    # Range plan of the fp16-split conv: True (calibrated per weight version) | 'exact' (measured per layer and image) | False
-    range_plan: object = True
-    backward_arith: str = 'fp16x3'      # dL/dx convs of the split kernels: 'bf16x3' | 'fp16x3' (ranged per image, autograd.py)
-    use_plane_padding: bool = True      # inference chain: parity planes of the transposed conv padded to whole lines + interleaved
-    use_split_chain: bool = True        # activations between split convs only in split form
-    use_rgb_fusion: bool = True         # ToRGB partial sums in the epilogue of the split conv that feeds it (no-grad path)
-    use_splitk: bool = True             # K-sliced launches for convs that cannot fill the chip (small batch / 4x4, 8x8 layers)
-    use_winograd: bool = True           # fp32 path, plain 3x3 layers: Winograd F(2x2,3x3) MFMA kernel when the shape allows it
-    winograd_min_blocks: int = 256      # below this many (64 cout x 64 tile) blocks the direct kernel's smaller tiles win
-    use_wsplit: bool = True             # inference chain, plain layers fed by a transposed conv + blur: 1-D Winograd form (wsplit.hip)
-    wsplit_f: int = 4                   # outputs per Winograd tile the chain prefers: 2 = F(2,3), 4 = F(4,3)
-    wsplit_min_cin: int = 128           # ... for layers with at least this many input channels (0 = never)
-    use_up_pp: bool = False             # transposed conv of the chain on the role-swapping kernel (csrc/uppp.hip)
-    use_upfir: bool = False             # upsampling layers as one launch (csrc/upfir.hip); off: slower than conv + blur (DESIGN 4.9)
-    upfir_min_w: int = 128              # ... for inputs at least this wide
-
-    def replace(self, **changes):
-        return dataclasses.replace(self, **changes)
-
-    @classmethod
-    def from_env(cls, env=None):
-        e = os.environ if env is None else env
-        rp = e.get('SGDFR_RANGE_PLAN', '1')
-        return cls(precision=e.get('SGDFR_PRECISION', 'fp16x3'),
-                   range_plan=False if rp == '0' else ('exact' if rp == 'exact' else True),
-                   backward_arith=e.get('SGDFR_BWD_ARITH', 'fp16x3'),
-                   use_plane_padding=e.get('SGDFR_PLANE_PADDING', '1') != '0',
-                   use_split_chain=e.get('SGDFR_SPLIT_CHAIN', '1') != '0',
-                   use_wsplit=e.get('SGDFR_WSPLIT', '1') != '0', wsplit_f=int(e.get('SGDFR_WSPLIT_F', '4')),
-                   wsplit_min_cin=int(e.get('SGDFR_WSPLIT_MIN_CIN', '128')),
-                   use_up_pp=e.get('SGDFR_UPPP', '0') != '0',
-                   use_upfir=e.get('SGDFR_UPFIR', '0') != '0', upfir_min_w=int(e.get('SGDFR_UPFIR_MIN_W', '128')))
-
-    def __post_init__(self):
-        if self.precision not in ('fp32', 'fp16x3', 'bf16x3'):
-            raise ValueError("precision must be 'fp32', 'fp16x3' or 'bf16x3', got %r" % (self.precision,))
-        if self.backward_arith not in ('fp16x3', 'bf16x3'):
-            raise ValueError("backward_arith must be 'fp16x3' or 'bf16x3', got %r" % (self.backward_arith,))
-        if self.wsplit_f not in (2, 4):
-            raise ValueError('wsplit_f must be 2 or 4')
+_CHAIN_NAMES = ('SplitAct', 'xin_ok', 'styled_conv_split', 'wsplit_chain_f', 'wsplit_chain_ok', 'rgb_fusable', 'StreamPipeline')
 
 
-DEFAULT = Config.from_env()
-_ambient = threading.local()
+class _Facade(types.ModuleType):
+    """functional's module class: F_.DEFAULT and the old switch names (F_.PRECISION, F_.USE_WSPLIT ...) are live views of
+    config.py; the chain layer's names come from chain.py on first use (it imports this module, so not at import time); the old
+    switch names cannot be assigned (an assignment would shadow the view while every launch ignores it)."""
+
+    def __getattr__(self, name):
+        if name in _config.LEGACY:
+            return getattr(config(), _config.LEGACY[name])
+        if name == 'DEFAULT':
+            return _config.DEFAULT
+        if name in _CHAIN_NAMES:
+            from . import chain
+            return getattr(chain, name)
+        raise AttributeError('module %r has no attribute %r' % (self.__name__, name))
+
+    def __setattr__(self, name, value):
+        if name in _config.LEGACY or name == 'DEFAULT':
+            raise AttributeError('functional.%s is a read-only view of the ambient Config: use `with functional.using(functional.'
+                                 'config().replace(%s=...))`, functional.set_default(...), or a Generator\'s `config`'
+                                 % (name, _config.LEGACY.get(name, 'field')))
+        super().__setattr__(name, value)
 
 
-def config():
-    """The Config in force for this thread (innermost `using` block, else DEFAULT)."""
-    return getattr(_ambient, 'cfg', None) or DEFAULT
-
-
-def set_default(cfg):
-    """Replace the process default (what bench.py --precision does); `using` blocks and generator-held configs are unaffected."""
-    global DEFAULT
-    if not isinstance(cfg, Config):
-        raise TypeError('set_default takes a functional.Config')
-    DEFAULT = cfg
-
-
-class using:
-    """`with functional.using(cfg):` -- cfg is the configuration of every launch issued by this thread inside the block."""
-
-    def __init__(self, cfg):
-        self.cfg, self.prev = cfg, None
-
-    def __enter__(self):
-        self.prev = getattr(_ambient, 'cfg', None)
-        _ambient.cfg = self.cfg
-        return self.cfg
-
-    def __exit__(self, *exc):
-        _ambient.cfg = self.prev
-
-
-_LEGACY = {n: n.lower() for n in ('PRECISION', 'RANGE_PLAN', 'USE_PLANE_PADDING', 'USE_SPLIT_CHAIN', 'USE_RGB_FUSION', 'BACKWARD_ARITH',
-                                  'USE_SPLITK', 'USE_WINOGRAD', 'USE_WSPLIT', 'WSPLIT_F', 'WSPLIT_MIN_CIN', 'WINOGRAD_MIN_BLOCKS',
-                                  'USE_UPFIR', 'UPFIR_MIN_W')}
-
-
-def __getattr__(name):
-    """Read-only views of the ambient config under the old module-level names (functional.PRECISION ...).  They cannot be
-    assigned any more: use `with using(config().replace(...))`, `set_default`, or a Generator's `config`."""
-    if name in _LEGACY:
-        return getattr(config(), _LEGACY[name])
-    raise AttributeError('module %r has no attribute %r' % (__name__, name))
-
-
-
-# bench.py sets this to a list to time the MFMA conv launches: entries are
-# (start_event, end_event, algorithmic_flops, description) recorded on the launch stream
-CONV_TIMING = None
-
-
-def _timed_conv(desc, flops, launch):
-    if CONV_TIMING is None:
-        return launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    launch()
-    e1.record()
-    CONV_TIMING.append((e0, e1, flops, desc))
-
-
-# bench.py sets this to a list to time the HBM-bound launches of the path (FIR blur after the transposed conv, ToRGB / its
-# finish): entries are (start_event, end_event, algorithmic_bytes, description)
-HBM_TIMING = None
-
-
-def _timed_hbm(desc, nbytes, launch):
-    if HBM_TIMING is None:
-        return launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    launch()
-    e1.record()
-    HBM_TIMING.append((e0, e1, nbytes, desc))
-
+sys.modules[__name__].__class__ = _Facade
 
 # ------------------------------------------------------------------ small dense ops
 
@@ -489,27 +398,6 @@ class capture_graph:
                 gc.enable()
 
 
-def set_precision(mode):
-    """Process default arithmetic of the 3x3 convs (bench.py --precision): replaces the DEFAULT config's `precision`."""
-    if mode not in ('fp32', 'fp16x3', 'bf16x3'):
-        raise ValueError("precision must be 'fp32', 'fp16x3' or 'bf16x3', got %r" % (mode,))
-    set_default(DEFAULT.replace(precision=mode))
-
-
-class precision(using):
-    """`with functional.precision('fp32'):` -- the arithmetic of the 3x3 convs inside the block (the ambient config otherwise)."""
-
-    def __init__(self, mode):
-        if mode not in ('fp32', 'fp16x3', 'bf16x3'):
-            raise ValueError("precision must be 'fp32', 'fp16x3' or 'bf16x3', got %r" % (mode,))
-        self.mode = mode
-        super().__init__(None)
-
-    def __enter__(self):
-        self.cfg = config().replace(precision=self.mode)
-        return super().__enter__()
-
-
 def _zero_words(device):
     z = _zeros.get(device)
     if z is None:
@@ -621,13 +509,6 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
         if not want_y and rgb is None and s_next is None:
             raise RuntimeError('modconv_split: want_y=False only makes sense with the fused ToRGB (rgb=...) or s_next')
         y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32) if want_y else None
-    if mode == N.MODE_UP3 and x_split is not None and plane_stride and config().use_up_pp and d is not None and \
-            _shape_query('sgdfr_modconv2d_up_pp_supported', B, cin, cout, H, W, int(plane_stride)):
-        # two wave groups per block swapping roles (MFMA | DMA + plane stores): csrc/uppp.hip, same planes bit for bit
-        _timed_conv(desc or ('up-pp %d->%d @%dx%d' % (cin, cout, H, W)), B * conv_flops(cin, cout, H, W), lambda: N.call(
-            'sgdfr_modconv2d_up_pp_f32', N.ptr(x), N.ptr(wsp), N.ptr(N.f32c(d)), N.ptr(_zero_words(x.device)), N.ptr(y), B, cin, cout,
-            H, W, int(plane_stride), arith, N.stream()))
-        return y
     st, sat = N.stream(), _sat()
     ks = _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cin, cout, H, W, mode) if config().use_splitk else 1
     if ks > 1 and y is None:
@@ -675,22 +556,6 @@ def prepack_wsplit(weight, arith=None, f=2):
 
 def wsplit_ok(B, cin, cout, H, W, f=2):
     return config().precision in _SPLIT_ARITH and bool(_shape_query('sgdfr_modconv2d_wsplit_supported', B, cin, cout, H, W, f))
-
-
-def wsplit_chain_f(B, cin, cout, H, W):
-    """Winograd form the inference chain runs this plain layer (fed by a transposed conv + blur) in: 0 (direct), 2 or 4 outputs
-    per tile."""
-    if not (config().use_wsplit and config().use_split_chain and config().wsplit_min_cin > 0 and cin >= config().wsplit_min_cin and W <= 128):
-        return 0
-    for f in ((4, 2) if config().wsplit_f == 4 else (2,)):
-        # (F(2,3) hands over 8 bytes per element and saves a third of the MFMAs: it only pays from 256 input channels on)
-        if wsplit_ok(B, cin, cout, H, W, f) and (f == 4 or cin >= max(config().wsplit_min_cin, 256)):
-            return f
-    return 0
-
-
-def wsplit_chain_ok(B, cin, cout, H, W):
-    return wsplit_chain_f(B, cin, cout, H, W) != 0
 
 
 WSPLIT_GROWTH_LOG2 = {2: 1, 4: 4}      # |B^T d| <= 2 max|d| (F(2,3)) / 10 max|d| (F(4,3)): binades the range plan adds
@@ -763,151 +628,6 @@ def to_split(x, s, arith=None):
     xs = torch.empty(B, cin // 8, 2, H * W, 8, device=x.device, dtype=torch.int16)
     N.call('sgdfr_to_split_f32', N.ptr(x), N.ptr(s), N.ptr(xs), B, cin, H, W, arith, _sat(), N.stream())
     return xs
-
-
-class SplitAct:
-    """An activation that only exists in the NEXT conv's split input form (x * s_next as 16-bit hi/lo pairs,
-    [B, C/8, 2, H*W, 8] int16): written by the producing kernel's epilogue, staged by DMA in the consumer.  wino=True: the
-    Winograd input form of that conv instead ([B, C/8, 4, 2, H*W/2, 8], see to_wsplit / modconv_wsplit)."""
-    __slots__ = ('xs', 'shape', 'wino')
-
-    def __init__(self, xs, shape, wino=0):
-        self.xs, self.shape, self.wino = xs, tuple(shape), (2 if wino is True else int(wino or 0))
-
-
-def xin_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
-    """Can the split conv of this shape take its input as a SplitAct?"""
-    return config().use_split_chain and split_ok(B, cin, cout, H, W, mode) and \
-        bool(_shape_query('sgdfr_modconv2d_split_xin_supported', B, cin, cout, H, W, mode))
-
-
-def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, noise_weight=None, bias=None, batch=None,
-                      s_next=None, rgb=None, want_y=True, wino_next=False):
-    """One StyledConv on the split kernels with the inference-only dataflow options: x may be a SplitAct (then `s` is
-    already applied), s_next asks for the output as a SplitAct for the next conv, rgb for the fused ToRGB partial sums.
-    A SplitAct in Winograd form (x.wino) runs on modconv_wsplit with `wsp` = the prepack_wsplit pack; wino_next (transposed
-    conv + blur only) asks for the output in that form.
-    Returns (activation: fp32 tensor | SplitAct | None, ToRGB partials | None)."""
-    if isinstance(x, SplitAct) and x.wino:
-        if upsample:
-            raise RuntimeError('styled_conv_split: the Winograd input form feeds plain convs only')
-        B, cin, H, W = x.shape
-        res = modconv_wsplit(x.xs, x.shape, wsp, d, cout, noise, noise_weight, bias, True, rgb=rgb,
-                             want_y=want_y and s_next is None, s_next=s_next, f=x.wino)
-        if s_next is not None:
-            _, part, xs = res
-            return SplitAct(xs, (B, cout, H, W)), part
-        return res if rgb is not None else (res, None)
-    if isinstance(x, SplitAct):
-        B, cin, H, W = x.shape
-        xin, x_split, s_arg = x.xs, x.shape, None
-        batch = B
-    else:
-        xin, x_split, s_arg = x, None, s
-        B = s.shape[0] if batch is None else batch
-        H, W = x.shape[2], x.shape[3]
-    if not upsample:
-        res = modconv_split(xin, wsp, s_arg, d, cout, noise, noise_weight, bias, True, batch=batch, rgb=rgb,
-                            want_y=want_y and s_next is None, x_split=x_split, s_next=s_next)
-        if s_next is not None:          # the activation leaves only as the next conv's split input
-            _, part, xs = res
-            return SplitAct(xs, (B, cout, H, W)), part
-        return res if rgb is not None else (res, None)
-    if s_next is not None and not wino_next and x_split is not None and upfir_chain_ok(B, x_split[1], cout, H, W):
-        xs = modconv_upfir_split(xin, x_split, wsp, d, cout, fir, s_next, noise, noise_weight, bias, True)
-        return SplitAct(xs, (B, cout, 2 * H, 2 * W)), None
-    if s_next is not None and config().use_plane_padding and \
-            _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, x_split[1] if x_split else x.shape[1], cout, H, W, N.MODE_UP3) == 1:
-        # parity planes padded to whole 128-byte lines: the odd-sized dense planes make every store run straddle two lines
-        ps = ((H + 1) * (W + 1) + 31) // 32 * 32
-        planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split, plane_stride=ps)
-        xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, plane_stride=ps, wino=wino_next)
-        return SplitAct(xs, (B, cout, 2 * H, 2 * W), wino_next), None
-    planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split)
-    if s_next is not None:
-        xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, wino=wino_next)
-        return SplitAct(xs, (B, cout, 2 * H, 2 * W), wino_next), None
-    return blur_bias_act(planes, fir, H, W, noise, noise_weight, bias, True), None
-
-
-# Upsampling layers as ONE launch: the FIR blur (+ noise, bias, leaky-ReLU, split hand-over) in the transposed conv's epilogue
-# (csrc/upfir.hip), so the parity planes -- 8 bytes of HBM traffic per output element between the two launches -- never leave the CU,
-# for a recomputed one-super-pixel halo ring per patch.  Bit-identical to the two-pass form (tests/test_gpu_upfir.py).  OFF by
-# default: measured at B=64 (scripts/upfir_ab.sh, scripts/upfir_probe.py; DESIGN 4.9) the fused launch of the 128 -> 256 level takes
-# 1.2-1.37 ms against 0.97 ms for conv + blur -- its FIR / conversion epilogue (0.9 ms alone) is as long as the blur launch it
-# replaces and, one block per CU, overlaps nothing, and the halo costs the K loop 1.35x the tiles.  SGDFR_UPFIR=1 takes it for
-# inputs at least UPFIR_MIN_W wide whose consumer takes the direct split hand-over.
-
-
-def upfir_ok(B, cin, cout, H, W):
-    return config().precision in _SPLIT_ARITH and bool(_shape_query('sgdfr_modconv2d_upfir_supported', B, cin, cout, H, W))
-
-
-def upfir_chain_ok(B, cin, cout, H, W):
-    """Does the inference chain run this upsampling layer as ONE launch (transposed conv + blur fused)?"""
-    return config().use_upfir and config().use_split_chain and config().upfir_min_w > 0 and W >= config().upfir_min_w and upfir_ok(B, cin, cout, H, W)
-
-
-def modconv_upfir_split(xs_in, shape, wsp, d, cout, fir, s_next, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2,
-                        gain=SQRT2, arith=None, desc=None):
-    """Upsampling StyledConv in one launch: xs_in = the split form of x*s (shape = (B, Cin, H, W)) -> the split form of
-    act(blur(conv_transpose(x*s) * d) + noise + bias) * s_next, [B, cout/8, 2, 2H*2W, 8] int16 (same bits as
-    modconv_split(mode=UP3) + blur_bias_act_split)."""
-    arith = _SPLIT_ARITH[arith or config().precision]
-    N.require_device(d, fir, bias, noise_weight, s_next)
-    if not xs_in.is_cuda or xs_in.dtype != torch.int16 or not wsp.is_cuda or wsp.dtype != torch.int16:
-        raise RuntimeError('modconv_upfir_split: xs_in / wsp are the int16 device buffers made by to_split / prepack_split')
-    B, cin, H, W = shape
-    nz, nzb = _noise_args(noise, B, 2 * H, 2 * W)
-    xs = torch.empty(B, cout // 8, 2, 4 * H * W, 8, device=xs_in.device, dtype=torch.int16)
-    st, sat = N.stream(), _sat()
-    _timed_conv(desc or ('upfir split %d->%d @%dx%d' % (cin, cout, H, W)), B * conv_flops(cin, cout, H, W), lambda: N.call(
-        'sgdfr_modconv2d_upfir_split_f32', N.ptr(xs_in), N.ptr(wsp), N.ptr(N.f32c(d)), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
-        N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(N.f32c(s_next)), N.ptr(_zero_words(xs_in.device)),
-        N.ptr(xs), B, cin, cout, H, W, arith, int(activate), float(slope), float(gain), sat, st))
-    return xs
-
-
-def rgb_fusable(B, cin, cout, H, W):
-    """True when the plain 3x3 conv of this shape runs on the split kernel in one pass, so the ToRGB that follows it can be
-    accumulated in its epilogue instead of re-reading the activation."""
-    return config().use_rgb_fusion and split_ok(B, cin, cout, H, W) and \
-        (not config().use_splitk or _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cin, cout, H, W, N.MODE_PLAIN3) == 1)
-
-
-class StreamPipeline:
-    """Consecutive INDEPENDENT batches on alternating HIP streams.  The head of a generator forward (4x4 ... 16x16 layers:
-    K-sliced launches that under-fill the chip, ~30 dependent launches with ~6 us of gap each) then runs beside the big layers
-    of the previous batch instead of in front of its own: 9.69 k -> 10.08 k frames/s at B=64 with two streams (three: 9.91 k),
-    bit-identical images (scripts/two_stream_probe.py).
-
-        pipe = StreamPipeline(2)
-        for w in batches:
-            with pipe.next():                 # the slot's stream first waits for what the caller's stream has queued so far
-                out.append(G([w], input_is_latent=True)[0])
-        pipe.join(*out)                       # the caller's stream now waits for every slot; tensors are handed over to it
-    """
-
-    def __init__(self, n=2, device=None):
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, int(n)))]
-        self._i = 0
-        self.last = None                      # stream of the latest slot
-
-    def next(self):
-        s = self.streams[self._i % len(self.streams)]
-        self._i += 1
-        s.wait_stream(torch.cuda.current_stream(s.device))
-        self.last = s
-        return torch.cuda.stream(s)
-
-    def join(self, *tensors, stream=None):
-        """The current stream waits for `stream` (default: every slot); `tensors` (made on slot streams) may then be used on it."""
-        cur = torch.cuda.current_stream(self.streams[0].device)
-        for s in ([stream] if stream is not None else self.streams):
-            cur.wait_stream(s)
-        for t in tensors:
-            if isinstance(t, torch.Tensor) and t.is_cuda:
-                t.record_stream(cur)
 
 
 class U8Target:

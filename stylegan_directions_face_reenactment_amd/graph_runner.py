@@ -5,6 +5,7 @@ import os
 import torch
 
 from . import functional as F_
+from . import timing
 
 USE_GRAPHS = os.environ.get('SGDFR_GRAPHS', '1') != '0'      # hipGraph replay of repeated no-grad forwards (Generator.forward)
 
@@ -12,7 +13,12 @@ USE_GRAPHS = os.environ.get('SGDFR_GRAPHS', '1') != '0'      # hipGraph replay o
 class GraphReplayMixin:
     """Methods of model.Generator (which provides _forward_impl, _weights_stamp, range_mode, the RangePlanMixin)."""
     GRAPH_AFTER = 2                 # eager no-grad forwards of one signature before the next one is captured as a hipGraph
-    MAX_GRAPHS = 4                  # captured signatures kept per generator (each holds its intermediates in a private pool)
+    # Captured signatures kept per generator.  Each capture keeps EVERY intermediate of its forward alive in a private memory pool
+    # (about 70 MB per image at 256^2, cm=1: 4.5 GB for a B=64 capture; the eager path frees layer by layer), and each HIP stream
+    # that replays gets its own capture (the stream id is part of the key).  Host-bound forwards (the default policy) are small;
+    # big ones are only captured when the caller asks for it (graph=True / verify_range=True), at most MAX_BIG_GRAPHS at a time.
+    MAX_GRAPHS = 4
+    MAX_BIG_GRAPHS = 2
 
     def _drop_graphs(self):
         self.__dict__.pop('_graphs', None)
@@ -21,19 +27,21 @@ class GraphReplayMixin:
     GRAPH_MAX_WORK = 6              # default policy: replay when batch * (size / 256)^2 <= this (host-bound forwards), or when verified
 
     def _graph_key(self, styles, return_latents, inject_index, truncation, truncation_latent, input_is_latent, noise,
-                   randomize_noise, image_out, verify_range, graph):
+                   randomize_noise, image_out, verify_range, graph, verify_explicit=False):
         """Signature under which a no-grad forward may be replayed as a hipGraph, or None when it must run eagerly: gradients,
-        style mixing, caller-supplied or fresh noise, a caller-owned uint8 target, hooks, an enclosing capture, bench timing --
-        and, unless graph=True, forwards that are neither host-bound nor verified (see forward)."""
+        style mixing, caller-supplied or fresh noise, a caller-owned uint8 target, hooks, an enclosing capture, launch timing --
+        and forwards that are not host-bound (GRAPH_MAX_WORK) unless the caller asked for a replay (graph=True) or for a verified
+        forward (verify_range=True passed EXPLICITLY: generate_image, whose wait exposes the enqueue time).  A forward that is
+        verified only because that is the default (a raw `G([w])`) keeps the gate: no multi-GB capture behind the caller's back."""
         if graph is False or not USE_GRAPHS or not getattr(self, 'use_graphs', True) or torch.is_grad_enabled() or \
-                F_.CONV_TIMING is not None or F_.HBM_TIMING is not None:
+                timing.active() is not None:
             return None
         if len(styles) != 1 or inject_index is not None or noise is not None or randomize_noise:
             return None
         w = styles[0]
         if not isinstance(w, torch.Tensor) or not w.is_cuda or w.dtype != torch.float32 or w.requires_grad:
             return None
-        if graph is None and not verify_range and w.shape[0] * (self.size / 256.0) ** 2 > self.GRAPH_MAX_WORK:
+        if graph is None and not (verify_range and verify_explicit) and self._graph_work(w) > self.GRAPH_MAX_WORK:
             return None
         if image_out is not None and image_out.frames is not None:
             return None
@@ -53,6 +61,9 @@ class GraphReplayMixin:
                 # a graph's static input / output buffers belong to the stream that replays it: forwards queued on different
                 # streams (functional.StreamPipeline) get their own capture instead of racing on one
                 F_.N.stream().value)
+
+    def _graph_work(self, w):
+        return w.shape[0] * (self.size / 256.0) ** 2
 
     def _replay_or_run(self, key, styles, return_latents, return_features, inject_index, truncation, truncation_latent, input_is_latent,
                        image_out, verify_range):
@@ -84,7 +95,8 @@ class GraphReplayMixin:
                 return self._forward_impl(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
                                           input_is_latent, None, False, image_out, verify_range)
             st = getattr(self, '_range_state', None)
-            if F_.config().precision == 'fp16x3' and F_.config().range_plan is True and (st is None or st['stamp'] != stamp):
+            if F_.config().precision == 'fp16x3' and F_.config().range_plan is True and \
+                    (st is None or st['stamp'] != stamp or st.get('recal')):
                 return self._forward_impl(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
                                           input_is_latent, None, False, image_out, verify_range)       # calibrate first (host read)
             s_in = w.detach().clone()
@@ -96,8 +108,13 @@ class GraphReplayMixin:
                                          None if image_out is None else F_.U8Target(None, 0, image_out.swap_rb), False)
             mode = self.range_mode()
             entry = {'graph': g, 'in': s_in, 'trunc': s_tr, 'out': out, 'stamp': stamp, 'mode': mode}
+            entry['big'] = self._graph_work(w) > self.GRAPH_MAX_WORK
             while len(graphs) >= self.MAX_GRAPHS:
                 graphs.pop(next(iter(graphs)))
+            if entry['big']:
+                big = [k for k, e in graphs.items() if e.get('big')]
+                for k in big[:max(0, len(big) + 1 - self.MAX_BIG_GRAPHS)]:
+                    graphs.pop(k)
             graphs[key] = entry
         entry['in'].copy_(w)
         if entry['trunc'] is not None:

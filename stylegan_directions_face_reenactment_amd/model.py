@@ -499,7 +499,9 @@ class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
         Default policy (measured, scripts/small_batch_time.py): a replay costs the device ~80 us more than the eager launches
         (B=8: 1.34 -> 1.43 ms), so it pays where the HOST is the bound -- small batches (B=1: 917 -> 1462 frames/s, B=4 +3 %),
         i.e. batch * (size/256)^2 <= GRAPH_MAX_WORK -- and for verified forwards, whose wait exposes the enqueue time at every
-        batch size (generate_image at B=32: 7.8 k -> 8.3 k frames/s).  Weight changes (tracked like the weight packs; after
+        batch size (generate_image at B=32: 7.8 k -> 8.3 k frames/s) -- verify_range=True passed explicitly; a raw `G([w])`, verified
+        only by default, is replayed when it is host-bound and runs eagerly otherwise (a B=64 capture pins ~4.5 GB of
+        intermediates, graph_runner.MAX_BIG_GRAPHS).  Weight changes (tracked like the weight packs; after
         `.data` edits call invalidate_packs()), a change of arithmetic / range plan, hooks, style mixing, caller-supplied
         noise and randomize_noise run eagerly.  Switch off: `G.use_graphs = False` or SGDFR_GRAPHS=0."""
         cfg = getattr(self, 'config', None)
@@ -507,10 +509,11 @@ class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
             with F_.using(cfg):                             # Functions, backward) run under it whatever the caller's ambient one is
                 return self.forward(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
                                     input_is_latent, noise, randomize_noise, image_out, verify_range, graph)
+        verify_explicit = verify_range is not None
         if verify_range is None:
             verify_range = bool(self.verify_range_default)
         key = self._graph_key(styles, return_latents, inject_index, truncation, truncation_latent, input_is_latent, noise,
-                              randomize_noise, image_out, verify_range, graph)
+                              randomize_noise, image_out, verify_range, graph, verify_explicit)
         if key is None:
             return self._forward_impl(styles, return_latents, return_features, inject_index, truncation, truncation_latent,
                                       input_is_latent, noise, randomize_noise, image_out, verify_range)

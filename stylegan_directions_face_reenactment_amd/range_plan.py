@@ -32,6 +32,12 @@ def _pinned_word():
 class RangePlanMixin:
     """Methods of model.Generator (which provides input, convs, noises, _weights_stamp, _wino_inputs, _drop_graphs)."""
     MAX_PENDING_TOKENS = 8          # unchecked forwards in flight before the oldest token is awaited (host far ahead of the device)
+    # A plan is calibrated on the first batch after a weight change; a later, systematically "louder" stream would otherwise pay
+    # a bf16x3 re-render per batch for good.  After a fallback the NEXT no-grad forward measures its own batch (every row) and
+    # WIDENS the plan (element-wise max with the old one), returning the generator to fp16x3 -- at most this many times per
+    # weight version (then bf16x3 stays: 1.1e-4 instead of 1.4e-5 from the fp64 evaluation, still inside the 1e-3 contract).
+    AUTO_RECALIBRATIONS = 3
+    CALIBRATION_ROWS = 8            # rows of the first batch the initial calibration looks at (a recalibration takes up to 64)
 
     def _sat_word(self):
         """This generator's saturation word (functional.saturation_sink): one int32 on the weights' device, owned by the
@@ -39,6 +45,13 @@ class RangePlanMixin:
         dev = self.input.input.device
         w = self.__dict__.get('_sat')
         if w is None or w.device != dev:
+            # tokens of the OLD word can never be resolved against the new one: whoever still holds one must re-render
+            for tok in self.__dict__.get('_sat_tokens') or []:
+                tok.delta, tok.suspect = 1, True
+                if tok.snap is not None:
+                    tok.event.synchronize()             # (the async copy into the pinned word must have landed before it is reused)
+                    _PINNED_WORDS.append(tok.snap)
+                    tok.snap = None
             w = self.__dict__['_sat'] = F_.new_saturation_word(dev)
             self.__dict__['_sat_seen'] = 0
             self.__dict__['_sat_tokens'] = []
@@ -110,8 +123,11 @@ class RangePlanMixin:
         st = getattr(self, '_range_state', None)
         if st is not None and st['mode'] == 'fp16x3':
             st['mode'] = 'bf16x3'
-            warnings.warn('Generator: %d fp16 operand pairs left the planned range (or were NaN/Inf) %s; this generator now runs '
-                          'the bf16x3 arithmetic (fp32 exponent range) until its weights change' % (pairs, where),
+            again = st.get('recal_left', self.AUTO_RECALIBRATIONS) > 0
+            st['recal'] = again                         # the next no-grad forward re-measures its batch and widens the plan
+            warnings.warn('Generator: %d fp16 operand pairs left the planned range (or were NaN/Inf) %s; this generator runs the '
+                          'bf16x3 arithmetic (fp32 exponent range) %s' % (pairs, where, 'until its next forward has widened the '
+                          'range plan' if again else 'until its weights change or recalibrate_ranges() is called'),
                           RuntimeWarning, stacklevel=4)
 
     def range_ok(self, token):
@@ -121,6 +137,11 @@ class RangePlanMixin:
             return True
         if token.delta is None:
             self._check_tokens(upto=token)
+        if token.delta is None:
+            # not in the queue any more (the word was re-made on another device, or the queue was reset): nothing can vouch
+            # for this forward -- unverifiable reads as "re-render", never as "verified"
+            token.delta, token.suspect = 1, True
+            return False
         if token.delta:
             st = getattr(self, '_range_state', None)
             # (a token of weights that have since been replaced: re-render, but leave the NEW weights' calibrated plan alone)
@@ -144,11 +165,28 @@ class RangePlanMixin:
         self.__dict__['_last_token'] = None
         return tok
 
-    def _calibrate_ranges(self, latent, noise, specs, layers):
-        """One forward of (at most 8 rows of) this batch on the fp32 kernels, recording max |x| of every 3x3 conv's input:
-        x_log2[l] = floor(log2 max)+1 feeds the range plan of functional.styles_batched.  Runs once per weight version
-        (tracked like the weight packs; after `.data` edits call invalidate_packs()).  One device->host read."""
-        n = min(latent.shape[0], 8)
+    def recalibrate_ranges(self, styles=None, widen=True, **forward_kwargs):
+        """Re-measure the activation ranges of the fp16x3 plan on a batch of the caller's choosing -- for a stream whose later
+        batches are louder than the one the plan was calibrated on (the first after a weight change).  With `styles` (and the
+        forward's keyword arguments: input_is_latent, truncation, truncation_latent ...) that batch is rendered now, every row
+        measured; without, the next no-grad forward measures its own batch.  widen=True keeps every layer's bound at least as
+        large as before (a plan that also covers the earlier batches); False replaces it.  The generator is back in fp16x3
+        afterwards, with a fresh budget of automatic widenings.  Returns the forward's result when `styles` was given."""
+        st = getattr(self, '_range_state', None)
+        if st is not None:
+            st['recal'], st['recal_widen'], st['recal_left'] = True, bool(widen), self.AUTO_RECALIBRATIONS + 1
+        self._drop_graphs()
+        if styles is None:
+            return None
+        with torch.no_grad():
+            return self.forward(styles, graph=False, **forward_kwargs)
+
+    def _calibrate_ranges(self, latent, noise, specs, layers, max_rows=None):
+        """One forward of (at most CALIBRATION_ROWS rows of) this batch on the fp32 kernels, recording max |x| of every 3x3
+        conv's input: x_log2[l] = floor(log2 max)+1 feeds the range plan of functional.styles_batched.  Runs once per weight
+        version (tracked like the weight packs; after `.data` edits call invalidate_packs()) and once per widening
+        (recalibrate_ranges / after a fallback).  One device->host read."""
+        n = min(latent.shape[0], max_rows or self.CALIBRATION_ROWS)
         lat = latent[:n].contiguous()
         words = torch.zeros(len(layers), device=latent.device, dtype=torch.int32)
         with F_.precision('fp32'):
@@ -190,6 +228,20 @@ class RangePlanMixin:
                 st['mode'] = 'fp32'
                 warnings.warn('Generator: non-finite activations during range calibration; this generator runs on the fp32 '
                               'kernels until its weights change', RuntimeWarning, stacklevel=3)
+        elif st.get('recal') and not capturing:
+            # a fallback (or recalibrate_ranges) asked for it: measure THIS batch, every row, and widen / replace the plan
+            x_log2, bad = self._calibrate_ranges(latent, noise, specs, layers, max_rows=64)
+            if self._sat_tokens:
+                self._check_tokens(upto=self._sat_tokens[-1])
+            st['recal'] = False
+            st['recal_left'] = st.get('recal_left', self.AUTO_RECALIBRATIONS) - 1
+            if bad:
+                st['mode'] = 'bf16x3'                  # non-finite activations in this batch: no plan can hold them
+            else:
+                st['x_log2'] = [max(a, b) for a, b in zip(st['x_log2'], x_log2)] if st.get('recal_widen', True) else x_log2
+                st['mode'] = 'fp16x3'
+            st['recal_widen'] = True
+            self._drop_graphs()                         # captured launch sequences carry the old plan's scales
         elif st['mode'] == 'fp16x3' and not capturing and self._sat_tokens:
             # every earlier forward left a token; the ones already finished are checked here WITHOUT blocking, so a
             # saturating batch is noticed one or two forwards later even by callers that never ask (verify_range=False)

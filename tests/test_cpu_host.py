@@ -230,8 +230,24 @@ def test_config_object_is_frozen_scoped_and_seeded_from_the_environment():
             assert F_.config().precision == 'bf16x3' and F_.config().use_wsplit is False
         assert F_.config() is c1
     assert F_.config() is base and F_.PRECISION == base.precision
-    env = F_.Config.from_env({'SGDFR_PRECISION': 'bf16x3', 'SGDFR_RANGE_PLAN': 'exact', 'SGDFR_WSPLIT_F': '2', 'SGDFR_UPFIR': '1'})
-    assert (env.precision, env.range_plan, env.wsplit_f, env.use_upfir, env.use_up_pp) == ('bf16x3', 'exact', 2, True, False)
+    env = F_.Config.from_env({'SGDFR_PRECISION': 'bf16x3', 'SGDFR_RANGE_PLAN': 'exact', 'SGDFR_WSPLIT_F': '2', 'SGDFR_WSPLIT': '0'})
+    assert (env.precision, env.range_plan, env.wsplit_f, env.use_wsplit) == ('bf16x3', 'exact', 2, False)
+    # the old module-level switch names are read-only views: an assignment must not silently shadow them
+    for name in ('PRECISION', 'USE_WSPLIT', 'WSPLIT_F', 'DEFAULT'):
+        with pytest.raises(AttributeError):
+            setattr(F_, name, None)
+    assert F_.USE_WSPLIT is base.use_wsplit and F_.DEFAULT is base
+    # launch timing is a per-thread context object, not a module global
+    from stylegan_directions_face_reenactment_amd import timing
+    assert timing.active() is None and not hasattr(F_, 'CONV_TIMING')
+    with timing.collect() as t:
+        assert timing.active() is t and t.conv == [] and t.hbm == []
+        seen = []
+        import threading
+        th = threading.Thread(target=lambda: seen.append(timing.active()))
+        th.start(); th.join()
+        assert seen == [None]
+    assert timing.active() is None
     from stylegan_directions_face_reenactment_amd.model import Generator
     G = Generator(32, 512, 8, channel_multiplier=1)
     assert G.config is None and G.range_mode() == base.precision
