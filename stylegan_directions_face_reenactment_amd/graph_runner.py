@@ -129,8 +129,8 @@ class GraphReplayMixin:
             tok = self._snapshot()
             if not verify_range:
                 self.__dict__['_last_token'] = tok
-            elif not self.range_ok(tok):                   # this batch clamped operands: render it again (eagerly, now in bf16x3)
-                self._drop_graphs()
+            elif not self.range_ok(tok):                   # this batch clamped operands: render it again, eagerly (measures the batch and
+                self._drop_graphs()                        # widens the plan while the budget lasts, else bf16x3), verified like the first
                 return self._forward_impl(styles, return_latents, return_features, inject_index, truncation,
-                                          truncation_latent, input_is_latent, None, False, image_out, False)
+                                          truncation_latent, input_is_latent, None, False, image_out, True, 1)
         return res

@@ -522,7 +522,7 @@ class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
 
     def _forward_impl(self, styles, return_latents=False, return_features=False, inject_index=None, truncation=1,
                       truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=False, image_out=None,
-                      verify_range=False):
+                      verify_range=False, depth=0):
         """Reference signature (model.py:471-482) plus two optional extensions (no-grad forwards only):
         image_out = functional.U8Target returns the image as uint8 HWC frames (the reference's tensor_to_image scaling), written
         by the last ToRGB launch itself when that ToRGB is fused into its conv (otherwise converted by one extra launch);
@@ -530,6 +530,7 @@ class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
         bf16x3 arithmetic before returning (what generate_image and ReenactmentSession use: a clamped frame is never handed
         back).  Without it the forward returns at once and leaves a RangeToken (take_range_token / range_ok); unchecked
         tokens are polled without blocking by the following forwards."""
+        styles_in, noise_in = styles, noise            # (a clamped batch is rendered a second time from the caller's arguments)
         if not input_is_latent:
             styles = [self.style(s) for s in styles]
         if noise is None:
@@ -591,7 +592,14 @@ class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
                 return out
             if self.range_ok(tok):
                 return out
-            with F_.precision('bf16x3'):                   # this batch clamped operands: render it again, now in bf16 terms
+            # This batch clamped operands: it is rendered again before anything is handed back.  range_ok() has switched the
+            # generator to bf16x3 and -- while the budget of automatic widenings lasts -- asked for a recalibration: the second
+            # pass below measures THIS batch, widens the plan and renders in fp16x3 again (verified like the first); without
+            # budget it renders in bf16 terms (fp32 exponent range, nothing to verify).
+            if depth <= self.AUTO_RECALIBRATIONS:
+                return self._forward_impl(styles_in, return_latents, return_features, inject_index, truncation, truncation_latent,
+                                          input_is_latent, noise_in, randomize_noise, image_out, True, depth + 1)
+            with F_.precision('bf16x3'):
                 return self._synthesis(latent, F_.styles_batched(latent, specs), layers, to_rgbs, noise, False, False,
                                        return_latents, image_out)
 

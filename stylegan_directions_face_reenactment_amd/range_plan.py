@@ -47,7 +47,7 @@ class RangePlanMixin:
         if w is None or w.device != dev:
             # tokens of the OLD word can never be resolved against the new one: whoever still holds one must re-render
             for tok in self.__dict__.get('_sat_tokens') or []:
-                tok.delta, tok.suspect = 1, True
+                tok.delta, tok.suspect = 0, True
                 if tok.snap is not None:
                     tok.event.synchronize()             # (the async copy into the pinned word must have landed before it is reused)
                     _PINNED_WORDS.append(tok.snap)
@@ -95,9 +95,8 @@ class RangePlanMixin:
                 self.__dict__['_sat_seen'] = val
                 for other in toks:
                     other.suspect = True
-            if tok.suspect and not tok.delta:
-                tok.delta = 1
-            new += tok.delta
+            new += tok.delta                            # (a merely suspect token -- delta 0 -- is re-rendered by whoever asks
+                                                        #  range_ok(), but it is no evidence against the plan)
             _PINNED_WORDS.append(tok.snap)
             tok.snap = None
             if tok is upto:
@@ -140,15 +139,14 @@ class RangePlanMixin:
         if token.delta is None:
             # not in the queue any more (the word was re-made on another device, or the queue was reset): nothing can vouch
             # for this forward -- unverifiable reads as "re-render", never as "verified"
-            token.delta, token.suspect = 1, True
-            return False
+            token.delta, token.suspect = 0, True
         if token.delta:
             st = getattr(self, '_range_state', None)
             # (a token of weights that have since been replaced: re-render, but leave the NEW weights' calibrated plan alone)
             if st is not None and (token.stamp is None or token.stamp == st['stamp']):
                 self._fall_back(token.delta, 'in the forward just checked')
             return False
-        return True
+        return not token.suspect
 
     def range_mode(self):
         """Arithmetic the next no-grad forward of this generator will run in ('fp16x3' with a live range plan, its fallback, or

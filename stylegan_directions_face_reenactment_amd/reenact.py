@@ -129,7 +129,7 @@ class ReenactmentSession:
     def reset_graph(self):
         self._graph = None
 
-    def _step(self, sv, image_out=None, no_graph=False, prefer_graph=False):
+    def _step(self, sv, image_out=None, no_graph=False, prefer_graph=False, verify=False):
         shift = self.A(sv)                                              # [b, L, 512] (w_plus) or [b, 512]
         b = sv.shape[0]
         w = self.source.expand(b, -1, -1).contiguous()
@@ -137,10 +137,11 @@ class ReenactmentSession:
         latent = F_.latent_prepare(w, self.G.n_latent, shift=shift, shift_layers=layers)
         # (a session with graph=True captures the whole step itself -- DirectionMatrix and latent shift included -- so the
         # generator's own per-forward graphs stay out of it)
-        # (verify_range=False: the session checks every chunk's RangeToken itself, one chunk behind the launches)
+        # (verify_range=False: the session checks every chunk's RangeToken itself, one chunk behind the launches; verify: the
+        #  second rendering of a chunk that clamped -- the generator measures it, widens its range plan or falls back to bf16x3)
         img, _ = self.G([latent], input_is_latent=True, truncation=self.truncation, truncation_latent=self.trunc,
-                        image_out=image_out, graph=False if (self.use_graph or no_graph) else (True if prefer_graph else None),
-                        verify_range=False)
+                        image_out=image_out, graph=False if (self.use_graph or no_graph or verify) else (True if prefer_graph else None),
+                        verify_range=bool(verify))
         return img
 
     def _graphed_step(self, sv):
@@ -179,11 +180,6 @@ class ReenactmentSession:
             pipe = self._pipe
 
         class Chunks:
-            poisoned = False    # a chunk clamped operands: chunks launched in fp16x3 before the fallback took hold are suspect too
-                                # (with two streams in flight the saturation word cannot tell which of them it was); cleared
-                                # once a chunk launched in the fallback arithmetic has settled, or when the weights changed
-            stamp = None        # weights (Generator._range_state stamp) the flag belongs to
-
             def launch(self, lo, sv, u8):
                 if sess.use_graph and sv.shape[0] == sess.batch:
                     img, tok = sess._graphed_step(sv)
@@ -201,23 +197,14 @@ class ReenactmentSession:
 
             def settle(self, item):
                 lo, sv, u8, img, tok, graphed, stream, mode = item
+                # False for a chunk that clamped operands AND for one that was in flight beside it on the other stream (the shared
+                # saturation word cannot tell the two apart: RangeToken.suspect)
                 ok = sess.G.range_ok(tok)
                 if stream is not None:
                     pipe.join(img, stream=stream)                           # the caller's stream may now read this chunk
-                st = getattr(sess.G, '_range_state', None)
-                stamp = st['stamp'] if st is not None else None
-                if self.poisoned and stamp != self.stamp:                   # new weights, fresh plan: old suspicions do not apply
-                    self.poisoned = False
-                    sess.reset_graph()
                 if not ok:
-                    self.poisoned, self.stamp = True, stamp
-                if not ok or (self.poisoned and pipe is not None and mode == 'fp16x3'):
-                    sess._graph = None                                      # clamped: this chunk again, eagerly, in bf16x3
-                    img, graphed = sess._step(sv, u8), False
-                elif self.poisoned and mode not in ('fp16x3', 'graph'):
-                    # every chunk launched before the fallback took hold has been re-rendered: nothing in flight is suspect now
-                    self.poisoned = False
-                    sess.reset_graph()
+                    sess._graph = None                                      # this chunk again, eagerly and VERIFIED: the generator measures
+                    img, graphed = sess._step(sv, u8, verify=True), False   # it and widens its range plan (or renders in bf16x3)
                 return lo, sv, u8, img, graphed
 
         return Chunks()
