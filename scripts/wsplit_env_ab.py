@@ -20,7 +20,7 @@ def timed(fn, reps=20):
 
 name, vals = sys.argv[1].split('=')
 vals = vals.split(',')
-B = 64
+B = int(os.environ.get('BATCH', '64'))
 for cin, cout, h in ((512, 512, 16), (512, 512, 32), (256, 256, 64), (128, 128, 128)):
     w = torch.randn(1, cout, cin, 3, 3, device='cuda'); x = torch.randn(B, cin, h, h, device='cuda'); s = torch.randn(B, cin, device='cuda')
     d = torch.rand(B, cout, device='cuda') + 0.5; nz = torch.randn(1, 1, h, h, device='cuda'); nw = torch.full((1,), 0.1, device='cuda')

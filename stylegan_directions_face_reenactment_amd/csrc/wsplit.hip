@@ -28,105 +28,11 @@
 // accumulators.  K loop: 16-channel blocks x 6 barrier-delimited half-stages (kernel row x position pair: 12 MFMAs per wave),
 // V double-buffered per channel block (40 KB each), U in a 4-slot ring of 16 KB half-slabs DMA'd three half-stages ahead; the
 // first fragments of a half-stage are requested before the barrier that precedes it (see the loop).
-#include <stdlib.h>
-
-#include <type_traits>
-
-#include "common.h"
+#include "wsplit_common.h"
 
 namespace sgdfr {
 
-typedef float ws_f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 ws_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 ws_bf16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 ws_f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 ws_f16x2 __attribute__((ext_vector_type(2)));
-typedef float ws_f32x2 __attribute__((ext_vector_type(2)));
-typedef int ws_frag __attribute__((ext_vector_type(4)));
-
 __device__ unsigned int g_wsplit_saturated = 0;     // clamped operand pairs of launches without a saturation word
-
-constexpr float WS_F16_XSCALE = 0.0625f, WS_F16_WSCALE = 64.f, WS_F16_OUT = 0.25f, WS_F16_MAX = 65504.f;     // as split.hip
-constexpr int WS_CB = 16;
-
-template <int ET>
-__device__ __forceinline__ ws_f32x16 ws_mfma(ws_frag a, ws_frag b, ws_f32x16 c) {
-    if (ET == SGDFR_SPLIT_FP16)
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ws_f16x8, a), __builtin_bit_cast(ws_f16x8, b), c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ws_bf16x8, a), __builtin_bit_cast(ws_bf16x8, b), c, 0, 0, 0);
-}
-
-// two floats -> packed hi pair, packed lo pair (split.hip's split_pair: same rounding, same clamp-and-count rule)
-template <int ET>
-__device__ __forceinline__ void ws_pair(float a, float b, unsigned& hi, unsigned& lo, unsigned& sat) {
-    if (ET == SGDFR_SPLIT_FP16) {
-        sat += (!(fabsf(a) <= WS_F16_MAX) || !(fabsf(b) <= WS_F16_MAX)) ? 1u : 0u;
-        a = __builtin_amdgcn_fmed3f(a, -WS_F16_MAX, WS_F16_MAX);
-        b = __builtin_amdgcn_fmed3f(b, -WS_F16_MAX, WS_F16_MAX);
-        const ws_f16x2 h = __builtin_convertvector((ws_f32x2){a, b}, ws_f16x2);
-        hi = __builtin_bit_cast(unsigned, h);
-        const ws_f32x2 hf = __builtin_convertvector(h, ws_f32x2);
-        lo = __builtin_bit_cast(unsigned, __builtin_convertvector((ws_f32x2){a - hf[0], b - hf[1]}, ws_f16x2));
-    } else {
-        hi = __builtin_bit_cast(unsigned, __builtin_convertvector((ws_f32x2){a, b}, ws_bf16x2));
-        const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
-        lo = __builtin_bit_cast(unsigned, __builtin_convertvector((ws_f32x2){a - ha, b - hb}, ws_bf16x2));
-    }
-}
-
-struct WsParams {
-    const unsigned char* v;      // WS input
-    const unsigned char* wsp;    // U pack
-    const unsigned char* zeros;  // >= 16 zero bytes
-    const float* d;
-    const float* noise;
-    int64_t noise_bstride;
-    const float* noise_w;
-    const float* bias;
-    float* y;
-    const float* rgb_w;          // fused ToRGB, as split.hip: [3][Cout] weights, [B][Cout] styles, partial sums [B][T*3][H*W]
-    const float* rgb_s;
-    float* rgb_part;
-    unsigned char* xs_out;       // the activation in the next (transposed) conv's split input form [B][Cout/8][hi,lo][H*W][8]
-    const float* s_next;
-    unsigned* sat;
-    int B, Cin, Cout, H, W;
-    int TW;                      // tiles per image row (W / 2)
-    int TCT, TR, tct_shift;      // patch: TR rows x TCT tile columns (TR * TCT = 128)
-    int tiles_x, tiles_y;
-    int xs;                      // staged positions per (t, part, k-half) run: (TR + 2) * TCT
-    int n_pix_tiles, n_cout_tiles;
-    int total_blocks;            // tiles x cout tiles; the grid may be smaller (persistent blocks)
-    int act;
-    float slope, gain;
-    int dbg;
-    int desync;                  // first-round start spread: estimated block time in 4096-clock units (0 = off)
-    FastDiv fd_xs, fd_tiles_x, fd_per_img, fd_npt;
-};
-
-template <int N>
-__device__ __forceinline__ void ws_wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// s_waitcnt vmcnt(n) for a wave-uniform runtime n in 0..12 (the instruction takes an immediate; larger n wait for 12: stricter)
-__device__ __forceinline__ void ws_wait_vmcnt_dyn(int n) {
-    switch (n) {
-        case 0: ws_wait_vmcnt<0>(); break;
-        case 1: ws_wait_vmcnt<1>(); break;
-        case 2: ws_wait_vmcnt<2>(); break;
-        case 3: ws_wait_vmcnt<3>(); break;
-        case 4: ws_wait_vmcnt<4>(); break;
-        case 5: ws_wait_vmcnt<5>(); break;
-        case 6: ws_wait_vmcnt<6>(); break;
-        case 7: ws_wait_vmcnt<7>(); break;
-        case 8: ws_wait_vmcnt<8>(); break;
-        case 9: ws_wait_vmcnt<9>(); break;
-        case 10: ws_wait_vmcnt<10>(); break;
-        case 11: ws_wait_vmcnt<11>(); break;
-        default: ws_wait_vmcnt<12>(); break;
-    }
-}
 
 // POS = transform positions of the 1-D Winograd form: 4 = F(2,3) (two outputs per tile), 6 = F(4,3) (four outputs per tile:
 // 18 instead of 36 MFMA columns per 16 channels and output quad, V 1.5x and U 2x the direct operands' bytes).
@@ -696,7 +602,7 @@ unsigned int wsplit_saturation_count(int reset) {
         const unsigned int z = 0;
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wsplit_saturated), &z, sizeof(z));
     }
-    return v;
+    return v + wswide_saturation_count(reset);
 }
 
 }  // namespace sgdfr
@@ -800,6 +706,10 @@ extern "C" int sgdfr_modconv2d_wsplit_f32(const unsigned short* v, const unsigne
     p.xs_out = reinterpret_cast<unsigned char*>(xs_out); p.s_next = s_next; p.sat = sat;
     p.act = act; p.slope = slope; p.gain = gain;
     p.dbg = getenv("SGDFR_WSPLIT_DBG") ? atoi(getenv("SGDFR_WSPLIT_DBG")) : 0;
+    if (f == 4) {      // 128 couts x 128 tiles per block where the tile count allows it (csrc/wswide.hip: the same outputs, bit for bit)
+        const int rc = wswide_try_launch(p, arith, stream);
+        if (rc >= 0) return rc;
+    }
     {
         // same-process A/B at B=64 (scripts/wsplit_env_ab.py, 60 % of the block-time estimate): 256@64^2 (8 rounds of blocks) 618 ->
         // 607 us, 128@128^2 (16 rounds) 733 -> 713 us, 512@32^2 (4 rounds: the spread costs part of a round) 557 -> 568 us

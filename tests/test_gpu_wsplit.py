@@ -62,6 +62,68 @@ def test_wsplit_conv_matches_fp64_oracle(cin, cout, H, B, arith, f):
     assert err <= (TOL if f == 2 else TOL4)[arith] * max(1.0, float(ref.abs().max())), err
 
 
+WIDE_CASES = [  # cin, cout, H, W, B, persist
+    (64, 128, 16, 32, 1, 0),       # one patch per image, one tile per block, 4 channel blocks (the shortest ring wrap)
+    (128, 256, 32, 32, 3, 0),      # two patches per image, two cout tiles
+    (80, 128, 64, 64, 2, 0),       # odd number of channel blocks, 4 x 2 patches
+    (128, 128, 128, 128, 2, 16),   # 64 tiles on 16 persistent blocks: four tiles per block, the ring runs across tiles
+    (64, 384, 48, 96, 5, 8),       # ragged everything: 3 cout tiles, 3 x 3 patches, 135 tiles on 8 blocks (16 or 17 each)
+    (256, 256, 64, 64, 40, 256),   # 640 tiles: the persistent grid of the bench shapes (2 or 3 tiles per block), start spread off
+]
+
+
+@pytest.mark.parametrize('arith', ['fp16x3', 'bf16x3'])
+@pytest.mark.parametrize('cin,cout,H,W,B,persist', WIDE_CASES)
+def test_wide_tile_kernel_writes_the_same_bits_as_the_64_tile_kernel(cin, cout, H, W, B, persist, arith, monkeypatch):
+    """csrc/wswide.hip (128 couts x 128 tiles per block, position-outer K loop, output transform folded into the loop) against
+    wsplit_kernel<., 6> on the same WS input and pack: y, the split hand-over and the fused ToRGB partial sums must be IDENTICAL
+    -- every accumulator sums (channel block, kernel row, product term) in the same order and A^T M keeps its expression tree --
+    with shared and per-sample noise, image borders inside and between patches (the zero rows come from the buffer load's bounds
+    check), one tile per block and persistent blocks whose ring runs across tiles; and y within the F(4,3) bound of the oracle."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    key = 'wide.%d.%d.%d.%d.%d' % (cin, cout, H, W, B)
+    w = S.counter_tensor(5, key + '.w', (1, cout, cin, 3, 3)).cuda()
+    x = S.counter_tensor(5, key + '.x', (B, cin, H, W)).cuda()
+    s = S.counter_tensor(5, key + '.s', (B, cin), 1.0, 0.3).cuda()
+    d = S.counter_tensor(5, key + '.d', (B, cout), 1.0, 0.2).cuda()
+    nw = torch.full((1,), 0.1).cuda()
+    bias = S.counter_tensor(5, key + '.b', (cout,), 0.0, 0.1).cuda()
+    sn = S.counter_tensor(5, key + '.sn', (B, cout), 1.0, 0.3).cuda()
+    rgb = (S.counter_tensor(5, key + '.rw', (3, cout)).cuda(), S.counter_tensor(5, key + '.rs', (B, cout), 1.0, 0.3).cuda())
+    vs = F_.to_wsplit(x, s, arith, f=4)
+    wsp = F_.prepack_wsplit(w, arith, f=4)
+    if persist:
+        monkeypatch.setenv('SGDFR_WSPLIT_PERSIST', str(persist))
+    for per_sample in (False, True):
+        noise = S.counter_tensor(5, key + '.n%d' % per_sample, (B if per_sample else 1, 1, H, W)).cuda()
+        for kw in ({}, {'s_next': sn, 'rgb': rgb, 'want_y': False}, {'s_next': sn, 'rgb': rgb, 'want_y': True}, {'rgb': rgb}):
+            out = {}
+            for wide in ('0', '2'):
+                monkeypatch.setenv('SGDFR_WSPLIT_WIDE_NOW', wide)
+                word = F_.new_saturation_word(x.device)
+                with F_.saturation_sink(word):
+                    r = F_.modconv_wsplit(vs, (B, cin, H, W), wsp, d, cout, noise, nw, bias, True, arith=arith, f=4, **kw)
+                torch.cuda.synchronize()
+                r = r if isinstance(r, tuple) else (r,)
+                out[wide] = [t.clone() if t is not None else None for t in r] + [int(word.item())]
+            for a, b in zip(out['0'], out['2']):
+                if isinstance(a, torch.Tensor):
+                    same = torch.equal(a, b)
+                    if not same:
+                        bad = (a != b).nonzero()
+                        print('mismatch', tuple(a.shape), a.dtype, 'first', bad[:6].tolist(), 'count', bad.shape[0], 'of', a.numel())
+                    assert same, (kw.keys(), per_sample)
+                else:
+                    assert a == b
+    monkeypatch.setenv('SGDFR_WSPLIT_WIDE_NOW', '2')
+    noise = S.counter_tensor(5, key + '.n0', (1, 1, H, W)).cuda()
+    y = F_.modconv_wsplit(vs, (B, cin, H, W), wsp, d, cout, noise, nw, bias, True, arith=arith, f=4)
+    xd, wd = x.double().cpu() * s.double().cpu()[:, :, None, None], w[0].double().cpu() / (cin * 9) ** 0.5
+    ref = torch.nn.functional.conv2d(xd, wd, padding=1) * d.double().cpu()[:, :, None, None]
+    ref = torch.nn.functional.leaky_relu(ref + 0.1 * noise.double().cpu() + bias.double().cpu().view(1, -1, 1, 1), 0.2) * 2 ** 0.5
+    assert maxabs(y, ref) <= TOL4[arith] * max(1.0, float(ref.abs().max()))
+
+
 def _decode_split(xs, arith):
     """[B, C/8, 2, HW, 8] int16 hi/lo -> fp32 [B, C, HW] (hi + lo)."""
     dt = torch.float16 if arith == 'fp16x3' else torch.bfloat16
