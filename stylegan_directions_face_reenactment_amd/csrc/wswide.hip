@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
     issue_group(L, 0, 0, 0);      // (channel block, position, slot): position 0 of channel blocks 0, 1, 2
     issue_group(L, 1, 0, 1);
     issue_group(L, 2, 0, 2);
-    int grace = 0;
+    int grace = 0, prev_issued = 0;
     bool primed = false;
     for (int jt = 0;; ++jt) {
         const int lid_n = lid_of(jt + 1);
@@ -201,6 +201,7 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
             for (int cb = 0; cb < ncb; ++cb, ++G) {
                 // look-ahead: the operands of the group three ahead (same position, or the next position's / the next TILE's first
                 // channel blocks) go into the slot the previous group has just left
+                int cur_issued = 4;       // pieces per wave and group (wave 0: 5 -- it then waits for one more of its own)
                 {
                     int cbl = cb + 3, tl = t;
                     if (cbl >= ncb) { cbl -= ncb; tl = t + 1; }
@@ -209,6 +210,8 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
                     } else if (has_next) {
                         if (cbl == 0) L = src_of(Tn);
                         issue_group(L, cbl, 0, (G + 3) & 3);
+                    } else {
+                        cur_issued = 0;   // the block's last tile: nothing left to stage
                     }
                 }
                 if (t == 0 && cb == 0) issue_tables(T);      // (the previous tile's epilogue is behind a barrier)
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
                     for (int m = 0; m < MI; ++m) acc[m] = ws_mfma<ET>(a[m][1], b[0], acc[m]);
                 }
                 // The next group's operands (issued two groups ago) must have landed and be published; what this group and the
-                // previous one issued (4 pieces each; wave 0: 5, it waits for one more of its own) stays in flight.  Loads and
+                // previous one issued stays in flight.  Loads and
                 // stores retire through ONE in-order counter: after an epilogue the first two groups wait for nothing -- their
                 // successors landed before the stores were issued (the vmcnt(0) of the tile's last group).
                 const bool last = (t == POS - 1) && (cb == ncb - 1);
@@ -248,8 +251,16 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
 #ifdef SGDFR_WSPLIT_PROBE
                     if (!(p.dbg & 32))
 #endif
-                    ws_wait_vmcnt<8>();
+                    {
+                        // (exactly what this group and the previous one issued may stay in flight -- a constant 8 would let the
+                        //  NEXT group's operands count as "recent" once the look-ahead has run dry at the end of the last tile)
+                        const int n = prev_issued + cur_issued;
+                        if (n == 8) ws_wait_vmcnt<8>();
+                        else if (n == 4) ws_wait_vmcnt<4>();
+                        else ws_wait_vmcnt<0>();
+                    }
                 }
+                prev_issued = cur_issued;
                 __builtin_amdgcn_s_barrier();
             }
             // fold M_t into the output transform (see above)
@@ -467,10 +478,11 @@ int wswide_try_launch(WsParams p, int arith, void* stream) {
     // buffer descriptors: one image of the WS tensor and the whole pack are addressed with 32-bit offsets
     if ((int64_t)(p.Cin / 8) * 12 * p.H * p.TW * 16 >= (1ll << 31) || (int64_t)p.Cout * p.Cin * 72 >= (1ll << 31)) return -1;
     if (mode_now == 1) {
-        // a wide tile is two of wsplit_kernel's tiles at ~0.87x the time of the pair (the probe's K-loop ratio): take it when
-        // that wins after rounding both to whole rounds of 256 CUs
+        // a wide tile is two of wsplit_kernel's tiles at 0.76x the time of the pair (measured at B = 32 / 64 on 512@32^2, 256@64^2,
+        // 128@128^2: 274 -> 209, 310 -> 232, 384 -> 278 us / 574 -> 430, 625 -> 487, 724 -> 552 us): take it when that wins after
+        // rounding both to whole rounds of 256 CUs
         const int r_wide = (p.total_blocks + 255) / 256, r_old = (old_blocks + 255) / 256;
-        if (p.total_blocks < 256 || r_wide * 2 * 0.87 >= (double)r_old) return -1;
+        if (p.total_blocks < 192 || r_wide * 2 * 0.76 >= (double)r_old) return -1;
     }
     p.fd_xs = make_fastdiv(p.xs);
     p.fd_tiles_x = make_fastdiv(p.tiles_x);
