@@ -7,7 +7,7 @@ reproduces every per-launch figure of the bench line without gpurun_out/."""
 import collections, csv, json, shutil, sys
 
 tag, out = sys.argv[1], sys.argv[2]
-CONV = ('modconv_mfma', 'wino_mfma', 'wino2_mfma', 'split_mfma', 'wsplit_kernel')
+CONV = ('modconv_mfma', 'wino_mfma', 'wino2_mfma', 'split_mfma', 'wsplit_kernel', 'wswide_kernel')
 HBM = ('blur', 'torgb')
 precision = sys.argv[3] if len(sys.argv) > 3 else 'fp16x3'
 HBM_PEAK, HBM_COPY = 8.0e12, 6.29e12      # MI355X_MICROARCH.md: spec / measured float4 copy
