@@ -74,11 +74,12 @@ def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, 
 def wsplit_chain_f(B, cin, cout, H, W):
     """Winograd form the inference chain runs this plain layer (fed by a transposed conv + blur) in: 0 (direct), 2 or 4 outputs
     per tile."""
-    if not (config().use_wsplit and config().use_split_chain and config().wsplit_min_cin > 0 and cin >= config().wsplit_min_cin and W <= 128):
+    if not (config().use_wsplit and config().use_split_chain and config().wsplit_min_cin > 0 and cin >= config().wsplit_min_cin and W <= 256):
         return 0
     for f in ((4, 2) if config().wsplit_f == 4 else (2,)):
-        # (F(2,3) hands over 8 bytes per element and saves a third of the MFMAs: it only pays from 256 input channels on)
-        if wsplit_ok(B, cin, cout, H, W, f) and (f == 4 or cin >= max(config().wsplit_min_cin, 256)):
+        # (F(2,3) hands over 8 bytes per element and saves a third of the MFMAs: it only pays from 256 input channels on;
+        #  256-wide rows -- ffhq-256's 128 -> 128 @ 256^2 -- come from the blur's two column tiles: F(4,3) hand-over only, round 5)
+        if wsplit_ok(B, cin, cout, H, W, f) and (f == 4 or cin >= max(config().wsplit_min_cin, 256)) and (W <= 128 or f == 4):
             return f
     return 0
 
@@ -104,7 +105,7 @@ class StreamPipeline:
         for w in batches:
             with pipe.next():                 # the slot's stream first waits for what the caller's stream has queued so far
                 img, _ = G([w], input_is_latent=True, verify_range=False)      # (the default verifies: it would WAIT per call
-                out.append(img); tokens.append(G.last_range_token)             #  and serialise the two streams)
+                out.append(img); tokens.append(G.take_range_token())           #  and serialise the two streams)
         pipe.join(*out)                       # the caller's stream now waits for every slot; tensors are handed over to it
         bad = [i for i, t in enumerate(tokens) if t is not None and not G.range_ok(t)]      # re-render those (ReenactmentSession does)
     """

@@ -253,6 +253,10 @@ __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(c
     // 8 waves = 8 channels, a wave = 64 quad columns (256-byte coalesced plane reads, as the fp32 kernel).
     __shared__ float tile_all[NG][8][2 * QC][9];
     __shared__ float sv_all[NG][8];
+    // WINO = 4 on rows of two column tiles (W = 2 QC = 128): a four-pixel Winograd tile reads one pixel on either side, so the
+    // block also computes the ONE output column beyond its inner edge (px 2 QC for the left half, px 2 QC - 1 for the right half)
+    // -- 64 threads, 16 plane loads each, the main path's tap order and epilogue, so the pixel has the bits the other half gives it
+    __shared__ float edge_all[(WINO == 4 && NG == 1) ? 8 : 1][8];
     static_assert(NG == 1 || QC < 32, "several groups per block only for the narrow levels");
     float kf[16];
 #pragma unroll
@@ -418,6 +422,27 @@ __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(c
             }
             if (sg + 1 < nseg && ms + BLUR_QV < H) load_segment(ms + BLUR_QV);
         }
+        if (WINO == 4 && NG == 1 && IL && col_tiles == 2 && lt < 64) {
+            const int row = lt >> 3, ch = lt & 7;
+            const int oy = 2 * ms + row, ox = ct == 0 ? 2 * QC : 2 * QC - 1;      // the neighbour half's first / last pixel
+            float v = 0.f;
+            if (oy < 2 * H && valid) {
+                const float* tq = t + ((int64_t)b * C + g * 8 + ch) * plane_t;
+                float o = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) {
+                        const int r = oy - 1 + ky, c2 = ox - 1 + kx;           // (columns 126 .. 130 of 0 .. 2W+1: always inside)
+                        const float tv = r >= 0 ? tq[((int64_t)(r >> 1) * GW + (c2 >> 1)) * 4 + (c2 & 1) * 2 + (r & 1)] : 0.f;
+                        o = fmaf(tv, kf[ky * 4 + kx], o);
+                    }
+                const float nzv = noise ? noise[(int64_t)b * noise_bstride + (int64_t)oy * OW + ox] : 0.f;
+                v = fmaf(nw, nzv, o + (bias ? bias[g * 8 + ch] : 0.f));
+                if (act) v = lrelu_gain(v, slope, gain);
+            }
+            edge_all[row][ch] = v;
+        }
         __syncthreads();
         if (WINO == 4) {
             // 8 rows x QC/2 four-pixel tiles, two threads per tile: each takes four of the eight channels through all six positions
@@ -426,17 +451,22 @@ __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(c
             const int chalf = lt & 1, item = lt >> 1;
             const int tc = item % TPR, row = item / TPR;
             const int oy = 2 * ms + row;
-            if (oy < 2 * H && 4 * tc < OW && valid && (NG == 1 || ms < H)) {
+            const int tcg = ct * TPR + tc;                // tile column of the image (two column tiles: W = 2 QC)
+            if (oy < 2 * H && 4 * tcg < OW && valid && (NG == 1 || ms < H)) {
                 const int HT = H * W;                     // tiles per channel (2H rows x 2W/4)
-                unsigned char* dst = xs + ((((int64_t)b * G + g) * 12) * HT + (int64_t)oy * (W / 2) + tc) * 16 + 8 * chalf;
+                unsigned char* dst = xs + ((((int64_t)b * G + g) * 12) * HT + (int64_t)oy * (W / 2) + tcg) * 16 + 8 * chalf;
                 float v[6][4];
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
                     float d[6], vv[6];
 #pragma unroll
                     for (int j = 0; j < 6; ++j) {
-                        const int px = 4 * tc - 1 + j;
-                        d[j] = (px >= 0 && px < OW) ? tile[row][px][4 * chalf + cc] * sv[4 * chalf + cc] : 0.f;
+                        const int px = 4 * tc - 1 + j, pxg = ct * 2 * QC + px;      // inside the block's tile / of the image
+                        float val = 0.f;
+                        if (pxg >= 0 && pxg < OW)
+                            val = (px >= 0 && px < 2 * QC) ? tile[row][px][4 * chalf + cc]
+                                                           : edge_all[(WINO == 4 && NG == 1) ? row : 0][4 * chalf + cc];
+                        d[j] = val * sv[4 * chalf + cc];
                     }
                     ws_input_transform<6>(d, vv);
 #pragma unroll
@@ -739,14 +769,16 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
                                              float slope, float gain, unsigned int* sat, void* stream) {
     SGDFR_REQUIRE(B >= 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "blur_bias_act_split: bad shape %d %d %d %d (C %% 8)", B, C, H, W);
     SGDFR_REQUIRE(wino == 0 || wino == 2 || wino == 4, "blur_bias_act_split: wino is 0, 2 or 4 (outputs per Winograd tile), got %d", wino);
-    SGDFR_REQUIRE(!wino || (W >= 8 && W <= 64 && (W & (W - 1)) == 0), "blur_bias_act_split: the Winograd hand-over takes W = 8, 16, 32 or 64 "
-                  "(output rows inside one column tile), got %d", W);
+    SGDFR_REQUIRE(!wino || (W >= 8 && W <= 64 && (W & (W - 1)) == 0) || (wino == 4 && W == 128 && plane_stride != 0),
+                  "blur_bias_act_split: the Winograd hand-over takes W = 8, 16, 32 or 64 (output rows inside one column tile; F(4,3) on "
+                  "interleaved planes also W = 128), got %d", W);
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "blur_bias_act_split: arith must be SGDFR_SPLIT_BF16/FP16");
     if (B == 0) return 0;
     SGDFR_REQUIRE(t && fir && s_next && xs && (reinterpret_cast<uintptr_t>(xs) & 15) == 0, "blur_bias_act_split: null / misaligned pointer");
     SGDFR_REQUIRE(!noise || noise_w, "blur_bias_act_split: noise without noise_w");
     static const int il_env = getenv("SGDFR_PLANE_IL") ? atoi(getenv("SGDFR_PLANE_IL")) : 1;      // (0: padded PLANAR planes, A/B only)
     const bool il = plane_stride != 0 && il_env != 0;       // padded planes are interleaved planes (see sgdfr.h)
+    SGDFR_REQUIRE(!(wino && W == 128) || il, "blur_bias_act_split: the Winograd hand-over of W = 128 needs interleaved planes");
     if (plane_stride == 0) plane_stride = (int64_t)(H + 1) * (W + 1);
     SGDFR_REQUIRE(plane_stride >= (int64_t)(H + 1) * (W + 1) && plane_stride < (1 << 30), "blur_bias_act_split: plane_stride < (H+1)*(W+1)");
     SGDFR_REQUIRE(!il || (reinterpret_cast<uintptr_t>(t) & 15) == 0, "blur_bias_act_split: interleaved planes must be 16-byte aligned");

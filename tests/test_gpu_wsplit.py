@@ -178,7 +178,7 @@ def test_wsplit_rejects_unsupported_shapes():
 
 @pytest.mark.parametrize('f', [2, 4])
 @pytest.mark.parametrize('arith', ['fp16x3', 'bf16x3'])
-@pytest.mark.parametrize('C,H,B', [(16, 8, 5), (64, 16, 3), (24, 32, 2), (16, 64, 2)])
+@pytest.mark.parametrize('C,H,B', [(16, 8, 5), (64, 16, 3), (24, 32, 2), (16, 64, 2), (16, 128, 2)])
 def test_blur_winograd_handover_is_bit_identical_to_transforming_the_fp32_result(C, H, B, arith, f):
     """sgdfr_blur_bias_act_split_f32(wino=f) == sgdfr_to_wsplit_f32(sgdfr_blur_bias_act_f32(...), s_next, f), dense and padded planes."""
     from stylegan_directions_face_reenactment_amd import functional as F_
@@ -191,10 +191,13 @@ def test_blur_winograd_handover_is_bit_identical_to_transforming_the_fp32_result
     nw = torch.full((1,), 0.3).cuda()
     bias = S.counter_tensor(6, key + '.b', (C,), 0.0, 0.1).cuda()
     sn = S.counter_tensor(6, key + '.s', (B, C), 1.0, 0.3).cuda()
+    if H == 128 and f != 4:
+        pytest.skip('rows of two column tiles (W = 128): F(4,3) hand-over on interleaved planes only')
     y = F_.blur_bias_act(planes, fir, H, H, noise, nw, bias, True)
     want = F_.to_wsplit(y, sn, arith, f=f)
-    got = F_.blur_bias_act_split(planes, fir, H, H, sn, noise, nw, bias, True, arith=arith, wino=f)
-    assert got.shape == want.shape and torch.equal(got, want)
+    if H < 128:
+        got = F_.blur_bias_act_split(planes, fir, H, H, sn, noise, nw, bias, True, arith=arith, wino=f)
+        assert got.shape == want.shape and torch.equal(got, want)
     ps = ((H + 1) * (H + 1) + 31) // 32 * 32
     # the padded form is interleaved: [B, C, positions, px, py] (include/sgdfr.h, plane_stride)
     il = torch.zeros(B, C, ps, 2, 2, device='cuda')
