@@ -207,7 +207,7 @@ int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const float* noise
 /* sgdfr_blur_bias_act_f32 with the result multiplied by the NEXT layer's modulation s_next [B,C] and written in that layer's
  * split input form xs [B][C/8][2][2H*2W][8] (see sgdfr_to_split_f32) instead of fp32 NCHW.  plane_stride: 0 = t is the dense
  * planar [B*C][4][(H+1)*(W+1)]; otherwise t is the interleaved [B*C][plane_stride][px][py] form of sgdfr_modconv2d_split_f32
- * (16-byte aligned).  wino = 2 | 4 (W = 8 ... 64): xs receives the
+ * (16-byte aligned).  wino = 2 | 4 (W = 8 ... 64; wino = 4 on interleaved planes also W = 128): xs receives the
  * Winograd input form [B][C/8][wino+2][2][2H*2W/wino][8] of sgdfr_to_wsplit_f32(f = wino) instead (2x / 1.5x the bytes), for
  * sgdfr_modconv2d_wsplit_f32. */
 int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, const float* noise, int64_t noise_bstride,

@@ -11,16 +11,21 @@
 // and 608 (with 1.4 filler instructions per MFMA) in the same probe: no faster than today's loop, DESIGN 4.10.
 //
 // What had to change to make it fit (160 KB of LDS, 256 registers per wave at two waves per SIMD):
-//  * POSITION-MAJOR K loop.  A channel block is walked as 6 groups = one Winograd position t each (3 kernel rows x 6 MFMAs per
-//    wave); a group needs the three (ky, t) chunks of U (24 KB) and only V_t = [part][k-half][144 staged positions] (9 KB) --
-//    so neither operand is double-buffered per channel block any more: two rings of four group slots (96 + 36 KB), every group's
-//    operands DMA'd three groups (~2.5k clocks of MFMA issue) ahead, one s_barrier per group.  wsplit_kernel's V double buffer alone
-//    would be 108 KB at this tile.
-//  * The ring runs ACROSS tiles: the look-ahead of a tile's last three groups stages the first three groups of the block's next
+//  * POSITION-OUTER K loop: (Winograd position t -> channel block -> kernel row).  One position is accumulated over ALL channel
+//    blocks -- two live MFMA accumulators per wave (64 couts x 32 tiles of M_t) -- and the finished M_t is folded into the output
+//    transform A^T M at once, in wsplit_kernel's expression tree, so at most 160 registers hold accumulators or partial outputs
+//    (all twelve M_t at once = 192 of 256: hipcc then rotated one through scratch every channel block).  Every accumulator still
+//    sums (channel block, kernel row, product term) in wsplit_kernel's order: same bits.
+//  * A group = (position, channel block) needs the three (ky, t) chunks of U (24 KB: contiguous 8 KB chunks of the existing pack)
+//    and only V_t = [part][k-half][144 staged positions] (9 KB), so neither operand is double-buffered per channel block: two rings
+//    of four group slots (96 + 36 KB), every group's operands DMA'd three groups (~2.5-3k clocks of MFMA issue) ahead, one s_barrier
+//    and one counted vmcnt per group.  wsplit_kernel's V double buffer alone would be 108 KB at this tile.
+//  * The rings run ACROSS tiles: the look-ahead of a tile's last three groups stages the first three groups of the block's next
 //    tile (persistent blocks), so a tile starts with its operands in LDS.
-//  * 192 accumulator registers per wave: one fragment set (the partner wave of the SIMD covers the LDS latency), per-lane state cut
-//    to a handful of registers -- epilogue coefficients arrive by 4-byte LDS-DMA (no staging registers), V source offsets are
-//    32 bits with the zero page as a flag, noise is fetched in the epilogue.
+//  * Per-lane state cut to a handful of registers: operand DMA by BUFFER loads (descriptor in SGPRs, 32-bit lane offset; rows
+//    outside the image are out-of-range offsets = zeros from the bounds check), epilogue coefficients by 4-byte LDS-DMA (no staging
+//    registers), noise fetched in the epilogue, lane coordinates laundered through an asm so the epilogue's addresses are not
+//    hoisted above the K loop.
 #include "wsplit_common.h"
 
 namespace sgdfr {
