@@ -967,7 +967,11 @@ def main():
         local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
         AFFINITY = D.gather_objects(D.bind_rank(local_rank, local_world, use_gpu=not args.host_check))
     if args.host_check:
-        return host_check(args, rank, world)
+        host_check(args, rank, world)
+        # (leave through the same door as a real run: a rank that lets the interpreter tear a live gloo group down races its
+        #  worker threads -- "terminate called without an active exception", SIGABRT about once in five 8-rank launches)
+        D.shutdown()
+        return
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
     dev = torch.device('cuda', torch.cuda.current_device() if world > 1 else 0)
