@@ -731,7 +731,8 @@ extern "C" int sgdfr_modconv2d_wsplit_f32(const unsigned short* v, const unsigne
     // weight half-slabs and the epilogue coefficients of the block's next tile (see the kernel).
     const int persist = getenv("SGDFR_WSPLIT_PERSIST") ? atoi(getenv("SGDFR_WSPLIT_PERSIST")) : 256;      // (read per launch: scripts/wsplit_env_ab.py)
     p.total_blocks = p.n_pix_tiles * p.n_cout_tiles;
-    const int grid = (persist > 0 && p.total_blocks >= 2 * persist) ? persist : p.total_blocks;
+    // (a persistent grid deals its tiles to the 8 XCDs -- blockIdx & 7 -- so it needs a block on each: fewer than 8 would skip ranges)
+    const int grid = (persist >= 8 && p.total_blocks >= 2 * persist) ? persist : p.total_blocks;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, as_stream(stream), p);
     return check_launch("modconv2d_wsplit");
 }

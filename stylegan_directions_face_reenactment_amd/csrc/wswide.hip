@@ -506,7 +506,8 @@ int wswide_try_launch(WsParams p, int arith, void* stream) {
         return 2;
     }
     const int persist = getenv("SGDFR_WSPLIT_PERSIST") ? atoi(getenv("SGDFR_WSPLIT_PERSIST")) : 256;
-    const int grid = (persist > 0 && p.total_blocks >= 2 * persist) ? persist : p.total_blocks;
+    // (a persistent grid deals its tiles to the 8 XCDs -- blockIdx & 7 -- so it needs a block on each: fewer than 8 would skip ranges)
+    const int grid = (persist >= 8 && p.total_blocks >= 2 * persist) ? persist : p.total_blocks;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, as_stream(stream), p);
     return check_launch("modconv2d_wsplit (wide tile)");
 }

@@ -69,6 +69,8 @@ WIDE_CASES = [  # cin, cout, H, W, B, persist
     (128, 128, 128, 128, 2, 16),   # 64 tiles on 16 persistent blocks: four tiles per block, the ring runs across tiles
     (64, 384, 48, 96, 5, 8),       # ragged everything: 3 cout tiles, 3 x 3 patches, 135 tiles on 8 blocks (16 or 17 each)
     (256, 256, 64, 64, 40, 256),   # 640 tiles: the persistent grid of the bench shapes (2 or 3 tiles per block), start spread off
+    (128, 128, 32, 256, 3, 8),     # 256-wide rows (ffhq-256's last plain layer): 8 patches across, 48 tiles on 8 blocks (a persistent
+                                   # grid deals tiles to the 8 XCDs: it must have at least 8 blocks -- the product's has 256)
 ]
 
 
