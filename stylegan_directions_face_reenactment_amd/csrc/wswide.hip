@@ -494,9 +494,13 @@ int wswide_try_launch(WsParams p, int arith, void* stream) {
     p.fd_per_img = make_fastdiv(p.tiles_x * p.tiles_y);
     p.fd_npt = make_fastdiv(p.n_pix_tiles);
     {
-        const int pct = getenv("SGDFR_WSPLIT_DESYNC") ? atoi(getenv("SGDFR_WSPLIT_DESYNC")) : 60;
+        // First-round start spread: OFF for this kernel.  Same-process A/B at B = 64 (SGDFR_WSWIDE_DESYNC = 0 / 30 / 60 / 100 % of a
+        // block time, us per launch): 512@32^2 454 / 468 / 494 / 538, 256@64^2 492 / 505 / 515 / 538, 128@128^2 585 / 580 / 579 / 587
+        // -- wsplit_kernel's 60 % costs the first two layers 5-9 % here (2-4 long tiles per block: the spread is a fraction of the
+        // whole launch) and buys the third nothing.
+        const int pct = getenv("SGDFR_WSWIDE_DESYNC") ? atoi(getenv("SGDFR_WSWIDE_DESYNC")) : 0;
         const double block_clk = (double)(p.Cin / WS_CB) * 108 * 32 * 2 / 0.7 + 20000.0;
-        p.desync = (pct > 0 && p.total_blocks >= 1024) ? (int)(block_clk * pct / 100 / 4096) : 0;
+        p.desync = pct > 0 ? (int)(block_clk * pct / 100 / 4096) : 0;
     }
     const size_t lds = (size_t)WW_RING * (WW_USLAB + WW_VSLAB) + 7 * 128 * sizeof(float);
     void (*kern)(WsParams) = arith == SGDFR_SPLIT_FP16 ? wswide_kernel<SGDFR_SPLIT_FP16> : wswide_kernel<SGDFR_SPLIT_BF16>;
