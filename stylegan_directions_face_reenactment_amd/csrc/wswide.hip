@@ -165,6 +165,12 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
     const int a_off = (hi * 128 + wm * 64 + l31) * 16;                   // + ((ky * 2 + part) * 2) * 2048 + mi * 512
     const int b_off = (hi * WW_XS + wn * 32 + l31) * 16;                 // + (part * 2) * 144 * 16 + ky * 8 * 16
 
+    // where in a group a wave issues its look-ahead: 0 = before the first kernel row's MFMAs, 1 / 2 = behind the first / second row's
+#ifdef SGDFR_WSPLIT_PROBE
+    const int issue_at = (p.dbg & 0x100) ? (wave >= 4 ? (p.dbg >> 11) & 3 : (p.dbg >> 9) & 3) : 1;
+#else
+    constexpr int issue_at = 1;
+#endif
     unsigned sat = 0;
     int G = 0;                    // groups issued to the rings so far = slot counter (runs across tiles)
     int lid = lid_of(0);
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
                 // look-ahead: the operands of the group three ahead (same position, or the next position's / the next TILE's first
                 // channel blocks) go into the slot the previous group has just left
                 int cur_issued = 4;       // pieces per wave and group (wave 0: 5 -- it then waits for one more of its own)
-                {
+                auto look_ahead = [&]() {
                     int cbl = cb + 3, tl = t;
                     if (cbl >= ncb) { cbl -= ncb; tl = t + 1; }
                     if (tl < POS) {
@@ -218,7 +224,12 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
                     } else {
                         cur_issued = 0;   // the block's last tile: nothing left to stage
                     }
-                }
+                };
+                // (every wave issues its pieces BEHIND the first kernel row's MFMAs, not in front of them: a group then opens with
+                //  fragment reads + MFMAs on every SIMD.  Same-process A/B of the position per wave half, probe build, us per launch at
+                //  512@32^2 / 256@64^2 / 128@128^2: both halves in front 475 / 519 / 604 (other box), waves 4-7 behind row 0 (wsplit.hip's
+                //  arrangement) 469 / 515 / 593, BOTH behind row 0 456 / 501 / 593, waves 4-7 behind row 1 472 / 519 / 607)
+                if (issue_at == 0) look_ahead();
                 if (t == 0 && cb == 0) issue_tables(T);      // (the previous tile's epilogue is behind a barrier)
                 const unsigned char* us = ub0 + (G & 3) * WW_USLAB + a_off;
                 const unsigned char* vs = vb0 + (G & 3) * WW_VSLAB + b_off;
@@ -241,6 +252,7 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
                     for (int m = 0; m < MI; ++m) acc[m] = ws_mfma<ET>(a[m][0], b[1], acc[m]);
 #pragma unroll
                     for (int m = 0; m < MI; ++m) acc[m] = ws_mfma<ET>(a[m][1], b[0], acc[m]);
+                    if (ky + 1 == issue_at) look_ahead();
                 }
                 // The next group's operands (issued two groups ago) must have landed and be published; what this group and the
                 // previous one issued stays in flight.  Loads and
