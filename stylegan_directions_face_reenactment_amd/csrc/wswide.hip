@@ -120,15 +120,30 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
 #endif
         // (wave-uniform values, said so explicitly: left in a VGPR an soffset makes hipcc wrap the load in a waterfall loop)
         const int wg = __builtin_amdgcn_readfirstlane(S.w_off + (cb * 18 + t) * 8192);
-#pragma unroll
-        for (int v = 0; v < 3; ++v)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)(ub0 + slot * WW_USLAB + (v * 8 + wave) * 1024), 16, lane_piece,
-                                                     wg + v * (6 * 8192), 0, 0);
         const auto rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(S.v), 0, img_bytes, 0x00020000);
         const int vg = __builtin_amdgcn_readfirstlane((cb * 24 + t * 2) * HT * 16);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_void*)(vb0 + slot * WW_VSLAB + wave * 1024), 16, S.voff, vg, 0, 0);
-        if (wave == 0)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_void*)(vb0 + slot * WW_VSLAB + 8 * 1024), 16, S.voff8, vg, 0, 0);
+        auto go = [&](auto unt, auto vnt) {      // cache policy of the two operand streams (aux = 2: non-temporal)
+            constexpr int UA = decltype(unt)::value, VA = decltype(vnt)::value;
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_void*)(ub0 + slot * WW_USLAB + (v * 8 + wave) * 1024), 16, lane_piece,
+                                                         wg + v * (6 * 8192), 0, UA);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_void*)(vb0 + slot * WW_VSLAB + wave * 1024), 16, S.voff, vg, 0, VA);
+            if (wave == 0)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_void*)(vb0 + slot * WW_VSLAB + 8 * 1024), 16, S.voff8, vg, 0, VA);
+        };
+        using c0 = std::integral_constant<int, 0>;
+        using c2 = std::integral_constant<int, 2>;
+#ifdef SGDFR_WSPLIT_PROBE
+        switch ((p.dbg >> 13) & 3) {
+            case 1: go(c0{}, c2{}); break;
+            case 2: go(c2{}, c0{}); break;
+            case 3: go(c2{}, c2{}); break;
+            default: go(c0{}, c0{}); break;
+        }
+#else
+        go(c0{}, c0{});
+#endif
     };
     // epilogue coefficients of a tile by 4-byte LDS-DMA: array k of `tab` is fetched by wave k (two 64-lane halves)
     auto issue_tables = [&](const Tile& T) {
