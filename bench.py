@@ -716,6 +716,33 @@ def other_config_legs(args, rank, world, dev):
         except Exception as e:
             legs['synthesis_cm2'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
         torch.cuda.empty_cache()
+    if args.config == 'synthesis' and args.precision == 'fp16x3' and F_.config().cross_terms == 'fp16':
+        # The same workload with Config.cross_terms='fp8' (opt-in, include/sgdfr.h SGDFR_SPLIT_FP16F8): the F(4,3) layers that take the
+        # wide-tile kernel keep both cross terms of the split product in e4m3 -- 2 MFMA units per product instead of 3.  Reported
+        # beside `value`, never as it: the default stays three fp16 products (1.4e-5 against the oracle); this leg's max-abs is measured
+        # on its own timed batch against the same oracle and the same 1e-3 bar.
+        sub = argparse.Namespace(**vars(args))
+        sub.no_alt, sub.sustain, sub.no_other_configs, sub.no_cpu_baseline, sub.layers = True, 0, True, True, False
+        sub.steps, sub.warmup = max(5, min(args.steps, 20)), max(3, min(args.warmup, 5))
+        t0 = time.perf_counter()
+        base_cfg = F_.config()
+        try:
+            F_.set_default(base_cfg.replace(cross_terms='fp8'))
+            line = run_synthesis(sub, rank, world, dev)
+            legs['synthesis_fp8_cross_terms'] = {
+                'metric': line['metric'], 'value': line['value'], 'unit': line['unit'], 'steps': sub.steps, 'warmup': sub.warmup,
+                'ms_per_step': line['ms_per_step'], 'per_gpu_batch': sub.batch, 'workload': line['config']['workload'],
+                'dtype': 'f32 (fp16 hi+lo operands; on the wide-tile F(4,3) layers the two cross terms as e4m3 pairs in one fp8 MFMA)',
+                'single_stream': line.get('single_stream', {}).get('value'),
+                'max_abs_vs_oracle': (line.get('max_abs_vs_oracle') or {}).get(sub.precision), 'bar': 1e-3,
+                'fp16_saturated_pairs': line.get('fp16_saturated_pairs'),
+                'conv_roofline': {k: line['roofline'][k] for k in ('achieved', 'peak', 'unit', 'frac', 'conv_ms_per_step', 'alg_gflop_per_unit')},
+                'conv_per_layer': line['roofline']['per_layer'], 'leg_wall_s': round(time.perf_counter() - t0, 1)}
+        except Exception as e:
+            legs['synthesis_fp8_cross_terms'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+        finally:
+            F_.set_default(F_.config().replace(cross_terms=base_cfg.cross_terms))
+        torch.cuda.empty_cache()
     for name, fn in (('inference', run_inference), ('trainer', run_trainer)):
         sub = argparse.Namespace(**vars(args))
         sub.config, sub.batch = name, DEFAULT_BATCH[name]

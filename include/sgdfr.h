@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 17
+#define SGDFR_ABI_VERSION 18
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -263,6 +263,10 @@ int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, cons
 #define SGDFR_SPLIT_BF16 0   /* bf16 hi+lo: 16 mantissa bits, fp32 range   (~1e-4 on the 256x256 generator) */
 #define SGDFR_SPLIT_FP16 1   /* fp16 hi+lo: 22 mantissa bits = fp32-grade; operands range-shifted by exact powers of two,
                                 |x*s| saturates at 1.04e6 */
+#define SGDFR_SPLIT_FP16F8 2 /* fp16 main term + fp8 (e4m3) cross terms: the "lo" chunk of eight channels holds (8 x fp8 | 8 x fp8)
+                                instead of 8 x fp16, both cross terms of 32 K-elements are one v_mfma_scale_f32_32x32x64_f8f6f4:
+                                2 MFMA units per product instead of 3, ~1e-5 of max|y| per layer.  Only the F(4,3) wide-tile
+                                conv (sgdfr_modconv2d_wsplit_f32, f = 4), its pack and its WS producers take it */
 int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin);
 int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int arith, int transpose_flip,
                                     unsigned int* sat, void* stream);
@@ -319,13 +323,22 @@ int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, in
  *                                      V1 = d1+d2, V2 = d2-d1, V3 = d1-d3.  Producers may emit it directly
  *                                      (sgdfr_blur_bias_act_split_f32 with wino = f).
  *   sgdfr_modconv_prepack_wsplit_f32:  weight [Cout,Cin,3,3] -> U = G (weight/sqrt(9 Cin)) per kernel row, 16-bit hi/lo in
- *                                      kernel order, sgdfr_modconv_prepack_wsplit_elems() uint16 elements (= 2*3*(f+2)*Cin*Cout).
+ *                                      kernel order, sgdfr_modconv_prepack_wsplit_elems() uint16 elements (= 2*3*(f+2)*Cin*Cout + an 8-element trailer).
  *   sgdfr_modconv2d_wsplit_supported:  Cin % 16 == 0, Cout % 128 == 0, W/f a multiple of the patch width (f = 2: min(16, W/2)
  *                                      >= 8 tiles; f = 4: min(8, W/4) >= 4), H a multiple of the patch height (256 / (f * width)).
  *   sgdfr_modconv2d_wsplit_f32:        outputs as sgdfr_modconv2d_split_f32 (PLAIN3, ksplit = 1, x_is_split = 1): y (may be
  *                                      NULL when xs_out or rgb_part is given), the next conv's split input xs_out (+ s_next),
- *                                      ToRGB partial sums rgb_part [B][(Cout/128)*3][H*W] (+ rgb_w, rgb_s). */
+ *                                      ToRGB partial sums rgb_part [B][(Cout/128)*3][H*W] (+ rgb_w, rgb_s).
+ * arith = SGDFR_SPLIT_FP16F8 (f = 4 only, in all three calls and in sgdfr_blur_bias_act_split_f32 with wino = 4): the fp16 main
+ * term plus BOTH cross terms in fp8 -- the 16-byte lo chunk of eight channels holds two 8-byte halves (channels 0-3, 4-7) of
+ * (4 x e4m3 lo * 2^7 | 4 x e4m3 hi * 2^-4) for activations and (4 x e4m3 hi * 2^-EW | 4 x e4m3 lo * 2^(11-EW)) for weights; the
+ * pack's 16-byte trailer keeps max |w * scale|, from which the kernels derive EW.  Same buffer sizes and shapes as the fp16 forms.
+ * The conv then runs on the wide-tile kernel only (csrc/wswide.hip: Cin % 32 == 0, Cin >= 64, W % 32 == 0, H % 16 == 0, d and
+ * bias given) and fails otherwise; sgdfr_modconv2d_wsplit_wide() = 1 for the shapes whose F(4,3) launch takes that kernel by its
+ * tile count anyway (what a host asks before choosing the arithmetic for a layer).  ~5e-5 of max|y| per layer (fp16x3: 4e-6),
+ * 1.3-1.5x the speed of the three-product form (scripts/f8_layer_probe.py). */
 int sgdfr_modconv2d_wsplit_supported(int B, int Cin, int Cout, int H, int W, int f);
+int sgdfr_modconv2d_wsplit_wide(int B, int Cin, int Cout, int H, int W);
 int64_t sgdfr_modconv_prepack_wsplit_elems(int Cout, int Cin, int f);
 int sgdfr_modconv_prepack_wsplit_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int f, int arith,
                                      unsigned int* sat, void* stream);

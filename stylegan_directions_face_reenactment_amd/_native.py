@@ -23,7 +23,7 @@ if os.environ.get('SGDFR_LIB'):
     else:
         import warnings as _warnings
         _warnings.warn('SGDFR_LIB is set but ignored (set SGDFR_ALLOW_LIB_OVERRIDE=1 to load a probe build)', RuntimeWarning)
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -114,6 +114,7 @@ SIGNATURES['sgdfr_absmax_f32'] = [_c_f32p, _i64, _i64, _i, ctypes.c_void_p, _i, 
 SIGNATURES['sgdfr_styles_batched_f32'] = [_c_f32p, _i, _i, _i, ctypes.POINTER(StyleLayer), _i, ctypes.c_void_p]
 MAX_STYLE_LAYERS = 40
 SIGNATURES['sgdfr_modconv2d_wsplit_supported'] = [_i, _i, _i, _i, _i, _i]
+SIGNATURES['sgdfr_modconv2d_wsplit_wide'] = [_i, _i, _i, _i, _i]
 SIGNATURES['sgdfr_modconv_prepack_wsplit_f32'] = [_c_f32p, ctypes.c_void_p, _i, _i, _i, _i, ctypes.c_void_p, ctypes.c_void_p]
 SIGNATURES['sgdfr_to_wsplit_f32'] = [_c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i, _i, ctypes.c_void_p, ctypes.c_void_p]
 SIGNATURES['sgdfr_modconv2d_wsplit_f32'] = [ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
@@ -127,7 +128,7 @@ DTYPES = {torch.float32: 0, torch.float16: 1, torch.float64: 2}      # SGDFR_DTY
 OPTIONAL_SIGNATURES = {'sgdfr_mfma_ceiling_probe': [_i, _i, _i, _i, _i, _c_f32p, ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]}
 
 MODE_PLAIN3, MODE_UP3, MODE_DOWN3 = 0, 1, 2
-SPLIT_BF16, SPLIT_FP16 = 0, 1
+SPLIT_BF16, SPLIT_FP16, SPLIT_FP16F8 = 0, 1, 2      # include/sgdfr.h SGDFR_SPLIT_*
 ACT_NONE, ACT_LRELU = 0, 1
 
 _lib = None

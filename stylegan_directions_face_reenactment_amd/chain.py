@@ -13,10 +13,11 @@ class SplitAct:
     """An activation that only exists in the NEXT conv's split input form (x * s_next as 16-bit hi/lo pairs,
     [B, C/8, 2, H*W, 8] int16): written by the producing kernel's epilogue, staged by DMA in the consumer.  wino=True: the
     Winograd input form of that conv instead ([B, C/8, 4, 2, H*W/2, 8], see to_wsplit / modconv_wsplit)."""
-    __slots__ = ('xs', 'shape', 'wino')
+    __slots__ = ('xs', 'shape', 'wino', 'arith')
 
-    def __init__(self, xs, shape, wino=0):
+    def __init__(self, xs, shape, wino=0, arith=None):
         self.xs, self.shape, self.wino = xs, tuple(shape), (2 if wino is True else int(wino or 0))
+        self.arith = arith          # None: the ambient precision; 'fp16f8': F(4,3) form with fp8 cross terms (wsplit_chain_arith)
 
 
 def xin_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
@@ -26,18 +27,18 @@ def xin_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
 
 
 def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, noise_weight=None, bias=None, batch=None,
-                      s_next=None, rgb=None, want_y=True, wino_next=False):
+                      s_next=None, rgb=None, want_y=True, wino_next=False, arith_next=None):
     """One StyledConv on the split kernels with the inference-only dataflow options: x may be a SplitAct (then `s` is
     already applied), s_next asks for the output as a SplitAct for the next conv, rgb for the fused ToRGB partial sums.
     A SplitAct in Winograd form (x.wino) runs on modconv_wsplit with `wsp` = the prepack_wsplit pack; wino_next (transposed
-    conv + blur only) asks for the output in that form.
+    conv + blur only) asks for the output in that form, arith_next ('fp16f8' | None) for the arithmetic of that hand-over.
     Returns (activation: fp32 tensor | SplitAct | None, ToRGB partials | None)."""
     if isinstance(x, SplitAct) and x.wino:
         if upsample:
             raise RuntimeError('styled_conv_split: the Winograd input form feeds plain convs only')
         B, cin, H, W = x.shape
         res = modconv_wsplit(x.xs, x.shape, wsp, d, cout, noise, noise_weight, bias, True, rgb=rgb,
-                             want_y=want_y and s_next is None, s_next=s_next, f=x.wino)
+                             want_y=want_y and s_next is None, s_next=s_next, f=x.wino, arith=x.arith)
         if s_next is not None:
             _, part, xs = res
             return SplitAct(xs, (B, cout, H, W)), part
@@ -62,12 +63,14 @@ def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, 
         # parity planes padded to whole 128-byte lines: the odd-sized dense planes make every store run straddle two lines
         ps = ((H + 1) * (W + 1) + 31) // 32 * 32
         planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split, plane_stride=ps)
-        xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, plane_stride=ps, wino=wino_next)
-        return SplitAct(xs, (B, cout, 2 * H, 2 * W), wino_next), None
+        xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, plane_stride=ps, wino=wino_next,
+                                 arith=arith_next if wino_next == 4 else None)
+        return SplitAct(xs, (B, cout, 2 * H, 2 * W), wino_next, arith_next if wino_next == 4 else None), None
     planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split)
     if s_next is not None:
-        xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, wino=wino_next)
-        return SplitAct(xs, (B, cout, 2 * H, 2 * W), wino_next), None
+        xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, wino=wino_next,
+                                 arith=arith_next if wino_next == 4 else None)
+        return SplitAct(xs, (B, cout, 2 * H, 2 * W), wino_next, arith_next if wino_next == 4 else None), None
     return blur_bias_act(planes, fir, H, W, noise, noise_weight, bias, True), None
 
 
@@ -82,6 +85,15 @@ def wsplit_chain_f(B, cin, cout, H, W):
         if wsplit_ok(B, cin, cout, H, W, f) and (f == 4 or cin >= max(config().wsplit_min_cin, 256)) and (W <= 128 or f == 4):
             return f
     return 0
+
+
+def wsplit_chain_arith(B, cin, cout, H, W, f):
+    """Arithmetic of a plain layer the chain runs in F(f,3) form: 'fp16f8' (fp16 main term + fp8 cross terms, Config.cross_terms) when
+    its launch takes the wide-tile kernel anyway -- the only reader of that form -- else None (the ambient precision)."""
+    if f == 4 and config().precision == 'fp16x3' and config().cross_terms == 'fp8' and cin % 32 == 0 and \
+            _shape_query('sgdfr_modconv2d_wsplit_wide', B, cin, cout, H, W):
+        return 'fp16f8'
+    return None
 
 
 def wsplit_chain_ok(B, cin, cout, H, W):

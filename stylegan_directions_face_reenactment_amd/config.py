@@ -26,6 +26,10 @@ class Config:
     use_wsplit: bool = True             # inference chain, plain layers fed by a transposed conv + blur: 1-D Winograd form (wsplit.hip)
     wsplit_f: int = 4                   # outputs per Winograd tile the chain prefers: 2 = F(2,3), 4 = F(4,3)
     wsplit_min_cin: int = 128           # ... for layers with at least this many input channels (0 = never)
+    # Cross terms (hi*lo, lo*hi) of the fp16x3 product on the F(4,3) layers that take the wide-tile kernel: 'fp16' (three fp16
+    # products) | 'fp8' (both cross terms in one e4m3 MFMA: 2 MFMA units per product instead of 3, ~5e-5 of max|y| per such layer
+    # instead of 4e-6; include/sgdfr.h SGDFR_SPLIT_FP16F8)
+    cross_terms: str = 'fp16'
 
     def replace(self, **changes):
         return dataclasses.replace(self, **changes)
@@ -40,13 +44,15 @@ class Config:
                    use_plane_padding=e.get('SGDFR_PLANE_PADDING', '1') != '0',
                    use_split_chain=e.get('SGDFR_SPLIT_CHAIN', '1') != '0',
                    use_wsplit=e.get('SGDFR_WSPLIT', '1') != '0', wsplit_f=int(e.get('SGDFR_WSPLIT_F', '4')),
-                   wsplit_min_cin=int(e.get('SGDFR_WSPLIT_MIN_CIN', '128')))
+                   wsplit_min_cin=int(e.get('SGDFR_WSPLIT_MIN_CIN', '128')), cross_terms=e.get('SGDFR_CROSS_TERMS', 'fp16'))
 
     def __post_init__(self):
         if self.precision not in ('fp32', 'fp16x3', 'bf16x3'):
             raise ValueError("precision must be 'fp32', 'fp16x3' or 'bf16x3', got %r" % (self.precision,))
         if self.backward_arith not in ('fp16x3', 'bf16x3'):
             raise ValueError("backward_arith must be 'fp16x3' or 'bf16x3', got %r" % (self.backward_arith,))
+        if self.cross_terms not in ('fp16', 'fp8'):
+            raise ValueError("cross_terms must be 'fp16' or 'fp8', got %r" % (self.cross_terms,))
         if self.wsplit_f not in (2, 4):
             raise ValueError('wsplit_f must be 2 or 4')
 

@@ -3,6 +3,7 @@
 // Both are HBM-bound: every output is written once, inputs are read once from HBM and the
 // FIR overlap is served by L1/L2 (generic op) or by registers across the 2x2 output quad (blur).
 #include "common.h"
+#include "wsplit_common.h"      // the fp8 cross-term chunks of SGDFR_SPLIT_FP16F8 (Winograd hand-over only)
 
 namespace sgdfr {
 
@@ -200,7 +201,7 @@ __device__ unsigned int g_blur_saturated = 0;    // operand pairs clamped to the
 
 template <int ET>
 __device__ __forceinline__ void blur_split2(float a, float b, unsigned& hi, unsigned& lo, unsigned& sat) {     // as split.hip's split_pair
-    if (ET == SGDFR_SPLIT_FP16) {
+    if (ET == SGDFR_SPLIT_FP16 || ET == SGDFR_SPLIT_FP16F8) {
         sat += (!(fabsf(a) <= 65504.f) || !(fabsf(b) <= 65504.f)) ? 1u : 0u;      // NaN counts too; flushed once per thread: no branch per pair
         a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
         b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
@@ -272,7 +273,8 @@ __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(c
     const int64_t n_groups = (int64_t)B * G * row_tiles;
     const int64_t n_tiles = paired ? ((n_groups + 7) / 8) * 16 : ((n_groups + NG - 1) / NG) * col_tiles;      // (NG > 1: one column tile)
     const float nw = (noise && noise_w) ? noise_w[0] : 0.f;
-    const float xsc = (ET == SGDFR_SPLIT_FP16) ? 0.0625f : 1.f;
+    const float xsc = (ET == SGDFR_SPLIT_FP16 || ET == SGDFR_SPLIT_FP16F8) ? 0.0625f : 1.f;
+    const float f8_mul_lo = exp2f((float)WS_F8_XLO), f8_mul_hi = exp2f((float)WS_F8_XHI);
     const int sub = threadIdx.x / (8 * QC), lt = threadIdx.x % (8 * QC);      // group of this thread inside the block, thread inside the group
     const int c8 = lt / QC, nx = lt % QC;
     float (*const tile)[2 * QC][9] = tile_all[sub];
@@ -478,7 +480,9 @@ __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(c
                     blur_split2<ET>(v[tt][0], v[tt][1], h01, l01, sat);
                     blur_split2<ET>(v[tt][2], v[tt][3], h23, l23, sat);
                     *reinterpret_cast<uint2*>(dst + (int64_t)(2 * tt) * HT * 16) = make_uint2(h01, h23);
-                    *reinterpret_cast<uint2*>(dst + (int64_t)(2 * tt + 1) * HT * 16) = make_uint2(l01, l23);
+                    // (fp8 cross terms: this thread's half of the lo chunk = (4 x lo | 4 x hi) in e4m3, wsplit_common.h)
+                    *reinterpret_cast<uint2*>(dst + (int64_t)(2 * tt + 1) * HT * 16) =
+                        ET == SGDFR_SPLIT_FP16F8 ? ws_f8_half(h01, h23, l01, l23, f8_mul_lo, f8_mul_hi, false) : make_uint2(l01, l23);
                 }
             }
         } else if (WINO == 2) {
@@ -554,7 +558,7 @@ __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(c
         __syncthreads();
         }       // segments
     }
-    if (ET == SGDFR_SPLIT_FP16 && sat != 0) atomicAdd(sat_word ? sat_word : &g_blur_saturated, sat);
+    if ((ET == SGDFR_SPLIT_FP16 || ET == SGDFR_SPLIT_FP16F8) && sat != 0) atomicAdd(sat_word ? sat_word : &g_blur_saturated, sat);
 }
 
 
@@ -772,7 +776,8 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
     SGDFR_REQUIRE(!wino || (W >= 8 && W <= 64 && (W & (W - 1)) == 0) || (wino == 4 && W == 128 && plane_stride != 0),
                   "blur_bias_act_split: the Winograd hand-over takes W = 8, 16, 32 or 64 (output rows inside one column tile; F(4,3) on "
                   "interleaved planes also W = 128), got %d", W);
-    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "blur_bias_act_split: arith must be SGDFR_SPLIT_BF16/FP16");
+    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16 || (arith == SGDFR_SPLIT_FP16F8 && wino == 4),
+                  "blur_bias_act_split: arith must be SGDFR_SPLIT_BF16/FP16 (or FP16F8 with the F(4,3) hand-over, wino = 4)");
     if (B == 0) return 0;
     SGDFR_REQUIRE(t && fir && s_next && xs && (reinterpret_cast<uintptr_t>(xs) & 15) == 0, "blur_bias_act_split: null / misaligned pointer");
     SGDFR_REQUIRE(!noise || noise_w, "blur_bias_act_split: noise without noise_w");
@@ -806,7 +811,8 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
      : (QC == 8 || WINO_ != 0) ? blur_split_kernel<ET_, 8, 4, WINO_, IL_>                                                         \
                 : blur_split_kernel<ET_, 4, (WINO_ != 0 ? 4 : 8), WINO_, IL_>)
 #define SGDFR_BLUR_PICK_W(ET_, IL_) (wino == 2 ? SGDFR_BLUR_PICK(ET_, 2, IL_) : wino == 4 ? SGDFR_BLUR_PICK(ET_, 4, IL_) : SGDFR_BLUR_PICK(ET_, 0, IL_))
-    if (arith == SGDFR_SPLIT_FP16) kern = il ? SGDFR_BLUR_PICK_W(SGDFR_SPLIT_FP16, true) : SGDFR_BLUR_PICK_W(SGDFR_SPLIT_FP16, false);
+    if (arith == SGDFR_SPLIT_FP16F8) kern = il ? SGDFR_BLUR_PICK(SGDFR_SPLIT_FP16F8, 4, true) : SGDFR_BLUR_PICK(SGDFR_SPLIT_FP16F8, 4, false);
+    else if (arith == SGDFR_SPLIT_FP16) kern = il ? SGDFR_BLUR_PICK_W(SGDFR_SPLIT_FP16, true) : SGDFR_BLUR_PICK_W(SGDFR_SPLIT_FP16, false);
     else kern = il ? SGDFR_BLUR_PICK_W(SGDFR_SPLIT_BF16, true) : SGDFR_BLUR_PICK_W(SGDFR_SPLIT_BF16, false);
 #undef SGDFR_BLUR_PICK_W
 #undef SGDFR_BLUR_PICK

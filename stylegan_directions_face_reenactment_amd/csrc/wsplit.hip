@@ -527,9 +527,10 @@ __global__ __launch_bounds__(256) void to_wsplit_kernel(const float* __restrict_
                                                        unsigned char* __restrict__ vs, int B, int Cin, int H, int W,
                                                        unsigned* __restrict__ sat_word) {
     constexpr int OUTP = POS - 2;
+    constexpr int ETM = ws_main_et<ET>::value;
     const int G = Cin / 8, TW = W / OUTP, HT = H * TW;
     const int64_t n = (int64_t)B * G * HT;
-    const float sc = (ET == SGDFR_SPLIT_FP16) ? WS_F16_XSCALE : 1.f;
+    const float sc = (ETM == SGDFR_SPLIT_FP16) ? WS_F16_XSCALE : 1.f;
     unsigned sat = 0;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
         const int pos = (int)(idx % HT);
@@ -557,23 +558,40 @@ __global__ __launch_bounds__(256) void to_wsplit_kernel(const float* __restrict_
             unsigned* ph = reinterpret_cast<unsigned*>(&vh);
             unsigned* pl = reinterpret_cast<unsigned*>(&vl);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) ws_pair<ET>(v[t][2 * c], v[t][2 * c + 1], ph[c], pl[c], sat);
+            for (int c = 0; c < 4; ++c) ws_pair<ETM>(v[t][2 * c], v[t][2 * c + 1], ph[c], pl[c], sat);
+            if (ET == SGDFR_SPLIT_FP16F8) ws_f8_lo_chunk(vh, vl, exp2f((float)WS_F8_XLO), exp2f((float)WS_F8_XHI), false);
             unsigned char* dst = vs + (((bg * POS + t) * 2) * HT + pos) * 16;
             *reinterpret_cast<uint4*>(dst) = vh;
             *reinterpret_cast<uint4*>(dst + (int64_t)HT * 16) = vl;
         }
     }
-    if (ET == SGDFR_SPLIT_FP16 && sat != 0) atomicAdd(sat_word ? sat_word : &g_wsplit_saturated, sat);
+    if (ETM == SGDFR_SPLIT_FP16 && sat != 0) atomicAdd(sat_word ? sat_word : &g_wsplit_saturated, sat);
 }
 
 // weight [Cout,Cin,3,3] fp32 -> 16-bit hi/lo of U = G (weight/sqrt(9 Cin)) per kernel row, in the kernel's LDS order:
 //   [cout tile 128][cin block][ky][t POS][part][k-half][128 couts][8 cin]
+// SGDFR_SPLIT_FP16F8: max |w| (as float bits: non-negative floats order like unsigned ints) into the pack's trailer word
+__global__ __launch_bounds__(256) void wsplit_absmax_kernel(const float* __restrict__ w, int64_t n, float scale, unsigned* __restrict__ trailer) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i] * scale));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(trailer, __builtin_bit_cast(unsigned, m));
+}
+
 template <int POS>
 __global__ __launch_bounds__(256) void prepack_wsplit_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
                                                             int Cout, int Cin, float scale, int et, unsigned* __restrict__ sat_word) {
     const int64_t n = (int64_t)Cout * Cin * 3;
     const int ncb = Cin / WS_CB;
     unsigned sat = 0;
+    // fp8 cross terms: the lo chunk of (cout, 8 channels) is bytes (w_hi * 2^-EW) x 8 | (w_lo * 2^(11 - EW)) x 8, EW from the trailer
+    float f8_hi = 0.f, f8_lo = 0.f;
+    if (et == SGDFR_SPLIT_FP16F8) {
+        const int ew = ws_f8_wexp(*reinterpret_cast<const float*>(out + (int64_t)Cout * Cin * 3 * POS * 2));
+        f8_hi = exp2f((float)-ew); f8_lo = exp2f((float)(11 - ew));
+    }
+    unsigned char* const out8 = reinterpret_cast<unsigned char*>(out);
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
         const int ky = (int)(idx % 3);
         const int ci = (int)((idx / 3) % Cin);
@@ -585,11 +603,20 @@ __global__ __launch_bounds__(256) void prepack_wsplit_kernel(const float* __rest
 #pragma unroll
         for (int t = 0; t < POS; ++t) {
             unsigned hp, lp;
-            if (et == SGDFR_SPLIT_FP16) ws_pair<SGDFR_SPLIT_FP16>(U[t], 0.f, hp, lp, sat);
+            if (et != SGDFR_SPLIT_BF16) ws_pair<SGDFR_SPLIT_FP16>(U[t], 0.f, hp, lp, sat);
             else ws_pair<SGDFR_SPLIT_BF16>(U[t], 0.f, hp, lp, sat);
             const int64_t base = ((((int64_t)ctile * ncb + cb) * 3 + ky) * POS + t) * 2;      // -> [part]
             out[(((base + 0) * 2 + h) * 128 + col) * 8 + c8] = (unsigned short)(hp & 0xffffu);
-            out[(((base + 1) * 2 + h) * 128 + col) * 8 + c8] = (unsigned short)(lp & 0xffffu);
+            if (et == SGDFR_SPLIT_FP16F8) {
+                const float fh = (float)__builtin_bit_cast(_Float16, (unsigned short)(hp & 0xffffu));
+                const float fl = (float)__builtin_bit_cast(_Float16, (unsigned short)(lp & 0xffffu));
+                const int two = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(fh * f8_hi, -448.f, 448.f), __builtin_amdgcn_fmed3f(fl * f8_lo, -448.f, 448.f), 0, false);
+                unsigned char* const chunk = out8 + (((base + 1) * 2 + h) * 128 + col) * 16 + (c8 >> 2) * 8 + (c8 & 3);      // (ws_f8_half's order)
+                chunk[0] = (unsigned char)(two & 0xff);
+                chunk[4] = (unsigned char)((two >> 8) & 0xff);
+            } else {
+                out[(((base + 1) * 2 + h) * 128 + col) * 8 + c8] = (unsigned short)(lp & 0xffffu);
+            }
         }
     }
     if (sat != 0) atomicAdd(sat_word ? sat_word : &g_wsplit_saturated, sat);
@@ -640,18 +667,31 @@ extern "C" int sgdfr_modconv2d_wsplit_supported(int B, int Cin, int Cout, int H,
     return wsplit_geometry(B, Cin, Cout, H, W, f, nullptr);
 }
 
-extern "C" int64_t sgdfr_modconv_prepack_wsplit_elems(int Cout, int Cin, int f) { return (int64_t)Cout * Cin * 3 * (f + 2) * 2; }
+extern "C" int sgdfr_modconv2d_wsplit_wide(int B, int Cin, int Cout, int H, int W) {
+    WsParams p;
+    return wsplit_geometry(B, Cin, Cout, H, W, 4, &p) && Cin % (2 * WS_CB) == 0 ? wswide_by_tile_count(p) : 0;
+}
+
+// (+ 8: a 16-byte trailer; SGDFR_SPLIT_FP16F8 packs keep max |w * scale| there, the source of their fp8 exponent)
+extern "C" int64_t sgdfr_modconv_prepack_wsplit_elems(int Cout, int Cin, int f) { return (int64_t)Cout * Cin * 3 * (f + 2) * 2 + 8; }
 
 extern "C" int sgdfr_modconv_prepack_wsplit_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int f, int arith,
                                                 unsigned int* sat, void* stream) {
-    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "prepack_wsplit: arith must be SGDFR_SPLIT_BF16/FP16");
+    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16 || (arith == SGDFR_SPLIT_FP16F8 && f == 4),
+                  "prepack_wsplit: arith must be SGDFR_SPLIT_BF16/FP16 (or FP16F8 with f = 4)");
     SGDFR_REQUIRE(f == 2 || f == 4, "prepack_wsplit: f (outputs per Winograd tile) must be 2 or 4, got %d", f);
     SGDFR_REQUIRE(Cout > 0 && Cin > 0 && Cin % WS_CB == 0 && Cout % 128 == 0,
                   "prepack_wsplit: needs Cin %% 16 == 0 and Cout %% 128 == 0, got Cin=%d Cout=%d", Cin, Cout);
     SGDFR_REQUIRE(weight && wsp, "prepack_wsplit: null pointer");
     int64_t g = ((int64_t)Cout * Cin * 3 + 255) / 256;
     if (g > 4096) g = 4096;
-    const float scale = (arith == SGDFR_SPLIT_FP16 ? WS_F16_WSCALE : 1.f) / sqrtf((float)Cin * 9);
+    const float scale = (arith != SGDFR_SPLIT_BF16 ? WS_F16_WSCALE : 1.f) / sqrtf((float)Cin * 9);
+    {
+        unsigned* const trailer = reinterpret_cast<unsigned*>(wsp + (int64_t)Cout * Cin * 3 * (f + 2) * 2);
+        if (hipMemsetAsync(trailer, 0, 16, as_stream(stream)) != hipSuccess) { (void)hipGetLastError(); set_error("prepack_wsplit: memset failed"); return 2; }
+        if (arith == SGDFR_SPLIT_FP16F8)
+            hipLaunchKernelGGL(wsplit_absmax_kernel, dim3(256), dim3(256), 0, as_stream(stream), weight, (int64_t)Cout * Cin * 9, scale, trailer);
+    }
     if (f == 2)
         hipLaunchKernelGGL(prepack_wsplit_kernel<4>, dim3((int)g), dim3(256), 0, as_stream(stream), weight, wsp, Cout, Cin, scale, arith, sat);
     else
@@ -663,15 +703,17 @@ extern "C" int sgdfr_to_wsplit_f32(const float* x, const float* s, unsigned shor
                                    unsigned int* sat, void* stream) {
     SGDFR_REQUIRE(f == 2 || f == 4, "to_wsplit: f (outputs per Winograd tile) must be 2 or 4, got %d", f);
     SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cin % 8 == 0 && H > 0 && W > 0 && W % f == 0, "to_wsplit: bad shape B=%d Cin=%d H=%d W=%d (Cin %% 8, W %% f)", B, Cin, H, W);
-    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "to_wsplit: arith must be SGDFR_SPLIT_BF16/FP16");
+    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16 || (arith == SGDFR_SPLIT_FP16F8 && f == 4),
+                  "to_wsplit: arith must be SGDFR_SPLIT_BF16/FP16 (or FP16F8 with f = 4)");
     if (B == 0) return 0;
     SGDFR_REQUIRE(x && s && vs && (reinterpret_cast<uintptr_t>(vs) & 15) == 0, "to_wsplit: null or misaligned pointer");
     int64_t g = ((int64_t)B * (Cin / 8) * H * (W / f) + 255) / 256;
     if (g > 256 * 32) g = 256 * 32;
     unsigned char* out = reinterpret_cast<unsigned char*>(vs);
     void (*kern)(const float*, const float*, unsigned char*, int, int, int, int, unsigned*) =
-        arith == SGDFR_SPLIT_FP16 ? (f == 2 ? to_wsplit_kernel<SGDFR_SPLIT_FP16, 4> : to_wsplit_kernel<SGDFR_SPLIT_FP16, 6>)
-                                  : (f == 2 ? to_wsplit_kernel<SGDFR_SPLIT_BF16, 4> : to_wsplit_kernel<SGDFR_SPLIT_BF16, 6>);
+        arith == SGDFR_SPLIT_FP16F8 ? to_wsplit_kernel<SGDFR_SPLIT_FP16F8, 6>
+        : arith == SGDFR_SPLIT_FP16 ? (f == 2 ? to_wsplit_kernel<SGDFR_SPLIT_FP16, 4> : to_wsplit_kernel<SGDFR_SPLIT_FP16, 6>)
+                                    : (f == 2 ? to_wsplit_kernel<SGDFR_SPLIT_BF16, 4> : to_wsplit_kernel<SGDFR_SPLIT_BF16, 6>);
     hipLaunchKernelGGL(kern, dim3((int)g), dim3(256), 0, as_stream(stream), x, s, out, B, Cin, H, W, sat);
     return check_launch("to_wsplit");
 }
@@ -681,7 +723,8 @@ extern "C" int sgdfr_modconv2d_wsplit_f32(const unsigned short* v, const unsigne
                                           float* y, const float* rgb_w, const float* rgb_s, float* rgb_part,
                                           unsigned short* xs_out, const float* s_next, int B, int Cin, int Cout, int H, int W,
                                           int f, int arith, int act, float slope, float gain, unsigned int* sat, void* stream) {
-    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "modconv_wsplit: arith must be SGDFR_SPLIT_BF16/FP16");
+    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16 || (arith == SGDFR_SPLIT_FP16F8 && f == 4),
+                  "modconv_wsplit: arith must be SGDFR_SPLIT_BF16/FP16 (or FP16F8 with f = 4)");
     SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "modconv_wsplit: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin,
                   Cout, H, W);
     if (B == 0) return 0;
@@ -710,6 +753,9 @@ extern "C" int sgdfr_modconv2d_wsplit_f32(const unsigned short* v, const unsigne
         const int rc = wswide_try_launch(p, arith, stream);
         if (rc >= 0) return rc;
     }
+    SGDFR_REQUIRE(arith != SGDFR_SPLIT_FP16F8,
+                  "modconv_wsplit: SGDFR_SPLIT_FP16F8 runs on the wide-tile kernel only (Cin %% 32 == 0, Cin >= 64, Cout %% 128 == 0, W %% 32 == 0, "
+                  "H %% 16 == 0, d and bias given); got Cin=%d Cout=%d H=%d W=%d", Cin, Cout, H, W);
     {
         // same-process A/B at B=64 (scripts/wsplit_env_ab.py, 60 % of the block-time estimate): 256@64^2 (8 rounds of blocks) 618 ->
         // 607 us, 128@128^2 (16 rounds) 733 -> 713 us, 512@32^2 (4 rounds: the spread costs part of a round) 557 -> 568 us

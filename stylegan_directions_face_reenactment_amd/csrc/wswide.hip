@@ -49,6 +49,11 @@ template <int ET>
 __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (the buffer-resource type does not exist in the host pass: without this the host stub is never instantiated)
     constexpr int POS = 6, OUTP = 4, NT = 128, MI = 2, NP = OUTP / 2;
+    // F8 (SGDFR_SPLIT_FP16F8): the main term on the fp16 matrix path, BOTH cross terms of two (kernel row, channel block) slices in
+    // one v_mfma_scale_f32_32x32x64_f8f6f4 -- 6 + 3 x 2 = 12 MFMA units per channel-block pair and 32-cout tile instead of 18.  The
+    // hi chunks, every scale and the hand-over are the fp16 arithmetic's.
+    constexpr bool F8 = (ET == SGDFR_SPLIT_FP16F8);
+    constexpr int ETM = ws_main_et<ET>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ub0 = smem;
     unsigned char* const vb0 = smem + WW_RING * WW_USLAB;
@@ -174,8 +179,14 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
     }
 
     const float e_slope = p.act ? p.slope : 1.f, e_gain = p.act ? p.gain : 1.f;
-    const float d_mul = ((ET == SGDFR_SPLIT_FP16) ? WS_F16_OUT : 1.f) * e_gain;
-    const float s_mul = (ET == SGDFR_SPLIT_FP16) ? WS_F16_XSCALE : 1.f;
+    const float d_mul = ((ETM == SGDFR_SPLIT_FP16) ? WS_F16_OUT : 1.f) * e_gain;
+    const float s_mul = (ETM == SGDFR_SPLIT_FP16) ? WS_F16_XSCALE : 1.f;
+    // F8: the cross-term MFMA's constant exponent, 2^(EW - 3) (wsplit_common.h); EW from the largest weight, kept in the pack's trailer
+    int f8_sa = 127;
+    if (F8) {
+        const float maxw = *reinterpret_cast<const float*>(p.wsp + (size_t)p.n_cout_tiles * ncb * (18 * 8192));
+        f8_sa = 127 + ws_f8_wexp(maxw) - WS_F8_XLO;
+    }
     const float rgb_mul = rsqrtf((float)p.Cout);
     const int a_off = (hi * 128 + wm * 64 + l31) * 16;                   // + ((ky * 2 + part) * 2) * 2048 + mi * 512
     const int b_off = (hi * WW_XS + wn * 32 + l31) * 16;                 // + (part * 2) * 144 * 16 + ky * 8 * 16
@@ -223,8 +234,9 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
             for (int m = 0; m < MI; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-#pragma unroll 1
-            for (int cb = 0; cb < ncb; ++cb, ++G) {
+            ws_frag carry_a[MI], carry_b;      // F8: kernel row 2's lo fragments of an even channel block wait for row 0 of the next one
+            auto group = [&](const int cb, auto phase_t) {
+                constexpr int PH = decltype(phase_t)::value;      // 0: three fp16 products; 1 / 2: fp8 cross terms, even / odd channel block
                 // look-ahead: the operands of the group three ahead (same position, or the next position's / the next TILE's first
                 // channel blocks) go into the slot the previous group has just left
                 int cur_issued = 4;       // pieces per wave and group (wave 0: 5 -- it then waits for one more of its own)
@@ -248,6 +260,7 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
                 if (t == 0 && cb == 0) issue_tables(T);      // (the previous tile's epilogue is behind a barrier)
                 const unsigned char* us = ub0 + (G & 3) * WW_USLAB + a_off;
                 const unsigned char* vs = vb0 + (G & 3) * WW_VSLAB + b_off;
+                ws_frag keep_a[MI], keep_b;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     ws_frag a[MI][2], b[2];
@@ -262,11 +275,27 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
                     if (p.dbg & 64) continue;
 #endif
 #pragma unroll
-                    for (int m = 0; m < MI; ++m) acc[m] = ws_mfma<ET>(a[m][0], b[0], acc[m]);
+                    for (int m = 0; m < MI; ++m) acc[m] = ws_mfma<ETM>(a[m][0], b[0], acc[m]);
+                    if (PH == 0) {
 #pragma unroll
-                    for (int m = 0; m < MI; ++m) acc[m] = ws_mfma<ET>(a[m][0], b[1], acc[m]);
+                        for (int m = 0; m < MI; ++m) acc[m] = ws_mfma<ETM>(a[m][0], b[1], acc[m]);
 #pragma unroll
-                    for (int m = 0; m < MI; ++m) acc[m] = ws_mfma<ET>(a[m][1], b[0], acc[m]);
+                        for (int m = 0; m < MI; ++m) acc[m] = ws_mfma<ETM>(a[m][1], b[0], acc[m]);
+                    } else if ((PH == 1 && ky == 0) || (PH == 2 && ky == 1)) {      // first of a pair: keep
+#pragma unroll
+                        for (int m = 0; m < MI; ++m) keep_a[m] = a[m][1];
+                        keep_b = b[1];
+                    } else if (PH == 1 && ky == 2) {                                // left over: the next channel block's row 0 takes it
+#pragma unroll
+                        for (int m = 0; m < MI; ++m) carry_a[m] = a[m][1];
+                        carry_b = b[1];
+                    } else if (PH == 2 && ky == 0) {
+#pragma unroll
+                        for (int m = 0; m < MI; ++m) acc[m] = ws_mfma_f8(carry_a[m], a[m][1], carry_b, b[1], acc[m], f8_sa);
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < MI; ++m) acc[m] = ws_mfma_f8(keep_a[m], a[m][1], keep_b, b[1], acc[m], f8_sa);
+                    }
                     if (ky + 1 == issue_at) look_ahead();
                 }
                 // The next group's operands (issued two groups ago) must have landed and be published; what this group and the
@@ -294,6 +323,18 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
                 }
                 prev_issued = cur_issued;
                 __builtin_amdgcn_s_barrier();
+            };
+            using ph0 = std::integral_constant<int, 0>;
+            using ph1 = std::integral_constant<int, 1>;
+            using ph2 = std::integral_constant<int, 2>;
+#pragma unroll 1
+            for (int cb = 0; cb < ncb;) {
+                if constexpr (!F8) {
+                    group(cb, ph0{}); ++cb; ++G;
+                } else {                              // (Cin % 32 == 0: the launcher's condition)
+                    group(cb, ph1{}); ++cb; ++G;
+                    group(cb, ph2{}); ++cb; ++G;
+                }
             }
             // fold M_t into the output transform (see above)
 #pragma unroll
@@ -392,8 +433,8 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
                             unsigned h01[2], l01[2], h23[2], l23[2];      // [pixel of the pair]
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
-                                ws_pair<ET>(pr[0][k], pr[1][k], h01[k], l01[k], sat);
-                                ws_pair<ET>(pr[2][k], pr[3][k], h23[k], l23[k], sat);
+                                ws_pair<ETM>(pr[0][k], pr[1][k], h01[k], l01[k], sat);
+                                ws_pair<ETM>(pr[2][k], pr[3][k], h23[k], l23[k], sat);
                             }
                             // one v_permlane32_swap per register: the lower lane half gets the first pixel's whole 8-channel chunk,
                             // the upper half the second's (wsplit_kernel's 16-byte hand-over stores)
@@ -476,7 +517,7 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
         if (!has_next) break;
         T = Tn;
     }
-    if (ET == SGDFR_SPLIT_FP16 && __builtin_expect(sat != 0, 0)) atomicAdd(p.sat ? p.sat : &g_wswide_saturated, sat);
+    if (ETM == SGDFR_SPLIT_FP16 && __builtin_expect(sat != 0, 0)) atomicAdd(p.sat ? p.sat : &g_wswide_saturated, sat);
 #endif
 }
 
@@ -490,14 +531,12 @@ unsigned int wswide_saturation_count(int reset) {
     return v;
 }
 
-// p: the parameter block sgdfr_modconv2d_wsplit_f32 filled for wsplit_kernel<., 6> (pointers, shape, activation, dbg); the tile
-// geometry is replaced by this kernel's.  -1: not this kernel's case.
-int wswide_try_launch(WsParams p, int arith, void* stream) {
-    static const int mode = getenv("SGDFR_WSPLIT_WIDE") ? atoi(getenv("SGDFR_WSPLIT_WIDE")) : 1;      // 0 off, 1 by tile count, 2 whenever the shape allows
-    const int mode_now = getenv("SGDFR_WSPLIT_WIDE_NOW") ? atoi(getenv("SGDFR_WSPLIT_WIDE_NOW")) : mode;     // (read per launch: same-process A/B)
+// The tile geometry of this kernel for the shape in p (wsplit_geometry's block for f = 4), and whether the launch takes it:
+// mode 0 never, 1 by tile count, 2 whenever the shape allows.  -1: not this kernel's case.
+static int wswide_plan(WsParams& p, int mode_now) {
     if (mode_now == 0) return -1;
     // (the look-ahead of three groups wraps at most once per position: >= 4 channel blocks)
-    if (p.Cin % WS_CB != 0 || p.Cin < 4 * WS_CB || p.Cout % 128 != 0 || p.W % 32 != 0 || p.H % WW_TR != 0 || !p.d || !p.bias) return -1;
+    if (p.Cin % WS_CB != 0 || p.Cin < 4 * WS_CB || p.Cout % 128 != 0 || p.W % 32 != 0 || p.H % WW_TR != 0) return -1;
     const int old_blocks = p.n_pix_tiles * p.n_cout_tiles;
     p.TW = p.W / 4;
     p.TCT = WW_TCT; p.TR = WW_TR; p.tct_shift = 3;
@@ -520,6 +559,26 @@ int wswide_try_launch(WsParams p, int arith, void* stream) {
     p.fd_tiles_x = make_fastdiv(p.tiles_x);
     p.fd_per_img = make_fastdiv(p.tiles_x * p.tiles_y);
     p.fd_npt = make_fastdiv(p.n_pix_tiles);
+    return 0;
+}
+
+// does an F(4,3) launch of this shape (p: wsplit_geometry's block) take the wide kernel by its tile count?  (what the host asks before
+// it chooses SGDFR_SPLIT_FP16F8 for a layer: only this kernel reads the fp8 chunks)
+int wswide_by_tile_count(WsParams p) {
+    static const int mode = getenv("SGDFR_WSPLIT_WIDE") ? atoi(getenv("SGDFR_WSPLIT_WIDE")) : 1;
+    return mode != 0 && wswide_plan(p, 1) == 0 ? 1 : 0;
+}
+
+// p: the parameter block sgdfr_modconv2d_wsplit_f32 filled for wsplit_kernel<., 6> (pointers, shape, activation, dbg); the tile
+// geometry is replaced by this kernel's.  -1: not this kernel's case.
+int wswide_try_launch(WsParams p, int arith, void* stream) {
+    static const int mode = getenv("SGDFR_WSPLIT_WIDE") ? atoi(getenv("SGDFR_WSPLIT_WIDE")) : 1;      // 0 off, 1 by tile count, 2 whenever the shape allows
+    int mode_now = getenv("SGDFR_WSPLIT_WIDE_NOW") ? atoi(getenv("SGDFR_WSPLIT_WIDE_NOW")) : mode;     // (read per launch: same-process A/B)
+    if (arith == SGDFR_SPLIT_FP16F8) {      // only this kernel reads the fp8 chunks: every shape it can run, or an error (never the 64-tile kernel)
+        mode_now = 2;
+        if (p.Cin % (2 * WS_CB) != 0) return -1;
+    }
+    if (!p.d || !p.bias || wswide_plan(p, mode_now) != 0) return -1;
     {
         // First-round start spread: OFF for this kernel.  Same-process A/B at B = 64 (SGDFR_WSWIDE_DESYNC = 0 / 30 / 60 / 100 % of a
         // block time, us per launch): 512@32^2 454 / 468 / 494 / 538, 256@64^2 492 / 505 / 515 / 538, 128@128^2 585 / 580 / 579 / 587
@@ -530,7 +589,8 @@ int wswide_try_launch(WsParams p, int arith, void* stream) {
         p.desync = pct > 0 ? (int)(block_clk * pct / 100 / 4096) : 0;
     }
     const size_t lds = (size_t)WW_RING * (WW_USLAB + WW_VSLAB) + 7 * 128 * sizeof(float);
-    void (*kern)(WsParams) = arith == SGDFR_SPLIT_FP16 ? wswide_kernel<SGDFR_SPLIT_FP16> : wswide_kernel<SGDFR_SPLIT_BF16>;
+    void (*kern)(WsParams) = arith == SGDFR_SPLIT_FP16F8 ? wswide_kernel<SGDFR_SPLIT_FP16F8>
+                             : arith == SGDFR_SPLIT_FP16 ? wswide_kernel<SGDFR_SPLIT_FP16> : wswide_kernel<SGDFR_SPLIT_BF16>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
         set_error("modconv_wsplit (wide tile): LDS request %zu B refused", lds);

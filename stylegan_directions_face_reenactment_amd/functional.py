@@ -26,7 +26,7 @@ from .timing import timed_conv as _timed_conv, timed_hbm as _timed_hbm
 
 SQRT2 = 2 ** 0.5
 
-_CHAIN_NAMES = ('SplitAct', 'xin_ok', 'styled_conv_split', 'wsplit_chain_f', 'wsplit_chain_ok', 'rgb_fusable', 'StreamPipeline')
+_CHAIN_NAMES = ('SplitAct', 'xin_ok', 'styled_conv_split', 'wsplit_chain_f', 'wsplit_chain_arith', 'wsplit_chain_ok', 'rgb_fusable', 'StreamPipeline')
 
 
 class _Facade(types.ModuleType):
@@ -443,6 +443,8 @@ def modconv_wino(x, u, s, d, cout, noise=None, noise_weight=None, bias=None, act
 
 
 _SPLIT_ARITH = {'bf16x3': N.SPLIT_BF16, 'fp16x3': N.SPLIT_FP16}
+# the F(4,3) wide-tile conv, its pack and its WS producers also take fp16 + fp8 cross terms (include/sgdfr.h SGDFR_SPLIT_FP16F8)
+_WSPLIT_ARITH = dict(_SPLIT_ARITH, fp16f8=N.SPLIT_FP16F8)
 
 
 def prepack_split(weight, arith=None, adjoint=False):
@@ -545,7 +547,7 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
 def prepack_wsplit(weight, arith=None, f=2):
     """weight [1,Cout,Cin,3,3] -> int16 buffer of the hi/lo terms of U = G (weight/sqrt(9 Cin)) per kernel row in wsplit.hip's
     LDS order (Cout % 128 == 0); f = outputs per Winograd tile (2: F(2,3), 4: F(4,3))."""
-    arith = _SPLIT_ARITH[arith or config().precision]
+    arith = _WSPLIT_ARITH[arith or config().precision]
     N.require_device(weight)
     w = N.f32c(weight)
     _, cout, cin, k, _ = w.shape
@@ -564,7 +566,7 @@ WSPLIT_GROWTH_LOG2 = {2: 1, 4: 4}      # |B^T d| <= 2 max|d| (F(2,3)) / 10 max|d
 def to_wsplit(x, s, arith=None, f=2):
     """x [B,Cin,H,W], s [B,Cin] -> int16 buffer [B, Cin/8, f+2, 2, H*W/f, 8]: the Winograd input transform of x*s per tile of f
     outputs, split (the "WS" form modconv_wsplit stages by DMA)."""
-    arith = _SPLIT_ARITH[arith or config().precision]
+    arith = _WSPLIT_ARITH[arith or config().precision]
     N.require_device(x, s)
     x, s = N.f32c(x), N.f32c(s)
     B, cin, H, W = x.shape
@@ -577,7 +579,7 @@ def modconv_wsplit(vs, shape, wsp, d, cout, noise=None, noise_weight=None, bias=
                    arith=None, rgb=None, want_y=True, s_next=None, desc=None, f=2):
     """Plain 3x3 modulated conv of a WS input (to_wsplit / the blur's Winograd hand-over; shape = (B, Cin, H, W)) with the pack of
     prepack_wsplit (same f).  Outputs as modconv_split with a pre-split input: y | (y, part) | (y, part, xs_out)."""
-    arith = _SPLIT_ARITH[arith or config().precision]
+    arith = _WSPLIT_ARITH[arith or config().precision]
     N.require_device(d, bias, noise_weight)
     if not vs.is_cuda or vs.dtype != torch.int16 or not wsp.is_cuda or wsp.dtype != torch.int16:
         raise RuntimeError('modconv_wsplit: vs / wsp are the int16 device buffers made by to_wsplit / prepack_wsplit')
@@ -724,12 +726,12 @@ def blur_bias_act_split(planes, fir, H, W, s_next, noise=None, noise_weight=None
     """blur_bias_act whose result goes out as the next layer's split input (x * s_next as 16-bit hi/lo pairs,
     [B, C/8, 2, 2H*2W, 8] int16) instead of fp32 NCHW.  plane_stride: floats between the parity planes when `planes` is the
     padded [B, C, 4, plane_stride] buffer of modconv_split(mode=UP3, plane_stride=...).  wino = 2 | 4: the Winograd input form
-    of to_wsplit(f=wino) instead ([B, C/8, wino+2, 2, 4HW/wino, 8], for modconv_wsplit)."""
-    arith = _SPLIT_ARITH[arith or config().precision]
+    of to_wsplit(f=wino) instead ([B, C/8, wino+2, 2, 4HW/wino, 8], for modconv_wsplit; wino = 4 also takes arith='fp16f8')."""
+    wino = 2 if wino is True else int(wino or 0)
+    arith = (_WSPLIT_ARITH if wino == 4 else _SPLIT_ARITH)[arith or config().precision]
     N.require_device(planes, fir, bias, noise_weight, s_next)
     B, C = planes.shape[0], planes.shape[1]
     nz, nzb = _noise_args(noise, B, 2 * H, 2 * W)
-    wino = 2 if wino is True else int(wino or 0)
     if wino:
         xs = torch.empty(B, C // 8, wino + 2, 2, 4 * H * W // wino, 8, device=planes.device, dtype=torch.int16)
     else:

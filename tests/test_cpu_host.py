@@ -208,8 +208,19 @@ def test_winograd_layer_plan_of_the_bench_configs():
     with F_.using(F_.config().replace(wsplit_f=2)):
         assert G._wino_inputs(64, layers) == {4: 2, 6: 2, 8: 2}         # (F(2,3) pays from 256 input channels on)
     lib = F_.N.load()
-    assert lib.sgdfr_modconv_prepack_wsplit_elems(512, 512, 4) == 512 * 512 * 3 * 6 * 2
-    assert lib.sgdfr_modconv_prepack_wsplit_elems(512, 512, 2) == 512 * 512 * 3 * 4 * 2
+    assert lib.sgdfr_modconv_prepack_wsplit_elems(512, 512, 4) == 512 * 512 * 3 * 6 * 2 + 8       # (+ the 16-byte trailer: max |w| of fp16f8 packs)
+    assert lib.sgdfr_modconv_prepack_wsplit_elems(512, 512, 2) == 512 * 512 * 3 * 4 * 2 + 8
+    # fp8 cross terms (Config.cross_terms='fp8', SGDFR_SPLIT_FP16F8): only for the layers whose F(4,3) launch takes the wide-tile
+    # kernel by its tile count -- the three big ones at B=64, not the 16^2 layer (128 wide tiles < 192), nothing at small batches
+    noise = [object()] * len(layers)
+    assert [p[5] for p in G._chain_plan(64, True, noise, layers)] == [None] * len(layers)                 # default: three fp16 products
+    with F_.using(F_.config().replace(cross_terms='fp8')):
+        assert [p[5] for p in G._chain_plan(64, True, noise, layers)] == [None] * 5 + ['fp16f8', None, 'fp16f8', None, 'fp16f8', None, None, None]
+        assert [p[5] for p in G._chain_plan(4, True, noise, layers)] == [None] * len(layers)
+        with F_.precision('bf16x3'):                                                                      # the saturation fallback keeps its own arithmetic
+            assert [p[5] for p in G._chain_plan(64, True, noise, layers)] == [None] * len(layers)
+    assert lib.sgdfr_modconv2d_wsplit_wide(64, 256, 256, 64, 64) == 1 and lib.sgdfr_modconv2d_wsplit_wide(64, 512, 512, 16, 16) == 0
+    assert lib.sgdfr_modconv2d_wsplit_wide(64, 80, 128, 64, 64) == 0                                      # Cin % 32: channel blocks pair up
     assert not lib.sgdfr_modconv2d_wsplit_supported(64, 64, 64, 256, 256, 4)          # Cout = 64: no 128-cout tile
 
 

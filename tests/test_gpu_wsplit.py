@@ -62,6 +62,59 @@ def test_wsplit_conv_matches_fp64_oracle(cin, cout, H, B, arith, f):
     assert err <= (TOL if f == 2 else TOL4)[arith] * max(1.0, float(ref.abs().max())), err
 
 
+@pytest.mark.parametrize('cin,cout,H,W,B,persist', [(64, 128, 16, 32, 2, 0), (128, 256, 32, 64, 3, 0), (256, 256, 64, 64, 5, 8), (96, 128, 32, 256, 2, 8)])
+def test_fp8_cross_terms_on_the_wide_kernel(cin, cout, H, W, B, persist, monkeypatch):
+    """SGDFR_SPLIT_FP16F8 (fp16 main term, both cross terms in e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4): the layer against the fp64
+    oracle -- 1.2e-4 of max|y| (measured 4.6-5.6e-5; three fp16 products: 4e-6, bound 6e-5) with inputs as loud as the generator's
+    range plan leaves them (calibrated maximum near 2^10 in the fp16 domain, single images up to 2^4 quieter) -- the same fused
+    outputs as the fp16 form (hand-over in fp16 pairs, ToRGB partial sums), one tile per block and persistent blocks whose
+    channel-block pairs run across tiles; and a shape the wide kernel cannot take fails loudly instead of reading fp8 chunks as fp16."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    key = 'f8.%d.%d.%d.%d.%d' % (cin, cout, H, W, B)
+    w = S.counter_tensor(5, key + '.w', (1, cout, cin, 3, 3)).cuda()
+    loud = 2.0 ** (12 - 4 * torch.arange(B, dtype=torch.float32) / max(B - 1, 1)).view(B, 1, 1, 1).cuda()
+    x = S.counter_tensor(5, key + '.x', (B, cin, H, W)).cuda() * loud
+    s = S.counter_tensor(5, key + '.s', (B, cin), 1.0, 0.3).cuda()
+    d = (S.counter_tensor(5, key + '.d', (B, cout), 1.0, 0.2).cuda() / loud.view(B, 1)).contiguous()
+    nw = torch.full((1,), 0.1).cuda()
+    bias = S.counter_tensor(5, key + '.b', (cout,), 0.0, 0.1).cuda()
+    sn = S.counter_tensor(5, key + '.sn', (B, cout), 1.0, 0.3).cuda()
+    rgb = (S.counter_tensor(5, key + '.rw', (3, cout)).cuda(), S.counter_tensor(5, key + '.rs', (B, cout), 1.0, 0.3).cuda())
+    noise = S.counter_tensor(5, key + '.n', (1, 1, H, W)).cuda()
+    if persist:
+        monkeypatch.setenv('SGDFR_WSPLIT_PERSIST', str(persist))
+    if cin % 32:
+        vs = F_.to_wsplit(x, s, 'fp16f8', f=4)
+        wsp = F_.prepack_wsplit(w, 'fp16f8', f=4)
+        with pytest.raises(RuntimeError, match='wide-tile kernel only'):
+            F_.modconv_wsplit(vs, (B, cin, H, W), wsp, d, cout, noise, nw, bias, True, arith='fp16f8', f=4)
+        return
+    ref = _oracle(x, w, s, d, noise, nw, bias)
+    out = {}
+    for arith in ('fp16x3', 'fp16f8'):
+        vs = F_.to_wsplit(x, s, arith, f=4)
+        wsp = F_.prepack_wsplit(w, arith, f=4)
+        monkeypatch.setenv('SGDFR_WSPLIT_WIDE_NOW', '2')
+        y, part, xs = F_.modconv_wsplit(vs, (B, cin, H, W), wsp, d, cout, noise, nw, bias, True, arith=arith, f=4, rgb=rgb, s_next=sn, want_y=True)
+        torch.cuda.synchronize()
+        out[arith] = (y, part, xs)
+        err = ((y.double().cpu() - ref).abs().amax(dim=(1, 2, 3)) / ref.abs().amax(dim=(1, 2, 3))).max().item()
+        print(arith, 'worst image: max err / max|y| = %.2e' % err)
+        assert err <= (6e-5 if arith == 'fp16x3' else 1.2e-4)
+    y3, p3, x3 = out['fp16x3']
+    y8, p8, x8 = out['fp16f8']
+    scale = y3.abs().amax(dim=(1, 2, 3), keepdim=True)
+    assert ((y8 - y3).abs() / scale).max().item() <= 1.2e-4 and not torch.equal(y8, y3)
+    assert ((p8 - p3).abs().amax(dim=(1, 2, 3)) / p3.abs().amax(dim=(1, 2, 3))).max().item() <= 5e-4
+    # the hand-over leaves as fp16 pairs in both (the next conv is a transposed one on the three-product kernels): same hi terms
+    # wherever y agrees to the last fp16 bit -- compare the decoded values instead
+    def decode(xs_):
+        v = xs_.view(torch.float16).float()
+        return v[:, :, 0] + v[:, :, 1]
+    a, b = decode(x3), decode(x8)
+    assert ((a - b).abs().amax(dim=(1, 2, 3)) / a.abs().amax(dim=(1, 2, 3))).max().item() <= 2e-4
+
+
 WIDE_CASES = [  # cin, cout, H, W, B, persist
     (64, 128, 16, 32, 1, 0),       # one patch per image, one tile per block, 4 channel blocks (the shortest ring wrap)
     (128, 256, 32, 32, 3, 0),      # two patches per image, two cout tiles
@@ -179,10 +232,13 @@ def test_wsplit_rejects_unsupported_shapes():
 
 
 @pytest.mark.parametrize('f', [2, 4])
-@pytest.mark.parametrize('arith', ['fp16x3', 'bf16x3'])
+@pytest.mark.parametrize('arith', ['fp16x3', 'bf16x3', 'fp16f8'])
 @pytest.mark.parametrize('C,H,B', [(16, 8, 5), (64, 16, 3), (24, 32, 2), (16, 64, 2), (16, 128, 2)])
 def test_blur_winograd_handover_is_bit_identical_to_transforming_the_fp32_result(C, H, B, arith, f):
-    """sgdfr_blur_bias_act_split_f32(wino=f) == sgdfr_to_wsplit_f32(sgdfr_blur_bias_act_f32(...), s_next, f), dense and padded planes."""
+    """sgdfr_blur_bias_act_split_f32(wino=f) == sgdfr_to_wsplit_f32(sgdfr_blur_bias_act_f32(...), s_next, f), dense and padded planes
+    (fp16f8: the F(4,3) form whose lo chunks hold the e4m3 cross-term operands)."""
+    if arith == 'fp16f8' and f != 4:
+        pytest.skip('fp8 cross terms exist for the F(4,3) form only')
     from stylegan_directions_face_reenactment_amd import functional as F_
     key = 'wblur.%d.%d.%d' % (C, H, B)
     fir = torch.tensor([[1., 3., 3., 1.]]).cuda()
