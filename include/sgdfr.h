@@ -271,6 +271,7 @@ int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin);
 int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int arith, int transpose_flip,
                                     unsigned int* sat, void* stream);
 int sgdfr_modconv2d_split_supported(int B, int Cin, int Cout, int H, int W, int mode);
+int sgdfr_modconv2d_split_f8_ok(int B, int Cin, int Cout, int H, int W, int mode);      /* arith = SGDFR_SPLIT_FP16F8 allowed (UP3 deep plan, x_is_split = 1, forward pack of the same arith) */
 int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, const unsigned short* wsp, const float* s, const float* d,
                               const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
                               const float* zeros, float* y, float* partials, int ksplit, const float* rgb_w,
@@ -339,6 +340,10 @@ int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, in
  * 1.3-1.5x the speed of the three-product form (scripts/f8_layer_probe.py). */
 int sgdfr_modconv2d_wsplit_supported(int B, int Cin, int Cout, int H, int W, int f);
 int sgdfr_modconv2d_wsplit_wide(int B, int Cin, int Cout, int H, int W);
+/* OR-ed into `arith` of sgdfr_modconv2d_wsplit_f32 (f = 4, wide-tile kernel, xs_out given): the hand-over's lo chunks leave as the fp8
+ * cross-term operands of SGDFR_SPLIT_FP16F8 -- for a next conv launched with that arithmetic (sgdfr_modconv2d_split_f32, mode UP3,
+ * where sgdfr_modconv2d_split_f8_ok() = 1: the transposed conv's deep plan, nine taps pair up per phase with (1,1) beside zeros). */
+#define SGDFR_SPLIT_HANDOVER_F8 0x100
 int64_t sgdfr_modconv_prepack_wsplit_elems(int Cout, int Cin, int f);
 int sgdfr_modconv_prepack_wsplit_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int f, int arith,
                                      unsigned int* sat, void* stream);

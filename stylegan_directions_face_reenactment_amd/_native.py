@@ -115,6 +115,8 @@ SIGNATURES['sgdfr_styles_batched_f32'] = [_c_f32p, _i, _i, _i, ctypes.POINTER(St
 MAX_STYLE_LAYERS = 40
 SIGNATURES['sgdfr_modconv2d_wsplit_supported'] = [_i, _i, _i, _i, _i, _i]
 SIGNATURES['sgdfr_modconv2d_wsplit_wide'] = [_i, _i, _i, _i, _i]
+SIGNATURES['sgdfr_modconv2d_split_f8_ok'] = [_i, _i, _i, _i, _i, _i]
+SPLIT_HANDOVER_F8 = 0x100
 SIGNATURES['sgdfr_modconv_prepack_wsplit_f32'] = [_c_f32p, ctypes.c_void_p, _i, _i, _i, _i, ctypes.c_void_p, ctypes.c_void_p]
 SIGNATURES['sgdfr_to_wsplit_f32'] = [_c_f32p, _c_f32p, ctypes.c_void_p, _i, _i, _i, _i, _i, _i, ctypes.c_void_p, ctypes.c_void_p]
 SIGNATURES['sgdfr_modconv2d_wsplit_f32'] = [ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p,

@@ -27,26 +27,32 @@ def xin_ok(B, cin, cout, H, W, mode=N.MODE_PLAIN3):
 
 
 def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, noise_weight=None, bias=None, batch=None,
-                      s_next=None, rgb=None, want_y=True, wino_next=False, arith_next=None):
+                      s_next=None, rgb=None, want_y=True, wino_next=False, arith_next=None, xs_arith=None):
     """One StyledConv on the split kernels with the inference-only dataflow options: x may be a SplitAct (then `s` is
     already applied), s_next asks for the output as a SplitAct for the next conv, rgb for the fused ToRGB partial sums.
     A SplitAct in Winograd form (x.wino) runs on modconv_wsplit with `wsp` = the prepack_wsplit pack; wino_next (transposed
-    conv + blur only) asks for the output in that form, arith_next ('fp16f8' | None) for the arithmetic of that hand-over.
+    conv + blur only) asks for the output in that form, arith_next ('fp16f8' | None) for the arithmetic of that hand-over;
+    xs_arith ('fp16f8' | None, F(4,3) layers on the wide-tile kernel only) for the arithmetic of the plain split hand-over s_next.
     Returns (activation: fp32 tensor | SplitAct | None, ToRGB partials | None)."""
     if isinstance(x, SplitAct) and x.wino:
         if upsample:
             raise RuntimeError('styled_conv_split: the Winograd input form feeds plain convs only')
         B, cin, H, W = x.shape
         res = modconv_wsplit(x.xs, x.shape, wsp, d, cout, noise, noise_weight, bias, True, rgb=rgb,
-                             want_y=want_y and s_next is None, s_next=s_next, f=x.wino, arith=x.arith)
+                             want_y=want_y and s_next is None, s_next=s_next, f=x.wino, arith=x.arith,
+                             xs_arith=xs_arith if s_next is not None else None)
         if s_next is not None:
             _, part, xs = res
-            return SplitAct(xs, (B, cout, H, W)), part
+            return SplitAct(xs, (B, cout, H, W), arith=xs_arith), part
         return res if rgb is not None else (res, None)
+    x_arith = None
     if isinstance(x, SplitAct):
         B, cin, H, W = x.shape
         xin, x_split, s_arg = x.xs, x.shape, None
         batch = B
+        x_arith = x.arith           # 'fp16f8': the producer wrote fp8 cross-term operands (transposed conv, deep plan; `wsp` packed alike)
+        if x_arith is not None and not upsample:
+            raise RuntimeError('styled_conv_split: a plain split hand-over with fp8 cross terms feeds transposed convs only')
     else:
         xin, x_split, s_arg = x, None, s
         B = s.shape[0] if batch is None else batch
@@ -62,11 +68,11 @@ def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, 
             _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, x_split[1] if x_split else x.shape[1], cout, H, W, N.MODE_UP3) == 1:
         # parity planes padded to whole 128-byte lines: the odd-sized dense planes make every store run straddle two lines
         ps = ((H + 1) * (W + 1) + 31) // 32 * 32
-        planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split, plane_stride=ps)
+        planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split, plane_stride=ps, arith=x_arith)
         xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, plane_stride=ps, wino=wino_next,
                                  arith=arith_next if wino_next == 4 else None)
         return SplitAct(xs, (B, cout, 2 * H, 2 * W), wino_next, arith_next if wino_next == 4 else None), None
-    planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split)
+    planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split, arith=x_arith)
     if s_next is not None:
         xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, wino=wino_next,
                                  arith=arith_next if wino_next == 4 else None)
@@ -92,6 +98,18 @@ def wsplit_chain_arith(B, cin, cout, H, W, f):
     its launch takes the wide-tile kernel anyway -- the only reader of that form -- else None (the ambient precision)."""
     if f == 4 and config().precision == 'fp16x3' and config().cross_terms == 'fp8' and cin % 32 == 0 and \
             _shape_query('sgdfr_modconv2d_wsplit_wide', B, cin, cout, H, W):
+        return 'fp16f8'
+    return None
+
+
+def xs_chain_arith(B, cin, cout, H, W, nxt_cout):
+    """Arithmetic of the plain split hand-over from an F(4,3) layer (B, cin -> cout @ H x W) to the transposed conv cout -> nxt_cout
+    that follows it: 'fp16f8' when Config.cross_terms says so, the producer's launch takes the wide-tile kernel (the only writer of that
+    form) and the consumer runs its deep plan (the only reader); else None."""
+    if config().precision == 'fp16x3' and config().cross_terms == 'fp8' and \
+            _shape_query('sgdfr_modconv2d_wsplit_wide', B, cin, cout, H, W) and \
+            _shape_query('sgdfr_modconv2d_split_f8_ok', B, cout, nxt_cout, H, W, N.MODE_UP3) and \
+            _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cout, nxt_cout, H, W, N.MODE_UP3) == 1:
         return 'fp16f8'
     return None
 

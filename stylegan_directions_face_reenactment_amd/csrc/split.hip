@@ -59,15 +59,17 @@ __global__ __launch_bounds__(256) void to_split_kernel(const float* __restrict__
         uint4 vh, vl;
         unsigned* ph = reinterpret_cast<unsigned*>(&vh);
         unsigned* pl = reinterpret_cast<unsigned*>(&vl);
-        const float sc = (ET == SGDFR_SPLIT_FP16) ? SPLIT_F16_XSCALE : 1.f;
+        constexpr int ETM = ws_main_et<ET>::value;
+        const float sc = (ETM == SGDFR_SPLIT_FP16) ? SPLIT_F16_XSCALE : 1.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            split_pair<ET>(xp[(int64_t)(2 * c) * HW] * (sp[2 * c] * sc), xp[(int64_t)(2 * c + 1) * HW] * (sp[2 * c + 1] * sc), ph[c], pl[c], sat);
+            split_pair<ETM>(xp[(int64_t)(2 * c) * HW] * (sp[2 * c] * sc), xp[(int64_t)(2 * c + 1) * HW] * (sp[2 * c + 1] * sc), ph[c], pl[c], sat);
+        if (ET == SGDFR_SPLIT_FP16F8) ws_f8_lo_chunk(vh, vl, exp2f((float)WS_F8_XLO), exp2f((float)WS_F8_XHI), false);
         unsigned char* dst = xs + ((bg * 2) * HW + pix) * 16;
         *reinterpret_cast<uint4*>(dst) = vh;
         *reinterpret_cast<uint4*>(dst + (int64_t)HW * 16) = vl;
     }
-    if (ET == SGDFR_SPLIT_FP16) split_flush_saturation(sat, sat_word);
+    if (ET != SGDFR_SPLIT_BF16) split_flush_saturation(sat, sat_word);
 }
 
 // gT [B,C,4,RP] fp32 parity planes and d [B,C] (or null) -> the phase-major split form of gT*d that the DOWN3 kernel stages:
@@ -106,6 +108,15 @@ __global__ __launch_bounds__(256) void planes_to_split_kernel(const float* __res
 
 // weight [Cout,Cin,3,3] fp32 -> bf16 hi/lo of Wc = weight/sqrt(9 Cin) in the kernel's LDS order:
 //   [cout tile][cin block][ky][kx][part][k-half][cout in tile (NT)][8 cin]
+// SGDFR_SPLIT_FP16F8: max |w * scale| (as float bits: non-negative floats order like unsigned ints) into the pack's trailer word
+__global__ __launch_bounds__(256) void split_absmax_kernel(const float* __restrict__ w, int64_t n, float scale, unsigned* __restrict__ trailer) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i] * scale));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(trailer, __builtin_bit_cast(unsigned, m));
+}
+
 __global__ __launch_bounds__(256) void prepack_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
                                                            int Cout, int Cin, int NT, float scale, int et, int transpose_flip,
                                                            unsigned* __restrict__ sat_word) {
@@ -122,7 +133,7 @@ __global__ __launch_bounds__(256) void prepack_split_kernel(const float* __restr
         const float v = (transpose_flip == 1 ? w[((int64_t)ci * Cin + co) * 9 + (8 - tap)]
                          : transpose_flip == 2 ? w[((int64_t)ci * Cin + co) * 9 + tap] : w[idx]) * scale;   // fp16: scale carries 2^6
         unsigned hp, lp, sat = 0;
-        if (et == SGDFR_SPLIT_FP16) split_pair<SGDFR_SPLIT_FP16>(v, 0.f, hp, lp, sat);
+        if (et != SGDFR_SPLIT_BF16) split_pair<SGDFR_SPLIT_FP16>(v, 0.f, hp, lp, sat);
         else split_pair<SGDFR_SPLIT_BF16>(v, 0.f, hp, lp, sat);
         split_flush_saturation(sat, sat_word);
         const unsigned hbits = hp & 0xffffu, lbits = lp & 0xffffu;
@@ -131,7 +142,17 @@ __global__ __launch_bounds__(256) void prepack_split_kernel(const float* __restr
         const int slot = transpose_flip == 2 ? down_pos[tap] : tap;
         const int64_t base = (((int64_t)ctile * ncb + cb) * 9 + slot) * 2;   // -> [part]
         out[(((base + 0) * 2 + h) * NT + col) * 8 + c8] = (unsigned short)hbits;
-        out[(((base + 1) * 2 + h) * NT + col) * 8 + c8] = (unsigned short)lbits;
+        if (et == SGDFR_SPLIT_FP16F8) {      // lo chunk of (cout, 8 channels) as fp8 bytes, ws_f8_half's order: (4 x hi | 4 x lo) per channel half
+            const int ew = ws_f8_wexp(*reinterpret_cast<const float*>(out + (int64_t)((n_out + 63) / 64 * 64) * n_in * 9 * 2));
+            const float fh = (float)__builtin_bit_cast(_Float16, (unsigned short)hbits), fl = (float)__builtin_bit_cast(_Float16, (unsigned short)lbits);
+            const int two = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(fh * exp2f((float)-ew), -448.f, 448.f),
+                                                            __builtin_amdgcn_fmed3f(fl * exp2f((float)(11 - ew)), -448.f, 448.f), 0, false);
+            unsigned char* const chunk = reinterpret_cast<unsigned char*>(out) + (((base + 1) * 2 + h) * NT + col) * 16 + (c8 >> 2) * 8 + (c8 & 3);
+            chunk[0] = (unsigned char)(two & 0xff);
+            chunk[4] = (unsigned char)((two >> 8) & 0xff);
+        } else {
+            out[(((base + 1) * 2 + h) * NT + col) * 8 + c8] = (unsigned short)lbits;
+        }
     }
 }
 
@@ -280,6 +301,13 @@ extern "C" int sgdfr_modconv2d_split_supported(int B, int Cin, int Cout, int H, 
     return split_plan(B, Cin, Cout, H, W, mode, &p) ? 1 : 0;
 }
 
+// SGDFR_SPLIT_FP16F8 (fp8 cross terms) exists for the transposed conv's deep plan (all nine taps of a channel block per stage) only
+extern "C" int sgdfr_modconv2d_split_f8_ok(int B, int Cin, int Cout, int H, int W, int mode) {
+    SplitParams p;
+    const SplitPlan* plan = mode == SGDFR_MODE_UP3 ? split_plan(B, Cin, Cout, H, W, mode, &p, true) : nullptr;
+    return plan && plan->cfg == 4 ? 1 : 0;
+}
+
 extern "C" int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, int mode) {
     SplitParams p;
     if (!split_plan(B, Cin, Cout, H, W, mode, &p)) return 1;
@@ -298,12 +326,15 @@ extern "C" int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H
 extern "C" int sgdfr_to_split_f32(const float* x, const float* s, unsigned short* xs, int B, int Cin, int H, int W, int arith,
                                   unsigned int* sat, void* stream) {
     SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cin % 8 == 0 && H > 0 && W > 0, "to_split: bad shape B=%d Cin=%d H=%d W=%d (Cin %% 8)", B, Cin, H, W);
-    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "to_split: arith must be SGDFR_SPLIT_BF16/FP16");
+    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16 || arith == SGDFR_SPLIT_FP16F8, "to_split: arith must be SGDFR_SPLIT_BF16/FP16/FP16F8");
     if (B == 0) return 0;
     SGDFR_REQUIRE(x && s && xs && (reinterpret_cast<uintptr_t>(xs) & 15) == 0, "to_split: null or misaligned pointer");
     int64_t g = ((int64_t)B * (Cin / 8) * H * W + 255) / 256;
     if (g > 256 * 32) g = 256 * 32;
-    if (arith == SGDFR_SPLIT_FP16)
+    if (arith == SGDFR_SPLIT_FP16F8)
+        hipLaunchKernelGGL(to_split_kernel<SGDFR_SPLIT_FP16F8>, dim3((int)g), dim3(256), 0, as_stream(stream), x, s,
+                           reinterpret_cast<unsigned char*>(xs), B, Cin, H * W, sat);
+    else if (arith == SGDFR_SPLIT_FP16)
         hipLaunchKernelGGL(to_split_kernel<SGDFR_SPLIT_FP16>, dim3((int)g), dim3(256), 0, as_stream(stream), x, s,
                            reinterpret_cast<unsigned char*>(xs), B, Cin, H * W, sat);
     else
@@ -372,11 +403,14 @@ extern "C" int sgdfr_modconv2d_split_cout_tiles_xin(int B, int Cin, int Cout, in
     return split_plan(B, Cin, Cout, H, W, mode, &p, true) ? p.n_cout_tiles : 0;
 }
 
-extern "C" int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin) { return (int64_t)((Cout + 63) / 64 * 64) * Cin * 9 * 2; }   // cout tiles of 64
+// cout tiles of 64, + a 16-byte trailer (SGDFR_SPLIT_FP16F8 packs keep max |w * scale| there: the source of their fp8 exponent)
+static int64_t split_pack_body_elems(int n_out, int n_in) { return (int64_t)((n_out + 63) / 64 * 64) * n_in * 9 * 2; }
+extern "C" int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin) { return split_pack_body_elems(Cout, Cin) + 8; }
 
 extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int arith,
                                                int transpose_flip, unsigned int* sat, void* stream) {
-    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "prepack_split: arith must be SGDFR_SPLIT_BF16/FP16");
+    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16 || (arith == SGDFR_SPLIT_FP16F8 && transpose_flip == 0),
+                  "prepack_split: arith must be SGDFR_SPLIT_BF16/FP16 (or FP16F8 for a forward pack)");
     SGDFR_REQUIRE(transpose_flip >= 0 && transpose_flip <= 2, "prepack_split: transpose_flip is 0 (forward), 1 (adjoint of "
                   "the plain conv) or 2 (adjoint of the transposed conv)");
     const int n_out = transpose_flip ? Cin : Cout, n_in = transpose_flip ? Cout : Cin;
@@ -385,7 +419,7 @@ extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned sho
                   n_in, n_out);
     SGDFR_REQUIRE(weight && wsp, "prepack_split: null pointer");
     if (n_out % 64 != 0) {       // zero rows for the padding half of the last 64-cout tile
-        if (hipMemsetAsync(wsp, 0, sizeof(unsigned short) * (size_t)sgdfr_modconv_prepack_split_elems(Cout, Cin), as_stream(stream)) !=
+        if (hipMemsetAsync(wsp, 0, sizeof(unsigned short) * (size_t)split_pack_body_elems(Cout, Cin), as_stream(stream)) !=
             hipSuccess) {
             set_error("prepack_split: hipMemsetAsync failed");
             return 2;
@@ -394,8 +428,14 @@ extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned sho
     const int64_t n = (int64_t)Cout * Cin * 9;
     int64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
+    const float scale = (arith != SGDFR_SPLIT_BF16 ? SPLIT_F16_WSCALE : 1.f) / sqrtf((float)Cin * 9);
+    {
+        unsigned* const trailer = reinterpret_cast<unsigned*>(wsp + split_pack_body_elems(n_out, n_in));
+        if (hipMemsetAsync(trailer, 0, 16, as_stream(stream)) != hipSuccess) { (void)hipGetLastError(); set_error("prepack_split: hipMemsetAsync failed"); return 2; }
+        if (arith == SGDFR_SPLIT_FP16F8) hipLaunchKernelGGL(split_absmax_kernel, dim3(256), dim3(256), 0, as_stream(stream), weight, n, scale, trailer);
+    }
     hipLaunchKernelGGL(prepack_split_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), weight, wsp, Cout, Cin,
-                       64, (arith == SGDFR_SPLIT_FP16 ? SPLIT_F16_WSCALE : 1.f) / sqrtf((float)Cin * 9), arith, transpose_flip, sat);
+                       64, scale, arith, transpose_flip, sat);
     return check_launch("modconv_prepack_split");
 }
 
@@ -471,7 +511,10 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
                                          unsigned short* xs_out, const float* s_next, int B, int Cin, int Cout, int H, int W,
                                          int mode, int64_t plane_stride, int arith, int act, float slope, float gain,
                                          unsigned int* sat, void* stream) {
-    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16, "modconv_split: arith must be SGDFR_SPLIT_BF16/FP16");
+    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16 ||
+                      (arith == SGDFR_SPLIT_FP16F8 && sgdfr_modconv2d_split_f8_ok(B, Cin, Cout, H, W, mode) && x_is_split && ksplit <= 1),
+                  "modconv_split: arith must be SGDFR_SPLIT_BF16/FP16 (FP16F8: only where sgdfr_modconv2d_split_f8_ok() says so, with a "
+                  "pre-split input and no K slices)");
     SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "modconv_split: bad shape B=%d Cin=%d Cout=%d H=%d W=%d",
                   B, Cin, Cout, H, W);
     if (B == 0) return 0;
@@ -508,6 +551,7 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
         p.n_pix_tiles = (int)((p.total_pix + plan->pt - 1) / plan->pt);
         p.simgs = (p.xlen - 1) / p.rps + 2;
     }
+    p.f8_max = nullptr;
     p.x = x; p.x_bstride = x_bstride; p.wsp = wsp; p.s = s; p.d = d; p.noise = noise; p.noise_bstride = noise_bstride;
     p.noise_w = noise_w; p.bias = bias; p.zeros = zeros; p.y = y;
     p.act = act; p.slope = slope; p.gain = gain; p.sat = sat;
@@ -538,6 +582,10 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
     }
     fill_fastdivs(p);
     hipStream_t st = as_stream(stream);
+    if (arith == SGDFR_SPLIT_FP16F8) {      // (the deep transposed plan with a pre-split input: checked above)
+        p.f8_max = reinterpret_cast<const float*>(wsp + split_pack_body_elems(Cout, Cin));
+        return launch_split<SGDFR_MODE_UP3, SGDFR_SPLIT_FP16F8, 2, 4, 1, 2, 1, true>(p, st);
+    }
     const int rc = arith == SGDFR_SPLIT_FP16 ? launch_plan<SGDFR_SPLIT_FP16>(plan->cfg, p, st, x_is_split != 0)
                                              : launch_plan<SGDFR_SPLIT_BF16>(plan->cfg, p, st, x_is_split != 0);
     if (rc || ksplit == 1) return rc;

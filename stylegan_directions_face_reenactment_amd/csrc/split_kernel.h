@@ -23,7 +23,7 @@ typedef int frag128 __attribute__((ext_vector_type(4)));   // 8 x 16-bit operand
 // split, weights by 2^6 in the pack, and the epilogue multiplies by 2^-2 (all exact powers of two).
 template <int ET>
 __device__ __forceinline__ f32x16 split_mfma(frag128 a, frag128 b, f32x16 c) {
-    if (ET == SGDFR_SPLIT_FP16)
+    if (ET == SGDFR_SPLIT_FP16 || ET == SGDFR_SPLIT_FP16F8)
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -91,6 +91,7 @@ struct SplitParams {
     int tstep_r, tstep_c, torg;  // patch tiles: tile (ty, tx) starts at (ty*tstep_r + torg, tx*tstep_c + torg) (plain conv: TR, TC, 0)
     int tpos;                    // UPF: positions per cout of the epilogue's exchange buffer (256 + a margin of TC + 1 either side)
     const float* fir;            // UPF: the 4x4 FIR taps on the device (row-major, as Blur.kernel)
+    const float* f8_max;         // SGDFR_SPLIT_FP16F8: the pack's trailer (max |w * scale|, source of the weights' fp8 exponent)
     // divisors of the per-tile index arithmetic (fill_fastdivs() on the host, after the geometry is final)
     FastDiv fd_xs, fd_seglen, fd_P, fd_R, fd_RP, fd_rps, fd_HW, fd_W, fd_TC, fd_tiles_x, fd_per_img, fd_npt, fd_tps, fd_Cin;
 };
@@ -170,8 +171,13 @@ __device__ __forceinline__ void split_flush_saturation(unsigned sat, unsigned* w
 // NSS: barrier-delimited sub-stages per 16-channel block: 3 = one kernel row (3 taps) each, 1 = all 9 taps.
 // XIN: the input is already in the kernel's own split form ("XS": x * s * range shift as 16-bit hi/lo pairs,
 // [B][Cin/8][hi,lo][H*W][8]), written by the producer; staging is then a pure global->LDS DMA (no registers, no VALU).
-template <int MODE, int ET, int WM, int WN, int MI, int NI, int NEX, int NSS, bool XIN = false>
+template <int MODE, int ET_, int WM, int WN, int MI, int NI, int NEX, int NSS, bool XIN = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma_kernel(SplitParams p) {
+    // ET_ = SGDFR_SPLIT_FP16F8 (transposed conv, all nine taps per stage, pre-split input only): the fp16 arithmetic with BOTH cross
+    // terms of two taps in one e4m3 MFMA (common.h); everything else of the kernel is the fp16 arithmetic's
+    constexpr bool F8 = (ET_ == SGDFR_SPLIT_FP16F8);
+    constexpr int ET = F8 ? SGDFR_SPLIT_FP16 : ET_;
+    static_assert(!F8 || ((MODE == SGDFR_MODE_UP3) && XIN && NSS == 1 && MI == 1), "fp8 cross terms: the deep transposed plan only");
     constexpr int NW = WM * WN;            // 8 waves, one block per CU (4-wave blocks, two per CU, measured slower: more
                                            // halo staging and 1.0 ds_read per MFMA)
     constexpr int NTHR = NW * 64;
@@ -206,6 +212,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     float* const ls = reinterpret_cast<float*>(wb0 + NWS * WROW_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // F8: the cross-term MFMA's constant exponent 2^(EW - 7) as an E8M0 scale (common.h)
+    const int f8_sa = F8 ? 127 + ws_f8_wexp(*p.f8_max) - WS_F8_XLO : 127;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hi = lane >> 5;
     const int HW = p.H * p.W;
@@ -696,6 +704,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             // SAME input row (offset P; row 2 reads offset 0), so a whole-channel-block stage (RPS = 3) fetches them once for both:
             // 16 instead of 24 activation fragment reads per channel block (34 instead of 42 ds_read_b128 per 54 MFMAs).
             frag128 ub[2][2][NI];
+            frag128 f8_ca[MI], f8_cb[NI];      // F8: lo fragments of tap (0, 1), waiting for tap (2, 1) of the same phase
             auto mfma_row = [&](int ky, auto&& mid) {
                 const unsigned char* wcur = wslot + (ky - ss * RPS) * WROW64;
                 if (UP) {
@@ -714,6 +723,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                                     *reinterpret_cast<const frag128*>(wcur + aoff[m] + (kx * 2 + part) * 2048);
                     };
                     fetch_a(0, 0);
+                    frag128 f8_a0[MI];      // F8: the lo fragment of tap kx = 0, paired with tap kx = 2 (same phase, same row)
                     if (!(RPS == 3 && ky - ss * RPS == 1)) {     // (the second row of a whole-block stage reuses the first row's)
 #pragma unroll
                         for (int part = 0; part < 2; ++part)
@@ -729,15 +739,53 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                         const int ph = 2 * (ky & 1) + (kx & 1);
                         const int o = (kx == 2) ? 0 : 1;
                         const int cur = kx & 1;
+                        if (F8 && kx == 0) {
+#pragma unroll
+                            for (int m = 0; m < MI; ++m) f8_a0[m] = a[cur][1][m];      // (set 0 is refilled with tap 2 below)
+                        }
                         if (kx < 2) fetch_a(cur ^ 1, kx + 1);
                         __builtin_amdgcn_sched_barrier(0);
+                        if (!F8) {
 #pragma unroll
-                        for (int t = 0; t < 3; ++t)          // product term outermost: dependent MFMAs are MI*NI apart
+                            for (int t = 0; t < 3; ++t)          // product term outermost: dependent MFMAs are MI*NI apart
+#pragma unroll
+                                for (int m = 0; m < MI; ++m)
+#pragma unroll
+                                    for (int n = 0; n < NI; ++n)
+                                        acc[ph][m][n] = split_mfma<ET>(a[cur][t == 2][m], b[o][t == 1][n], acc[ph][m][n]);
+                        } else {
+                            // main term per tap; cross terms two taps of ONE phase at a time: (ky, 0) + (ky, 2) inside the row,
+                            // (0, 1) + (2, 1) across rows (kernel row 0's fragments wait in f8_ca / f8_cb), (1, 1) alone beside zeros
 #pragma unroll
                             for (int m = 0; m < MI; ++m)
 #pragma unroll
-                                for (int n = 0; n < NI; ++n)
-                                    acc[ph][m][n] = split_mfma<ET>(a[cur][t == 2][m], b[o][t == 1][n], acc[ph][m][n]);
+                                for (int n = 0; n < NI; ++n) acc[ph][m][n] = split_mfma<ET>(a[cur][0][m], b[o][0][n], acc[ph][m][n]);
+                            if (kx == 2) {
+#pragma unroll
+                                for (int m = 0; m < MI; ++m)
+#pragma unroll
+                                    for (int n = 0; n < NI; ++n)
+                                        acc[ph][m][n] = ws_mfma_f8(f8_a0[m], a[cur][1][m], b[1][1][n], b[0][1][n], acc[ph][m][n], f8_sa);
+                            } else if (kx == 1 && ky == 0) {
+#pragma unroll
+                                for (int m = 0; m < MI; ++m) f8_ca[m] = a[cur][1][m];
+#pragma unroll
+                                for (int n = 0; n < NI; ++n) f8_cb[n] = b[1][1][n];
+                            } else if (kx == 1 && ky == 1) {
+                                const frag128 zero = {0, 0, 0, 0};
+#pragma unroll
+                                for (int m = 0; m < MI; ++m)
+#pragma unroll
+                                    for (int n = 0; n < NI; ++n)
+                                        acc[ph][m][n] = ws_mfma_f8(a[cur][1][m], a[cur][1][m], b[1][1][n], zero, acc[ph][m][n], f8_sa);
+                            } else if (kx == 1) {
+#pragma unroll
+                                for (int m = 0; m < MI; ++m)
+#pragma unroll
+                                    for (int n = 0; n < NI; ++n)
+                                        acc[ph][m][n] = ws_mfma_f8(f8_ca[m], a[cur][1][m], f8_cb[n], b[1][1][n], acc[ph][m][n], f8_sa);
+                            }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                         if (kx == 1) mid();
                     }

@@ -723,6 +723,8 @@ extern "C" int sgdfr_modconv2d_wsplit_f32(const unsigned short* v, const unsigne
                                           float* y, const float* rgb_w, const float* rgb_s, float* rgb_part,
                                           unsigned short* xs_out, const float* s_next, int B, int Cin, int Cout, int H, int W,
                                           int f, int arith, int act, float slope, float gain, unsigned int* sat, void* stream) {
+    const int xs_f8 = (arith & SGDFR_SPLIT_HANDOVER_F8) ? 1 : 0;      // (a flag beside the input's arithmetic)
+    arith &= ~SGDFR_SPLIT_HANDOVER_F8;
     SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16 || (arith == SGDFR_SPLIT_FP16F8 && f == 4),
                   "modconv_wsplit: arith must be SGDFR_SPLIT_BF16/FP16 (or FP16F8 with f = 4)");
     SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "modconv_wsplit: bad shape B=%d Cin=%d Cout=%d H=%d W=%d", B, Cin,
@@ -749,10 +751,13 @@ extern "C" int sgdfr_modconv2d_wsplit_f32(const unsigned short* v, const unsigne
     p.xs_out = reinterpret_cast<unsigned char*>(xs_out); p.s_next = s_next; p.sat = sat;
     p.act = act; p.slope = slope; p.gain = gain;
     p.dbg = getenv("SGDFR_WSPLIT_DBG") ? atoi(getenv("SGDFR_WSPLIT_DBG")) : 0;
+    p.xs_f8 = xs_f8;
+    SGDFR_REQUIRE(!xs_f8 || (xs_out && arith != SGDFR_SPLIT_BF16 && f == 4), "modconv_wsplit: SGDFR_SPLIT_HANDOVER_F8 needs xs_out, f = 4 and an fp16 arithmetic");
     if (f == 4) {      // 128 couts x 128 tiles per block where the tile count allows it (csrc/wswide.hip: the same outputs, bit for bit)
         const int rc = wswide_try_launch(p, arith, stream);
         if (rc >= 0) return rc;
     }
+    SGDFR_REQUIRE(!xs_f8, "modconv_wsplit: SGDFR_SPLIT_HANDOVER_F8 is written by the wide-tile kernel only (ask sgdfr_modconv2d_wsplit_wide())");
     SGDFR_REQUIRE(arith != SGDFR_SPLIT_FP16F8,
                   "modconv_wsplit: SGDFR_SPLIT_FP16F8 runs on the wide-tile kernel only (Cin %% 32 == 0, Cin >= 64, Cout %% 128 == 0, W %% 32 == 0, "
                   "H %% 16 == 0, d and bias given); got Cin=%d Cout=%d H=%d W=%d", Cin, Cout, H, W);

@@ -45,7 +45,9 @@ __device__ __forceinline__ void ws_lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
-template <int ET>
+// XSF8: the hand-over's lo chunks leave as fp8 cross-term operands (SGDFR_SPLIT_HANDOVER_F8) -- its own instantiation: the conversion
+// inside the epilogue of the plain kernels (behind a block-uniform branch) cost them 870 spilled registers
+template <int ET, bool XSF8 = false>
 __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (the buffer-resource type does not exist in the host pass: without this the host stub is never instantiated)
     constexpr int POS = 6, OUTP = 4, NT = 128, MI = 2, NP = OUTP / 2;
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
         f8_sa = 127 + ws_f8_wexp(maxw) - WS_F8_XLO;
     }
     const float rgb_mul = rsqrtf((float)p.Cout);
+    const float f8_mul_lo = exp2f((float)WS_F8_XLO), f8_mul_hi = exp2f((float)WS_F8_XHI);
     const int a_off = (hi * 128 + wm * 64 + l31) * 16;                   // + ((ky * 2 + part) * 2) * 2048 + mi * 512
     const int b_off = (hi * WW_XS + wn * 32 + l31) * 16;                 // + (part * 2) * 144 * 16 + ky * 8 * 16
 
@@ -444,8 +447,11 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
                             };
                             swap32(h01[0], h01[1]); swap32(h23[0], h23[1]); swap32(l01[0], l01[1]); swap32(l23[0], l23[1]);
                             unsigned char* const d16 = dst - 8 * hi_e + 16 * (2 * pp + hi_e);
-                            *reinterpret_cast<uint4*>(d16) = make_uint4(h01[0], h23[0], h01[1], h23[1]);
-                            *reinterpret_cast<uint4*>(d16 + (int64_t)HW * 16) = make_uint4(l01[0], l23[0], l01[1], l23[1]);
+                            const uint4 vh = make_uint4(h01[0], h23[0], h01[1], h23[1]);
+                            uint4 vl = make_uint4(l01[0], l23[0], l01[1], l23[1]);
+                            if constexpr (XSF8) ws_f8_lo_chunk(vh, vl, f8_mul_lo, f8_mul_hi, false);      // (the next conv reads fp8 cross-term operands)
+                            *reinterpret_cast<uint4*>(d16) = vh;
+                            *reinterpret_cast<uint4*>(d16 + (int64_t)HW * 16) = vl;
                         }
                     }
                     if (FUSE_RGB) {
@@ -589,8 +595,9 @@ int wswide_try_launch(WsParams p, int arith, void* stream) {
         p.desync = pct > 0 ? (int)(block_clk * pct / 100 / 4096) : 0;
     }
     const size_t lds = (size_t)WW_RING * (WW_USLAB + WW_VSLAB) + 7 * 128 * sizeof(float);
-    void (*kern)(WsParams) = arith == SGDFR_SPLIT_FP16F8 ? wswide_kernel<SGDFR_SPLIT_FP16F8>
-                             : arith == SGDFR_SPLIT_FP16 ? wswide_kernel<SGDFR_SPLIT_FP16> : wswide_kernel<SGDFR_SPLIT_BF16>;
+    void (*kern)(WsParams) = arith == SGDFR_SPLIT_FP16F8 ? (p.xs_f8 ? wswide_kernel<SGDFR_SPLIT_FP16F8, true> : wswide_kernel<SGDFR_SPLIT_FP16F8>)
+                             : arith == SGDFR_SPLIT_FP16 ? (p.xs_f8 ? wswide_kernel<SGDFR_SPLIT_FP16, true> : wswide_kernel<SGDFR_SPLIT_FP16>)
+                                                         : wswide_kernel<SGDFR_SPLIT_BF16>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
         set_error("modconv_wsplit (wide tile): LDS request %zu B refused", lds);

@@ -26,7 +26,7 @@ from .timing import timed_conv as _timed_conv, timed_hbm as _timed_hbm
 
 SQRT2 = 2 ** 0.5
 
-_CHAIN_NAMES = ('SplitAct', 'xin_ok', 'styled_conv_split', 'wsplit_chain_f', 'wsplit_chain_arith', 'wsplit_chain_ok', 'rgb_fusable', 'StreamPipeline')
+_CHAIN_NAMES = ('SplitAct', 'xin_ok', 'styled_conv_split', 'wsplit_chain_f', 'wsplit_chain_arith', 'xs_chain_arith', 'wsplit_chain_ok', 'rgb_fusable', 'StreamPipeline')
 
 
 class _Facade(types.ModuleType):
@@ -451,7 +451,7 @@ def prepack_split(weight, arith=None, adjoint=False):
     """weight [1,Cout,Cin,3,3] -> uint16 buffer of 16-bit hi/lo terms of weight/sqrt(9 Cin) in split.hip's LDS order
     (arith: 'bf16x3' or 'fp16x3', default = the current PRECISION; adjoint: True = the pack of dL/dx of the plain conv,
     'down' = of dL/dx of the transposed conv, mode DOWN3)."""
-    arith = _SPLIT_ARITH[arith or config().precision]
+    arith = _WSPLIT_ARITH[arith or config().precision]      # ('fp16f8': forward packs of the transposed conv's deep plan)
     N.require_device(weight)
     w = N.f32c(weight)
     _, cout, cin, k, _ = w.shape
@@ -478,7 +478,7 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
     """3x3 modulated conv in a split arithmetic (same contract as modconv_raw, modes PLAIN3 and UP3); `wsp` must have
     been packed for the same `arith`.  rgb = (w_rgb [3,Cout], s_rgb [B,Cout]) also returns the per-cout-tile partial sums
     [B, T*3, H, W] of the ToRGB 1x1 conv that follows the layer (see rgb_fusable / torgb_finish)."""
-    arith = _SPLIT_ARITH[arith or config().precision]
+    arith = _WSPLIT_ARITH[arith or config().precision]      # ('fp16f8': where sgdfr_modconv2d_split_f8_ok says so; the library checks)
     N.require_device(s, d, bias, noise_weight)
     if not wsp.is_cuda or wsp.dtype != torch.int16:
         raise RuntimeError('modconv_split: wsp must be the int16 device buffer made by prepack_split')
@@ -576,10 +576,15 @@ def to_wsplit(x, s, arith=None, f=2):
 
 
 def modconv_wsplit(vs, shape, wsp, d, cout, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2,
-                   arith=None, rgb=None, want_y=True, s_next=None, desc=None, f=2):
+                   arith=None, rgb=None, want_y=True, s_next=None, desc=None, f=2, xs_arith=None):
     """Plain 3x3 modulated conv of a WS input (to_wsplit / the blur's Winograd hand-over; shape = (B, Cin, H, W)) with the pack of
-    prepack_wsplit (same f).  Outputs as modconv_split with a pre-split input: y | (y, part) | (y, part, xs_out)."""
+    prepack_wsplit (same f).  Outputs as modconv_split with a pre-split input: y | (y, part) | (y, part, xs_out).  xs_arith='fp16f8':
+    the hand-over xs_out carries the fp8 cross-term operands (for a next conv launched with that arithmetic; wide-tile kernel only)."""
     arith = _WSPLIT_ARITH[arith or config().precision]
+    if xs_arith not in (None, 'fp16f8'):
+        raise ValueError("modconv_wsplit: xs_arith is None or 'fp16f8'")
+    if xs_arith == 'fp16f8':
+        arith |= N.SPLIT_HANDOVER_F8
     N.require_device(d, bias, noise_weight)
     if not vs.is_cuda or vs.dtype != torch.int16 or not wsp.is_cuda or wsp.dtype != torch.int16:
         raise RuntimeError('modconv_wsplit: vs / wsp are the int16 device buffers made by to_wsplit / prepack_wsplit')
@@ -623,7 +628,7 @@ def planes_to_split(gt, d, arith=None):
 def to_split(x, s, arith=None):
     """x [B,Cin,H,W], s [B,Cin] -> int16 buffer [B, Cin/8, 2, H*W, 8]: x*s in the split form the kernels stage
     (modconv_split(x=that, s=None, x_split=(B,Cin,H,W)) then fills LDS by DMA)."""
-    arith = _SPLIT_ARITH[arith or config().precision]
+    arith = _WSPLIT_ARITH[arith or config().precision]
     N.require_device(x, s)
     x, s = N.f32c(x), N.f32c(s)
     B, cin, H, W = x.shape

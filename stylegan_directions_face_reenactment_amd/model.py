@@ -655,7 +655,7 @@ class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
             sdl = sd[sd_of_layer[li]]
             nz = noise[li]
             first = li == 0
-            use_chain, fuse, to_next, want_y, wino_next, arith_next = plan[li]
+            use_chain, fuse, to_next, want_y, wino_next, arith_next, xs_arith = plan[li]
             k = li // 2
             if not use_chain:
                 if isinstance(x, F_.SplitAct):
@@ -665,10 +665,11 @@ class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
                 rgb_arg = (to_rgbs[k].conv.weight.view(3, c.out_channel), sd[sd_of_rgb[k]][0]) if fuse else None
                 wino_in = x.wino if isinstance(x, F_.SplitAct) else 0
                 out, part = F_.styled_conv_split(
-                    x, c.packed_wsplit(arith=x.arith, f=wino_in) if wino_in else c.packed_split(), sdl[0], sdl[1], c.out_channel, upsample=up,
+                    x, c.packed_wsplit(arith=x.arith, f=wino_in) if wino_in else c.packed_split(arith=getattr(x, 'arith', None)),
+                    sdl[0], sdl[1], c.out_channel, upsample=up,
                     fir=c.blur.kernel if up else None, noise=nz, noise_weight=layer.noise.weight, bias=layer.activate.bias,
                     batch=batch if first else None, s_next=sd[sd_of_layer[li + 1]][0] if to_next else None, rgb=rgb_arg,
-                    want_y=want_y, wino_next=wino_next, arith_next=arith_next)
+                    want_y=want_y, wino_next=wino_next, arith_next=arith_next, xs_arith=xs_arith)
             if not up:
                 skip = rgb(to_rgbs[k], out, part, skip, sd[sd_of_rgb[k]], last=li == len(layers) - 1)
             x = out

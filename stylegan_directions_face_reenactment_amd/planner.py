@@ -27,7 +27,8 @@ class PlannerMixin:
 
     def _chain_plan(self, batch, chain, noise, layers):
         """Per layer [runs on the split chain, fuses its ToRGB, hands its output over in split form, stores y, Winograd form of the
-        hand-over (0 | 2 | 4), arithmetic of that hand-over (None | 'fp16f8')].  Depends only on (batch, configuration, which noises are given): cached, so a forward does not
+        hand-over (0 | 2 | 4), arithmetic of that hand-over (None | 'fp16f8'), arithmetic of the PLAIN split hand-over of an F(4,3)
+        layer to the transposed conv after it (None | 'fp16f8')].  Depends only on (batch, configuration, which noises are given): cached, so a forward does not
         query the library 40 times (it matters for the launch-bound small batches)."""
         key = (batch, chain, F_.config(), tuple(n is None for n in noise))
         plan = self._chain_plans.get(key) if hasattr(self, '_chain_plans') else None
@@ -49,7 +50,7 @@ class PlannerMixin:
                     F_.xin_ok(batch, nxt.in_channel, nxt.out_channel, res_out, res_out,
                               F_.N.MODE_UP3 if nxt.upsample else F_.N.MODE_PLAIN3)
                 want_y = not (fuse and (nxt is None or to_next))
-                plan.append([use_chain, fuse, to_next, want_y, 0, None])
+                plan.append([use_chain, fuse, to_next, want_y, 0, None, None])
                 res = res_out
             # plain layers in Winograd form: the producing transposed conv's blur hands over the transformed input
             for li, f in (self._wino_inputs(batch, layers).items() if chain else ()):
@@ -57,6 +58,9 @@ class PlannerMixin:
                     plan[li - 1][4] = f
                     c = layers[li].conv
                     plan[li - 1][5] = F_.wsplit_chain_arith(batch, c.in_channel, c.out_channel, res_in[li], res_in[li], f)
+                    nxt = layers[li + 1].conv if li + 1 < len(layers) else None
+                    if f == 4 and plan[li][2] and nxt is not None and nxt.upsample and plan[li + 1][0]:
+                        plan[li][6] = F_.xs_chain_arith(batch, c.in_channel, c.out_channel, res_in[li], res_in[li], nxt.out_channel)
             if not hasattr(self, '_chain_plans'):
                 self._chain_plans = {}
             self._chain_plans[key] = plan
