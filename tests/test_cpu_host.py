@@ -216,11 +216,15 @@ def test_winograd_layer_plan_of_the_bench_configs():
     assert [p[5] for p in G._chain_plan(64, True, noise, layers)] == [None] * len(layers)                 # default: three fp16 products
     with F_.using(F_.config().replace(cross_terms='fp8')):
         assert [p[5] for p in G._chain_plan(64, True, noise, layers)] == [None] * 5 + ['fp16f8', None, 'fp16f8', None, 'fp16f8', None, None, None]
+        # ... and those layers hand over to the transposed convs after them (deep plan) in the same form
+        assert [p[6] for p in G._chain_plan(64, True, noise, layers)] == [None] * 6 + ['fp16f8', None, 'fp16f8', None, 'fp16f8', None, None]
         assert [p[5] for p in G._chain_plan(4, True, noise, layers)] == [None] * len(layers)
+        assert [p[6] for p in G._chain_plan(4, True, noise, layers)] == [None] * len(layers)
         with F_.precision('bf16x3'):                                                                      # the saturation fallback keeps its own arithmetic
             assert [p[5] for p in G._chain_plan(64, True, noise, layers)] == [None] * len(layers)
     assert lib.sgdfr_modconv2d_wsplit_wide(64, 256, 256, 64, 64) == 1 and lib.sgdfr_modconv2d_wsplit_wide(64, 512, 512, 16, 16) == 0
     assert lib.sgdfr_modconv2d_wsplit_wide(64, 80, 128, 64, 64) == 0                                      # Cin % 32: channel blocks pair up
+    assert lib.sgdfr_modconv2d_split_f8_ok(64, 256, 128, 64, 64, F_.N.MODE_UP3) == 1 and lib.sgdfr_modconv2d_split_f8_ok(64, 512, 512, 4, 4, F_.N.MODE_UP3) == 0
     assert not lib.sgdfr_modconv2d_wsplit_supported(64, 64, 64, 256, 256, 4)          # Cout = 64: no 128-cout tile
 
 

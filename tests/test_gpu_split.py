@@ -150,6 +150,75 @@ def _decode_split(xs, shape, arith):
     return v * (16.0 if arith == 'fp16x3' else 1.0)
 
 
+def _decode_f8_lo_chunks(lo_plane_i16, weights_order=False):
+    """int16 view of fp8 "lo" chunks [..., 8] (16 bytes per 8 channels) -> (first, second) fp32 [..., 8]: per channel half
+    (4 x first | 4 x second) in e4m3 -- first = lo, second = hi for activations (include/sgdfr.h SGDFR_SPLIT_FP16F8)."""
+    b = lo_plane_i16.contiguous().view(torch.uint8)
+    b = b.view(*lo_plane_i16.shape[:-1], 2, 2, 4)                    # [.., channel half, first/second, 4]
+    v = b.view(torch.float8_e4m3fn).float()
+    first = v[..., 0, :].reshape(*lo_plane_i16.shape[:-1], 8)
+    second = v[..., 1, :].reshape(*lo_plane_i16.shape[:-1], 8)
+    return first, second
+
+
+def test_fp8_cross_term_chunks_of_the_split_form():
+    """to_split(arith='fp16f8'): the hi chunks are the fp16 form's, the lo chunk of eight channels is 16 e4m3 bytes -- per channel half
+    (4 x lo * 2^7 | 4 x hi * 2^-4), clamped at 448 -- decoded here on the host from the fp16 form's own hi / lo pairs."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    B, cin, h = 2, 32, 16
+    x = S.counter_tensor(8, 'f8fmt.x', (B, cin, h, h)).cuda() * 2.0 ** 12
+    x[0, 0, 0, 0] = 2.0 ** 19                                          # beyond the fp8 range of the cross terms: clamps, not NaN
+    s = S.counter_tensor(8, 'f8fmt.s', (B, cin), 1.0, 0.3).cuda()
+    a, b = F_.to_split(x, s, 'fp16x3'), F_.to_split(x, s, 'fp16f8')    # [B, cin/8, 2, HW, 8] int16
+    assert torch.equal(a[:, :, 0], b[:, :, 0])
+    hi, lo = a[:, :, 0].view(torch.float16).float(), a[:, :, 1].view(torch.float16).float()
+    first, second = _decode_f8_lo_chunks(b[:, :, 1])
+    want_first = (lo * 2.0 ** 7).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    want_second = (hi * 2.0 ** -4).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    assert torch.equal(first, want_first) and torch.equal(second, want_second)
+    assert torch.isfinite(first).all() and torch.isfinite(second).all() and second.abs().max() == 448.0
+
+
+@pytest.mark.parametrize('cin,cout,h,B', [(64, 128, 64, 8), (128, 64, 64, 16), (256, 128, 32, 40)])
+def test_fp8_cross_terms_on_the_transposed_conv(cin, cout, h, B):
+    """SGDFR_SPLIT_FP16F8 on the transposed conv's deep plan (all nine taps of a channel block per stage; the taps of a parity phase
+    pair up in one e4m3 MFMA, (1,1) beside zeros): parity planes against the fp64 oracle -- 4e-5 of max|T| (measured 1.1e-5; three fp16
+    products 1e-6, bound 2e-5) with inputs as loud as the range plan leaves them -- dense and padded / interleaved planes alike; where
+    the deep plan does not apply the library refuses the arithmetic."""
+    from stylegan_directions_face_reenactment_amd import functional as F_, _native as N
+    key = 'f8up.%d.%d.%d.%d' % (cin, cout, h, B)
+    lib = N.load()
+    assert lib.sgdfr_modconv2d_split_f8_ok(B, cin, cout, h, h, N.MODE_UP3) == 1
+    assert lib.sgdfr_modconv2d_split_f8_ok(B, cin, cout, h, h, N.MODE_PLAIN3) == 0 and lib.sgdfr_modconv2d_split_f8_ok(1, cin, cout, 8, 8, N.MODE_UP3) == 0
+    w = S.counter_tensor(8, key + '.w', (1, cout, cin, 3, 3)).cuda()
+    loud = 2.0 ** (12 - 4 * torch.arange(B, dtype=torch.float32) / max(B - 1, 1)).view(B, 1, 1, 1).cuda()
+    x = S.counter_tensor(8, key + '.x', (B, cin, h, h)).cuda() * loud
+    s = S.counter_tensor(8, key + '.s', (B, cin), 1.0, 0.3).cuda()
+    d = (S.counter_tensor(8, key + '.d', (B, cout), 1.0, 0.2).cuda() / loud.view(B, 1)).contiguous()
+    EB = min(B, 3)
+    idx = [0, B // 2, B - 1][:EB]
+    xs64 = x[idx].double() * s[idx].double()[:, :, None, None]
+    t = torch.nn.functional.conv_transpose2d(xs64, (w[0].double() / (cin * 9) ** 0.5).transpose(0, 1), stride=2) * d[idx].double()[:, :, None, None]
+    t = torch.nn.functional.pad(t, (0, 1, 0, 1))
+    ref = t.view(EB, cout, h + 1, 2, h + 1, 2).permute(0, 1, 3, 5, 2, 4).reshape(EB, cout, 4, h + 1, h + 1)
+    scale = ref.abs().amax(dim=(1, 2, 3, 4), keepdim=True)
+    ps = ((h + 1) * (h + 1) + 31) // 32 * 32
+    for arith, bound in (('fp16x3', 2e-5), ('fp16f8', 4e-5)):
+        xs = F_.to_split(x, s, arith)
+        wsp = F_.prepack_split(w, arith)
+        planes = F_.modconv_split(xs, wsp, None, d, cout, arith=arith, mode=N.MODE_UP3, x_split=(B, cin, h, h), batch=B)
+        err = ((planes[idx].double() - ref).abs() / scale).max().item()
+        print(arith, 'worst image: %.2e of max|T|' % err)
+        assert err <= bound
+        padded = F_.modconv_split(xs, wsp, None, d, cout, arith=arith, mode=N.MODE_UP3, x_split=(B, cin, h, h), batch=B, plane_stride=ps)
+        il = padded.view(B, cout, ps, 2, 2)[:, :, :(h + 1) * (h + 1)]           # [.., position, px, py]
+        assert torch.equal(il.permute(0, 1, 4, 3, 2).reshape(B, cout, 4, h + 1, h + 1), planes)
+    with pytest.raises(RuntimeError, match='FP16F8'):
+        F_.modconv_split(F_.to_split(x[:1, :, :8, :8].contiguous(), s[:1], 'fp16f8'), F_.prepack_split(w, 'fp16f8'), None, d[:1], cout,
+                         arith='fp16f8', mode=N.MODE_UP3, x_split=(1, cin, 8, 8), batch=1)
+
+
+
 @pytest.mark.parametrize('arith', ['fp16x3', 'bf16x3'])
 def test_split_form_handover_pieces(arith):
     """The inference dataflow's pieces one by one: to_split() keeps 22 (16) mantissa bits of x*s; a conv fed with that form

@@ -113,6 +113,16 @@ def test_fp8_cross_terms_on_the_wide_kernel(cin, cout, H, W, B, persist, monkeyp
         return v[:, :, 0] + v[:, :, 1]
     a, b = decode(x3), decode(x8)
     assert ((a - b).abs().amax(dim=(1, 2, 3)) / a.abs().amax(dim=(1, 2, 3))).max().item() <= 2e-4
+    # SGDFR_SPLIT_HANDOVER_F8 (xs_arith='fp16f8'): the hand-over carries the fp8 cross-term operands of the NEXT conv -- the same
+    # bits as to_split(y * s_next, 'fp16f8'), from either input arithmetic; y and the ToRGB sums do not change
+    for arith in ('fp16x3', 'fp16f8'):
+        vs = F_.to_wsplit(x, s, arith, f=4)
+        wsp = F_.prepack_wsplit(w, arith, f=4)
+        y, part, xs = F_.modconv_wsplit(vs, (B, cin, H, W), wsp, d, cout, noise, nw, bias, True, arith=arith, f=4, rgb=rgb, s_next=sn, want_y=True,
+                                        xs_arith='fp16f8')
+        assert torch.equal(y, out[arith][0]) and torch.equal(part, out[arith][1])
+        assert torch.equal(xs[:, :, 0], out[arith][2][:, :, 0])
+        assert torch.equal(xs, F_.to_split(y, sn, 'fp16f8'))
 
 
 WIDE_CASES = [  # cin, cout, H, W, B, persist
