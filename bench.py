@@ -718,7 +718,7 @@ def other_config_legs(args, rank, world, dev):
         torch.cuda.empty_cache()
     if args.config == 'synthesis' and args.precision == 'fp16x3' and F_.config().cross_terms == 'fp16':
         # The same workload with Config.cross_terms='fp8' (opt-in, include/sgdfr.h SGDFR_SPLIT_FP16F8): the F(4,3) layers that take the
-        # wide-tile kernel and the transposed convs they feed (deep plan) keep both cross terms of the split product in e4m3 -- 2 MFMA
+        # wide-tile kernel, the transposed convs they feed (deep plan) and the direct 64 -> 64 layer keep both cross terms in e4m3 -- 2 MFMA
         # units per product instead of 3.  Reported
         # beside `value`, never as it: the default stays three fp16 products (1.4e-5 against the oracle); this leg's max-abs is measured
         # on its own timed batch against the same oracle and the same 1e-3 bar.
@@ -733,7 +733,7 @@ def other_config_legs(args, rank, world, dev):
             legs['synthesis_fp8_cross_terms'] = {
                 'metric': line['metric'], 'value': line['value'], 'unit': line['unit'], 'steps': sub.steps, 'warmup': sub.warmup,
                 'ms_per_step': line['ms_per_step'], 'per_gpu_batch': sub.batch, 'workload': line['config']['workload'],
-                'dtype': 'f32 (fp16 hi+lo operands; on the wide-tile F(4,3) layers and the transposed convs after them the two cross terms as e4m3 pairs in one fp8 MFMA)',
+                'dtype': 'f32 (fp16 hi+lo operands; on the wide-tile F(4,3) layers, the transposed convs after them and the last direct layer the two cross terms as e4m3 pairs in one fp8 MFMA)',
                 'single_stream': line.get('single_stream', {}).get('value'),
                 'max_abs_vs_oracle': (line.get('max_abs_vs_oracle') or {}).get(sub.precision), 'bar': 1e-3,
                 'fp16_saturated_pairs': line.get('fp16_saturated_pairs'),

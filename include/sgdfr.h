@@ -342,7 +342,8 @@ int sgdfr_modconv2d_wsplit_supported(int B, int Cin, int Cout, int H, int W, int
 int sgdfr_modconv2d_wsplit_wide(int B, int Cin, int Cout, int H, int W);
 /* OR-ed into `arith` of sgdfr_modconv2d_wsplit_f32 (f = 4, wide-tile kernel, xs_out given): the hand-over's lo chunks leave as the fp8
  * cross-term operands of SGDFR_SPLIT_FP16F8 -- for a next conv launched with that arithmetic (sgdfr_modconv2d_split_f32, mode UP3,
- * where sgdfr_modconv2d_split_f8_ok() = 1: the transposed conv's deep plan, nine taps pair up per phase with (1,1) beside zeros). */
+ * where sgdfr_modconv2d_split_f8_ok() = 1: the transposed conv's deep plan, nine taps pair up per phase with (1,1) beside zeros;
+ * mode PLAIN3 where it says so: the 4-wave plan of short-K layers, fed by sgdfr_blur_bias_act_split_f32(arith = FP16F8, wino = 0)). */
 #define SGDFR_SPLIT_HANDOVER_F8 0x100
 int64_t sgdfr_modconv_prepack_wsplit_elems(int Cout, int Cin, int f);
 int sgdfr_modconv_prepack_wsplit_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int f, int arith,

@@ -46,3 +46,26 @@ for cin, cout, h in [(512, 256, 32), (256, 128, 64), (128, 64, 128)]:
         line += '  %s %.0f us, err %.2e of max|T|' % (arith, tm, err)
         del xs, wsp, planes, buf
     print(line, flush=True)
+
+# the direct plain layer of the bench generator (4-wave plan, fused ToRGB, nothing else stored)
+for cin, cout, h in [(64, 64, 256)]:
+    w = torch.randn(1, cout, cin, 3, 3, device='cuda')
+    x = torch.randn(B, cin, h, h, device='cuda') * 2.0 ** (12 - 4 * torch.rand(B, 1, 1, 1, device='cuda'))
+    x = torch.where(x > 0, x, 0.2 * x)
+    s = torch.randn(B, cin, device='cuda') * 0.3 + 1.0
+    d = torch.rand(B, cout, device='cuda') + 0.5
+    bias = torch.zeros(cout, device='cuda')
+    rgb = (torch.randn(3, cout, device='cuda'), torch.randn(B, cout, device='cuda') * 0.3 + 1.0)
+    assert N.load().sgdfr_modconv2d_split_f8_ok(B, cin, cout, h, h, N.MODE_PLAIN3)
+    ref = torch.nn.functional.conv2d(x[:EB].double() * s[:EB].double()[:, :, None, None], w[0].double() / (cin * 9) ** 0.5, padding=1) * d[:EB].double()[:, :, None, None]
+    line = 'plain %d->%d@%d B=%d:' % (cin, cout, h, B)
+    for arith in ('fp16x3', 'fp16f8'):
+        xs = F_.to_split(x, s, arith)
+        wsp = F_.prepack_split(w, arith)
+        y = F_.modconv_split(xs, wsp, None, d, cout, None, None, bias, False, arith=arith, x_split=(B, cin, h, h), batch=B)
+        err = (y[:EB].double() - ref).abs().max().item() / ref.abs().max().item()
+        del y
+        tm = bench(lambda: F_.modconv_split(xs, wsp, None, d, cout, None, None, bias, True, arith=arith, x_split=(B, cin, h, h), batch=B, rgb=rgb, want_y=False))
+        line += '  %s %.0f us, err %.2e of max|y|' % (arith, tm, err)
+        del xs, wsp
+    print(line, flush=True)

@@ -50,16 +50,14 @@ def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, 
         B, cin, H, W = x.shape
         xin, x_split, s_arg = x.xs, x.shape, None
         batch = B
-        x_arith = x.arith           # 'fp16f8': the producer wrote fp8 cross-term operands (transposed conv, deep plan; `wsp` packed alike)
-        if x_arith is not None and not upsample:
-            raise RuntimeError('styled_conv_split: a plain split hand-over with fp8 cross terms feeds transposed convs only')
+        x_arith = x.arith           # 'fp16f8': the producer wrote fp8 cross-term operands (where sgdfr_modconv2d_split_f8_ok; `wsp` packed alike)
     else:
         xin, x_split, s_arg = x, None, s
         B = s.shape[0] if batch is None else batch
         H, W = x.shape[2], x.shape[3]
     if not upsample:
         res = modconv_split(xin, wsp, s_arg, d, cout, noise, noise_weight, bias, True, batch=batch, rgb=rgb,
-                            want_y=want_y and s_next is None, x_split=x_split, s_next=s_next)
+                            want_y=want_y and s_next is None, x_split=x_split, s_next=s_next, arith=x_arith)
         if s_next is not None:          # the activation leaves only as the next conv's split input
             _, part, xs = res
             return SplitAct(xs, (B, cout, H, W)), part
@@ -70,13 +68,13 @@ def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, 
         ps = ((H + 1) * (W + 1) + 31) // 32 * 32
         planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split, plane_stride=ps, arith=x_arith)
         xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, plane_stride=ps, wino=wino_next,
-                                 arith=arith_next if wino_next == 4 else None)
-        return SplitAct(xs, (B, cout, 2 * H, 2 * W), wino_next, arith_next if wino_next == 4 else None), None
+                                 arith=arith_next if wino_next != 2 else None)
+        return SplitAct(xs, (B, cout, 2 * H, 2 * W), wino_next, arith_next if wino_next != 2 else None), None
     planes = modconv_split(xin, wsp, s_arg, d, cout, batch=batch, mode=N.MODE_UP3, x_split=x_split, arith=x_arith)
     if s_next is not None:
         xs = blur_bias_act_split(planes, fir, H, W, s_next, noise, noise_weight, bias, True, wino=wino_next,
-                                 arith=arith_next if wino_next == 4 else None)
-        return SplitAct(xs, (B, cout, 2 * H, 2 * W), wino_next, arith_next if wino_next == 4 else None), None
+                                 arith=arith_next if wino_next != 2 else None)
+        return SplitAct(xs, (B, cout, 2 * H, 2 * W), wino_next, arith_next if wino_next != 2 else None), None
     return blur_bias_act(planes, fir, H, W, noise, noise_weight, bias, True), None
 
 
@@ -110,6 +108,17 @@ def xs_chain_arith(B, cin, cout, H, W, nxt_cout):
             _shape_query('sgdfr_modconv2d_wsplit_wide', B, cin, cout, H, W) and \
             _shape_query('sgdfr_modconv2d_split_f8_ok', B, cout, nxt_cout, H, W, N.MODE_UP3) and \
             _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cout, nxt_cout, H, W, N.MODE_UP3) == 1:
+        return 'fp16f8'
+    return None
+
+
+def xs_plain_arith(B, cin, cout, H, W):
+    """Arithmetic of the plain split hand-over from a transposed conv + blur to the DIRECT plain conv (B, cin -> cout @ H x W) after it:
+    'fp16f8' when Config.cross_terms says so and that conv runs the plan that reads the form (sgdfr_modconv2d_split_f8_ok: the 4-wave
+    plan of the 64 -> 64 @ 256^2 layer), without K slices; else None."""
+    if config().precision == 'fp16x3' and config().cross_terms == 'fp8' and \
+            _shape_query('sgdfr_modconv2d_split_f8_ok', B, cin, cout, H, W, N.MODE_PLAIN3) and \
+            _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cin, cout, H, W, N.MODE_PLAIN3) == 1:
         return 'fp16f8'
     return None
 

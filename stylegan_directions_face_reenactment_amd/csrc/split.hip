@@ -301,11 +301,13 @@ extern "C" int sgdfr_modconv2d_split_supported(int B, int Cin, int Cout, int H, 
     return split_plan(B, Cin, Cout, H, W, mode, &p) ? 1 : 0;
 }
 
-// SGDFR_SPLIT_FP16F8 (fp8 cross terms) exists for the transposed conv's deep plan (all nine taps of a channel block per stage) only
+// SGDFR_SPLIT_FP16F8 (fp8 cross terms) exists for the transposed conv's deep plan (all nine taps of a channel block per stage) and
+// the 4-wave plain plan (64 -> 64 @ 256^2 of the bench generator), both with a pre-split input and without K slices
 extern "C" int sgdfr_modconv2d_split_f8_ok(int B, int Cin, int Cout, int H, int W, int mode) {
     SplitParams p;
-    const SplitPlan* plan = mode == SGDFR_MODE_UP3 ? split_plan(B, Cin, Cout, H, W, mode, &p, true) : nullptr;
-    return plan && plan->cfg == 4 ? 1 : 0;
+    if (mode != SGDFR_MODE_UP3 && mode != SGDFR_MODE_PLAIN3) return 0;
+    const SplitPlan* plan = split_plan(B, Cin, Cout, H, W, mode, &p, true);
+    return plan && plan->cfg == (mode == SGDFR_MODE_UP3 ? 4 : 8) ? 1 : 0;
 }
 
 extern "C" int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, int mode) {
@@ -584,7 +586,8 @@ extern "C" int sgdfr_modconv2d_split_f32(const float* x, int64_t x_bstride, cons
     hipStream_t st = as_stream(stream);
     if (arith == SGDFR_SPLIT_FP16F8) {      // (the deep transposed plan with a pre-split input: checked above)
         p.f8_max = reinterpret_cast<const float*>(wsp + split_pack_body_elems(Cout, Cin));
-        return launch_split<SGDFR_MODE_UP3, SGDFR_SPLIT_FP16F8, 2, 4, 1, 2, 1, true>(p, st);
+        return mode == SGDFR_MODE_UP3 ? launch_split<SGDFR_MODE_UP3, SGDFR_SPLIT_FP16F8, 2, 4, 1, 2, 1, true>(p, st)
+                                      : launch_split<SGDFR_MODE_PLAIN3, SGDFR_SPLIT_FP16F8, 1, 4, 2, 2, 3, true>(p, st);
     }
     const int rc = arith == SGDFR_SPLIT_FP16 ? launch_plan<SGDFR_SPLIT_FP16>(plan->cfg, p, st, x_is_split != 0)
                                              : launch_plan<SGDFR_SPLIT_BF16>(plan->cfg, p, st, x_is_split != 0);

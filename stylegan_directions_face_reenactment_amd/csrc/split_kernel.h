@@ -177,7 +177,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
     // terms of two taps in one e4m3 MFMA (common.h); everything else of the kernel is the fp16 arithmetic's
     constexpr bool F8 = (ET_ == SGDFR_SPLIT_FP16F8);
     constexpr int ET = F8 ? SGDFR_SPLIT_FP16 : ET_;
-    static_assert(!F8 || ((MODE == SGDFR_MODE_UP3) && XIN && NSS == 1 && MI == 1), "fp8 cross terms: the deep transposed plan only");
+    static_assert(!F8 || (XIN && ((MODE == SGDFR_MODE_UP3 && NSS == 1 && MI == 1) || (MODE == SGDFR_MODE_PLAIN3 && NSS == 3 && NI == 2 && WM * WN == 4))),
+                  "fp8 cross terms: the deep transposed plan and the 4-wave plain plan only");
     constexpr int NW = WM * WN;            // 8 waves, one block per CU (4-wave blocks, two per CU, measured slower: more
                                            // halo staging and 1.0 ds_read per MFMA)
     constexpr int NTHR = NW * 64;
@@ -640,6 +641,9 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         const bool conv_next = cb + 1 < ncb, load_next = cb + 2 < ncb;
         // the last channel block of a persistent block's tile stages the first block (and weight slab) of its next tile
         const bool pre_next = XIN && !conv_next && has_next;
+        // F8: lo fragments that wait for their partner -- transposed conv: tap (0, 1) for tap (2, 1) of the same phase; plain conv:
+        // a kernel row's third tap for the next row's (rows are sub-stages: across a barrier, in registers)
+        frag128 f8_ca[MI], f8_cb[NI];
 #pragma unroll
         for (int ss = 0; ss < NSS; ++ss) {
             const int u = cb * NSS + ss;
@@ -704,7 +708,6 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
             // SAME input row (offset P; row 2 reads offset 0), so a whole-channel-block stage (RPS = 3) fetches them once for both:
             // 16 instead of 24 activation fragment reads per channel block (34 instead of 42 ds_read_b128 per 54 MFMAs).
             frag128 ub[2][2][NI];
-            frag128 f8_ca[MI], f8_cb[NI];      // F8: lo fragments of tap (0, 1), waiting for tap (2, 1) of the same phase
             auto mfma_row = [&](int ky, auto&& mid) {
                 const unsigned char* wcur = wslot + (ky - ss * RPS) * WROW64;
                 if (UP) {
@@ -827,6 +830,38 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
                                 acc[0][m][n] =
                                     split_mfma<ET>(a[cur][0][m], b[cur][0][n], acc[0][m][n]);
                         __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (F8) {
+                            // cross terms two taps at a time: (ky, 0) + (ky, 1) here; the row's third tap pairs with the NEXT row's
+                            // third tap (row 0 -> row 1), row 2's stands beside zeros
+                            if (kx == 0) {
+                                fetch(1, 1);
+                            } else if (kx == 1) {
+#pragma unroll
+                                for (int m = 0; m < MI; ++m)
+#pragma unroll
+                                    for (int n = 0; n < NI; ++n)
+                                        acc[0][m][n] = ws_mfma_f8(a[0][1][m], a[1][1][m], b[0][1][n], b[1][1][n], acc[0][m][n], f8_sa);
+                                fetch(0, 2);
+                            } else if (ky == 0) {
+#pragma unroll
+                                for (int m = 0; m < MI; ++m) f8_ca[m] = a[0][1][m];
+#pragma unroll
+                                for (int n = 0; n < NI; ++n) f8_cb[n] = b[0][1][n];
+                            } else if (ky == 1) {
+#pragma unroll
+                                for (int m = 0; m < MI; ++m)
+#pragma unroll
+                                    for (int n = 0; n < NI; ++n)
+                                        acc[0][m][n] = ws_mfma_f8(f8_ca[m], a[0][1][m], f8_cb[n], b[0][1][n], acc[0][m][n], f8_sa);
+                            } else {
+                                const frag128 zero = {0, 0, 0, 0};
+#pragma unroll
+                                for (int m = 0; m < MI; ++m)
+#pragma unroll
+                                    for (int n = 0; n < NI; ++n)
+                                        acc[0][m][n] = ws_mfma_f8(a[0][1][m], a[0][1][m], b[0][1][n], zero, acc[0][m][n], f8_sa);
+                            }
+                        } else {
 #ifndef SGDFR_PROBE_NOFETCH
                         if (NSET == 2 && kx < 2) fetch(cur ^ 1, kx + 1);
 #endif
@@ -838,6 +873,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
 #pragma unroll
                                 for (int n = 0; n < NI; ++n)
                                     acc[0][m][n] = split_mfma<ET>(a[cur][t == 2][m], b[cur][t == 1][n], acc[0][m][n]);
+                        }
                         if (kx == 1) {
                             __builtin_amdgcn_sched_barrier(0);
                             mid();

@@ -538,6 +538,7 @@ __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(c
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc)
                     blur_split2<ET>(tile[row][px][2 * cc] * sv[2 * cc], tile[row][px][2 * cc + 1] * sv[2 * cc + 1], ph[cc], pl[cc], sat);
+                if (ET == SGDFR_SPLIT_FP16F8) ws_f8_lo_chunk(vh, vl, f8_mul_lo, f8_mul_hi, false);      // (fp8 cross-term operands, common.h)
                 unsigned char* dst = xs + ((((int64_t)b * G + g) * 2) * OHW + (int64_t)oy * OW + ox) * 16;
 #if defined(SGDFR_BLUR_PROBE) && SGDFR_BLUR_PROBE == 1      // ablation: no stores (unless a value is NaN: keeps the work alive)
                 if (vh.x == 0x7fc07fc0u)
@@ -776,8 +777,8 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
     SGDFR_REQUIRE(!wino || (W >= 8 && W <= 64 && (W & (W - 1)) == 0) || (wino == 4 && W == 128 && plane_stride != 0),
                   "blur_bias_act_split: the Winograd hand-over takes W = 8, 16, 32 or 64 (output rows inside one column tile; F(4,3) on "
                   "interleaved planes also W = 128), got %d", W);
-    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16 || (arith == SGDFR_SPLIT_FP16F8 && wino == 4),
-                  "blur_bias_act_split: arith must be SGDFR_SPLIT_BF16/FP16 (or FP16F8 with the F(4,3) hand-over, wino = 4)");
+    SGDFR_REQUIRE(arith == SGDFR_SPLIT_BF16 || arith == SGDFR_SPLIT_FP16 || (arith == SGDFR_SPLIT_FP16F8 && wino != 2),
+                  "blur_bias_act_split: arith must be SGDFR_SPLIT_BF16/FP16 (or FP16F8 with the plain or the F(4,3) hand-over)");
     if (B == 0) return 0;
     SGDFR_REQUIRE(t && fir && s_next && xs && (reinterpret_cast<uintptr_t>(xs) & 15) == 0, "blur_bias_act_split: null / misaligned pointer");
     SGDFR_REQUIRE(!noise || noise_w, "blur_bias_act_split: noise without noise_w");
@@ -811,7 +812,9 @@ extern "C" int sgdfr_blur_bias_act_split_f32(const float* t, const float* fir, c
      : (QC == 8 || WINO_ != 0) ? blur_split_kernel<ET_, 8, 4, WINO_, IL_>                                                         \
                 : blur_split_kernel<ET_, 4, (WINO_ != 0 ? 4 : 8), WINO_, IL_>)
 #define SGDFR_BLUR_PICK_W(ET_, IL_) (wino == 2 ? SGDFR_BLUR_PICK(ET_, 2, IL_) : wino == 4 ? SGDFR_BLUR_PICK(ET_, 4, IL_) : SGDFR_BLUR_PICK(ET_, 0, IL_))
-    if (arith == SGDFR_SPLIT_FP16F8) kern = il ? SGDFR_BLUR_PICK(SGDFR_SPLIT_FP16F8, 4, true) : SGDFR_BLUR_PICK(SGDFR_SPLIT_FP16F8, 4, false);
+    if (arith == SGDFR_SPLIT_FP16F8)
+        kern = wino == 4 ? (il ? SGDFR_BLUR_PICK(SGDFR_SPLIT_FP16F8, 4, true) : SGDFR_BLUR_PICK(SGDFR_SPLIT_FP16F8, 4, false))
+                         : (il ? SGDFR_BLUR_PICK(SGDFR_SPLIT_FP16F8, 0, true) : SGDFR_BLUR_PICK(SGDFR_SPLIT_FP16F8, 0, false));
     else if (arith == SGDFR_SPLIT_FP16) kern = il ? SGDFR_BLUR_PICK_W(SGDFR_SPLIT_FP16, true) : SGDFR_BLUR_PICK_W(SGDFR_SPLIT_FP16, false);
     else kern = il ? SGDFR_BLUR_PICK_W(SGDFR_SPLIT_BF16, true) : SGDFR_BLUR_PICK_W(SGDFR_SPLIT_BF16, false);
 #undef SGDFR_BLUR_PICK_W

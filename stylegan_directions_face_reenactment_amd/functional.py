@@ -26,7 +26,7 @@ from .timing import timed_conv as _timed_conv, timed_hbm as _timed_hbm
 
 SQRT2 = 2 ** 0.5
 
-_CHAIN_NAMES = ('SplitAct', 'xin_ok', 'styled_conv_split', 'wsplit_chain_f', 'wsplit_chain_arith', 'xs_chain_arith', 'wsplit_chain_ok', 'rgb_fusable', 'StreamPipeline')
+_CHAIN_NAMES = ('SplitAct', 'xin_ok', 'styled_conv_split', 'wsplit_chain_f', 'wsplit_chain_arith', 'xs_chain_arith', 'xs_plain_arith', 'wsplit_chain_ok', 'rgb_fusable', 'StreamPipeline')
 
 
 class _Facade(types.ModuleType):
@@ -733,7 +733,7 @@ def blur_bias_act_split(planes, fir, H, W, s_next, noise=None, noise_weight=None
     padded [B, C, 4, plane_stride] buffer of modconv_split(mode=UP3, plane_stride=...).  wino = 2 | 4: the Winograd input form
     of to_wsplit(f=wino) instead ([B, C/8, wino+2, 2, 4HW/wino, 8], for modconv_wsplit; wino = 4 also takes arith='fp16f8')."""
     wino = 2 if wino is True else int(wino or 0)
-    arith = (_WSPLIT_ARITH if wino == 4 else _SPLIT_ARITH)[arith or config().precision]
+    arith = (_WSPLIT_ARITH if wino != 2 else _SPLIT_ARITH)[arith or config().precision]
     N.require_device(planes, fir, bias, noise_weight, s_next)
     B, C = planes.shape[0], planes.shape[1]
     nz, nzb = _noise_args(noise, B, 2 * H, 2 * W)

@@ -61,6 +61,13 @@ class PlannerMixin:
                     nxt = layers[li + 1].conv if li + 1 < len(layers) else None
                     if f == 4 and plan[li][2] and nxt is not None and nxt.upsample and plan[li + 1][0]:
                         plan[li][6] = F_.xs_chain_arith(batch, c.in_channel, c.out_channel, res_in[li], res_in[li], nxt.out_channel)
+            # direct plain layers fed by a transposed conv + blur in plain split form: fp8 cross-term operands where the consumer's
+            # plan reads them (Config.cross_terms)
+            for li in range(1, len(layers)):
+                c = layers[li].conv
+                if chain and not c.upsample and layers[li - 1].conv.upsample and plan[li][0] and plan[li][1] and plan[li - 1][0] and \
+                        plan[li - 1][2] and plan[li - 1][4] == 0:
+                    plan[li - 1][5] = F_.xs_plain_arith(batch, c.in_channel, c.out_channel, res_in[li], res_in[li])
             if not hasattr(self, '_chain_plans'):
                 self._chain_plans = {}
             self._chain_plans[key] = plan

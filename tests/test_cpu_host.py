@@ -215,7 +215,7 @@ def test_winograd_layer_plan_of_the_bench_configs():
     noise = [object()] * len(layers)
     assert [p[5] for p in G._chain_plan(64, True, noise, layers)] == [None] * len(layers)                 # default: three fp16 products
     with F_.using(F_.config().replace(cross_terms='fp8')):
-        assert [p[5] for p in G._chain_plan(64, True, noise, layers)] == [None] * 5 + ['fp16f8', None, 'fp16f8', None, 'fp16f8', None, None, None]
+        assert [p[5] for p in G._chain_plan(64, True, noise, layers)] == [None] * 5 + ['fp16f8', None, 'fp16f8', None, 'fp16f8', None, 'fp16f8', None]      # (the last one: plain form, for the direct 64 -> 64 @ 256^2 layer)
         # ... and those layers hand over to the transposed convs after them (deep plan) in the same form
         assert [p[6] for p in G._chain_plan(64, True, noise, layers)] == [None] * 6 + ['fp16f8', None, 'fp16f8', None, 'fp16f8', None, None]
         assert [p[5] for p in G._chain_plan(4, True, noise, layers)] == [None] * len(layers)

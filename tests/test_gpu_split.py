@@ -218,6 +218,49 @@ def test_fp8_cross_terms_on_the_transposed_conv(cin, cout, h, B):
                          arith='fp16f8', mode=N.MODE_UP3, x_split=(1, cin, 8, 8), batch=1)
 
 
+def test_fp8_cross_terms_on_the_direct_plain_layer_and_its_blur_handover():
+    """SGDFR_SPLIT_FP16F8 on the 4-wave plan of the direct plain conv (the 64 -> 64 @ 256^2 layer of the bench generator: a kernel
+    row's first two taps share one e4m3 MFMA, its third pairs with the next row's across the sub-stage barrier, row 2's stands beside
+    zeros): y and the fused ToRGB sums against the fp64 oracle (4e-5 of max|y|, measured 1.2e-5), and the blur that feeds it writes the
+    same bits as to_split(its fp32 result, 'fp16f8')."""
+    from stylegan_directions_face_reenactment_amd import functional as F_, _native as N
+    B, c, h = 8, 64, 256
+    assert N.load().sgdfr_modconv2d_split_f8_ok(B, c, c, h, h, N.MODE_PLAIN3) == 1
+    w = S.counter_tensor(8, 'f8pl.w', (1, c, c, 3, 3)).cuda()
+    loud = 2.0 ** (12 - 4 * torch.arange(B, dtype=torch.float32) / (B - 1)).view(B, 1, 1, 1).cuda()
+    x = S.counter_tensor(8, 'f8pl.x', (B, c, h, h)).cuda() * loud
+    s = S.counter_tensor(8, 'f8pl.s', (B, c), 1.0, 0.3).cuda()
+    d = (S.counter_tensor(8, 'f8pl.d', (B, c), 1.0, 0.2).cuda() / loud.view(B, 1)).contiguous()
+    bias = S.counter_tensor(8, 'f8pl.b', (c,), 0.0, 0.1).cuda()
+    noise = S.counter_tensor(8, 'f8pl.n', (1, 1, h, h)).cuda()
+    nw = torch.full((1,), 0.1).cuda()
+    rgb = (S.counter_tensor(8, 'f8pl.rw', (3, c)).cuda(), S.counter_tensor(8, 'f8pl.rs', (B, c), 1.0, 0.3).cuda())
+    idx = [0, B - 1]
+    ref = torch.nn.functional.conv2d(x[idx].double() * s[idx].double()[:, :, None, None], w[0].double() / (c * 9) ** 0.5, padding=1)
+    ref = ref * d[idx].double()[:, :, None, None] + 0.1 * noise.double() + bias.double().view(1, -1, 1, 1)
+    ref = torch.nn.functional.leaky_relu(ref, 0.2) * 2 ** 0.5
+    out = {}
+    for arith, bound in (('fp16x3', 2e-5), ('fp16f8', 4e-5)):
+        y, part = F_.modconv_split(F_.to_split(x, s, arith), F_.prepack_split(w, arith), None, d, c, noise, nw, bias, True, arith=arith,
+                                   x_split=(B, c, h, h), batch=B, rgb=rgb)
+        err = ((y[idx].double() - ref).abs().amax(dim=(1, 2, 3)) / ref.abs().amax(dim=(1, 2, 3))).max().item()
+        print(arith, 'worst image: %.2e of max|y|' % err)
+        assert err <= bound
+        out[arith] = (y, part)
+    assert ((out['fp16f8'][1] - out['fp16x3'][1]).abs().amax(dim=(1, 2, 3)) / out['fp16x3'][1].abs().amax(dim=(1, 2, 3))).max().item() <= 2e-4
+    # the producer: blur hand-over in the plain split form with fp8 lo chunks
+    Hh = 32
+    fir = torch.tensor([[1., 3., 3., 1.]]).cuda()
+    fir = fir.t() @ fir
+    fir = fir / fir.sum() * 4
+    planes = S.counter_tensor(8, 'f8pl.t', (3, 16, 4, Hh + 1, Hh + 1)).cuda() * 2.0 ** 11
+    nz = S.counter_tensor(8, 'f8pl.nz', (1, 1, 2 * Hh, 2 * Hh)).cuda()
+    b16 = S.counter_tensor(8, 'f8pl.b16', (16,), 0.0, 0.1).cuda()
+    sn = S.counter_tensor(8, 'f8pl.sn', (3, 16), 1.0, 0.3).cuda()
+    yb = F_.blur_bias_act(planes, fir, Hh, Hh, nz, nw, b16, True)
+    assert torch.equal(F_.blur_bias_act_split(planes, fir, Hh, Hh, sn, nz, nw, b16, True, arith='fp16f8'), F_.to_split(yb, sn, 'fp16f8'))
+
+
 
 @pytest.mark.parametrize('arith', ['fp16x3', 'bf16x3'])
 def test_split_form_handover_pieces(arith):
