@@ -340,7 +340,7 @@ int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, in
  * 1.3-1.5x the speed of the three-product form (scripts/f8_layer_probe.py). */
 int sgdfr_modconv2d_wsplit_supported(int B, int Cin, int Cout, int H, int W, int f);
 int sgdfr_modconv2d_wsplit_wide(int B, int Cin, int Cout, int H, int W);
-/* OR-ed into `arith` of sgdfr_modconv2d_wsplit_f32 (f = 4, wide-tile kernel, xs_out given): the hand-over's lo chunks leave as the fp8
+/* OR-ed into `arith` of sgdfr_modconv2d_wsplit_f32 (f = 4, either tile size, xs_out given): the hand-over's lo chunks leave as the fp8
  * cross-term operands of SGDFR_SPLIT_FP16F8 -- for a next conv launched with that arithmetic (sgdfr_modconv2d_split_f32, mode UP3,
  * where sgdfr_modconv2d_split_f8_ok() = 1: the transposed conv's deep plan, nine taps pair up per phase with (1,1) beside zeros;
  * mode PLAIN3 where it says so: the 4-wave plan of short-K layers, fed by sgdfr_blur_bias_act_split_f32(arith = FP16F8, wino = 0)). */

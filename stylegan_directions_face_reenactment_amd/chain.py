@@ -32,7 +32,7 @@ def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, 
     already applied), s_next asks for the output as a SplitAct for the next conv, rgb for the fused ToRGB partial sums.
     A SplitAct in Winograd form (x.wino) runs on modconv_wsplit with `wsp` = the prepack_wsplit pack; wino_next (transposed
     conv + blur only) asks for the output in that form, arith_next ('fp16f8' | None) for the arithmetic of that hand-over;
-    xs_arith ('fp16f8' | None, F(4,3) layers on the wide-tile kernel only) for the arithmetic of the plain split hand-over s_next.
+    xs_arith ('fp16f8' | None, F(4,3) layers only) for the arithmetic of the plain split hand-over s_next.
     Returns (activation: fp32 tensor | SplitAct | None, ToRGB partials | None)."""
     if isinstance(x, SplitAct) and x.wino:
         if upsample:
@@ -102,10 +102,9 @@ def wsplit_chain_arith(B, cin, cout, H, W, f):
 
 def xs_chain_arith(B, cin, cout, H, W, nxt_cout):
     """Arithmetic of the plain split hand-over from an F(4,3) layer (B, cin -> cout @ H x W) to the transposed conv cout -> nxt_cout
-    that follows it: 'fp16f8' when Config.cross_terms says so, the producer's launch takes the wide-tile kernel (the only writer of that
-    form) and the consumer runs its deep plan (the only reader); else None."""
+    that follows it: 'fp16f8' when Config.cross_terms says so and the consumer runs its deep plan (the only reader of the form; both
+    F(4,3) kernels write it); else None."""
     if config().precision == 'fp16x3' and config().cross_terms == 'fp8' and \
-            _shape_query('sgdfr_modconv2d_wsplit_wide', B, cin, cout, H, W) and \
             _shape_query('sgdfr_modconv2d_split_f8_ok', B, cout, nxt_cout, H, W, N.MODE_UP3) and \
             _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cout, nxt_cout, H, W, N.MODE_UP3) == 1:
         return 'fp16f8'

@@ -36,7 +36,8 @@ __device__ unsigned int g_wsplit_saturated = 0;     // clamped operand pairs of 
 
 // POS = transform positions of the 1-D Winograd form: 4 = F(2,3) (two outputs per tile), 6 = F(4,3) (four outputs per tile:
 // 18 instead of 36 MFMA columns per 16 channels and output quad, V 1.5x and U 2x the direct operands' bytes).
-template <int ET, int POS>
+// XSF8: the hand-over's lo chunks leave as fp8 cross-term operands (SGDFR_SPLIT_HANDOVER_F8; its own instantiation, as in wswide.hip)
+template <int ET, int POS, bool XSF8 = false>
 __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
     constexpr int NT = 128;
     constexpr int OUTP = POS - 2;                 // output pixels per tile
@@ -430,8 +431,11 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
                             };
                             swap32(h01[0], h01[1]); swap32(h23[0], h23[1]); swap32(l01[0], l01[1]); swap32(l23[0], l23[1]);
                             unsigned char* const d16 = dst - 8 * hi + 16 * (2 * pp + hi);
-                            *reinterpret_cast<uint4*>(d16) = make_uint4(h01[0], h23[0], h01[1], h23[1]);
-                            *reinterpret_cast<uint4*>(d16 + (int64_t)HW * 16) = make_uint4(l01[0], l23[0], l01[1], l23[1]);
+                            const uint4 vh = make_uint4(h01[0], h23[0], h01[1], h23[1]);
+                            uint4 vl = make_uint4(l01[0], l23[0], l01[1], l23[1]);
+                            if constexpr (XSF8) ws_f8_lo_chunk(vh, vl, exp2f((float)WS_F8_XLO), exp2f((float)WS_F8_XHI), false);
+                            *reinterpret_cast<uint4*>(d16) = vh;
+                            *reinterpret_cast<uint4*>(d16 + (int64_t)HW * 16) = vl;
                         }
                     }
                 }
@@ -757,7 +761,6 @@ extern "C" int sgdfr_modconv2d_wsplit_f32(const unsigned short* v, const unsigne
         const int rc = wswide_try_launch(p, arith, stream);
         if (rc >= 0) return rc;
     }
-    SGDFR_REQUIRE(!xs_f8, "modconv_wsplit: SGDFR_SPLIT_HANDOVER_F8 is written by the wide-tile kernel only (ask sgdfr_modconv2d_wsplit_wide())");
     SGDFR_REQUIRE(arith != SGDFR_SPLIT_FP16F8,
                   "modconv_wsplit: SGDFR_SPLIT_FP16F8 runs on the wide-tile kernel only (Cin %% 32 == 0, Cin >= 64, Cout %% 128 == 0, W %% 32 == 0, "
                   "H %% 16 == 0, d and bias given); got Cin=%d Cout=%d H=%d W=%d", Cin, Cout, H, W);
@@ -771,7 +774,7 @@ extern "C" int sgdfr_modconv2d_wsplit_f32(const unsigned short* v, const unsigne
     }
     // V double buffer + four weight half-slabs + tables: f = 2: 80 + 64 + 3.5 KB, f = 4: 60 + 96 + 3.5 KB (of 160)
     const size_t lds = 2 * (size_t)(f + 2) * 64 * p.xs + 4 * (size_t)((f + 2) / 2) * 8192 + 7 * 128 * sizeof(float);
-    void (*kern)(WsParams) = arith == SGDFR_SPLIT_FP16 ? (f == 2 ? wsplit_kernel<SGDFR_SPLIT_FP16, 4> : wsplit_kernel<SGDFR_SPLIT_FP16, 6>)
+    void (*kern)(WsParams) = arith == SGDFR_SPLIT_FP16 ? (f == 2 ? wsplit_kernel<SGDFR_SPLIT_FP16, 4> : xs_f8 ? wsplit_kernel<SGDFR_SPLIT_FP16, 6, true> : wsplit_kernel<SGDFR_SPLIT_FP16, 6>)
                                                         : (f == 2 ? wsplit_kernel<SGDFR_SPLIT_BF16, 4> : wsplit_kernel<SGDFR_SPLIT_BF16, 6>);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();

@@ -579,7 +579,7 @@ def modconv_wsplit(vs, shape, wsp, d, cout, noise=None, noise_weight=None, bias=
                    arith=None, rgb=None, want_y=True, s_next=None, desc=None, f=2, xs_arith=None):
     """Plain 3x3 modulated conv of a WS input (to_wsplit / the blur's Winograd hand-over; shape = (B, Cin, H, W)) with the pack of
     prepack_wsplit (same f).  Outputs as modconv_split with a pre-split input: y | (y, part) | (y, part, xs_out).  xs_arith='fp16f8':
-    the hand-over xs_out carries the fp8 cross-term operands (for a next conv launched with that arithmetic; wide-tile kernel only)."""
+    the hand-over xs_out carries the fp8 cross-term operands (for a next conv launched with that arithmetic; f = 4)."""
     arith = _WSPLIT_ARITH[arith or config().precision]
     if xs_arith not in (None, 'fp16f8'):
         raise ValueError("modconv_wsplit: xs_arith is None or 'fp16f8'")

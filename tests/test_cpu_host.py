@@ -217,9 +217,11 @@ def test_winograd_layer_plan_of_the_bench_configs():
     with F_.using(F_.config().replace(cross_terms='fp8')):
         assert [p[5] for p in G._chain_plan(64, True, noise, layers)] == [None] * 5 + ['fp16f8', None, 'fp16f8', None, 'fp16f8', None, 'fp16f8', None]      # (the last one: plain form, for the direct 64 -> 64 @ 256^2 layer)
         # ... and those layers hand over to the transposed convs after them (deep plan) in the same form
-        assert [p[6] for p in G._chain_plan(64, True, noise, layers)] == [None] * 6 + ['fp16f8', None, 'fp16f8', None, 'fp16f8', None, None]
+        assert [p[6] for p in G._chain_plan(64, True, noise, layers)] == [None] * 4 + ['fp16f8', None, 'fp16f8', None, 'fp16f8', None, 'fp16f8', None, None]
         assert [p[5] for p in G._chain_plan(4, True, noise, layers)] == [None] * len(layers)
-        assert [p[6] for p in G._chain_plan(4, True, noise, layers)] == [None] * len(layers)
+        # (B=4: only the 128 @ 128^2 layer is in F(4,3) form -- on the 64-tile kernel -- and the last transposed conv just reaches its deep plan)
+        assert [p[6] for p in G._chain_plan(4, True, noise, layers)] == [None] * 10 + ['fp16f8', None, None]
+        assert [p[6] for p in G._chain_plan(2, True, noise, layers)] == [None] * len(layers)
         with F_.precision('bf16x3'):                                                                      # the saturation fallback keeps its own arithmetic
             assert [p[5] for p in G._chain_plan(64, True, noise, layers)] == [None] * len(layers)
     assert lib.sgdfr_modconv2d_wsplit_wide(64, 256, 256, 64, 64) == 1 and lib.sgdfr_modconv2d_wsplit_wide(64, 512, 512, 16, 16) == 0

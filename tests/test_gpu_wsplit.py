@@ -123,6 +123,13 @@ def test_fp8_cross_terms_on_the_wide_kernel(cin, cout, H, W, B, persist, monkeyp
         assert torch.equal(y, out[arith][0]) and torch.equal(part, out[arith][1])
         assert torch.equal(xs[:, :, 0], out[arith][2][:, :, 0])
         assert torch.equal(xs, F_.to_split(y, sn, 'fp16f8'))
+    # ... and from the 64-tile kernel (the layers whose tile count keeps them there: 512 @ 16^2 at B=64)
+    monkeypatch.setenv('SGDFR_WSPLIT_WIDE_NOW', '0')
+    vs = F_.to_wsplit(x, s, 'fp16x3', f=4)
+    wsp = F_.prepack_wsplit(w, 'fp16x3', f=4)
+    y, part, xs = F_.modconv_wsplit(vs, (B, cin, H, W), wsp, d, cout, noise, nw, bias, True, arith='fp16x3', f=4, rgb=rgb, s_next=sn, want_y=True,
+                                    xs_arith='fp16f8')
+    assert torch.equal(y, out['fp16x3'][0]) and torch.equal(xs, F_.to_split(y, sn, 'fp16f8'))
 
 
 WIDE_CASES = [  # cin, cout, H, W, B, persist
