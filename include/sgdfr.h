@@ -265,8 +265,9 @@ int sgdfr_torgb_fwd_f32(const float* x, const float* w_rgb, const float* s, cons
                                 |x*s| saturates at 1.04e6 */
 #define SGDFR_SPLIT_FP16F8 2 /* fp16 main term + fp8 (e4m3) cross terms: the "lo" chunk of eight channels holds (8 x fp8 | 8 x fp8)
                                 instead of 8 x fp16, both cross terms of 32 K-elements are one v_mfma_scale_f32_32x32x64_f8f6f4:
-                                2 MFMA units per product instead of 3, ~1e-5 of max|y| per layer.  Only the F(4,3) wide-tile
-                                conv (sgdfr_modconv2d_wsplit_f32, f = 4), its pack and its WS producers take it */
+                                2 MFMA units per product instead of 3, ~1e-5 of max|y| per layer (5e-5 in F(4,3) form).  Taken by
+                                the F(4,3) wide-tile conv (sgdfr_modconv2d_wsplit_f32, f = 4), the transposed conv's deep plan and
+                                the 4-wave plain plan (sgdfr_modconv2d_split_f8_ok), their packs and the producers of their inputs */
 int64_t sgdfr_modconv_prepack_split_elems(int Cout, int Cin);
 int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned short* wsp, int Cout, int Cin, int arith, int transpose_flip,
                                     unsigned int* sat, void* stream);
@@ -330,7 +331,9 @@ int sgdfr_modconv2d_split_ksplit_hint(int B, int Cin, int Cout, int H, int W, in
  *   sgdfr_modconv2d_wsplit_f32:        outputs as sgdfr_modconv2d_split_f32 (PLAIN3, ksplit = 1, x_is_split = 1): y (may be
  *                                      NULL when xs_out or rgb_part is given), the next conv's split input xs_out (+ s_next),
  *                                      ToRGB partial sums rgb_part [B][(Cout/128)*3][H*W] (+ rgb_w, rgb_s).
- * arith = SGDFR_SPLIT_FP16F8 (f = 4 only, in all three calls and in sgdfr_blur_bias_act_split_f32 with wino = 4): the fp16 main
+ * arith = SGDFR_SPLIT_FP16F8 (f = 4 only, in all three calls and in sgdfr_blur_bias_act_split_f32 with wino = 4; the direct kernels'
+ * side of it -- sgdfr_to_split_f32, sgdfr_modconv_prepack_split_f32, sgdfr_modconv2d_split_f32 where sgdfr_modconv2d_split_f8_ok(),
+ * sgdfr_blur_bias_act_split_f32 with wino = 0 -- uses the same chunk format): the fp16 main
  * term plus BOTH cross terms in fp8 -- the 16-byte lo chunk of eight channels holds two 8-byte halves (channels 0-3, 4-7) of
  * (4 x e4m3 lo * 2^7 | 4 x e4m3 hi * 2^-4) for activations and (4 x e4m3 hi * 2^-EW | 4 x e4m3 lo * 2^(11-EW)) for weights; the
  * pack's 16-byte trailer keeps max |w * scale|, from which the kernels derive EW.  Same buffer sizes and shapes as the fp16 forms.

@@ -71,7 +71,7 @@ struct WsParams {
     float slope, gain;
     int dbg;
     int desync;                  // first-round start spread: estimated block time in 4096-clock units (0 = off)
-    int xs_f8;                   // the hand-over's lo chunks as fp8 cross-term operands (SGDFR_SPLIT_HANDOVER_F8; wide-tile kernel only)
+    int xs_f8;                   // the hand-over's lo chunks as fp8 cross-term operands (SGDFR_SPLIT_HANDOVER_F8: the XSF8 instantiations of both F(4,3) kernels)
     FastDiv fd_xs, fd_tiles_x, fd_per_img, fd_npt;
 };
 
