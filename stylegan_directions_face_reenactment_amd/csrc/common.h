@@ -146,17 +146,22 @@ __device__ __forceinline__ unsigned ws_f8x4(float v0, float v1, float v2, float 
 // The fp8 "lo" chunk of eight channels is two 8-byte halves (channels 0-3, 4-7), each (4 x first | 4 x second): first = lo, second =
 // hi for activations, first = hi, second = lo for weights -- so byte k of a weight chunk meets byte k of an activation chunk in
 // w_hi * x_lo or w_lo * x_hi.  One half from the packed fp16 pairs of its four channels:
-__device__ __forceinline__ uint2 ws_f8_half(unsigned h01, unsigned h23, unsigned l01, unsigned l23, float mul_lo, float mul_hi, bool weights_order) {
+// `sat` counts the halves whose hi term had to be clamped (the lo term follows it: |lo| <= 2^-11 |hi|, and the two exponents differ by
+// 11) -- into the caller's saturation word, like a clamped fp16 pair: a batch louder than 2^2.8 x the calibrated maximum is re-rendered
+// under a wider plan instead of running its cross terms at single-fp16 accuracy.
+__device__ __forceinline__ uint2 ws_f8_half(unsigned h01, unsigned h23, unsigned l01, unsigned l23, float mul_lo, float mul_hi, bool weights_order,
+                                            unsigned& sat) {
     const ws_f32x2 a = __builtin_convertvector(__builtin_bit_cast(ws_f16x2, h01), ws_f32x2), b = __builtin_convertvector(__builtin_bit_cast(ws_f16x2, h23), ws_f32x2);
     const ws_f32x2 c = __builtin_convertvector(__builtin_bit_cast(ws_f16x2, l01), ws_f32x2), d = __builtin_convertvector(__builtin_bit_cast(ws_f16x2, l23), ws_f32x2);
+    sat += (fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(b[0]), fabsf(b[1]))) * mul_hi > 448.f) ? 1u : 0u;
     const unsigned hi8 = ws_f8x4(a[0], a[1], b[0], b[1], mul_hi), lo8 = ws_f8x4(c[0], c[1], d[0], d[1], mul_lo);
     return weights_order ? make_uint2(hi8, lo8) : make_uint2(lo8, hi8);
 }
 
 // hi chunk (8 x fp16) + lo chunk (8 x fp16) of eight channels -> the lo chunk rewritten as fp8
-__device__ __forceinline__ void ws_f8_lo_chunk(const uint4& vh, uint4& vl, float mul_lo, float mul_hi, bool weights_order) {
-    const uint2 h0 = ws_f8_half(vh.x, vh.y, vl.x, vl.y, mul_lo, mul_hi, weights_order);
-    const uint2 h1 = ws_f8_half(vh.z, vh.w, vl.z, vl.w, mul_lo, mul_hi, weights_order);
+__device__ __forceinline__ void ws_f8_lo_chunk(const uint4& vh, uint4& vl, float mul_lo, float mul_hi, bool weights_order, unsigned& sat) {
+    const uint2 h0 = ws_f8_half(vh.x, vh.y, vl.x, vl.y, mul_lo, mul_hi, weights_order, sat);
+    const uint2 h1 = ws_f8_half(vh.z, vh.w, vl.z, vl.w, mul_lo, mul_hi, weights_order, sat);
     vl = make_uint4(h0.x, h0.y, h1.x, h1.y);
 }
 

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void to_split_kernel(const float* __restrict__
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             split_pair<ETM>(xp[(int64_t)(2 * c) * HW] * (sp[2 * c] * sc), xp[(int64_t)(2 * c + 1) * HW] * (sp[2 * c + 1] * sc), ph[c], pl[c], sat);
-        if (ET == SGDFR_SPLIT_FP16F8) ws_f8_lo_chunk(vh, vl, exp2f((float)WS_F8_XLO), exp2f((float)WS_F8_XHI), false);
+        if (ET == SGDFR_SPLIT_FP16F8) ws_f8_lo_chunk(vh, vl, exp2f((float)WS_F8_XLO), exp2f((float)WS_F8_XHI), false, sat);
         unsigned char* dst = xs + ((bg * 2) * HW + pix) * 16;
         *reinterpret_cast<uint4*>(dst) = vh;
         *reinterpret_cast<uint4*>(dst + (int64_t)HW * 16) = vl;

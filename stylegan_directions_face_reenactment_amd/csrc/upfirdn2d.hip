@@ -482,7 +482,7 @@ __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(c
                     *reinterpret_cast<uint2*>(dst + (int64_t)(2 * tt) * HT * 16) = make_uint2(h01, h23);
                     // (fp8 cross terms: this thread's half of the lo chunk = (4 x lo | 4 x hi) in e4m3, wsplit_common.h)
                     *reinterpret_cast<uint2*>(dst + (int64_t)(2 * tt + 1) * HT * 16) =
-                        ET == SGDFR_SPLIT_FP16F8 ? ws_f8_half(h01, h23, l01, l23, f8_mul_lo, f8_mul_hi, false) : make_uint2(l01, l23);
+                        ET == SGDFR_SPLIT_FP16F8 ? ws_f8_half(h01, h23, l01, l23, f8_mul_lo, f8_mul_hi, false, sat) : make_uint2(l01, l23);
                 }
             }
         } else if (WINO == 2) {
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(8 * QC * NG, WINO ? 3 : 4) void blur_split_kernel(c
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc)
                     blur_split2<ET>(tile[row][px][2 * cc] * sv[2 * cc], tile[row][px][2 * cc + 1] * sv[2 * cc + 1], ph[cc], pl[cc], sat);
-                if (ET == SGDFR_SPLIT_FP16F8) ws_f8_lo_chunk(vh, vl, f8_mul_lo, f8_mul_hi, false);      // (fp8 cross-term operands, common.h)
+                if (ET == SGDFR_SPLIT_FP16F8) ws_f8_lo_chunk(vh, vl, f8_mul_lo, f8_mul_hi, false, sat);      // (fp8 cross-term operands, common.h)
                 unsigned char* dst = xs + ((((int64_t)b * G + g) * 2) * OHW + (int64_t)oy * OW + ox) * 16;
 #if defined(SGDFR_BLUR_PROBE) && SGDFR_BLUR_PROBE == 1      // ablation: no stores (unless a value is NaN: keeps the work alive)
                 if (vh.x == 0x7fc07fc0u)

@@ -433,7 +433,7 @@ __global__ __launch_bounds__(512, 1) void wsplit_kernel(WsParams p) {
                             unsigned char* const d16 = dst - 8 * hi + 16 * (2 * pp + hi);
                             const uint4 vh = make_uint4(h01[0], h23[0], h01[1], h23[1]);
                             uint4 vl = make_uint4(l01[0], l23[0], l01[1], l23[1]);
-                            if constexpr (XSF8) ws_f8_lo_chunk(vh, vl, exp2f((float)WS_F8_XLO), exp2f((float)WS_F8_XHI), false);
+                            if constexpr (XSF8) ws_f8_lo_chunk(vh, vl, exp2f((float)WS_F8_XLO), exp2f((float)WS_F8_XHI), false, sat);
                             *reinterpret_cast<uint4*>(d16) = vh;
                             *reinterpret_cast<uint4*>(d16 + (int64_t)HW * 16) = vl;
                         }
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void to_wsplit_kernel(const float* __restrict_
             unsigned* pl = reinterpret_cast<unsigned*>(&vl);
 #pragma unroll
             for (int c = 0; c < 4; ++c) ws_pair<ETM>(v[t][2 * c], v[t][2 * c + 1], ph[c], pl[c], sat);
-            if (ET == SGDFR_SPLIT_FP16F8) ws_f8_lo_chunk(vh, vl, exp2f((float)WS_F8_XLO), exp2f((float)WS_F8_XHI), false);
+            if (ET == SGDFR_SPLIT_FP16F8) ws_f8_lo_chunk(vh, vl, exp2f((float)WS_F8_XLO), exp2f((float)WS_F8_XHI), false, sat);
             unsigned char* dst = vs + (((bg * POS + t) * 2) * HT + pos) * 16;
             *reinterpret_cast<uint4*>(dst) = vh;
             *reinterpret_cast<uint4*>(dst + (int64_t)HT * 16) = vl;

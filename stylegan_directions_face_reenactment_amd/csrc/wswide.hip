@@ -449,7 +449,7 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
                             unsigned char* const d16 = dst - 8 * hi_e + 16 * (2 * pp + hi_e);
                             const uint4 vh = make_uint4(h01[0], h23[0], h01[1], h23[1]);
                             uint4 vl = make_uint4(l01[0], l23[0], l01[1], l23[1]);
-                            if constexpr (XSF8) ws_f8_lo_chunk(vh, vl, f8_mul_lo, f8_mul_hi, false);      // (the next conv reads fp8 cross-term operands)
+                            if constexpr (XSF8) ws_f8_lo_chunk(vh, vl, f8_mul_lo, f8_mul_hi, false, sat);      // (the next conv reads fp8 cross-term operands)
                             *reinterpret_cast<uint4*>(d16) = vh;
                             *reinterpret_cast<uint4*>(d16 + (int64_t)HW * 16) = vl;
                         }

@@ -156,6 +156,23 @@ def test_fp8_cross_terms_stay_inside_the_contract_at_bench_size():
         ref, _ = O.generator_forward(synthetic_state(256, 1), [w[62:64].cpu()], input_is_latent=True)
         assert maxabs(img[62:64], ref) <= 5e-4                       # (north-star bar: 1e-3)
         assert maxabs(base[62:64], ref) <= IMG_TOL
+        # A batch louder than the fp8 operands' range but NOT than the fp16 terms' (one noise map x 2^11: that layer's input lands between
+        # 2^12.8 and 2^16 of the fp16 domain): the clamped cross-term halves are counted like clamped fp16 pairs, so the (verifying)
+        # call measures the batch, widens the plan and renders again -- instead of handing back single-fp16 cross terms.
+        G2 = hip_generator(256, 1)
+        with F_.using(F_.config().replace(cross_terms='fp8')):
+            G2([w], input_is_latent=True)
+            plan0 = list(G2._range_state['x_log2'])
+            loud = [getattr(G2.noises, 'noise_%d' % i) * (2.0 ** 11 if i == 8 else 1.0) for i in range(G2.num_layers)]
+            got, _ = G2([w], input_is_latent=True, noise=loud)
+            assert G2.saturated_pairs() > 0 and G2.range_mode() == 'fp16x3'
+            plan1 = list(G2._range_state['x_log2'])
+            assert max(b - a for a, b in zip(plan0, plan1)) >= 2 and all(b >= a for a, b in zip(plan0, plan1))
+        ref_loud, _ = O.generator_forward(synthetic_state(256, 1), [w[62:64].cpu()], input_is_latent=True, noise=[n.cpu() for n in loud])
+        scale = max(1.0, float(ref_loud.abs().max()) / 8)
+        print('loud fp8 batch: %.2e vs the oracle (|image| <= %.1f), plan widened by %d binades' % (
+            maxabs(got[62:64], ref_loud), float(ref_loud.abs().max()), max(b - a for a, b in zip(plan0, plan1))))
+        assert maxabs(got[62:64], ref_loud) <= 5e-4 * scale
 
 
 def test_noise_modes_and_truncation_quirks():

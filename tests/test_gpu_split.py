@@ -169,6 +169,14 @@ def test_fp8_cross_term_chunks_of_the_split_form():
     x = S.counter_tensor(8, 'f8fmt.x', (B, cin, h, h)).cuda() * 2.0 ** 12
     x[0, 0, 0, 0] = 2.0 ** 19                                          # beyond the fp8 range of the cross terms: clamps, not NaN
     s = S.counter_tensor(8, 'f8fmt.s', (B, cin), 1.0, 0.3).cuda()
+    words = {}
+    for arith in ('fp16x3', 'fp16f8'):
+        words[arith] = F_.new_saturation_word(x.device)
+        with F_.saturation_sink(words[arith]):
+            F_.to_split(x, s, arith)
+    torch.cuda.synchronize()
+    # the clamped half is COUNTED (the range plan's verification then re-renders such a batch); the fp16 terms themselves fit
+    assert int(words['fp16x3'].item()) == 0 and int(words['fp16f8'].item()) == 1
     a, b = F_.to_split(x, s, 'fp16x3'), F_.to_split(x, s, 'fp16f8')    # [B, cin/8, 2, HW, 8] int16
     assert torch.equal(a[:, :, 0], b[:, :, 0])
     hi, lo = a[:, :, 0].view(torch.float16).float(), a[:, :, 1].view(torch.float16).float()
