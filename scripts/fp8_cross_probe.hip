@@ -20,7 +20,8 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-// FORM 0: three fp16 products; 1: fp16 main term + fp8 cross terms; 2: the main term alone (what dropping both cross terms would run at)
+// FORM 0: three fp16 products; 1: fp16 main term + fp8 cross terms; 2: the main term alone (what dropping both cross terms would run at);
+// 3: fp16 main term + fp6 (e2m3) cross terms -- the same instruction at format code 2: 32 clocks for K = 64 (fragment reads left as they are)
 template <int FORM, int DMA>
 __global__ __launch_bounds__(512, 1) void cross_probe(float* out, const unsigned* seed, int iters, unsigned long long* clk, const unsigned char* src) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -77,14 +78,15 @@ __global__ __launch_bounds__(512, 1) void cross_probe(float* out, const unsigned
                                                                              acc[m][n], 0, 0, 0);
                         }
                     }
-            if (FORM == 1) {
+            if (FORM == 1 || FORM == 3) {
 #pragma unroll
                 for (int m = 0; m < MI; ++m)
 #pragma unroll
                     for (int n = 0; n < NI; ++n) {
                         const i32x8 a8 = {a[1][0][m][0], a[1][0][m][1], a[1][0][m][2], a[1][0][m][3], a[1][1][m][0], a[1][1][m][1], a[1][1][m][2], a[1][1][m][3]};
                         const i32x8 b8 = {b[1][0][n][0], b[1][0][n][1], b[1][0][n][2], b[1][0][n][3], b[1][1][n][0], b[1][1][n][1], b[1][1][n][2], b[1][1][n][3]};
-                        acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[m][n], 0, 0, 0, scale_a, 0, scale_b);
+                        if (FORM == 1) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[m][n], 0, 0, 0, scale_a, 0, scale_b);
+                        else acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[m][n], 2, 2, 0, scale_a, 0, scale_b);
                     }
             }
             if (step % 3 == 2) __builtin_amdgcn_s_barrier();
@@ -147,11 +149,13 @@ int main() {
         const double a0 = run<0, 0>("fp16 x 3, no DMA", seed, src);
         const double a1 = run<1, 0>("fp16 main + fp8 cross terms, no DMA", seed, src);
         const double a2 = run<2, 0>("fp16 main term alone, no DMA", seed, src);
+        const double a3 = run<3, 0>("fp16 main + fp6 cross terms, no DMA", seed, src);
         const double b0 = run<0, 25>("fp16 x 3, operand DMA", seed, src);
         const double b1 = run<1, 25>("fp16 main + fp8 cross terms, operand DMA", seed, src);
         const double b2 = run<2, 25>("fp16 main term alone, operand DMA", seed, src);
-        printf("  speed-up of the fp8 cross terms: x%.2f without DMA, x%.2f with (ideal 1.50); main term alone x%.2f / x%.2f (ideal 3)\n", a0 / a1, b0 / b1,
-               a0 / a2, b0 / b2);
+        const double b3 = run<3, 25>("fp16 main + fp6 cross terms, operand DMA", seed, src);
+        printf("  speed-up of the fp8 cross terms: x%.2f without DMA, x%.2f with (ideal 1.50); fp6: x%.2f / x%.2f (ideal 2); main term alone x%.2f / x%.2f (ideal 3)\n",
+               a0 / a1, b0 / b1, a0 / a3, b0 / b3, a0 / a2, b0 / b2);
     }
     return 0;
 }
