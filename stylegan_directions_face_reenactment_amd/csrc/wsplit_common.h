@@ -71,8 +71,9 @@ struct WsParams {
     float slope, gain;
     int dbg;
     int desync;                  // first-round start spread: estimated block time in 4096-clock units (0 = off)
-    int xs_f8;                   // the hand-over's lo chunks as fp8 cross-term operands (SGDFR_SPLIT_HANDOVER_F8: the XSF8 instantiations of both F(4,3) kernels)
     FastDiv fd_xs, fd_tiles_x, fd_per_img, fd_npt;
+    // (last: the fields above keep the offsets the kernels' scalar loads were tuned with -- moving them cost wsplit_kernel 450 SGPR reloads)
+    int xs_f8;                   // the hand-over's lo chunks as fp8 cross-term operands (SGDFR_SPLIT_HANDOVER_F8: the XSF8 instantiations of both F(4,3) kernels)
 };
 
 template <int N>

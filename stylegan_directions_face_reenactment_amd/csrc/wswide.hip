@@ -330,13 +330,14 @@ __global__ __launch_bounds__(512, 1) void wswide_kernel(WsParams p) {
             using ph0 = std::integral_constant<int, 0>;
             using ph1 = std::integral_constant<int, 1>;
             using ph2 = std::integral_constant<int, 2>;
+            if constexpr (!F8) {
 #pragma unroll 1
-            for (int cb = 0; cb < ncb;) {
-                if constexpr (!F8) {
-                    group(cb, ph0{}); ++cb; ++G;
-                } else {                              // (Cin % 32 == 0: the launcher's condition)
-                    group(cb, ph1{}); ++cb; ++G;
-                    group(cb, ph2{}); ++cb; ++G;
+                for (int cb = 0; cb < ncb; ++cb, ++G) group(cb, ph0{});
+            } else {                                  // (Cin % 32 == 0: the launcher's condition)
+#pragma unroll 1
+                for (int cb = 0; cb < ncb; cb += 2) {
+                    group(cb, ph1{}); ++G;
+                    group(cb + 1, ph2{}); ++G;
                 }
             }
             // fold M_t into the output transform (see above)
