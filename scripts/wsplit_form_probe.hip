@@ -108,7 +108,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void form_probe(float* out, const un
 }
 
 template <int WAVES, int MI, int NI, int DMA, int FILL10 = 0, int ST = 0, int BAR = 1>
-void run(const char* name, const unsigned* seed_dev, const unsigned char* src, uint4* sink) {
+void run(const char* name, const unsigned* seed_dev, const unsigned char* src, uint4* sink, double alg_per_issued = 2.0) {
     float* out; unsigned long long* clk;
     const int blocks = 256, iters = 3000 / (MI * NI);
     hipMalloc(&out, sizeof(float) * blocks * WAVES * 64); hipMalloc(&clk, 8);
@@ -127,7 +127,7 @@ void run(const char* name, const unsigned* seed_dev, const unsigned char* src, u
     }
     const double mfmas = (double)iters * 54 * MI * NI;          // per wave
     const double flops = (double)blocks * WAVES * mfmas * 2.0 * 32 * 32 * 16;
-    const double alg = flops / 3 * 2;                            // F(4,3): half the MFMA work of the direct form, 3 products per fp32 product
+    const double alg = flops / 3 * alg_per_issued;               // F(4,3): half the MFMA work of the direct form (2.0), 3 products per fp32 product
     hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void*)kern);
     printf("%-44s waves %d tile %dx%d regs %3d: %8.3f ms %7.1f TF 16-bit issued = %6.1f algorithmic fp32 TF, clock %.2f GHz, MFMA duty %.2f, %5.1f clk/MFMA/SIMD\n",
            name, WAVES, 32 * MI, 32 * NI, fa.numRegs, best, flops / best / 1e9, alg / best / 1e9, c / (best * 1e6), mfmas * 32 * (WAVES / 4) / (double)c,
@@ -171,6 +171,19 @@ int main() {
         // ... and with four waves of 64 x 64
         run<4, 2, 2, 0>("128x128 4w 64x64, no DMA", dr, src, sink);
         run<4, 2, 2, 50>("128x128 4w 64x64 + DMA 50/216", dr, src, sink);
+        // Round 6: the TRANSPOSED conv (split_kernel.h deep plan: block 64 couts x 256 super-pixels, 8 waves of
+        // 32 x 64, all nine taps of a channel block per stage) as a 1-D Winograd form along x -- the even output phase is a 2-tap
+        // correlation (kx in {0, 2}), the odd phase 1 tap -- priced at each form's operand bytes per MFMA.  Per block and 16-channel block:
+        //   direct      9 taps: W 36 KB + X 16 KB per 432 MFMAs (120 B / MFMA)                              -> 13 pieces per 108 MFMAs of a wave
+        //   F(2,2) on x 7.5 taps: U (3 + 1) / 3 x 36 KB + V (3 + 2) / 2 x 16 KB per 360 MFMAs (244 B / MFMA)   -> 26 per 108
+        //   F(4,2) on x 6.75 taps: U (5 + 1) / 3 x 36 KB + V (5 + 4) / 4 x 16 KB per 324 MFMAs (333 B / MFMA)  -> 36 per 108
+        // (a Winograd position has its own U_t AND its own V_t: the nine taps of the direct form share ONE staged x image)
+        run<8, 1, 2, 0>("up direct 8w 32x64, no DMA", dr, src, sink, 1.0);
+        run<8, 1, 2, 13>("up direct 8w 32x64 + DMA 13/108", dr, src, sink, 1.0);
+        run<8, 1, 2, 26>("up F(2,2)x 8w 32x64 + DMA 26/108", dr, src, sink, 9.0 / 7.5);
+        run<8, 1, 2, 36>("up F(4,2)x 8w 32x64 + DMA 36/108", dr, src, sink, 9.0 / 6.75);
+        // ... the output transform A^T M of the even phase folded into the loop (wswide's position-outer arrangement): ~0.5 VALU per MFMA
+        run<8, 1, 2, 36, 5>("up F(4,2)x + DMA 36/108 + filler 0.5", dr, src, sink, 9.0 / 6.75);
         // what the filler costs the 8-wave form (the deferred epilogue is a 4-wave idea; for reference)
         run<8, 1, 1, 22, 14, 2>("today 8w + DMA + filler 1.4 + 2 st", dr, src, sink);
     }

@@ -78,10 +78,25 @@ def styled_conv_split(x, wsp, s, d, cout, upsample=False, fir=None, noise=None, 
     return blur_bias_act(planes, fir, H, W, noise, noise_weight, bias, True), None
 
 
+def _interleaved_planes_ok(B, cin, H, W):
+    """256-wide rows reach the Winograd hand-over only from INTERLEAVED padded parity planes (sgdfr_blur_bias_act_split_f32 REQUIREs
+    them for an input W of 128): styled_conv_split takes that branch when plane padding is on, the library's SGDFR_PLANE_IL switch is
+    not 0 and the producing transposed conv (?->cin at H/2 x W/2) is not K-sliced.  Otherwise the plain layer stays on the direct
+    kernel (a cm=2 generator under use_plane_padding=False raised instead)."""
+    import os
+    if not config().use_plane_padding or os.environ.get('SGDFR_PLANE_IL', '1') == '0':
+        return False
+    # (the producer's Cin is not known here -- this generator's channel table steps by x1 or x2 between resolutions; the hint
+    #  depends on the block count, and on Cin only through the cap of two channel blocks per slice)
+    return all(_shape_query('sgdfr_modconv2d_split_ksplit_hint', B, c, cin, H // 2, W // 2, N.MODE_UP3) == 1 for c in (cin, 2 * cin))
+
+
 def wsplit_chain_f(B, cin, cout, H, W):
     """Winograd form the inference chain runs this plain layer (fed by a transposed conv + blur) in: 0 (direct), 2 or 4 outputs
     per tile."""
     if not (config().use_wsplit and config().use_split_chain and config().wsplit_min_cin > 0 and cin >= config().wsplit_min_cin and W <= 256):
+        return 0
+    if W > 128 and not _interleaved_planes_ok(B, cin, H, W):
         return 0
     for f in ((4, 2) if config().wsplit_f == 4 else (2,)):
         # (F(2,3) hands over 8 bytes per element and saves a third of the MFMAs: it only pays from 256 input channels on;
@@ -91,10 +106,16 @@ def wsplit_chain_f(B, cin, cout, H, W):
     return 0
 
 
+def _f8_cross_on():
+    """The opt-in fp8 cross terms apply: fp16x3 with the CALIBRATED range plan -- the fixed e4m3 exponents (WS_F8_XHI / WS_F8_XLO)
+    assume the plan has put max|x*s| near 2^10; without it the cross terms would fall into e4m3 subnormals silently."""
+    return config().precision == 'fp16x3' and config().cross_terms == 'fp8' and config().range_plan is True
+
+
 def wsplit_chain_arith(B, cin, cout, H, W, f):
     """Arithmetic of a plain layer the chain runs in F(f,3) form: 'fp16f8' (fp16 main term + fp8 cross terms, Config.cross_terms) when
     its launch takes the wide-tile kernel anyway -- the only reader of that form -- else None (the ambient precision)."""
-    if f == 4 and config().precision == 'fp16x3' and config().cross_terms == 'fp8' and cin % 32 == 0 and \
+    if f == 4 and _f8_cross_on() and cin % 32 == 0 and \
             _shape_query('sgdfr_modconv2d_wsplit_wide', B, cin, cout, H, W):
         return 'fp16f8'
     return None
@@ -104,7 +125,7 @@ def xs_chain_arith(B, cin, cout, H, W, nxt_cout):
     """Arithmetic of the plain split hand-over from an F(4,3) layer (B, cin -> cout @ H x W) to the transposed conv cout -> nxt_cout
     that follows it: 'fp16f8' when Config.cross_terms says so and the consumer runs its deep plan (the only reader of the form; both
     F(4,3) kernels write it); else None."""
-    if config().precision == 'fp16x3' and config().cross_terms == 'fp8' and \
+    if _f8_cross_on() and \
             _shape_query('sgdfr_modconv2d_split_f8_ok', B, cout, nxt_cout, H, W, N.MODE_UP3) and \
             _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cout, nxt_cout, H, W, N.MODE_UP3) == 1:
         return 'fp16f8'
@@ -115,7 +136,7 @@ def xs_plain_arith(B, cin, cout, H, W):
     """Arithmetic of the plain split hand-over from a transposed conv + blur to the DIRECT plain conv (B, cin -> cout @ H x W) after it:
     'fp16f8' when Config.cross_terms says so and that conv runs the plan that reads the form (sgdfr_modconv2d_split_f8_ok: the 4-wave
     plan of the 64 -> 64 @ 256^2 layer), without K slices; else None."""
-    if config().precision == 'fp16x3' and config().cross_terms == 'fp8' and \
+    if _f8_cross_on() and \
             _shape_query('sgdfr_modconv2d_split_f8_ok', B, cin, cout, H, W, N.MODE_PLAIN3) and \
             _shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cin, cout, H, W, N.MODE_PLAIN3) == 1:
         return 'fp16f8'

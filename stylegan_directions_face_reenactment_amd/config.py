@@ -53,6 +53,9 @@ class Config:
             raise ValueError("backward_arith must be 'fp16x3' or 'bf16x3', got %r" % (self.backward_arith,))
         if self.cross_terms not in ('fp16', 'fp8'):
             raise ValueError("cross_terms must be 'fp16' or 'fp8', got %r" % (self.cross_terms,))
+        if self.cross_terms == 'fp8' and self.precision == 'fp16x3' and self.range_plan is not True:
+            raise ValueError("cross_terms='fp8' needs the calibrated range plan (range_plan=True): its fixed fp8 exponents assume "
+                             "range-shifted operands")
         if self.wsplit_f not in (2, 4):
             raise ValueError('wsplit_f must be 2 or 4')
 

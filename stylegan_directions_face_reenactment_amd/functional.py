@@ -22,6 +22,7 @@ from torch.autograd import Function
 from . import _native as N
 from . import config as _config
 from .config import Config, config, precision, set_default, set_precision, using      # noqa: F401  (the facade's exports)
+from . import timing
 from .timing import timed_conv as _timed_conv, timed_hbm as _timed_hbm
 
 SQRT2 = 2 ** 0.5
@@ -447,6 +448,20 @@ _SPLIT_ARITH = {'bf16x3': N.SPLIT_BF16, 'fp16x3': N.SPLIT_FP16}
 _WSPLIT_ARITH = dict(_SPLIT_ARITH, fp16f8=N.SPLIT_FP16F8)
 
 
+def _f8_tag(arith):
+    """Suffix of a conv launch's timing description when its cross terms run as ONE fp8 MFMA (SGDFR_SPLIT_FP16F8): bench.py prices
+    those rows against 1/(1/2500 + 1/5000) = 1667 TFLOP/s (one fp16 + one fp8 MFMA per product), not the three-fp16-product peak."""
+    return ' [f8 cross]' if (arith & 0xff) == N.SPLIT_FP16F8 else ''
+
+
+def _plan_tag(B, cin, cout, H, W, mode, ks):
+    """'/deep' for transposed-conv launches on split_kernel.h's deep plan (<1,1,2,4,1,2,2,1,true>: all nine taps of a channel block per
+    stage -- the kernel VERDICT r5 calls dominant), so bench.py can report that instantiation apart from the small K-sliced layers."""
+    if mode == N.MODE_UP3 and ks <= 1 and timing.active() is not None and _shape_query('sgdfr_modconv2d_split_f8_ok', B, cin, cout, H, W, mode):
+        return '/deep'
+    return ''
+
+
 def prepack_split(weight, arith=None, adjoint=False):
     """weight [1,Cout,Cin,3,3] -> uint16 buffer of 16-bit hi/lo terms of weight/sqrt(9 Cin) in split.hip's LDS order
     (arith: 'bf16x3' or 'fp16x3', default = the current PRECISION; adjoint: True = the pack of dL/dx of the plain conv,
@@ -531,7 +546,8 @@ def modconv_split(x, wsp, s, d, cout, noise=None, noise_weight=None, bias=None, 
         tiles = _shape_query('sgdfr_modconv2d_split_cout_tiles_xin' if (x_split is not None and ks <= 1) else
                              'sgdfr_modconv2d_split_cout_tiles', B, cin, cout, H, W, mode)
         part = torch.empty(B, tiles * 3, H, W, device=x.device, dtype=torch.float32)
-    _timed_conv(desc or ('split mode%d %d->%d @%dx%d%s' % (mode, cin, cout, H, W, ' K/%d' % ks if ks > 1 else '')),
+    _timed_conv((desc or ('split mode%d%s %d->%d @%dx%d%s' % (mode, _plan_tag(B, cin, cout, H, W, mode, ks), cin, cout, H, W,
+                                                              ' K/%d' % ks if ks > 1 else ''))) + _f8_tag(arith),
                 B * conv_flops(cin, cout, H, W), lambda: N.call(
         'sgdfr_modconv2d_split_f32', N.ptr(x), xb, N.ptr(wsp), N.ptr(s), N.ptr(d), N.ptr(nz), nzb,
         N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(_zero_words(x.device)), N.ptr(y),
@@ -602,7 +618,7 @@ def modconv_wsplit(vs, shape, wsp, d, cout, noise=None, noise_weight=None, bias=
         rgb_w, rgb_s = N.f32c(rgb[0]), N.f32c(rgb[1])
         N.require_device(rgb_w, rgb_s)
         part = torch.empty(B, (cout // 128) * 3, H, W, device=vs.device, dtype=torch.float32)
-    _timed_conv(desc or ('wsplit F(%d,3) %d->%d @%dx%d' % (f, cin, cout, H, W)), B * conv_flops(cin, cout, H, W), lambda: N.call(
+    _timed_conv((desc or ('wsplit F(%d,3) %d->%d @%dx%d' % (f, cin, cout, H, W))) + _f8_tag(arith), B * conv_flops(cin, cout, H, W), lambda: N.call(
         'sgdfr_modconv2d_wsplit_f32', N.ptr(vs), N.ptr(wsp), N.ptr(d), N.ptr(nz), nzb,
         N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(_zero_words(vs.device)), N.ptr(y), N.ptr(rgb_w),
         N.ptr(rgb_s), N.ptr(part), N.ptr(xs_out), N.ptr(s_next) if s_next is not None else None, B, cin, cout, H, W, f, arith,

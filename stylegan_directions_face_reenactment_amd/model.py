@@ -530,12 +530,18 @@ class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
         bf16x3 arithmetic before returning (what generate_image and ReenactmentSession use: a clamped frame is never handed
         back).  Without it the forward returns at once and leaves a RangeToken (take_range_token / range_ok); unchecked
         tokens are polled without blocking by the following forwards."""
-        styles_in, noise_in = styles, noise            # (a clamped batch is rendered a second time from the caller's arguments)
+        styles_in = styles                             # (a clamped batch is rendered a second time from the caller's styles)
         if not input_is_latent:
             styles = [self.style(s) for s in styles]
         if noise is None:
             noise = [None] * self.num_layers if randomize_noise else \
                 [getattr(self.noises, 'noise_{}'.format(i)) for i in range(self.num_layers)]
+            if randomize_noise and verify_range and not torch.is_grad_enabled():
+                # a verified forward may have to render the batch a second time: draw the per-image noise HERE (what NoiseInjection
+                # would draw, model.py:296-298) so that the second pass renders the same image
+                nb = styles[0].shape[0]
+                noise = [torch.randn(nb, 1, 2 ** (2 + (i + 1) // 2), 2 ** (2 + (i + 1) // 2), device=styles[0].device)
+                         for i in range(self.num_layers)]
         trunc = truncation_latent if truncation < 1 else None
         if truncation < 1 and truncation_latent is None:
             raise RuntimeError('truncation < 1 needs truncation_latent')
@@ -596,9 +602,11 @@ class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
             # generator to bf16x3 and -- while the budget of automatic widenings lasts -- asked for a recalibration: the second
             # pass below measures THIS batch, widens the plan and renders in fp16x3 again (verified like the first); without
             # budget it renders in bf16 terms (fp32 exponent range, nothing to verify).
-            if depth <= self.AUTO_RECALIBRATIONS:
+            # (rendered again from the caller's styles with THIS pass's resolved inject_index and noise tensors -- the same image,
+            #  not a new random draw; a token that is merely suspect / stale asked for no recalibration: straight to bf16 terms)
+            if depth <= self.AUTO_RECALIBRATIONS and (getattr(self, '_range_state', None) or {}).get('recal'):
                 return self._forward_impl(styles_in, return_latents, return_features, inject_index, truncation, truncation_latent,
-                                          input_is_latent, noise_in, randomize_noise, image_out, True, depth + 1)
+                                          input_is_latent, noise, False, image_out, True, depth + 1)
             with F_.precision('bf16x3'):
                 return self._synthesis(latent, F_.styles_batched(latent, specs), layers, to_rgbs, noise, False, False,
                                        return_latents, image_out)

@@ -16,10 +16,12 @@ class RangeToken:
     when the token is checked (Generator.range_ok / the non-blocking poll of the next forward).  `stamp` = the weights the forward
     ran on (a saturation of OLD weights must not switch the arithmetic of new ones); `suspect`: another forward that was in flight
     beside this one (other HIP stream) clamped operands and the shared word cannot tell the two apart -- range_ok() says False."""
-    __slots__ = ('event', 'snap', 'delta', 'stamp', 'suspect')
+    __slots__ = ('event', 'snap', 'delta', 'stamp', 'suspect', 'version')
 
-    def __init__(self, event, snap, stamp=None):
+    def __init__(self, event, snap, stamp=None, version=0):
         self.event, self.snap, self.delta, self.stamp, self.suspect = event, snap, None, stamp, False
+        self.version = version      # the range plan's version the forward ran under: a clamp under a plan that has since been
+                                    # widened is no evidence against the widened one (range_ok re-renders, but does not fall back)
 
 
 _PINNED_WORDS = []      # free list of pinned int32 [1] host tensors (a fresh pin_memory() per forward would cost ~20 us)
@@ -37,7 +39,8 @@ class RangePlanMixin:
     # WIDENS the plan (element-wise max with the old one), returning the generator to fp16x3 -- at most this many times per
     # weight version (then bf16x3 stays: 1.1e-4 instead of 1.4e-5 from the fp64 evaluation, still inside the 1e-3 contract).
     AUTO_RECALIBRATIONS = 3
-    CALIBRATION_ROWS = 8            # rows of the first batch the initial calibration looks at (a recalibration takes up to 64)
+    CALIBRATION_ROWS = 8            # rows of the first batch the initial calibration looks at (a recalibration takes every row,
+    CALIBRATION_CHUNK = 64          #  this many at a time)
 
     def _sat_word(self):
         """This generator's saturation word (functional.saturation_sink): one int32 on the weights' device, owned by the
@@ -68,7 +71,7 @@ class RangePlanMixin:
         ev = torch.cuda.Event()
         ev.record()
         st = getattr(self, '_range_state', None)
-        tok = RangeToken(ev, snap, st['stamp'] if st is not None else None)
+        tok = RangeToken(ev, snap, st['stamp'] if st is not None else None, st.get('version', 0) if st is not None else 0)
         self._sat_tokens.append(tok)
         return tok
 
@@ -143,7 +146,9 @@ class RangePlanMixin:
         if token.delta:
             st = getattr(self, '_range_state', None)
             # (a token of weights that have since been replaced: re-render, but leave the NEW weights' calibrated plan alone)
-            if st is not None and (token.stamp is None or token.stamp == st['stamp']):
+            # (nor a token of a plan that has been widened since: the other chunk of a StreamPipeline would otherwise spend a second
+            #  widening credit and drop the graphs on evidence that belongs to the old plan)
+            if st is not None and (token.stamp is None or token.stamp == st['stamp']) and token.version == st.get('version', 0):
                 self._fall_back(token.delta, 'in the forward just checked')
             return False
         return not token.suspect
@@ -184,20 +189,25 @@ class RangePlanMixin:
         conv's input: x_log2[l] = floor(log2 max)+1 feeds the range plan of functional.styles_batched.  Runs once per weight
         version (tracked like the weight packs; after `.data` edits call invalidate_packs()) and once per widening
         (recalibrate_ranges / after a fallback).  One device->host read."""
-        n = min(latent.shape[0], max_rows or self.CALIBRATION_ROWS)
-        lat = latent[:n].contiguous()
-        words = torch.zeros(len(layers), device=latent.device, dtype=torch.int32)
-        with F_.precision('fp32'):
-            sd = F_.styles_batched(lat, specs)
-            sd_of_layer = [0] + [2 + 3 * (i // 2) + (i % 2) for i in range(len(self.convs))]
-            x = self.input.input
-            for li, layer in enumerate(layers):
-                F_.absmax(x, per_image=False, out=words[li:li + 1])
-                nz = noise[li]
-                if nz is not None and nz.shape[0] not in (1, n):
-                    nz = nz[:n]
-                x = layer(x, None, noise=nz, batch=n if li == 0 else None, sd=sd[sd_of_layer[li]], ranged=True)
-        bits = words.cpu().tolist()
+        rows = min(latent.shape[0], max_rows or self.CALIBRATION_ROWS)
+        chunks = []
+        sd_of_layer = [0] + [2 + 3 * (i // 2) + (i % 2) for i in range(len(self.convs))]
+        for r0 in range(0, rows, self.CALIBRATION_CHUNK):          # (a B > 64 batch is measured 64 rows at a time: fp32 intermediates)
+            n = min(self.CALIBRATION_CHUNK, rows - r0)
+            lat = latent[r0:r0 + n].contiguous()
+            words = torch.zeros(len(layers), device=latent.device, dtype=torch.int32)
+            with F_.precision('fp32'):
+                sd = F_.styles_batched(lat, specs)
+                x = self.input.input
+                for li, layer in enumerate(layers):
+                    F_.absmax(x, per_image=False, out=words[li:li + 1])
+                    nz = noise[li]
+                    if nz is not None and nz.shape[0] != 1:
+                        nz = nz[r0:r0 + n]
+                    x = layer(x, None, noise=nz, batch=n if li == 0 else None, sd=sd[sd_of_layer[li]], ranged=True)
+            chunks.append(words)
+        # (max of non-negative floats == max of their bit patterns as int32; NaN/Inf patterns sort above every finite one)
+        bits = torch.stack(chunks).max(0).values.cpu().tolist()
         x_log2, bad = [], False
         for b in bits:
             v = struct.unpack('f', struct.pack('I', b & 0xffffffff))[0]
@@ -228,10 +238,11 @@ class RangePlanMixin:
                               'kernels until its weights change', RuntimeWarning, stacklevel=3)
         elif st.get('recal') and not capturing:
             # a fallback (or recalibrate_ranges) asked for it: measure THIS batch, every row, and widen / replace the plan
-            x_log2, bad = self._calibrate_ranges(latent, noise, specs, layers, max_rows=64)
+            x_log2, bad = self._calibrate_ranges(latent, noise, specs, layers, max_rows=latent.shape[0])
             if self._sat_tokens:
                 self._check_tokens(upto=self._sat_tokens[-1])
             st['recal'] = False
+            st['version'] = st.get('version', 0) + 1        # tokens taken under the old plan stop counting against this one
             st['recal_left'] = st.get('recal_left', self.AUTO_RECALIBRATIONS) - 1
             if bad:
                 st['mode'] = 'bf16x3'                  # non-finite activations in this batch: no plan can hold them

@@ -88,12 +88,24 @@ def _run_bench(*argv, env=None, timeout=280, retry_abort=True):
     r = subprocess.run(cmd, capture_output=True, text=True, env=e, timeout=timeout)
     if r.returncode != 0 and 'Signal 6' in r.stderr and retry_abort:
         # One rank of an 8-process gloo launch on this 8-core container has been seen to die with SIGABRT about once in five
-        # suite runs (never reproduced by the same command outside pytest): keep the evidence, try once more, fail if it repeats.
-        with open(os.path.join(tempfile.gettempdir(), 'sgdfr_bench_abort_%d.log' % os.getpid()), 'a') as f:
+        # suite runs (never reproduced by the same command outside pytest; bench.py now leaves through distributed.shutdown()):
+        # keep the evidence, REPORT the retry in the test summary (a warning), try once more, fail if it repeats.
+        import warnings
+        log = os.path.join(tempfile.gettempdir(), 'sgdfr_bench_abort_%d.log' % os.getpid())
+        with open(log, 'a') as f:
             f.write(' '.join(cmd) + '\n' + r.stderr + '\n')
+        warnings.warn('bench.py %s died with SIGABRT once and was retried (log: %s)' % (' '.join(argv), log), RuntimeWarning)
         r = subprocess.run(cmd, capture_output=True, text=True, env=e, timeout=timeout)
-    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
-    return r, (json.loads(lines[-1]) if lines else None)
+    out = r.stdout.splitlines()
+    if not out or not out[-1].startswith('{'):
+        return r, None
+    # the driver's view: the LAST stdout line, alone, compact (bench.LINE_LIMIT); the tables travel on the BENCH_DETAIL stderr line
+    assert sum(l.startswith('{') for l in out) == 1, 'bench.py must print exactly one JSON line on stdout'
+    assert len(out[-1]) <= 4096, 'the bench line is %d bytes: the driver stopped parsing it at ~21 KB in round 5' % len(out[-1])
+    line = json.loads(out[-1])
+    detail = [l for l in r.stderr.splitlines() if l.startswith('BENCH_DETAIL ')]
+    line['_detail'] = json.loads(detail[-1][len('BENCH_DETAIL '):]) if detail else None
+    return r, line
 
 
 @pytest.mark.timeout(300)
@@ -102,10 +114,11 @@ def test_bench_gpus2_spawns_two_ranks_host_check():
     weight broadcast, contiguous shards -- is checked on CPU tensors over gloo."""
     r, line = _run_bench('--gpus', '2', '--host-check', '--size', '32', '--batch', '64')
     assert r.returncode == 0, r.stderr[-2000:]
-    assert line['n_gpus'] == 2 and line['backend'] == 'gloo'
-    assert line['shards'] == [[0, 64], [64, 128]]
-    assert line['weights_identical_on_all_ranks'] is True
-    assert line['weight_broadcast_bytes'] > 4 * 20e6
+    full = line['_detail']
+    assert line['n_gpus'] == 2 and full['backend'] == 'gloo'
+    assert full['shards'] == [[0, 64], [64, 128]]
+    assert full['weights_identical_on_all_ranks'] is True
+    assert line['config']['weight_broadcast_bytes'] > 4 * 20e6
 
 
 @pytest.mark.timeout(600)
@@ -114,18 +127,22 @@ def test_bench_gpus8_host_check_with_rank_affinity():
     every rank pinned to its own non-empty CPU slice (distributed.bind_rank)."""
     r, line = _run_bench('--gpus', '8', '--host-check', '--size', '32', '--batch', '64', timeout=560)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert line['n_gpus'] == 8 and line['backend'] == 'gloo'
-    assert line['shards'] == [[64 * i, 64 * (i + 1)] for i in range(8)]
-    assert line['weights_identical_on_all_ranks'] is True
-    aff = line['rank_affinity']
+    full = line['_detail']
+    assert line['n_gpus'] == 8 and full['backend'] == 'gloo'
+    assert full['shards'] == [[64 * i, 64 * (i + 1)] for i in range(8)]
+    assert full['weights_identical_on_all_ranks'] is True
+    aff = full['rank_affinity']
     assert len(aff) == 8 and all(a['bound'] and a['n_cpus'] >= 1 for a in aff)
     host = len(os.sched_getaffinity(0))
     # the JSON contract of an N > 1 line (VERDICT r4 #8): bench.finalize_line has checked this line's keys; here the test pins
     # what the 8-rank line carries -- a roofline object, cpu_baseline null WITH a reason, the last rank's oracle field
     assert line['scaling'] == 'weak' and line['config']['global_batch'] == 8 * 64 and line['vs_baseline'] is None
+    # (the compact line the driver parses carries them all; the detail object keeps the long form)
+    from bench import CONTRACT_KEYS
+    assert set(CONTRACT_KEYS) <= set(line)
     assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(line['roofline'])
     assert line['cpu_baseline']['value'] is None and 'N=1' in line['cpu_baseline']['reason']
-    assert 'last_rank_shard' in line['max_abs_vs_oracle']
+    assert 'last_rank_shard' in full['max_abs_vs_oracle']
     if host >= 8:       # disjoint slices that cover the host's allowed CPUs
         from stylegan_directions_face_reenactment_amd.distributed import parse_cpulist
         sets = [set(parse_cpulist(a['cpus'])) for a in aff]

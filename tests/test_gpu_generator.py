@@ -269,6 +269,25 @@ def test_split_chain_is_bit_identical_to_layer_by_layer():
         assert G.saturated_pairs() == 0 or F_.PRECISION != 'fp16x3'     # nothing of this generator hit the fp16 clamp
 
 
+def test_cm2_generator_without_plane_padding_takes_the_direct_kernel_at_256():
+    """the Winograd hand-over of 256-wide rows exists only on interleaved padded planes; with plane padding off the
+    128 -> 128 @ 256^2 layer of a cm=2 generator must stay on the direct kernel (it raised before) and give the same image
+    within the arithmetic's bound."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    if F_.PRECISION == 'fp32':
+        pytest.skip('the chain exists only for the split arithmetics')
+    G = hip_generator(256, 2)
+    w = S.synthetic_latents(SEED, 8, n_latent=G.n_latent, key='nopad.w').cuda()
+    with torch.no_grad():
+        a, _ = G([w], input_is_latent=True)
+        G.config = F_.config().replace(use_plane_padding=False)
+        assert F_.wsplit_chain_f(8, 128, 128, 256, 256) == 4
+        with F_.using(G.config):
+            assert F_.wsplit_chain_f(8, 128, 128, 256, 256) == 0 and F_.wsplit_chain_f(8, 256, 256, 128, 128) == 4
+        b, _ = G([w], input_is_latent=True)
+    assert maxabs(a, b) <= IMG_TOL
+
+
 def test_winograd_chain_layers_stay_within_the_per_image_bound():
     """The wide plain layers of the chain run in 1-D Winograd form (F(4,3) by default, F(2,3) with functional.WSPLIT_F = 2;
     csrc/wsplit.hip, fed by the blur's transformed hand-over): a different summation order, so not bit-identical to the direct
