@@ -1065,13 +1065,17 @@ def run_trainer(args, rank, world, dev):
     lo, hi = D.shard_range(B * world, rank, world)
     zs = S.synthetic_z(SEED, B * world, key='train.zs')[lo:hi].contiguous().to(dev)
     zt = S.synthetic_z(SEED, B * world, key='train.zt')[lo:hi].contiguous().to(dev)
+    zst = torch.cat([zs, zt])
     losses = []
 
     def step():                                                                       # trainer.py:155-189
         with torch.no_grad():
-            imgs_source, _ = generate_image(G, zs, 0.7, trunc, input_is_latent=False, return_latents=True)
+            # trainer.py:157-166 renders source and target with two generator calls; the images of a batch do not depend on their
+            # neighbours (tests/test_gpu_generator.py::test_batch_independence_at_bench_size), so both go through ONE forward of
+            # 2B rows -- the same frames, fuller tiles
+            both = generate_image(G, zst, 0.7, trunc, input_is_latent=False, return_latents=False)
+            imgs_source, imgs_target = both[:B], both[B:]
             params_source, angles_source = deca(imgs_source)
-            imgs_target = generate_image(G, zt, 0.7, trunc, input_is_latent=False, return_latents=False)
             params_target, angles_target = deca(imgs_target)
             shift_vector, which = shifts.make_shift_vector_50(params_source, params_target, angles_source, angles_target)
         shift = A(shift_vector)
@@ -1098,8 +1102,7 @@ def run_trainer(args, rank, world, dev):
     # where the step goes: generator-only legs timed on their own (same shapes), the rest is the loss heads + optimizer
     def gen_only():
         with torch.no_grad():
-            generate_image(G, zs, 0.7, trunc, input_is_latent=False)
-            generate_image(G, zt, 0.7, trunc, input_is_latent=False)
+            generate_image(G, zst, 0.7, trunc, input_is_latent=False)
         sv = S.counter_tensor(SEED, 'train.sv', (B, 15), 0.0, 3.0).to(dev)
         im = generate_image(G, zs, 0.7, trunc, shift_code=A(sv), input_is_latent=False)
         A.zero_grad()
@@ -1117,7 +1120,7 @@ def run_trainer(args, rank, world, dev):
     if rank != 0:
         return None
     out = base_line(args, world, 'direction-learning samples/sec @%dx%d' % (args.size, args.size), 'samples/s', B * world * args.steps / elapsed, elapsed,
-                    '%dxMI355X libs/trainer.py step: 2 no-grad forwards + shape-model stand-in, make_shift_vector_50 on device, grad '
+                    '%dxMI355X libs/trainer.py step: source + target frames in one no-grad forward of 2B rows + shape-model stand-in, make_shift_vector_50 on device, grad '
                     'forward + backward to A through the HIP Generator(%d,cm=%d) (frozen), IR-SE-50 id loss + LPIPS-shaped stack + '
                     'DECA stand-in (PyTorch-ROCm, random weights), all-reduce of dA, Adam; B=%d per GPU'
                     % (world, args.size, args.cm, B),
@@ -1131,7 +1134,7 @@ def run_trainer(args, rank, world, dev):
     out['dtype'] = DTYPE[args.precision] + ('; backward: dL/dx convs in the same fp16 hi+lo arithmetic, range-planned per image from max|g| (bf16 hi+lo with '
                                             'SGDFR_BWD_ARITH=bf16x3), no weight gradients (G frozen), everything else f32' if args.precision != 'fp32' else '')
     out['roofline'] = roof
-    out['roofline']['note'] = ('conv launches of the generator legs of a step (2 no-grad forwards + grad forward + the dL/dx convs of '
+    out['roofline']['note'] = ('conv launches of the generator legs of a step (the no-grad forward of 2B rows + grad forward + the dL/dx convs of '
                                'the backward), loss heads excluded')
     return out
 

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 18
+#define SGDFR_ABI_VERSION 19
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -450,6 +450,42 @@ int sgdfr_scale_reduce_f32(const float* gu, const float* x, int64_t x_bstride, c
 /* ToRGB backward: dx[b,i,p] = s[b,i]/sqrt(Cin) * sum_j w_rgb[j,i] g[b,j,p] ; r[b,j,i] = sum_p x[b,i,p] g[b,j,p] */
 int sgdfr_torgb_bwd_f32(const float* x, const float* g, const float* w_rgb, const float* s, float* dx, float* r, int B,
                         int Cin, int H, int W, void* stream);
+
+/* One pass over a saved StyledConv activation `out` [B,C,HW] in the backward of the frozen generator (libs/trainer.py:177-189:
+ * only A is optimised).  The gradient of `out` arrives as up to three terms,
+ *     g = gu * s_next[b,c]                                             (gu [B,C,HW] = dL/d(x*s) of the conv that reads `out`)
+ *       + s_rgb[b,c]/sqrt(C) * sum_j w_rgb[j,c] * g_rgb[b,j,p]         (g_rgb [B,3,HW] = gradient of the ToRGB that reads `out`)
+ *       + g_add                                                        (any of the three may be NULL, not all)
+ * and the pass returns, besides everything sgdfr_act_grad_reduce_f32 computes from g for the layer that PRODUCED `out`
+ * (g_pre, sums [B,C,3], g_absmax [B,C]):  r_next[b,c] += sum_p out*gu  (sgdfr_scale_reduce_f32's r)  and
+ * r_rgb[b,j,c] += sum_p out*g_rgb[b,j]  (sgdfr_torgb_bwd_f32's r).  zero_outputs != 0: the call zeroes sums / g_absmax / r_next /
+ * r_rgb first; 0: the caller carved them out of a zeroed workspace (one memset per backward instead of four per layer). */
+int sgdfr_grad_join_f32(const float* out, const float* gu, const float* s_next, const float* g_rgb, const float* w_rgb,
+                        const float* s_rgb, const float* g_add, const float* noise, int64_t noise_bstride, const float* noise_w,
+                        const float* bias, float* g_pre, float* sums, unsigned int* g_absmax, float* r_next, float* r_rgb, int B,
+                        int C, int HW, float slope, float gain, int want_y, int zero_outputs, void* stream);
+
+/* Backward of sgdfr_styles_batched_f32 with respect to the latent (frozen weights), all layers in two launches:
+ *   ds_l = gs_l + s_l * ((-(a_l / d_l) * d_l^3) @ qt_l^T)      demodulated 3x3 conv (a = d * dL/dd: sums[:,:,2] of the activation-
+ *                                                             gradient pass with a_stride 3, or the blur adjoint's asum, stride 1)
+ *   ds_l = gs_l                                                a == NULL
+ *   ds_l[b,i] = (sum_j rgb_r[b,j,i] * rgb_w[j,i]) / sqrt(cin)  ToRGB (rgb_r [B,3,cin] = sum_p x*g_j, rgb_w [3,cin])
+ *   glat[b, latent_index_l, :] = sum_l ds_l[b,:] @ mod_w_l / sqrt(D);  latent rows no layer reads are written as zeros. */
+typedef struct sgdfr_style_grad_layer {
+    const float* gs;    /* [B, cin] or NULL (rgb_r given) */
+    const float* rgb_r; /* [B, 3, cin] or NULL */
+    const float* rgb_w; /* [3, cin] */
+    const float* a;     /* [B, cout] with element stride a_stride, or NULL */
+    const float* d;     /* [B, cout] */
+    const float* s;     /* [B, cin] */
+    const float* qt;    /* [cin, cout] */
+    const float* mod_w; /* [cin, D] */
+    float* ds;          /* [B, cin] out */
+    long long a_stride;
+    int cin, cout, latent_index;
+} sgdfr_style_grad_layer;
+int sgdfr_styles_batched_bwd_f32(const sgdfr_style_grad_layer* layers, int n_layers, float* glat, int B, int L, int D,
+                                 void* stream);
 
 /* ds[b,i] = gs[b,i] + s[b,i] * sum_o (-gd[b,o] * d[b,o]^3) * qt[i,o]   (chain rule through d = rsqrt(sum s^2 q + eps)) */
 int sgdfr_demod_grad_f32(const float* gd, const float* d, const float* qt, const float* s, const float* gs, float* ds,

@@ -12,7 +12,7 @@ from stylegan_directions_face_reenactment_amd.generic import generate_image
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-    freeze = (sys.argv[2] != 'full') if len(sys.argv) > 2 else True
+    freeze = 'full' not in sys.argv[2:]
     G = Generator(256, 512, 8, channel_multiplier=1)
     G.load_state_dict(S.synthetic_state_dict(G.state_dict(), seed=7))
     G = G.eval().cuda()
@@ -24,11 +24,17 @@ def main():
     trunc = S.counter_tensor(7, 'trunc', (1, 512)).cuda()
     z_s, z_t = S.synthetic_z(7, B, key='zs').cuda(), S.synthetic_z(7, B, key='zt').cuda()
     sv = S.counter_tensor(7, 'sv', (B, 15), 0.0, 3.0).cuda()
+    z_st = torch.cat([z_s, z_t])
+    two_calls = 'two_calls' in sys.argv[2:]
+    G.fused_frozen_backward = 'per_layer' not in sys.argv[2:]        # (the whole-synthesis Function is the default)
     import warnings; warnings.simplefilter('ignore')
     def step():
         with torch.no_grad():
-            generate_image(G, z_s, 0.7, trunc, input_is_latent=False, return_latents=True)
-            generate_image(G, z_t, 0.7, trunc, input_is_latent=False, return_latents=True)
+            if two_calls:
+                generate_image(G, z_s, 0.7, trunc, input_is_latent=False, return_latents=True)
+                generate_image(G, z_t, 0.7, trunc, input_is_latent=False, return_latents=True)
+            else:       # source and target rows in one forward (what bench.py --config trainer does)
+                generate_image(G, z_st, 0.7, trunc, input_is_latent=False, return_latents=True)
         opt.zero_grad()
         img, lat = generate_image(G, z_s, 0.7, trunc, shift_code=A(sv), input_is_latent=False, return_latents=True)
         (img ** 2).mean().backward()

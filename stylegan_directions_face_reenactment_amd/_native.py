@@ -23,7 +23,7 @@ if os.environ.get('SGDFR_LIB'):
     else:
         import warnings as _warnings
         _warnings.warn('SGDFR_LIB is set but ignored (set SGDFR_ALLOW_LIB_OVERRIDE=1 to load a probe build)', RuntimeWarning)
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -113,6 +113,19 @@ SIGNATURES['sgdfr_split_range_f32'] = [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctype
 SIGNATURES['sgdfr_absmax_f32'] = [_c_f32p, _i64, _i64, _i, ctypes.c_void_p, _i, ctypes.c_void_p]
 SIGNATURES['sgdfr_styles_batched_f32'] = [_c_f32p, _i, _i, _i, ctypes.POINTER(StyleLayer), _i, ctypes.c_void_p]
 MAX_STYLE_LAYERS = 40
+
+
+class StyleGradLayer(ctypes.Structure):
+    """struct sgdfr_style_grad_layer (include/sgdfr.h)."""
+    _fields_ = [('gs', ctypes.c_void_p), ('rgb_r', ctypes.c_void_p), ('rgb_w', ctypes.c_void_p), ('a', ctypes.c_void_p),
+                ('d', ctypes.c_void_p), ('s', ctypes.c_void_p), ('qt', ctypes.c_void_p), ('mod_w', ctypes.c_void_p),
+                ('ds', ctypes.c_void_p), ('a_stride', ctypes.c_longlong), ('cin', ctypes.c_int), ('cout', ctypes.c_int),
+                ('latent_index', ctypes.c_int)]
+
+
+SIGNATURES['sgdfr_styles_batched_bwd_f32'] = [ctypes.POINTER(StyleGradLayer), _i, _c_f32p, _i, _i, _i, ctypes.c_void_p]
+SIGNATURES['sgdfr_grad_join_f32'] = ([_c_f32p] * 7 + [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p,
+                                                                  _c_f32p, _c_f32p, _i, _i, _i, _f, _f, _i, _i, ctypes.c_void_p])
 SIGNATURES['sgdfr_modconv2d_wsplit_supported'] = [_i, _i, _i, _i, _i, _i]
 SIGNATURES['sgdfr_modconv2d_wsplit_wide'] = [_i, _i, _i, _i, _i]
 SIGNATURES['sgdfr_modconv2d_split_f8_ok'] = [_i, _i, _i, _i, _i, _i]

@@ -187,6 +187,61 @@ class StylesBatchedFn(Function):
 
 # ------------------------------------------------------------------ modulated convs
 
+
+def _conv_input_grad(mod, g_pre, g_max, d, planes, shape, bw_arith, want_planes_grad):
+    """dL/d(x*s) of one modulated 3x3 conv from the gradient g_pre of its (pre-activation) output -- the MFMA part of a layer's
+    backward, shared by the per-layer Function and the frozen generator's whole-synthesis Function.
+    Returns (gu [B,Cin,H,W], A = sum gT*T [B,Cout] for the transposed conv (else None), gT = the fp32 plane gradient when
+    want_planes_grad (the weight gradient reads it) and the conv is a transposed one, else None)."""
+    B, cin, cout, H, W = shape
+    up = mod.upsample
+    dev = g_pre.device
+    ones_d = d if d is not None else F_.ones_like_rows(B, cout, dev)
+    # Arithmetic of the dL/dx convs on the split kernels.  'bf16x3': 8+8-bit terms, fp32 range -- needs no scale.
+    # 'fp16x3' (functional.BACKWARD_ARITH): 11+11-bit terms like the forward, made usable for gradients (which have no
+    # natural scale) by the same exact power-of-two plan as the forward: e from the true max |g| of each image, d * 2^e
+    # on the way in, 2^-e on the way out.
+    d_in, d_out = ones_d, None
+    if bw_arith == 'fp16x3':
+        # (max |g_pre| per image comes out of the activation-gradient pass.  The plane gradient of the transposed conv is the
+        # adjoint of the 4x4 blur FIR, whose taps are scaled by factor^2 and sum to 4 (model.py:78-79): |gT| <= 4 max |g_pre|,
+        # two binades of headroom; with the true maximum and that headroom finite gradients cannot saturate)
+        d_in, d_out = F_.split_range(ones_d, F_.ones_like_rows(B, cin, dev), g_max, headroom=2 if up else 0)
+    A = gT = None
+    if up:
+        split_down = F_.config().precision != 'fp32' and F_.split_ok(B, cout, cin, H, W, N.MODE_DOWN3)
+        if split_down and not want_planes_grad:
+            # frozen weights: only the conv below reads the plane gradient -> the blur adjoint writes it directly in the
+            # conv's split input form (no fp32 planes, no conversion pass)
+            gxs, A = F_.blur_adjoint_split(g_pre, mod.blur.kernel, planes if d is not None else None,
+                                           d_in if (d is not None or d_out is not None) else None, bw_arith)
+        else:
+            gT, A = F_.blur_adjoint(g_pre, mod.blur.kernel, planes if d is not None else None)
+            gxs = F_.planes_to_split(gT, d_in if (d is not None or d_out is not None) else None, bw_arith) if split_down else None
+        if split_down:
+            # dL/d(x*s) of the transposed conv on the split kernels too (bw_arith terms, see above):
+            # the planes times d come in the phase-major split form, the conv walks (channel block, phase) pairs
+            gu = F_.modconv_split(gxs, mod.packed_split(adjoint='down', arith=bw_arith), None, d_out, cin, mode=N.MODE_DOWN3,
+                                  arith=bw_arith, x_split=(B, cout, H, W), batch=B,
+                                  desc='bwd split down3 %d->%d @%dx%d' % (cout, cin, H, W))
+        else:
+            gu = F_.modconv_raw(gT, mod.packed_t(), ones_d, None, cin, N.MODE_DOWN3, H, W,
+                                desc='bwd down3 %d->%d @%dx%d' % (cout, cin, H, W))
+    else:
+        if F_.split_ok(B, cout, cin, H, W):    # dL/dx of a plain conv is a plain conv: same kernels, adjoint packs.
+            # Gradients have no natural scale (1e-8 is as likely as 1e+3): the fp16 terms are planned from max |g_pre| of each
+            # image (d_in / d_out above), bf16 terms (fp32 range, 2^-17 per product) need no plan.
+            gu = F_.modconv_split(g_pre, mod.packed_split(adjoint=True, arith=bw_arith), d_in, d_out, cin,
+                                  desc='bwd split3 %d->%d @%dx%d' % (cout, cin, H, W), arith=bw_arith)
+        elif F_.wino_ok(B, cout, cin, H, W):
+            gu = F_.modconv_wino(g_pre, mod.packed_wino(adjoint=True), ones_d, None, cin,
+                                 desc='bwd wino3 %d->%d @%dx%d' % (cout, cin, H, W))
+        else:
+            gu = F_.modconv_raw(g_pre, mod.packed_t(), ones_d, None, cin, N.MODE_PLAIN3, H, W,
+                                desc='bwd plain3 %d->%d @%dx%d' % (cout, cin, H, W))
+    return gu, A, gT
+
+
 class StyledConvFn(Function):
     """act(d * conv(x*s, Wc) + noise_w*noise + bias)  -- StyledConv.forward (model.py:331-337), plain or upsampling.
     `mod` is the owning ModulatedConv2d (packed weights, FIR taps, shapes); it is not a tensor input."""
@@ -228,50 +283,8 @@ class StyledConvFn(Function):
         else:
             (g_pre, sums), g_max = F_.act_grad_reduce(g, out, noise, noise_w, bias, want_y=(not up) and d is not None,
                                                       slope=slope, gain=gain), None
-        ones_d = d if d is not None else F_.ones_like_rows(B, cout, out.device)
-        # Arithmetic of the dL/dx convs on the split kernels.  'bf16x3': 8+8-bit terms, fp32 range -- needs no scale.
-        # 'fp16x3' (functional.BACKWARD_ARITH): 11+11-bit terms like the forward, made usable for gradients (which have no
-        # natural scale) by the same exact power-of-two plan as the forward: e from the true max |g| of each image, d * 2^e
-        # on the way in, 2^-e on the way out.
-        d_in, d_out = ones_d, None
-        if bw_arith == 'fp16x3':
-            # (max |g_pre| per image comes out of the act_grad_reduce pass.  The plane gradient of the transposed conv is the
-            # adjoint of the 4x4 blur FIR, whose taps are scaled by factor^2 and sum to 4 (model.py:78-79): |gT| <= 4 max |g_pre|,
-            # two binades of headroom; with the true maximum and that headroom finite gradients cannot saturate)
-            d_in, d_out = F_.split_range(ones_d, F_.ones_like_rows(B, cin, out.device), g_max, headroom=2 if up else 0)
-        if up:
-            split_down = F_.config().precision != 'fp32' and F_.split_ok(B, cout, cin, H, W, N.MODE_DOWN3)
-            gT = None
-            if split_down and not ctx.needs_input_grad[3]:
-                # frozen weights: only the conv below reads the plane gradient -> the blur adjoint writes it directly in the
-                # conv's split input form (no fp32 planes, no conversion pass)
-                gxs, A = F_.blur_adjoint_split(g_pre, mod.blur.kernel, planes if d is not None else None,
-                                               d_in if (d is not None or d_out is not None) else None, bw_arith)
-            else:
-                gT, A = F_.blur_adjoint(g_pre, mod.blur.kernel, planes if d is not None else None)
-                gxs = F_.planes_to_split(gT, d_in if (d is not None or d_out is not None) else None, bw_arith) if split_down else None
-            if split_down:
-                # dL/d(x*s) of the transposed conv on the split kernels too (bw_arith terms, see above):
-                # the planes times d come in the phase-major split form, the conv walks (channel block, phase) pairs
-                gu = F_.modconv_split(gxs, mod.packed_split(adjoint='down', arith=bw_arith), None, d_out, cin, mode=N.MODE_DOWN3,
-                                      arith=bw_arith, x_split=(B, cout, H, W), batch=B,
-                                      desc='bwd split down3 %d->%d @%dx%d' % (cout, cin, H, W))
-            else:
-                gu = F_.modconv_raw(gT, mod.packed_t(), ones_d, None, cin, N.MODE_DOWN3, H, W,
-                                    desc='bwd down3 %d->%d @%dx%d' % (cout, cin, H, W))
-        else:
-            A = sums[:, :, 2] if d is not None else None
-            if F_.split_ok(B, cout, cin, H, W):    # dL/dx of a plain conv is a plain conv: same kernels, adjoint packs.
-                # Gradients have no natural scale (1e-8 is as likely as 1e+3): the fp16 terms are planned from max |g_pre| of each
-                # image (d_in / d_out above), bf16 terms (fp32 range, 2^-17 per product) need no plan.
-                gu = F_.modconv_split(g_pre, mod.packed_split(adjoint=True, arith=bw_arith), d_in, d_out, cin,
-                                      desc='bwd split3 %d->%d @%dx%d' % (cout, cin, H, W), arith=bw_arith)
-            elif F_.wino_ok(B, cout, cin, H, W):
-                gu = F_.modconv_wino(g_pre, mod.packed_wino(adjoint=True), ones_d, None, cin,
-                                     desc='bwd wino3 %d->%d @%dx%d' % (cout, cin, H, W))
-            else:
-                gu = F_.modconv_raw(g_pre, mod.packed_t(), ones_d, None, cin, N.MODE_PLAIN3, H, W,
-                                    desc='bwd plain3 %d->%d @%dx%d' % (cout, cin, H, W))
+        gu, A_up, gT = _conv_input_grad(mod, g_pre, g_max, d, planes, (B, cin, cout, H, W), bw_arith, ctx.needs_input_grad[3])
+        A = A_up if up else (sums[:, :, 2] if d is not None else None)
         dx, r = F_.scale_reduce(gu, x, s)
         if x.shape[0] == 1 and B != 1:            # broadcast ConstantInput: gradient sums over the batch
             dx = dx.sum(0, keepdim=True)
@@ -322,3 +335,132 @@ class ToRGBFn(Function):
             gskip = upfirdn2d_native_op(g.reshape(B * 3, H, W, 1), torch.flip(fir, [0, 1]), 1, 1, 2, 2, 1, 1, 1, 1)
             gskip = gskip.view(B, 3, H // 2, W // 2)
         return gx, gs, gw, gb, gskip, None
+
+
+# ------------------------------------------------------------------ the whole synthesis network, frozen weights
+
+class SynthesisFrozenFn(Function):
+    """image = synthesis(latent) of a FROZEN generator (the direction trainer optimises A alone, libs/trainer.py:106-111,144,
+    177-189): one Function for conv1 ... convs / to_rgbs, differentiable w.r.t. the W+ latent only.
+
+    Forward = the launches of StyledConvFn / ToRGBFn, layer by layer.  Backward = the same MFMA launches (`_conv_input_grad`),
+    but every saved activation is walked ONCE: the per-layer Functions pay, per layer, scale_reduce (dx = s*gu, r = sum x*gu),
+    torgb_bwd (dx_rgb, r_rgb), autograd's add of the two dx and act_grad_reduce of the layer below -- four HBM-bound passes
+    over the same tensor, 36 bytes per element -- which `functional.grad_join` does in one (12-16 bytes per element).  The 20
+    style modulations' backward (A/d, demod_grad, a transposed copy of the modulation weight, a linear and an indexed add
+    PER LAYER) is two launches (`functional.styles_batched_bwd`), and all reduction buffers of a backward come from one zeroed
+    workspace.  Same expressions per term as the per-layer path (tests/test_gpu_backward.py compares the two)."""
+
+    @staticmethod
+    def forward(ctx, latent, gen, order, layers, to_rgbs, noise):
+        B = latent.shape[0]
+        sd = F_.styles_batched(latent, [m.style_spec(li) for m, li in order])
+        sd_of_layer = [0] + [2 + 3 * (i // 2) + (i % 2) for i in range(len(layers) - 1)]
+        sd_of_rgb = [1] + [4 + 3 * k for k in range(len(to_rgbs) - 1)]
+        x, skip = gen.input.input, None
+        saved, noises = [], []
+        for li, layer in enumerate(layers):
+            mod = layer.conv
+            s, d = sd[sd_of_layer[li]]
+            nz = noise[li]
+            if nz is None:          # fresh per-sample noise, model.py:283-285
+                r = x.shape[-1] * (2 if mod.upsample else 1)
+                nz = torch.empty(B, 1, r, r, device=latent.device, dtype=torch.float32).normal_()
+            planes = None
+            if mod.upsample:
+                out, planes = F_.modconv3x3(x, mod.packed()[0], s, d, mod.out_channel, upsample=True, fir=mod.blur.kernel, noise=nz,
+                                            noise_weight=layer.noise.weight, bias=layer.activate.bias, activate=True,
+                                            batch=B if li == 0 else None, return_planes=True, split=mod.packed_split)
+            else:
+                out = F_.modconv3x3(x, mod.packed()[0], s, d, mod.out_channel, noise=nz, noise_weight=layer.noise.weight,
+                                    bias=layer.activate.bias, activate=True, batch=B if li == 0 else None, wino=mod.packed_wino,
+                                    split=mod.packed_split)
+                k = li // 2
+                rgb = to_rgbs[k]
+                fir = None
+                if skip is not None:
+                    up = getattr(rgb, 'upsample', None)
+                    if up is None or tuple(up.kernel.shape) != (4, 4) or up.pad != (2, 1):
+                        raise NotImplementedError('ToRGB skip path is built for the 4-tap 2x Upsample')
+                    fir = up.kernel
+                skip = F_.torgb(out, rgb.conv.weight.view(3, mod.out_channel), sd[sd_of_rgb[k]][0], bias=rgb.bias.view(3), skip=skip, fir=fir)
+            saved.append((out, planes))
+            noises.append(nz)
+            x = out
+        ctx.gen, ctx.order, ctx.layers, ctx.to_rgbs = gen, order, layers, to_rgbs
+        ctx.sd, ctx.saved, ctx.noises = sd, saved, noises
+        ctx.lat_shape = tuple(latent.shape)
+        ctx.sat = F_.current_sink()
+        ctx.cfg = F_.config()
+        return skip
+
+    @staticmethod
+    def backward(ctx, g_img):
+        with F_.using(ctx.cfg), F_.saturation_sink(ctx.sat):
+            return SynthesisFrozenFn._backward(ctx, g_img)
+
+    @staticmethod
+    def _backward(ctx, g_img):
+        from .op.upfirdn2d import upfirdn2d_native_op
+        gen, order, layers, to_rgbs, sd = ctx.gen, ctx.order, ctx.layers, ctx.to_rgbs, ctx.sd
+        B, L, D = ctx.lat_shape
+        n = len(layers)
+        sd_of_layer = [0] + [2 + 3 * (i // 2) + (i % 2) for i in range(n - 1)]
+        sd_of_rgb = [1] + [4 + 3 * k for k in range(len(to_rgbs) - 1)]
+        dev = g_img.device
+        bw_arith = F_.config().backward_arith if F_.config().precision != 'fp32' else 'bf16x3'
+        # gradient of every level's RGB image: the skip path is Upsample (upfirdn2d up=2, pad (2,1)); its adjoint = flipped taps,
+        # down=2, pad (1,1)  (op/upfirdn2d.py:104-117) -- 3-channel tensors
+        g_rgb = [None] * len(to_rgbs)
+        g_rgb[-1] = N.f32c(g_img)
+        for k in range(len(to_rgbs) - 1, 0, -1):
+            g = g_rgb[k]
+            H, W = g.shape[2], g.shape[3]
+            fir = to_rgbs[k].upsample.kernel
+            g_rgb[k - 1] = upfirdn2d_native_op(g.reshape(B * 3, H, W, 1), torch.flip(fir, [0, 1]), 1, 1, 2, 2, 1, 1, 1, 1).view(B, 3, H // 2, W // 2)
+        # one zeroed workspace for every reduction of this backward (sums, max |g|, r, r_rgb: 8 words per (image, channel) plane)
+        work = torch.zeros(8 * B * sum(l.conv.out_channel for l in layers), device=dev, dtype=torch.float32)
+        woff = 0
+        gs = [None] * n            # dL/ds of layer li's modulation (sum_q x * gu)
+        A = [None] * n             # d * dL/dd
+        rgb_r = [None] * len(to_rgbs)
+        gu_next = None
+        for li in range(n - 1, -1, -1):
+            layer, mod = layers[li], layers[li].conv
+            out, planes = ctx.saved[li]
+            s, d = sd[sd_of_layer[li]]
+            C = mod.out_channel
+            cin = mod.in_channel                       # (H, W: of the conv's INPUT)
+            H, W = (out.shape[2] // 2, out.shape[3] // 2) if mod.upsample else (out.shape[2], out.shape[3])
+            k = li // 2
+            has_rgb = not mod.upsample
+            w = work[woff:woff + 8 * B * C]
+            woff += 8 * B * C
+            g_pre, sums, g_max, r_next, r_rgb = F_.grad_join(
+                out, gu=gu_next, s_next=sd[sd_of_layer[li + 1]][0] if gu_next is not None else None,
+                g_rgb=g_rgb[k] if has_rgb else None, w_rgb=to_rgbs[k].conv.weight.view(3, C) if has_rgb else None,
+                s_rgb=sd[sd_of_rgb[k]][0] if has_rgb else None, noise=ctx.noises[li], noise_weight=layer.noise.weight,
+                bias=layer.activate.bias, want_y=(not mod.upsample) and d is not None, work=w)
+            if gu_next is not None:
+                gs[li + 1] = r_next
+            if has_rgb:
+                rgb_r[k] = r_rgb
+            gu_next, A_up, _ = _conv_input_grad(mod, g_pre, g_max if bw_arith == 'fp16x3' else None, d, planes,
+                                                (B, cin, C, H, W), bw_arith, False)
+            A[li] = A_up if mod.upsample else (sums[:, :, 2] if d is not None else None)
+        _, gs[0] = F_.scale_reduce(gu_next, gen.input.input, sd[sd_of_layer[0]][0])        # conv1 reads the broadcast ConstantInput
+        layer_of = {id(l.conv): i for i, l in enumerate(layers)}
+        rgb_of = {id(r.conv): i for i, r in enumerate(to_rgbs)}
+        entries = []
+        for (m, lat_i), (s, d) in zip(order, sd):
+            e = {'latent_index': lat_i, 'mod_w': m.modulation.weight}
+            if id(m) in rgb_of:
+                e['rgb_r'], e['rgb_w'] = rgb_r[rgb_of[id(m)]], m.weight.view(3, m.in_channel)
+            else:
+                li = layer_of[id(m)]
+                e['gs'] = gs[li]
+                if d is not None:
+                    e['a'], e['d'], e['s'], e['qt'] = A[li], d, s, m.packed()[2]
+            entries.append(e)
+        glat = F_.styles_batched_bwd(entries, B, L, D)
+        return glat, None, None, None, None, None

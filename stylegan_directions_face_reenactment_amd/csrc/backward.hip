@@ -65,6 +65,129 @@ __global__ __launch_bounds__(256) void act_grad_reduce_kernel(const float* __res
     }
 }
 
+// The backward of the FROZEN generator (whole-synthesis Function, autograd.SynthesisFrozenFn) walks a saved activation `out`
+// ONCE: its gradient arrives as up to three terms that the per-layer Functions materialised separately --
+//     g = gu * s_next                                  (scale_reduce of the conv that read `out`: dL/d(x*s) times its style)
+//       + s_rgb * sum_j (w_rgb[j,c] * rgb_scale) g_rgb[b,j]    (torgb_bwd of the ToRGB that read it)
+//       + g_add                                        (anything else, e.g. a caller-side gradient)
+// and the same pass yields both style reductions that need `out` as x (r_next = sum out*gu, r_rgb[j] = sum out*g_rgb[j]) and
+// everything act_grad_reduce computes for the layer that PRODUCED `out` (g_pre, the three sums, max |g_pre| per plane).
+// Per element 12-16 bytes instead of the 36 of scale_reduce + torgb_bwd + autograd's add + act_grad_reduce; the
+// expressions per term are those kernels' (a two-term sum is commutative: same bits as the per-layer path).
+// VEC = 4: float4 per lane (HW % 4 == 0, the generator's planes are powers of two), VEC = 1: any HW.
+template <int VEC>
+__global__ __launch_bounds__(256) void grad_join_kernel(const float* __restrict__ out, const float* __restrict__ gu,
+                                                       const float* __restrict__ s_next, const float* __restrict__ g_rgb,
+                                                       const float* __restrict__ w_rgb, const float* __restrict__ s_rgb,
+                                                       float rgb_scale, const float* __restrict__ g_add,
+                                                       const float* __restrict__ noise, int64_t noise_bstride,
+                                                       const float* __restrict__ noise_w, const float* __restrict__ bias,
+                                                       float* __restrict__ g_pre, float* __restrict__ sums,
+                                                       unsigned* __restrict__ g_absmax, float* __restrict__ r_next,
+                                                       float* __restrict__ r_rgb, int B, int C, int HW, int chunks, float slope,
+                                                       float gain, int want_y) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    if (wid >= (int64_t)B * C * chunks) return;
+    const int ch = (int)(wid % chunks);
+    const int64_t pl = wid / chunks;
+    const int c = (int)(pl % C), b = (int)(pl / C);
+    const float nwv = (noise && noise_w) ? noise_w[0] : 0.f;
+    const float bv = bias ? bias[c] : 0.f;
+    const float inv_pos = 1.f / gain, inv_neg = 1.f / (gain * slope);
+    const float sn = gu ? s_next[pl] : 0.f;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, sr = 0.f;
+    if (g_rgb) {
+        c0 = w_rgb[c] * rgb_scale; c1 = w_rgb[C + c] * rgb_scale; c2 = w_rgb[2 * C + c] * rgb_scale;
+        sr = s_rgb[pl];
+    }
+    const float* gb = g_rgb ? g_rgb + (int64_t)b * 3 * HW : nullptr;
+    const float* nzb = noise ? noise + (int64_t)b * noise_bstride : nullptr;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, rn = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
+    unsigned gm = 0u;
+    const int lo = ch * kChunk, hi = min(HW, lo + kChunk);
+    const int64_t base = pl * HW;
+    for (int p = lo + lane * VEC; p < hi; p += 64 * VEC) {
+        float o[VEC], g[VEC], nz[VEC];
+        if (VEC == 4) {
+            *reinterpret_cast<float4*>(o) = *reinterpret_cast<const float4*>(out + base + p);
+            if (nzb) *reinterpret_cast<float4*>(nz) = *reinterpret_cast<const float4*>(nzb + p);
+        } else {
+            o[0] = out[base + p];
+            if (nzb) nz[0] = nzb[p];
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) g[v] = 0.f;
+        if (gu) {
+            float u[VEC];
+            if (VEC == 4) *reinterpret_cast<float4*>(u) = *reinterpret_cast<const float4*>(gu + base + p);
+            else u[0] = gu[base + p];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                rn = fmaf(o[v], u[v], rn);
+                g[v] = u[v] * sn;
+            }
+        }
+        if (gb) {
+            float g0[VEC], g1[VEC], g2[VEC];
+            if (VEC == 4) {
+                *reinterpret_cast<float4*>(g0) = *reinterpret_cast<const float4*>(gb + p);
+                *reinterpret_cast<float4*>(g1) = *reinterpret_cast<const float4*>(gb + HW + p);
+                *reinterpret_cast<float4*>(g2) = *reinterpret_cast<const float4*>(gb + 2 * (int64_t)HW + p);
+            } else {
+                g0[0] = gb[p]; g1[0] = gb[HW + p]; g2[0] = gb[2 * (int64_t)HW + p];
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float t = sr * (c0 * g0[v] + c1 * g1[v] + c2 * g2[v]);
+                g[v] = gu ? g[v] + t : t;
+                q0 = fmaf(o[v], g0[v], q0);
+                q1 = fmaf(o[v], g1[v], q1);
+                q2 = fmaf(o[v], g2[v], q2);
+            }
+        }
+        if (g_add) {
+            float a[VEC];
+            if (VEC == 4) *reinterpret_cast<float4*>(a) = *reinterpret_cast<const float4*>(g_add + base + p);
+            else a[0] = g_add[base + p];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) g[v] = (gu || gb) ? g[v] + a[v] : a[v];
+        }
+        float gp[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            gp[v] = g[v] * (o[v] > 0.f ? 1.f : slope) * gain;
+            gm = max(gm, __float_as_uint(fabsf(gp[v])));
+            const float nzv = nzb ? nz[v] : 0.f;
+            s0 += gp[v];
+            s1 = fmaf(gp[v], nzv, s1);
+            if (want_y) {
+                const float pre = o[v] * (o[v] > 0.f ? inv_pos : inv_neg);
+                s2 = fmaf(gp[v], pre - nwv * nzv - bv, s2);
+            }
+        }
+        if (VEC == 4) *reinterpret_cast<float4*>(g_pre + base + p) = *reinterpret_cast<const float4*>(gp);
+        else g_pre[base + p] = gp[0];
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    rn = wave_sum(rn); q0 = wave_sum(q0); q1 = wave_sum(q1); q2 = wave_sum(q2);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gm = max(gm, (unsigned)__shfl_xor((int)gm, o, 64));
+    if (lane == 0) {
+        atomicAdd(&sums[pl * 3 + 0], s0);
+        atomicAdd(&sums[pl * 3 + 1], s1);
+        if (want_y) atomicAdd(&sums[pl * 3 + 2], s2);
+        if (gu) atomicAdd(&r_next[pl], rn);
+        if (gb) {
+            float* rb = r_rgb + (int64_t)b * 3 * C;
+            atomicAdd(&rb[c], q0);
+            atomicAdd(&rb[C + c], q1);
+            atomicAdd(&rb[2 * C + c], q2);
+        }
+        if (g_absmax && gm != 0u) atomicMax(g_absmax + pl, gm);
+    }
+}
+
 // Adjoint of blur_bias_act's FIR: g [planes, 2H, 2W] -> gT parity planes [planes, 4, H+1, W+1]
 //   gT[i,j] = sum_{oy,ox} g[oy,ox] * K[3-(i+1-oy)][3-(j+1-ox)]   (0 <= i+1-oy, j+1-ox <= 3)
 // and, when the forward planes t are given, asum[plane] += sum gT * t  (= d * dL/dd).
@@ -248,6 +371,43 @@ extern "C" int sgdfr_act_grad_reduce_f32(const float* g_out, const float* out, c
     hipLaunchKernelGGL(act_grad_reduce_kernel, dim3(wave_grid(waves)), dim3(256), 0, st, g_out, out, noise, noise_bstride,
                        noise_w, bias, g_pre, sums, B, C, HW, chunks, slope, gain, want_y, g_absmax);
     return check_launch("act_grad_reduce");
+}
+
+extern "C" int sgdfr_grad_join_f32(const float* out, const float* gu, const float* s_next, const float* g_rgb, const float* w_rgb,
+                                  const float* s_rgb, const float* g_add, const float* noise, int64_t noise_bstride,
+                                  const float* noise_w, const float* bias, float* g_pre, float* sums, unsigned int* g_absmax,
+                                  float* r_next, float* r_rgb, int B, int C, int HW, float slope, float gain, int want_y,
+                                  int zero_outputs, void* stream) {
+    SGDFR_REQUIRE(B >= 0 && C > 0 && HW > 0, "grad_join: bad shape %d %d %d", B, C, HW);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(out && g_pre && sums, "grad_join: null pointer");
+    SGDFR_REQUIRE(gu || g_rgb || g_add, "grad_join: no incoming gradient term");
+    SGDFR_REQUIRE(!gu || (s_next && r_next), "grad_join: gu needs s_next and r_next");
+    SGDFR_REQUIRE(!g_rgb || (w_rgb && s_rgb && r_rgb), "grad_join: g_rgb needs w_rgb, s_rgb and r_rgb");
+    SGDFR_REQUIRE(!noise || noise_w, "grad_join: noise without noise_w");
+    hipStream_t st = as_stream(stream);
+    const size_t planes = (size_t)B * C;
+    if (zero_outputs) {     // (a caller that carves all reduction buffers of a backward out of ONE zeroed workspace passes 0)
+        if (hipMemsetAsync(sums, 0, sizeof(float) * planes * 3, st) != hipSuccess) return check_launch("memset");
+        if (g_absmax && hipMemsetAsync(g_absmax, 0, sizeof(unsigned) * planes, st) != hipSuccess) return check_launch("memset");
+        if (gu && hipMemsetAsync(r_next, 0, sizeof(float) * planes, st) != hipSuccess) return check_launch("memset");
+        if (g_rgb && hipMemsetAsync(r_rgb, 0, sizeof(float) * planes * 3, st) != hipSuccess) return check_launch("memset");
+    }
+    const int chunks = (HW + kChunk - 1) / kChunk;
+    const int64_t waves = (int64_t)B * C * chunks;
+    const float rgb_scale = 1.0f / sqrtf((float)C);
+    auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec = HW % 4 == 0 && noise_bstride % 4 == 0 && aligned(out) && aligned(gu) && aligned(g_rgb) && aligned(g_add) &&
+                     aligned(noise) && aligned(g_pre);
+    if (vec)
+        hipLaunchKernelGGL(grad_join_kernel<4>, dim3(wave_grid(waves)), dim3(256), 0, st, out, gu, s_next, g_rgb, w_rgb, s_rgb, rgb_scale,
+                           g_add, noise, noise_bstride, noise_w, bias, g_pre, sums, g_absmax, r_next, r_rgb, B, C, HW, chunks, slope,
+                           gain, want_y);
+    else
+        hipLaunchKernelGGL(grad_join_kernel<1>, dim3(wave_grid(waves)), dim3(256), 0, st, out, gu, s_next, g_rgb, w_rgb, s_rgb, rgb_scale,
+                           g_add, noise, noise_bstride, noise_w, bias, g_pre, sums, g_absmax, r_next, r_rgb, B, C, HW, chunks, slope,
+                           gain, want_y);
+    return check_launch("grad_join");
 }
 
 extern "C" int sgdfr_blur_adjoint_f32(const float* g, const float* fir, const float* t, float* gt, float* asum, int B,

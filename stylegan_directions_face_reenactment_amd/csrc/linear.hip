@@ -483,6 +483,149 @@ extern "C" int sgdfr_absmax_f32(const float* x, int64_t x_bstride, int64_t n_per
     return check_launch("absmax");
 }
 
+// ---- backward of sgdfr_styles_batched_f32 for the frozen generator (autograd.StylesBatchedFn): every layer's
+//   ds_l[b,i] = gs_l[b,i] + s_l[b,i] * sum_o (-(A_l/d_l) * d_l^3)[b,o] * qt_l[i,o]           (demodulated 3x3 convs; sgdfr_demod_grad_f32)
+//   ds_l[b,i] = (sum_j rgb_r[b,j,i] * rgb_w[j,i]) / sqrt(cin)                                (ToRGB: no demodulation)
+// in ONE launch (stage 0), and the latent gradient glat[b,l,:] = sum_{layers of latent row l} ds_l[b,:] @ mod_w_l / sqrt(D) in a
+// second (stage 1) -- instead of (A/d, demod_grad, a transposed copy of mod_w, a linear, an indexed add) x 20 layers.
+struct StyleGradBatch {
+    sgdfr_style_grad_layer layer[SGDFR_MAX_STYLE_LAYERS];
+    int tile_start[SGDFR_MAX_STYLE_LAYERS + 1];   // stage 0: prefix sums of 4-column groups per layer
+    int n_layers;
+    float* glat;
+    int B, L, D;
+    float wscale;
+};
+
+__global__ __launch_bounds__(256) void styles_batched_bwd_ds_kernel(StyleGradBatch sb) {
+    constexpr int NC = 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = blockIdx.x * 4 + wave;
+    int li = 0;
+    while (li + 1 < sb.n_layers && grp >= sb.tile_start[li + 1]) ++li;
+    if (grp >= sb.tile_start[sb.n_layers]) return;
+    const sgdfr_style_grad_layer& ly = sb.layer[li];
+    const int n0 = (grp - sb.tile_start[li]) * NC;
+    const int cin = ly.cin, K = ly.cout;
+    if (ly.rgb_r) {          // ToRGB: lane = column within the group's 4 (x 16 images per pass)
+        const float sc = 1.0f / sqrtf((float)cin);
+        for (int e = lane; e < NC * sb.B; e += 64) {
+            const int b = e / NC, i = n0 + e % NC;
+            if (i >= cin) continue;
+            const float* r = ly.rgb_r + (int64_t)b * 3 * cin;
+            ly.ds[(int64_t)b * cin + i] = (r[i] * ly.rgb_w[i] + r[cin + i] * ly.rgb_w[cin + i] + r[2 * cin + i] * ly.rgb_w[2 * cin + i]) * sc;
+        }
+        return;
+    }
+    if (!ly.a) {             // a 3x3 conv without demodulation: ds = gs
+        for (int e = lane; e < NC * sb.B; e += 64) {
+            const int b = e / NC, i = n0 + e % NC;
+            if (i < cin) ly.ds[(int64_t)b * cin + i] = ly.gs[(int64_t)b * cin + i];
+        }
+        return;
+    }
+    constexpr int KPL = 8;   // cout <= 512
+    float w[NC][KPL];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int n = min(n0 + c, cin - 1);
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const int k = lane + 64 * j;
+            w[c][j] = k < K ? ly.qt[(int64_t)n * K + k] : 0.f;
+        }
+    }
+    for (int b = 0; b < sb.B; ++b) {
+        float acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const int k = lane + 64 * j;
+            float v = 0.f;
+            if (k < K) {
+                const float dv = ly.d[(int64_t)b * K + k];
+                const float gd = ly.a[((int64_t)b * K + k) * ly.a_stride] / dv;
+                v = -gd * dv * dv * dv;
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = fmaf(v, w[c][j], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = wave_sum(acc[c]);
+        if (lane < NC && n0 + lane < cin) {
+            float a = acc[0];
+#pragma unroll
+            for (int c = 1; c < NC; ++c) a = lane == c ? acc[c] : a;
+            const int64_t o = (int64_t)b * cin + n0 + lane;
+            ly.ds[o] = ly.gs[o] + ly.s[o] * a;
+        }
+    }
+}
+
+// glat[b, l, n] for one latent row l = blockIdx.y, 64 columns n per wave, SG_BU images at a time: lanes run along the D
+// columns of mod_w [cin, D] (coalesced rows), ds[b, i] is wave-uniform (scalar loads).  Layers of one latent row are summed
+// in layer order inside the wave: no atomics, rows nobody reads come out as zeros.
+constexpr int SG_BU = 8;
+__global__ __launch_bounds__(256) void styles_batched_bwd_lat_kernel(StyleGradBatch sb) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l = blockIdx.y;
+    const int n = (blockIdx.x * 4 + wave) * 64 + lane;
+    const int b0 = blockIdx.z * SG_BU;
+    if ((blockIdx.x * 4 + wave) * 64 >= sb.D) return;
+    float acc[SG_BU];
+#pragma unroll
+    for (int u = 0; u < SG_BU; ++u) acc[u] = 0.f;
+    for (int li = 0; li < sb.n_layers; ++li) {
+        const sgdfr_style_grad_layer& ly = sb.layer[li];
+        if (ly.latent_index != l) continue;
+        float part[SG_BU];
+#pragma unroll
+        for (int u = 0; u < SG_BU; ++u) part[u] = 0.f;
+        for (int i = 0; i < ly.cin; ++i) {
+            const float wv = n < sb.D ? ly.mod_w[(int64_t)i * sb.D + n] : 0.f;
+#pragma unroll
+            for (int u = 0; u < SG_BU; ++u) {
+                const int b = min(b0 + u, sb.B - 1);
+                part[u] = fmaf(ly.ds[(int64_t)b * ly.cin + i], wv, part[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SG_BU; ++u) acc[u] += part[u] * sb.wscale;
+    }
+    if (n < sb.D) {
+#pragma unroll
+        for (int u = 0; u < SG_BU; ++u)
+            if (b0 + u < sb.B) sb.glat[((int64_t)(b0 + u) * sb.L + l) * sb.D + n] = acc[u];
+    }
+}
+
+extern "C" int sgdfr_styles_batched_bwd_f32(const sgdfr_style_grad_layer* layers, int n_layers, float* glat, int B, int L, int D,
+                                            void* stream) {
+    SGDFR_REQUIRE(B >= 0 && L > 0 && D > 0 && n_layers > 0 && n_layers <= SGDFR_MAX_STYLE_LAYERS, "styles_batched_bwd: bad shape B=%d L=%d D=%d layers=%d",
+                  B, L, D, n_layers);
+    if (B == 0) return 0;
+    SGDFR_REQUIRE(layers && glat, "styles_batched_bwd: null pointer");
+    StyleGradBatch sb;
+    sb.n_layers = n_layers; sb.glat = glat; sb.B = B; sb.L = L; sb.D = D; sb.wscale = 1.0f / sqrtf((float)D);
+    int groups = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const sgdfr_style_grad_layer& ly = layers[i];
+        SGDFR_REQUIRE(ly.cin > 0 && ly.latent_index >= 0 && ly.latent_index < L && ly.mod_w && ly.ds, "styles_batched_bwd: layer %d: bad cin / latent row / null pointer", i);
+        SGDFR_REQUIRE(ly.rgb_r ? (ly.rgb_w != nullptr) : (ly.gs != nullptr), "styles_batched_bwd: layer %d: needs gs, or rgb_r with rgb_w", i);
+        SGDFR_REQUIRE(!ly.a || (ly.d && ly.s && ly.qt && ly.cout > 0 && ly.cout <= 512 && ly.a_stride >= 1), "styles_batched_bwd: layer %d: a needs d, s, qt and cout <= 512", i);
+        sb.layer[i] = ly;
+        sb.tile_start[i] = groups;
+        groups += (ly.cin + 3) / 4;
+    }
+    sb.tile_start[n_layers] = groups;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(styles_batched_bwd_ds_kernel, dim3((groups + 3) / 4), dim3(256), 0, st, sb);
+    if (int rc = check_launch("styles_batched_bwd(ds)")) return rc;
+    hipLaunchKernelGGL(styles_batched_bwd_lat_kernel, dim3((D + 255) / 256, L, (B + SG_BU - 1) / SG_BU), dim3(256), 0, st, sb);
+    return check_launch("styles_batched_bwd(latent)");
+}
+
 extern "C" int sgdfr_demod_grad_f32(const float* gd, const float* d, const float* qt, const float* s, const float* gs,
                                     float* ds, int B, int Cin, int Cout, void* stream) {
     SGDFR_REQUIRE(B >= 0 && Cin > 0 && Cout > 0, "demod_grad: bad shape %d %d %d", B, Cin, Cout);

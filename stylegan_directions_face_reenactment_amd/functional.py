@@ -930,6 +930,73 @@ def torgb_bwd(x, g, w_rgb, s):
     return dx, r
 
 
+def grad_join(out, gu=None, s_next=None, g_rgb=None, w_rgb=None, s_rgb=None, g_add=None, noise=None, noise_weight=None, bias=None,
+              want_y=True, slope=0.2, gain=SQRT2, work=None):
+    """One pass over a saved StyledConv activation `out` [B,C,H,W] in the frozen generator's backward (sgdfr_grad_join_f32): the
+    gradient of `out` = gu*s_next (the conv that reads it) + the ToRGB term (g_rgb [B,3,H,W], w_rgb [3,C], s_rgb [B,C]) + g_add;
+    returns (g_pre, sums [B,C,3], gmax int32 [B,C], r_next [B,C] | None, r_rgb [B,3,C] | None) -- act_grad_reduce's outputs for the
+    layer that produced `out`, scale_reduce's r for the reading conv, torgb_bwd's r for the reading ToRGB.
+    work: a ZEROED float32 tensor with at least B*C*8 elements to carve the reduction buffers from (None: allocated and zeroed here)."""
+    N.require_device(out, gu, s_next, g_rgb, w_rgb, s_rgb, g_add, bias, noise_weight)
+    out = N.f32c(out)
+    B, C, H, W = out.shape
+    nz, nzb = _noise_args(noise, B, H, W)
+    g_pre = torch.empty_like(out)
+    n = B * C
+    zero = work is None
+    if work is None:
+        work = torch.empty(n * 8, device=out.device, dtype=torch.float32)
+    sums, gmax = work[:n * 3].view(B, C, 3), work[n * 3:n * 4].view(torch.int32).view(B, C)
+    r_next = work[n * 4:n * 5].view(B, C) if gu is not None else None
+    r_rgb = work[n * 5:n * 8].view(B, 3, C) if g_rgb is not None else None
+    N.call('sgdfr_grad_join_f32', N.ptr(out), N.ptr(N.f32c(gu)) if gu is not None else None, N.ptr(s_next),
+           N.ptr(N.f32c(g_rgb)) if g_rgb is not None else None, N.ptr(N.f32c(w_rgb)) if w_rgb is not None else None, N.ptr(s_rgb),
+           N.ptr(N.f32c(g_add)) if g_add is not None else None, N.ptr(nz), nzb, N.ptr(noise_weight) if nz is not None else None,
+           N.ptr(bias), N.ptr(g_pre), N.ptr(sums), N.ptr(gmax), N.ptr(r_next), N.ptr(r_rgb), B, C, H * W, float(slope), float(gain),
+           int(bool(want_y)), int(zero), N.stream())
+    return g_pre, sums, gmax, r_next, r_rgb
+
+
+def styles_batched_bwd(entries, B, L, D):
+    """dL/dlatent [B, L, D] of functional.styles_batched for frozen weights, two launches (sgdfr_styles_batched_bwd_f32).
+    entries: one dict per layer with latent_index, mod_w [cin,D], and either gs [B,cin] (+ for demodulated convs a = d*dL/dd
+    ([B,cout] view, any element stride), d, s, qt) or rgb_r [B,3,cin] + rgb_w [3,cin]."""
+    if len(entries) > N.MAX_STYLE_LAYERS:
+        raise RuntimeError('too many modulated layers (%d)' % len(entries))
+    arr = (N.StyleGradLayer * len(entries))()
+    dev = entries[0]['mod_w'].device
+    ds = torch.empty(B * sum(e['mod_w'].shape[0] for e in entries), device=dev, dtype=torch.float32)
+    keep, off = [ds], 0
+    for i, e in enumerate(entries):
+        c = arr[i]
+        mw = N.f32c(e['mod_w'])
+        cin = mw.shape[0]
+        N.require_device(mw, e.get('gs'), e.get('rgb_r'), e.get('rgb_w'), e.get('a'), e.get('d'), e.get('s'), e.get('qt'))
+        c.mod_w, c.cin, c.latent_index = mw.data_ptr(), cin, int(e['latent_index'])
+        c.ds = ds[off:off + B * cin].data_ptr()
+        off += B * cin
+        c.gs = c.rgb_r = c.rgb_w = c.a = c.d = c.s = c.qt = None
+        c.a_stride, c.cout = 1, 0
+        keep.append(mw)
+        if e.get('rgb_r') is not None:
+            r, w = N.f32c(e['rgb_r']), N.f32c(e['rgb_w'])
+            keep += [r, w]
+            c.rgb_r, c.rgb_w = r.data_ptr(), w.data_ptr()
+            continue
+        gs = N.f32c(e['gs'])
+        keep.append(gs)
+        c.gs = gs.data_ptr()
+        if e.get('a') is not None:
+            a, d, s_, qt = e['a'], N.f32c(e['d']), N.f32c(e['s']), N.f32c(e['qt'])
+            if a.dim() != 2 or a.stride(0) != a.shape[1] * a.stride(1):
+                raise RuntimeError('styles_batched_bwd: a must be a [B,cout] view with a uniform element stride')
+            keep += [a, d, s_, qt]
+            c.a, c.a_stride, c.d, c.s, c.qt, c.cout = a.data_ptr(), a.stride(1), d.data_ptr(), s_.data_ptr(), qt.data_ptr(), d.shape[1]
+    glat = torch.empty(B, L, D, device=dev, dtype=torch.float32)
+    N.call('sgdfr_styles_batched_bwd_f32', arr, len(entries), N.ptr(glat), B, L, D, N.stream())
+    return glat
+
+
 def demod_grad(gd, d, qt, s, gs):
     """ds = gs + s * ((-gd * d^3) @ Q)."""
     N.require_device(gd, d, qt, s, gs)

@@ -484,6 +484,8 @@ class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
     # (ReenactmentSession, functional.StreamPipeline loops, bench.py) pass verify_range=False; `G.verify_range_default = False`
     # or SGDFR_VERIFY_RANGE=0 changes the default for a generator / the process.
     verify_range_default = os.environ.get('SGDFR_VERIFY_RANGE', '1') != '0'
+    # frozen generator under autograd: the whole-synthesis Function (False / SGDFR_FUSED_BACKWARD=0: one Function per layer)
+    fused_frozen_backward = os.environ.get('SGDFR_FUSED_BACKWARD', '1') != '0'
 
     def forward(self, styles, return_latents=False, return_features=False, inject_index=None, truncation=1,
                 truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=False, image_out=None,
@@ -570,8 +572,15 @@ class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
         self.__dict__['_last_token'] = None
         with F_.saturation_sink(self._sat_word()):         # every split launch below (and its backward) counts into OUR word
             if grad:
-                if not any(p.requires_grad for p in self._params()):
-                    # frozen generator (the direction trainer): the two batched launches, differentiable w.r.t. the latent only
+                frozen = not any(p.requires_grad for p in self._params())
+                hooked = any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in layers + to_rgbs)
+                if frozen and self.fused_frozen_backward and not hooked and not return_features and image_out is None:
+                    # frozen generator (the direction trainer): ONE Function for the whole synthesis network -- its backward walks
+                    # every saved activation once (autograd.SynthesisFrozenFn)
+                    image = AG.SynthesisFrozenFn.apply(latent, self, order, layers, to_rgbs, noise)
+                    return (image, latent) if return_latents else (image, None)
+                if frozen:
+                    # ... per-layer Functions (hooked modules): the two batched style launches, differentiable w.r.t. the latent only
                     flat = iter(AG.StylesBatchedFn.apply(latent, order))
                     sd = [(next(flat), next(flat) if (m.kernel_size == 3 and m.demodulate) else None) for m, _ in order]
                 else:   # differentiable per-layer modulation (autograd routes dL/ds back into the latent rows and the weights)

@@ -127,6 +127,73 @@ def test_generator_gradient_to_latent_small():
     assert _rel(wh.grad, wr.grad) <= 2e-4
 
 
+def test_fused_frozen_backward_matches_the_per_layer_functions():
+    """autograd.SynthesisFrozenFn (one Function for the frozen synthesis network: functional.grad_join walks every saved
+    activation once, functional.styles_batched_bwd does the 20 modulations' backward in two launches) against the per-layer
+    Functions it replaces, on the same generator and latents: same image bits, dL/dW+ within the reduction-order noise of the
+    atomics both paths use -- and against autograd of the fp64 oracle like the per-layer path."""
+    for size, B in ((64, 3), (256, 2)):
+        G = hip_generator(size, 1)
+        for p in G.parameters():
+            p.requires_grad_(False)
+        w = S.synthetic_latents(31, B, n_latent=G.n_latent, key='fz.w')
+        tr = S.counter_tensor(31, 'fz.t', (1, 512)).cuda()
+        gimg = S.counter_tensor(31, 'fz.g', (B, 3, size, size)).cuda()
+        grads, imgs = [], []
+        for fused in (True, False):
+            G.fused_frozen_backward = fused
+            wh = w.cuda().requires_grad_(True)
+            img, lat = G([wh], input_is_latent=True, truncation=0.7, truncation_latent=tr, return_latents=True)
+            assert (type(img.grad_fn).__name__ == 'SynthesisFrozenFnBackward') == fused
+            assert lat.shape == (B, G.n_latent, 512)
+            (img * gimg).sum().backward()
+            grads.append(wh.grad.clone())
+            imgs.append(img.detach())
+        assert torch.equal(imgs[0], imgs[1])
+        assert _rel(grads[0], grads[1]) <= 2e-6
+        if size == 64:
+            P = {k: v.double() for k, v in synthetic_state(64, 1).items()}
+            wr = w.double().requires_grad_(True)
+            ref, _ = O.generator_forward(P, [wr], input_is_latent=True, truncation=0.7, truncation_latent=tr.cpu().double())
+            (ref * gimg.cpu().double()).sum().backward()
+            # (a random upstream gradient cancels far more than the mean(img^2) of the tests above; under --precision fp32 the dL/dx
+            #  convs of both paths run on bf16 hi+lo terms -- 16 operand bits -- and measure 1.6e-3 here, the fp16 terms 1e-4)
+            from stylegan_directions_face_reenactment_amd import functional as F_
+            assert _rel(grads[0], wr.grad) <= (2e-4 if F_.PRECISION == 'fp16x3' else 5e-3)
+        assert G.saturated_pairs() == 0
+
+
+def test_grad_join_equals_the_three_passes_it_replaces():
+    """functional.grad_join on one activation: g = gu*s_next + ToRGB term, then act_grad_reduce -- against scale_reduce + torgb_bwd +
+    a tensor add + act_grad_reduce (g_pre bit-identical: same expressions, a two-term sum; reductions within summation order)."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    for B, C, H in ((3, 16, 4), (2, 64, 32), (2, 8, 64), (1, 24, 6)):
+        mk = lambda key, shape, scale=1.0: S.counter_tensor(33, key, shape, 0.0, scale).cuda()
+        out, gu, g_rgb = mk('o', (B, C, H, H)), mk('gu', (B, C, H, H)), mk('gr', (B, 3, H, H))
+        s_next, s_rgb, w_rgb = mk('sn', (B, C)), mk('sr', (B, C)), mk('wr', (3, C))
+        noise, nw, bias = mk('nz', (1, 1, H, H)), mk('nw', (1,), 0.3), mk('b', (C,), 0.5)
+        for use_gu, use_rgb in ((True, True), (True, False), (False, True)):
+            dx = dx2 = r = r2 = None
+            if use_gu:
+                dx, r = F_.scale_reduce(gu.clone(), out, s_next)
+            if use_rgb:
+                dx2, r2 = F_.torgb_bwd(out, g_rgb, w_rgb, s_rgb)
+            g = dx + dx2 if (use_gu and use_rgb) else (dx if use_gu else dx2)
+            g_pre, sums, gmax = F_.act_grad_reduce(g, out, noise, nw, bias, want_y=True, want_absmax=True)
+            j_pre, j_sums, j_gmax, j_r, j_r2 = F_.grad_join(out, gu=gu if use_gu else None, s_next=s_next if use_gu else None,
+                                                            g_rgb=g_rgb if use_rgb else None, w_rgb=w_rgb if use_rgb else None,
+                                                            s_rgb=s_rgb if use_rgb else None, noise=noise, noise_weight=nw, bias=bias,
+                                                            want_y=True)
+            assert torch.equal(j_pre, g_pre) and torch.equal(j_gmax, gmax)
+            assert _rel(j_sums, sums) <= 1e-5
+            if use_gu:
+                assert _rel(j_r, r) <= 1e-5
+            else:
+                assert j_r is None
+            if use_rgb:
+                assert _rel(j_r2, r2) <= 1e-5
+
+
 def test_direction_matrix_gradient_golden():
     """KAT-5: dL/dA for L = mean(img^2) through generate_image, z path and W+ path, vs the REAL reference's autograd."""
     from stylegan_directions_face_reenactment_amd.direction_matrix import DirectionMatrix

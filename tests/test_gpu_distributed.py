@@ -165,10 +165,13 @@ def test_bench_inference_and_trainer_configs_small():
     r, line = _run_bench('--config', 'inference', '--steps', '2', '--warmup', '1', '--batch', '4', timeout=700)
     assert r.returncode == 0, r.stderr[-3000:]
     assert line['n_gpus'] == 1 and line['unit'] == 'frames/s' and line['value'] > 0
-    assert line['roofline']['per_layer'] and line['config']['e4e_source_ms'] > 0
+    assert line['_detail']['roofline']['per_layer'] and line['config']['e4e_source_ms'] > 0
     r, line = _run_bench('--config', 'trainer', '--steps', '2', '--warmup', '1', '--batch', '4', timeout=700)
     assert r.returncode == 0, r.stderr[-3000:]
-    assert line['unit'] == 'samples/s' and line['value'] > 0 and line['config']['losses_finite'] is True
+    assert line['unit'] == 'samples/s' and line['value'] > 0
+    compact, line = line, line['_detail']          # (the long-form record; the compact line keeps value / roofline / the leg scalars)
+    assert compact['roofline']['frac'] > 0 and compact['config']['generator_only_ms_per_step'] > 0
+    assert line['config']['losses_finite'] is True
     # the arithmetic that actually ran, not a substring of the prose: forward = the bench default, backward = functional.BACKWARD_ARITH
     from stylegan_directions_face_reenactment_amd import functional as F_
     assert line['config']['forward_arithmetic'] == 'fp16x3' and line['config']['backward_arithmetic'] == F_.BACKWARD_ARITH
