@@ -535,68 +535,106 @@ __global__ __launch_bounds__(256) void styles_batched_bwd_ds_kernel(StyleGradBat
             w[c][j] = k < K ? ly.qt[(int64_t)n * K + k] : 0.f;
         }
     }
-    for (int b = 0; b < sb.B; ++b) {
-        float acc[NC];
+    constexpr int RB = 2;          // images per iteration: their loads are in flight together
+    for (int bb = 0; bb < sb.B; bb += RB) {
+        float dv[RB][KPL], av[RB][KPL];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+        for (int r = 0; r < RB; ++r) {
+            const int b = min(bb + r, sb.B - 1);
 #pragma unroll
-        for (int j = 0; j < KPL; ++j) {
-            const int k = lane + 64 * j;
-            float v = 0.f;
-            if (k < K) {
-                const float dv = ly.d[(int64_t)b * K + k];
-                const float gd = ly.a[((int64_t)b * K + k) * ly.a_stride] / dv;
-                v = -gd * dv * dv * dv;
+            for (int j = 0; j < KPL; ++j) {
+                const int k = lane + 64 * j;
+                dv[r][j] = k < K ? ly.d[(int64_t)b * K + k] : 1.f;
+                av[r][j] = k < K ? ly.a[((int64_t)b * K + k) * ly.a_stride] : 0.f;
             }
-#pragma unroll
-            for (int c = 0; c < NC; ++c) acc[c] = fmaf(v, w[c][j], acc[c]);
         }
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] = wave_sum(acc[c]);
-        if (lane < NC && n0 + lane < cin) {
-            float a = acc[0];
+        for (int r = 0; r < RB; ++r) {
+            const int b = bb + r;
+            if (b >= sb.B) break;
+            float acc[NC];
 #pragma unroll
-            for (int c = 1; c < NC; ++c) a = lane == c ? acc[c] : a;
-            const int64_t o = (int64_t)b * cin + n0 + lane;
-            ly.ds[o] = ly.gs[o] + ly.s[o] * a;
+            for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                const float gd = av[r][j] / dv[r][j];
+                const float v = -gd * dv[r][j] * dv[r][j] * dv[r][j];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = fmaf(v, w[c][j], acc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = wave_sum(acc[c]);
+            if (lane < NC && n0 + lane < cin) {
+                float a = acc[0];
+#pragma unroll
+                for (int c = 1; c < NC; ++c) a = lane == c ? acc[c] : a;
+                const int64_t o = (int64_t)b * cin + n0 + lane;
+                ly.ds[o] = ly.gs[o] + ly.s[o] * a;
+            }
         }
     }
 }
 
-// glat[b, l, n] for one latent row l = blockIdx.y, 64 columns n per wave, SG_BU images at a time: lanes run along the D
-// columns of mod_w [cin, D] (coalesced rows), ds[b, i] is wave-uniform (scalar loads).  Layers of one latent row are summed
-// in layer order inside the wave: no atomics, rows nobody reads come out as zeros.
+// glat[b, l, n] for one latent row l = blockIdx.y, 64 columns n per BLOCK, SG_BU images per block (blockIdx.z): lanes run along
+// the D columns of mod_w [cin, D] (coalesced rows); the block's ds rows sit in LDS (broadcast reads); the four waves split the
+// cin range and their partial sums meet in LDS, added in wave order.  Layers of one latent row are summed in layer order: no
+// atomics, rows nobody reads come out as zeros.  (First version: one wave walked all of cin with ds from global memory -- 56
+// blocks of a 512-step dependent loop, 468 us per launch at B=16; this form takes a few us.)
 constexpr int SG_BU = 8;
+constexpr int SG_MAXC = 512;
 __global__ __launch_bounds__(256) void styles_batched_bwd_lat_kernel(StyleGradBatch sb) {
+    __shared__ float dsl[SG_BU][SG_MAXC];
+    __shared__ float part[4][SG_BU][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int l = blockIdx.y;
-    const int n = (blockIdx.x * 4 + wave) * 64 + lane;
+    const int n = blockIdx.x * 64 + lane;
     const int b0 = blockIdx.z * SG_BU;
-    if ((blockIdx.x * 4 + wave) * 64 >= sb.D) return;
     float acc[SG_BU];
 #pragma unroll
     for (int u = 0; u < SG_BU; ++u) acc[u] = 0.f;
     for (int li = 0; li < sb.n_layers; ++li) {
         const sgdfr_style_grad_layer& ly = sb.layer[li];
         if (ly.latent_index != l) continue;
-        float part[SG_BU];
-#pragma unroll
-        for (int u = 0; u < SG_BU; ++u) part[u] = 0.f;
-        for (int i = 0; i < ly.cin; ++i) {
-            const float wv = n < sb.D ? ly.mod_w[(int64_t)i * sb.D + n] : 0.f;
-#pragma unroll
-            for (int u = 0; u < SG_BU; ++u) {
-                const int b = min(b0 + u, sb.B - 1);
-                part[u] = fmaf(ly.ds[(int64_t)b * ly.cin + i], wv, part[u]);
+        const int cin = ly.cin;
+        for (int c0 = 0; c0 < cin; c0 += SG_MAXC) {
+            const int cn = min(SG_MAXC, cin - c0);
+            __syncthreads();
+            for (int e = threadIdx.x; e < SG_BU * cn; e += 256) {
+                const int u = e / cn, i = e - u * cn;
+                dsl[u][i] = ly.ds[(int64_t)min(b0 + u, sb.B - 1) * cin + c0 + i];
             }
-        }
+            __syncthreads();
+            const int per = (cn + 3) / 4, i_lo = wave * per, i_hi = min(cn, i_lo + per);
+            float p[SG_BU];
 #pragma unroll
-        for (int u = 0; u < SG_BU; ++u) acc[u] += part[u] * sb.wscale;
+            for (int u = 0; u < SG_BU; ++u) p[u] = 0.f;
+            int i = i_lo;
+            for (; i + 4 <= i_hi; i += 4) {
+                float wv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wv[q] = n < sb.D ? ly.mod_w[(int64_t)(c0 + i + q) * sb.D + n] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int u = 0; u < SG_BU; ++u) p[u] = fmaf(dsl[u][i + q], wv[q], p[u]);
+            }
+            for (; i < i_hi; ++i) {
+                const float wv = n < sb.D ? ly.mod_w[(int64_t)(c0 + i) * sb.D + n] : 0.f;
+#pragma unroll
+                for (int u = 0; u < SG_BU; ++u) p[u] = fmaf(dsl[u][i], wv, p[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < SG_BU; ++u) acc[u] += p[u] * sb.wscale;
+        }
     }
-    if (n < sb.D) {
+#pragma unroll
+    for (int u = 0; u < SG_BU; ++u) part[wave][u][lane] = acc[u];
+    __syncthreads();
+    if (wave == 0 && n < sb.D) {
 #pragma unroll
         for (int u = 0; u < SG_BU; ++u)
-            if (b0 + u < sb.B) sb.glat[((int64_t)(b0 + u) * sb.L + l) * sb.D + n] = acc[u];
+            if (b0 + u < sb.B)
+                sb.glat[((int64_t)(b0 + u) * sb.L + l) * sb.D + n] = ((part[0][u][lane] + part[1][u][lane]) + part[2][u][lane]) + part[3][u][lane];
     }
 }
 
@@ -622,7 +660,7 @@ extern "C" int sgdfr_styles_batched_bwd_f32(const sgdfr_style_grad_layer* layers
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(styles_batched_bwd_ds_kernel, dim3((groups + 3) / 4), dim3(256), 0, st, sb);
     if (int rc = check_launch("styles_batched_bwd(ds)")) return rc;
-    hipLaunchKernelGGL(styles_batched_bwd_lat_kernel, dim3((D + 255) / 256, L, (B + SG_BU - 1) / SG_BU), dim3(256), 0, st, sb);
+    hipLaunchKernelGGL(styles_batched_bwd_lat_kernel, dim3((D + 63) / 64, L, (B + SG_BU - 1) / SG_BU), dim3(256), 0, st, sb);
     return check_launch("styles_batched_bwd(latent)");
 }
 
