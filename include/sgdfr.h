@@ -481,11 +481,40 @@ typedef struct sgdfr_style_grad_layer {
     const float* qt;    /* [cin, cout] */
     const float* mod_w; /* [cin, D] */
     float* ds;          /* [B, cin] out */
-    long long a_stride;
+    float* gmod_w;      /* [cin, D] out or NULL: dL/d(modulation weight) = ds^T @ latent[:, latent_index] / sqrt(D)  (model.py:148-157) */
+    float* gmod_b;      /* [cin] out or NULL:    dL/d(modulation bias)   = sum_b ds */
+    int64_t a_stride;
     int cin, cout, latent_index;
 } sgdfr_style_grad_layer;
-int sgdfr_styles_batched_bwd_f32(const sgdfr_style_grad_layer* layers, int n_layers, float* glat, int B, int L, int D,
-                                 void* stream);
+/* latent [B,L,D]: needed (non-NULL) only when some layer asks for gmod_w / gmod_b (PTI trains them, libs/optimization.py:31-40);
+ * glat may be NULL when only those are wanted. */
+int sgdfr_styles_batched_bwd_f32(const sgdfr_style_grad_layer* layers, int n_layers, const float* latent, float* glat, int B, int L,
+                                 int D, void* stream);
+
+/* dq[o,i] = sum_b (-0.5 * (a/d) * d^3)[b,o] * s[b,i]^2 = dL/dQ of the demodulation (Q = sum_k Wc^2), the term
+ * sgdfr_modconv_wgrad_finish*_f32 adds to the weight gradient; a = d * dL/dd with element stride a_stride (see above). */
+int sgdfr_demod_dq_f32(const float* a, int64_t a_stride, const float* d, const float* s, float* dq, int B, int Cin, int Cout,
+                       void* stream);
+
+/* The small parameter gradients of one generator backward in ONE launch (the reference gets them from autograd's sum ops:
+ * op/fused_act.py:32-37 for the bias, model.py:287 for the noise strength, model.py:350-359 for ToRGB):
+ *   SGDFR_PGRAD_BIAS   out[c]     = sum_b in[b,c,0]                       in = sums [B,C,3] of the activation-gradient pass
+ *   SGDFR_PGRAD_NOISE  out[0]     = sum_{b,c} in[b,c,1]
+ *   SGDFR_PGRAD_RGB_W  out[j,i]   = scale * sum_b in[b,j,i] * aux[b,i]    in = r_rgb [B,3,C], aux = s [B,C], scale = 1/sqrt(C)
+ *   SGDFR_PGRAD_RGB_B  out[j]    += sum_{b,p} in[b,j,p]                   in = g_rgb [B,3,HW]; out must be ZEROED by the caller */
+#define SGDFR_PGRAD_BIAS 0
+#define SGDFR_PGRAD_NOISE 1
+#define SGDFR_PGRAD_RGB_W 2
+#define SGDFR_PGRAD_RGB_B 3
+#define SGDFR_MAX_PARAM_GRADS 64
+typedef struct sgdfr_param_grad {
+    const float* in;
+    const float* aux;
+    float* out;
+    int kind, C, HW;
+    float scale;
+} sgdfr_param_grad;
+int sgdfr_param_grads_f32(const sgdfr_param_grad* entries, int n, int B, void* stream);
 
 /* ds[b,i] = gs[b,i] + s[b,i] * sum_o (-gd[b,o] * d[b,o]^3) * qt[i,o]   (chain rule through d = rsqrt(sum s^2 q + eps)) */
 int sgdfr_demod_grad_f32(const float* gd, const float* d, const float* qt, const float* s, const float* gs, float* ds,

@@ -26,7 +26,7 @@ def main():
     sv = S.counter_tensor(7, 'sv', (B, 15), 0.0, 3.0).cuda()
     z_st = torch.cat([z_s, z_t])
     two_calls = 'two_calls' in sys.argv[2:]
-    G.fused_frozen_backward = 'per_layer' not in sys.argv[2:]        # (the whole-synthesis Function is the default)
+    G.fused_backward = 'per_layer' not in sys.argv[2:]        # (the whole-synthesis Function is the default)
     import warnings; warnings.simplefilter('ignore')
     def step():
         with torch.no_grad():

@@ -119,11 +119,21 @@ class StyleGradLayer(ctypes.Structure):
     """struct sgdfr_style_grad_layer (include/sgdfr.h)."""
     _fields_ = [('gs', ctypes.c_void_p), ('rgb_r', ctypes.c_void_p), ('rgb_w', ctypes.c_void_p), ('a', ctypes.c_void_p),
                 ('d', ctypes.c_void_p), ('s', ctypes.c_void_p), ('qt', ctypes.c_void_p), ('mod_w', ctypes.c_void_p),
-                ('ds', ctypes.c_void_p), ('a_stride', ctypes.c_longlong), ('cin', ctypes.c_int), ('cout', ctypes.c_int),
-                ('latent_index', ctypes.c_int)]
+                ('ds', ctypes.c_void_p), ('gmod_w', ctypes.c_void_p), ('gmod_b', ctypes.c_void_p), ('a_stride', ctypes.c_longlong),
+                ('cin', ctypes.c_int), ('cout', ctypes.c_int), ('latent_index', ctypes.c_int)]
 
 
-SIGNATURES['sgdfr_styles_batched_bwd_f32'] = [ctypes.POINTER(StyleGradLayer), _i, _c_f32p, _i, _i, _i, ctypes.c_void_p]
+class ParamGrad(ctypes.Structure):
+    """struct sgdfr_param_grad (include/sgdfr.h)."""
+    _fields_ = [('inp', ctypes.c_void_p), ('aux', ctypes.c_void_p), ('out', ctypes.c_void_p), ('kind', ctypes.c_int), ('C', ctypes.c_int),
+                ('HW', ctypes.c_int), ('scale', ctypes.c_float)]
+
+
+PGRAD_BIAS, PGRAD_NOISE, PGRAD_RGB_W, PGRAD_RGB_B = 0, 1, 2, 3
+MAX_PARAM_GRADS = 64
+SIGNATURES['sgdfr_styles_batched_bwd_f32'] = [ctypes.POINTER(StyleGradLayer), _i, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p]
+SIGNATURES['sgdfr_demod_dq_f32'] = [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p]
+SIGNATURES['sgdfr_param_grads_f32'] = [ctypes.POINTER(ParamGrad), _i, _i, ctypes.c_void_p]
 SIGNATURES['sgdfr_grad_join_f32'] = ([_c_f32p] * 7 + [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_void_p,
                                                                   _c_f32p, _c_f32p, _i, _i, _i, _f, _f, _i, _i, ctypes.c_void_p])
 SIGNATURES['sgdfr_modconv2d_wsplit_supported'] = [_i, _i, _i, _i, _i, _i]

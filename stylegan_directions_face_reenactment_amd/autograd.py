@@ -337,22 +337,38 @@ class ToRGBFn(Function):
         return gx, gs, gw, gb, gskip, None
 
 
-# ------------------------------------------------------------------ the whole synthesis network, frozen weights
+# ------------------------------------------------------------------ the whole synthesis network as one Function
 
-class SynthesisFrozenFn(Function):
-    """image = synthesis(latent) of a FROZEN generator (the direction trainer optimises A alone, libs/trainer.py:106-111,144,
-    177-189): one Function for conv1 ... convs / to_rgbs, differentiable w.r.t. the W+ latent only.
+def synthesis_params(gen, layers, to_rgbs):
+    """The parameter tensors SynthesisFn takes (and returns gradients for), in its order."""
+    ps = [gen.input.input]
+    for l in layers:
+        ps += [l.conv.weight, l.conv.modulation.weight, l.conv.modulation.bias, l.noise.weight, l.activate.bias]
+    for r in to_rgbs:
+        ps += [r.conv.weight, r.conv.modulation.weight, r.conv.modulation.bias, r.bias]
+    return ps
 
-    Forward = the launches of StyledConvFn / ToRGBFn, layer by layer.  Backward = the same MFMA launches (`_conv_input_grad`),
-    but every saved activation is walked ONCE: the per-layer Functions pay, per layer, scale_reduce (dx = s*gu, r = sum x*gu),
-    torgb_bwd (dx_rgb, r_rgb), autograd's add of the two dx and act_grad_reduce of the layer below -- four HBM-bound passes
-    over the same tensor, 36 bytes per element -- which `functional.grad_join` does in one (12-16 bytes per element).  The 20
-    style modulations' backward (A/d, demod_grad, a transposed copy of the modulation weight, a linear and an indexed add
-    PER LAYER) is two launches (`functional.styles_batched_bwd`), and all reduction buffers of a backward come from one zeroed
-    workspace.  Same expressions per term as the per-layer path (tests/test_gpu_backward.py compares the two)."""
+
+class SynthesisFn(Function):
+    """image = synthesis(latent) -- conv1 ... convs / to_rgbs (model.py:519-534) -- as ONE Function, differentiable w.r.t. the W+
+    latent (the direction trainer, libs/trainer.py:177-189: the generator is frozen) and w.r.t. every generator parameter
+    (PTI, libs/optimization.py:47-68).
+
+    Forward = the launches of StyledConvFn / ToRGBFn layer by layer, all styles in two launches.  Backward = the same MFMA
+    launches (`_conv_input_grad`, `functional.wgrad`), but every saved activation is walked ONCE: the per-layer Functions pay, per
+    layer, scale_reduce (dx = s*gu, r = sum x*gu), torgb_bwd (dx_rgb, r_rgb), autograd's add of the two dx and act_grad_reduce of
+    the layer below -- four HBM-bound passes over the same tensor, 36 bytes per element -- which `functional.grad_join` does in one
+    (12-16 bytes per element).  The 20 style modulations' backward (A/d, demod_grad, a transposed copy of the modulation weight, a
+    linear and an indexed add PER LAYER, plus two more linears and a column sum when the modulation is trained) is two or three
+    launches (`functional.styles_batched_bwd`), dL/dQ of a layer one (`functional.demod_dq`), all bias / noise-strength / ToRGB
+    parameter gradients one (`functional.param_grads`), and all reduction buffers of a backward come from one zeroed workspace:
+    ~700 -> ~200 device launches for a PTI step.  Same expressions per term as the per-layer path
+    (tests/test_gpu_backward.py compares the two)."""
+
+    N_FIXED = 6          # latent, gen, order, layers, to_rgbs, noise -- then synthesis_params(...)
 
     @staticmethod
-    def forward(ctx, latent, gen, order, layers, to_rgbs, noise):
+    def forward(ctx, latent, gen, order, layers, to_rgbs, noise, *params):
         B = latent.shape[0]
         sd = F_.styles_batched(latent, [m.style_spec(li) for m, li in order])
         sd_of_layer = [0] + [2 + 3 * (i // 2) + (i % 2) for i in range(len(layers) - 1)]
@@ -389,6 +405,7 @@ class SynthesisFrozenFn(Function):
             x = out
         ctx.gen, ctx.order, ctx.layers, ctx.to_rgbs = gen, order, layers, to_rgbs
         ctx.sd, ctx.saved, ctx.noises = sd, saved, noises
+        ctx.latent = latent if any(ctx.needs_input_grad[SynthesisFn.N_FIXED:]) else None     # (the modulation weight gradients read it)
         ctx.lat_shape = tuple(latent.shape)
         ctx.sat = F_.current_sink()
         ctx.cfg = F_.config()
@@ -397,23 +414,28 @@ class SynthesisFrozenFn(Function):
     @staticmethod
     def backward(ctx, g_img):
         with F_.using(ctx.cfg), F_.saturation_sink(ctx.sat):
-            return SynthesisFrozenFn._backward(ctx, g_img)
+            return SynthesisFn._backward(ctx, g_img)
 
     @staticmethod
     def _backward(ctx, g_img):
         from .op.upfirdn2d import upfirdn2d_native_op
         gen, order, layers, to_rgbs, sd = ctx.gen, ctx.order, ctx.layers, ctx.to_rgbs, ctx.sd
         B, L, D = ctx.lat_shape
-        n = len(layers)
+        n, nr = len(layers), len(to_rgbs)
+        F0 = SynthesisFn.N_FIXED
+        need = ctx.needs_input_grad
+        grads = [None] * len(need)
+        lay_p = lambda li, j: F0 + 1 + 5 * li + j                   # weight, modulation.weight, modulation.bias, noise.weight, activate.bias
+        rgb_p = lambda k, j: F0 + 1 + 5 * n + 4 * k + j             # weight, modulation.weight, modulation.bias, bias
         sd_of_layer = [0] + [2 + 3 * (i // 2) + (i % 2) for i in range(n - 1)]
-        sd_of_rgb = [1] + [4 + 3 * k for k in range(len(to_rgbs) - 1)]
+        sd_of_rgb = [1] + [4 + 3 * k for k in range(nr - 1)]
         dev = g_img.device
         bw_arith = F_.config().backward_arith if F_.config().precision != 'fp32' else 'bf16x3'
         # gradient of every level's RGB image: the skip path is Upsample (upfirdn2d up=2, pad (2,1)); its adjoint = flipped taps,
         # down=2, pad (1,1)  (op/upfirdn2d.py:104-117) -- 3-channel tensors
-        g_rgb = [None] * len(to_rgbs)
+        g_rgb = [None] * nr
         g_rgb[-1] = N.f32c(g_img)
-        for k in range(len(to_rgbs) - 1, 0, -1):
+        for k in range(nr - 1, 0, -1):
             g = g_rgb[k]
             H, W = g.shape[2], g.shape[3]
             fir = to_rgbs[k].upsample.kernel
@@ -423,7 +445,8 @@ class SynthesisFrozenFn(Function):
         woff = 0
         gs = [None] * n            # dL/ds of layer li's modulation (sum_q x * gu)
         A = [None] * n             # d * dL/dd
-        rgb_r = [None] * len(to_rgbs)
+        rgb_r = [None] * nr
+        small = []                 # (index into grads, shape, functional.param_grads entry)
         gu_next = None
         for li in range(n - 1, -1, -1):
             layer, mod = layers[li], layers[li].conv
@@ -445,22 +468,53 @@ class SynthesisFrozenFn(Function):
                 gs[li + 1] = r_next
             if has_rgb:
                 rgb_r[k] = r_rgb
-            gu_next, A_up, _ = _conv_input_grad(mod, g_pre, g_max if bw_arith == 'fp16x3' else None, d, planes,
-                                                (B, cin, C, H, W), bw_arith, False)
+            want_w = need[lay_p(li, 0)]
+            gu_next, A_up, gT = _conv_input_grad(mod, g_pre, g_max if bw_arith == 'fp16x3' else None, d, planes,
+                                                 (B, cin, C, H, W), bw_arith, want_w)
             A[li] = A_up if mod.upsample else (sums[:, :, 2] if d is not None else None)
-        _, gs[0] = F_.scale_reduce(gu_next, gen.input.input, sd[sd_of_layer[0]][0])        # conv1 reads the broadcast ConstantInput
+            if want_w:
+                x = ctx.saved[li - 1][0] if li > 0 else gen.input.input
+                dq = F_.demod_dq(A[li], d, s) if d is not None else None
+                grads[lay_p(li, 0)] = F_.wgrad(gT if mod.upsample else g_pre, d, x, s, C, mod.upsample, wp=mod.packed()[0], dq=dq)
+            if need[lay_p(li, 3)]:
+                small.append((lay_p(li, 3), (1,), (N.PGRAD_NOISE, sums, None, C, 0)))
+            if need[lay_p(li, 4)]:
+                small.append((lay_p(li, 4), tuple(layer.activate.bias.shape), (N.PGRAD_BIAS, sums, None, C, 0)))
+        dx0, gs[0] = F_.scale_reduce(gu_next, gen.input.input, sd[sd_of_layer[0]][0])        # conv1 reads the broadcast ConstantInput
+        if need[F0]:
+            grads[F0] = dx0.sum(0, keepdim=True)
+        for k, rgb in enumerate(to_rgbs):
+            C = rgb.conv.in_channel
+            if need[rgb_p(k, 0)]:
+                small.append((rgb_p(k, 0), tuple(rgb.conv.weight.shape), (N.PGRAD_RGB_W, rgb_r[k], sd[sd_of_rgb[k]][0], C, 0)))
+            if need[rgb_p(k, 3)]:
+                g = g_rgb[k]
+                small.append((rgb_p(k, 3), tuple(rgb.bias.shape), (N.PGRAD_RGB_B, g, None, 3, g.shape[2] * g.shape[3])))
+        if small:
+            for (gi, shape, _), o in zip(small, F_.param_grads([e for _, _, e in small], B)):
+                grads[gi] = o.view(shape)
         layer_of = {id(l.conv): i for i, l in enumerate(layers)}
         rgb_of = {id(r.conv): i for i, r in enumerate(to_rgbs)}
-        entries = []
+        entries, slots = [], []
         for (m, lat_i), (s, d) in zip(order, sd):
             e = {'latent_index': lat_i, 'mod_w': m.modulation.weight}
             if id(m) in rgb_of:
-                e['rgb_r'], e['rgb_w'] = rgb_r[rgb_of[id(m)]], m.weight.view(3, m.in_channel)
+                k = rgb_of[id(m)]
+                e['rgb_r'], e['rgb_w'] = rgb_r[k], m.weight.view(3, m.in_channel)
+                slot = (rgb_p(k, 1), rgb_p(k, 2))
             else:
                 li = layer_of[id(m)]
                 e['gs'] = gs[li]
                 if d is not None:
                     e['a'], e['d'], e['s'], e['qt'] = A[li], d, s, m.packed()[2]
+                slot = (lay_p(li, 1), lay_p(li, 2))
+            e['want_w'], e['want_b'] = need[slot[0]], need[slot[1]]
             entries.append(e)
-        glat = F_.styles_batched_bwd(entries, B, L, D)
-        return glat, None, None, None, None, None
+            slots.append(slot)
+        grads[0] = F_.styles_batched_bwd(entries, B, L, D, latent=ctx.latent, want_latent=need[0])
+        for e, (iw, ib) in zip(entries, slots):
+            if e.get('gmod_w') is not None:
+                grads[iw] = e['gmod_w']
+            if e.get('gmod_b') is not None:
+                grads[ib] = e['gmod_b']
+        return tuple(grads)

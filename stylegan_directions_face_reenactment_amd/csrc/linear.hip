@@ -638,12 +638,144 @@ __global__ __launch_bounds__(256) void styles_batched_bwd_lat_kernel(StyleGradBa
     }
 }
 
-extern "C" int sgdfr_styles_batched_bwd_f32(const sgdfr_style_grad_layer* layers, int n_layers, float* glat, int B, int L, int D,
-                                            void* stream) {
+// Stage 2 (only when the modulation weights are trained: PTI, libs/optimization.py:31-40): per layer
+//   gmod_w[i, n] = sum_b ds[b,i] * latent[b, latent_index, n] / sqrt(D)      gmod_b[i] = sum_b ds[b,i]
+// lanes along n (coalesced latent rows and gmod_w rows), one wave per 4 rows i.
+__global__ __launch_bounds__(256) void styles_batched_bwd_w_kernel(StyleGradBatch sb, const float* __restrict__ latent) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = blockIdx.x * 4 + wave;
+    int li = 0;
+    while (li + 1 < sb.n_layers && grp >= sb.tile_start[li + 1]) ++li;
+    if (grp >= sb.tile_start[sb.n_layers]) return;
+    const sgdfr_style_grad_layer& ly = sb.layer[li];
+    if (!ly.gmod_w && !ly.gmod_b) return;
+    const int i0 = (grp - sb.tile_start[li]) * 4;
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + r;
+        if (i >= ly.cin) break;
+        if (ly.gmod_b && lane == 0) {
+            float t = 0.f;
+            for (int b = 0; b < sb.B; ++b) t += ly.ds[(int64_t)b * ly.cin + i];
+            ly.gmod_b[i] = t;
+        }
+        if (ly.gmod_w) {
+            for (int n = lane; n < sb.D; n += 64) {
+                float t = 0.f;
+                for (int b = 0; b < sb.B; ++b)
+                    t = fmaf(ly.ds[(int64_t)b * ly.cin + i], latent[((int64_t)b * sb.L + ly.latent_index) * sb.D + n], t);
+                ly.gmod_w[(int64_t)i * sb.D + n] = t * sb.wscale;
+            }
+        }
+    }
+}
+
+// dq[o,i] = sum_b (-0.5 * (a/d) * d^3)[b,o] * s[b,i]^2 : dL/dQ of the demodulation d = rsqrt(sum_i s^2 Q + eps), one launch instead of
+// (A/d, d^3, two products, two transposed copies, s*s, a linear)
+__global__ __launch_bounds__(256) void demod_dq_kernel(const float* __restrict__ a, int64_t a_stride, const float* __restrict__ d,
+                                                      const float* __restrict__ s, float* __restrict__ dq, int B, int Cin, int Cout) {
+    const int64_t total = (int64_t)Cout * Cin;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % Cin), o = (int)(idx / Cin);
+        float t = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float dv = d[(int64_t)b * Cout + o];
+            const float coeff = (a[((int64_t)b * Cout + o) * a_stride] / dv) * (dv * dv * dv) * -0.5f;
+            const float sv = s[(int64_t)b * Cin + i];
+            t = fmaf(coeff, sv * sv, t);
+        }
+        dq[idx] = t;
+    }
+}
+
+// Small parameter gradients of one backward, every layer in one launch (sgdfr_param_grads_f32): blockIdx -> (entry, block of it)
+struct ParamGradBatch {
+    sgdfr_param_grad e[SGDFR_MAX_PARAM_GRADS];
+    int block_start[SGDFR_MAX_PARAM_GRADS + 1];
+    int n, B;
+};
+
+__global__ __launch_bounds__(256) void param_grads_kernel(ParamGradBatch pb) {
+    __shared__ float red[4];
+    int ei = 0;
+    while (ei + 1 < pb.n && (int)blockIdx.x >= pb.block_start[ei + 1]) ++ei;
+    const sgdfr_param_grad& e = pb.e[ei];
+    const int blk = blockIdx.x - pb.block_start[ei], nblk = pb.block_start[ei + 1] - pb.block_start[ei];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int B = pb.B, C = e.C;
+    if (e.kind == SGDFR_PGRAD_BIAS) {               // out[c] = sum_b in[(b*C+c)*3]
+        const int c = blk * 256 + tid;
+        if (c >= C) return;
+        float t = 0.f;
+        for (int b = 0; b < B; ++b) t += e.in[((int64_t)b * C + c) * 3];
+        e.out[c] = t;
+    } else if (e.kind == SGDFR_PGRAD_RGB_W) {       // out[j*C+i] = scale * sum_b in[(b*3+j)*C+i] * aux[b*C+i]
+        const int idx = blk * 256 + tid;
+        if (idx >= 3 * C) return;
+        const int j = idx / C, i = idx - j * C;
+        float t = 0.f;
+        for (int b = 0; b < B; ++b) t = fmaf(e.in[((int64_t)b * 3 + j) * C + i], e.aux[(int64_t)b * C + i], t);
+        e.out[idx] = t * e.scale;
+    } else if (e.kind == SGDFR_PGRAD_NOISE) {       // out[0] = sum_{b,c} in[(b*C+c)*3+1]      (one block)
+        float t = 0.f;
+        for (int64_t k = tid; k < (int64_t)B * C; k += 256) t += e.in[k * 3 + 1];
+        t = wave_sum(t);
+        if (lane == 0) red[wave] = t;
+        __syncthreads();
+        if (tid == 0) e.out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+    } else {                                        // RGB_B: out[j] += sum_{b,p} in[(b*3+j)*HW+p]   (nblk/3 blocks per j, atomics into zeroed out)
+        const int per_j = nblk / 3, j = blk / per_j, part = blk - j * per_j;
+        float t = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float* src = e.in + ((int64_t)b * 3 + j) * e.HW;
+            for (int p = part * 256 + tid; p < e.HW; p += per_j * 256) t += src[p];
+        }
+        t = wave_sum(t);
+        if (lane == 0) red[wave] = t;
+        __syncthreads();
+        if (tid == 0) atomicAdd(&e.out[j], (red[0] + red[1]) + (red[2] + red[3]));
+    }
+}
+
+extern "C" int sgdfr_param_grads_f32(const sgdfr_param_grad* entries, int n, int B, void* stream) {
+    SGDFR_REQUIRE(n > 0 && n <= SGDFR_MAX_PARAM_GRADS && B > 0, "param_grads: bad n=%d B=%d", n, B);
+    SGDFR_REQUIRE(entries, "param_grads: null pointer");
+    ParamGradBatch pb;
+    pb.n = n; pb.B = B;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const sgdfr_param_grad& e = entries[i];
+        SGDFR_REQUIRE(e.in && e.out && e.C > 0 && e.kind >= 0 && e.kind <= 3, "param_grads: entry %d: bad kind / C / null pointer", i);
+        SGDFR_REQUIRE(e.kind != SGDFR_PGRAD_RGB_W || e.aux, "param_grads: entry %d: the ToRGB weight gradient needs aux = s", i);
+        SGDFR_REQUIRE(e.kind != SGDFR_PGRAD_RGB_B || e.HW > 0, "param_grads: entry %d: the ToRGB bias gradient needs HW", i);
+        pb.e[i] = e;
+        pb.block_start[i] = blocks;
+        if (e.kind == SGDFR_PGRAD_BIAS) blocks += (e.C + 255) / 256;
+        else if (e.kind == SGDFR_PGRAD_RGB_W) blocks += (3 * e.C + 255) / 256;
+        else if (e.kind == SGDFR_PGRAD_NOISE) blocks += 1;
+        else { int per = (int)(((int64_t)B * e.HW + 16383) / 16384); per = per < 1 ? 1 : (per > 64 ? 64 : per); blocks += 3 * per; }
+    }
+    pb.block_start[n] = blocks;
+    hipLaunchKernelGGL(param_grads_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), pb);
+    return check_launch("param_grads");
+}
+
+extern "C" int sgdfr_demod_dq_f32(const float* a, int64_t a_stride, const float* d, const float* s, float* dq, int B, int Cin,
+                                  int Cout, void* stream) {
+    SGDFR_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && a_stride >= 1, "demod_dq: bad shape %d %d %d", B, Cin, Cout);
+    SGDFR_REQUIRE(a && d && s && dq, "demod_dq: null pointer");
+    const int64_t total = (int64_t)Cout * Cin;
+    int64_t g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(demod_dq_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), a, a_stride, d, s, dq, B, Cin, Cout);
+    return check_launch("demod_dq");
+}
+
+extern "C" int sgdfr_styles_batched_bwd_f32(const sgdfr_style_grad_layer* layers, int n_layers, const float* latent, float* glat,
+                                            int B, int L, int D, void* stream) {
     SGDFR_REQUIRE(B >= 0 && L > 0 && D > 0 && n_layers > 0 && n_layers <= SGDFR_MAX_STYLE_LAYERS, "styles_batched_bwd: bad shape B=%d L=%d D=%d layers=%d",
                   B, L, D, n_layers);
     if (B == 0) return 0;
-    SGDFR_REQUIRE(layers && glat, "styles_batched_bwd: null pointer");
+    SGDFR_REQUIRE(layers && (glat || latent), "styles_batched_bwd: null pointer");
     StyleGradBatch sb;
     sb.n_layers = n_layers; sb.glat = glat; sb.B = B; sb.L = L; sb.D = D; sb.wscale = 1.0f / sqrtf((float)D);
     int groups = 0;
@@ -660,6 +792,14 @@ extern "C" int sgdfr_styles_batched_bwd_f32(const sgdfr_style_grad_layer* layers
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(styles_batched_bwd_ds_kernel, dim3((groups + 3) / 4), dim3(256), 0, st, sb);
     if (int rc = check_launch("styles_batched_bwd(ds)")) return rc;
+    bool want_w = false;
+    for (int i = 0; i < n_layers; ++i) want_w = want_w || layers[i].gmod_w || layers[i].gmod_b;
+    SGDFR_REQUIRE(!want_w || latent, "styles_batched_bwd: modulation weight gradients need the latent");
+    if (want_w) {
+        hipLaunchKernelGGL(styles_batched_bwd_w_kernel, dim3((groups + 3) / 4), dim3(256), 0, st, sb, latent);
+        if (int rc = check_launch("styles_batched_bwd(weights)")) return rc;
+    }
+    if (!glat) return 0;
     hipLaunchKernelGGL(styles_batched_bwd_lat_kernel, dim3((D + 63) / 64, L, (B + SG_BU - 1) / SG_BU), dim3(256), 0, st, sb);
     return check_launch("styles_batched_bwd(latent)");
 }

@@ -12,6 +12,7 @@ tests) import as `F_`:
                  rgb_fusable, xin_ok, StreamPipeline                                       (served lazily as F_.<name>)
 """
 import functools
+import math
 import sys
 import threading
 import types
@@ -957,10 +958,12 @@ def grad_join(out, gu=None, s_next=None, g_rgb=None, w_rgb=None, s_rgb=None, g_a
     return g_pre, sums, gmax, r_next, r_rgb
 
 
-def styles_batched_bwd(entries, B, L, D):
-    """dL/dlatent [B, L, D] of functional.styles_batched for frozen weights, two launches (sgdfr_styles_batched_bwd_f32).
+def styles_batched_bwd(entries, B, L, D, latent=None, want_latent=True):
+    """dL/dlatent [B, L, D] of functional.styles_batched, two launches (sgdfr_styles_batched_bwd_f32).
     entries: one dict per layer with latent_index, mod_w [cin,D], and either gs [B,cin] (+ for demodulated convs a = d*dL/dd
-    ([B,cout] view, any element stride), d, s, qt) or rgb_r [B,3,cin] + rgb_w [3,cin]."""
+    ([B,cout] view, any element stride), d, s, qt) or rgb_r [B,3,cin] + rgb_w [3,cin].  Entries with want_w / want_b set get
+    'gmod_w' [cin,D] / 'gmod_b' [cin] (the modulation's parameter gradients, a third launch) written into the dict; needs `latent`.
+    Returns glat (None when want_latent is False)."""
     if len(entries) > N.MAX_STYLE_LAYERS:
         raise RuntimeError('too many modulated layers (%d)' % len(entries))
     arr = (N.StyleGradLayer * len(entries))()
@@ -975,9 +978,15 @@ def styles_batched_bwd(entries, B, L, D):
         c.mod_w, c.cin, c.latent_index = mw.data_ptr(), cin, int(e['latent_index'])
         c.ds = ds[off:off + B * cin].data_ptr()
         off += B * cin
-        c.gs = c.rgb_r = c.rgb_w = c.a = c.d = c.s = c.qt = None
+        c.gs = c.rgb_r = c.rgb_w = c.a = c.d = c.s = c.qt = c.gmod_w = c.gmod_b = None
         c.a_stride, c.cout = 1, 0
         keep.append(mw)
+        if e.get('want_w'):
+            e['gmod_w'] = torch.empty(cin, D, device=dev, dtype=torch.float32)
+            c.gmod_w = e['gmod_w'].data_ptr()
+        if e.get('want_b'):
+            e['gmod_b'] = torch.empty(cin, device=dev, dtype=torch.float32)
+            c.gmod_b = e['gmod_b'].data_ptr()
         if e.get('rgb_r') is not None:
             r, w = N.f32c(e['rgb_r']), N.f32c(e['rgb_w'])
             keep += [r, w]
@@ -992,9 +1001,50 @@ def styles_batched_bwd(entries, B, L, D):
                 raise RuntimeError('styles_batched_bwd: a must be a [B,cout] view with a uniform element stride')
             keep += [a, d, s_, qt]
             c.a, c.a_stride, c.d, c.s, c.qt, c.cout = a.data_ptr(), a.stride(1), d.data_ptr(), s_.data_ptr(), qt.data_ptr(), d.shape[1]
-    glat = torch.empty(B, L, D, device=dev, dtype=torch.float32)
-    N.call('sgdfr_styles_batched_bwd_f32', arr, len(entries), N.ptr(glat), B, L, D, N.stream())
+    glat = torch.empty(B, L, D, device=dev, dtype=torch.float32) if want_latent else None
+    if latent is not None:
+        N.require_device(latent)
+        latent = N.f32c(latent)
+    N.call('sgdfr_styles_batched_bwd_f32', arr, len(entries), N.ptr(latent), N.ptr(glat), B, L, D, N.stream())
     return glat
+
+
+def demod_dq(a, d, s):
+    """dL/dQ [Cout,Cin] of the demodulation from a = d*dL/dd ([B,Cout] view, any element stride), d [B,Cout], s [B,Cin] (one launch)."""
+    N.require_device(a, d, s)
+    if a.dim() != 2 or a.stride(0) != a.shape[1] * a.stride(1):
+        raise RuntimeError('demod_dq: a must be a [B,cout] view with a uniform element stride')
+    B, cout = d.shape
+    cin = s.shape[1]
+    dq = torch.empty(cout, cin, device=d.device, dtype=torch.float32)
+    N.call('sgdfr_demod_dq_f32', N.ptr(a), a.stride(1), N.ptr(N.f32c(d)), N.ptr(N.f32c(s)), N.ptr(dq), B, cin, cout, N.stream())
+    return dq
+
+
+def param_grads(entries, B):
+    """The small parameter gradients of one backward in one launch (sgdfr_param_grads_f32).  entries: (kind, in, aux | None, C, HW);
+    kind in N.PGRAD_*.  Returns one output tensor per entry ([C] bias, [1] noise strength, [3,C] ToRGB weight, [3] ToRGB bias)."""
+    if len(entries) > N.MAX_PARAM_GRADS:
+        raise RuntimeError('too many parameter-gradient entries (%d)' % len(entries))
+    sizes = [{N.PGRAD_BIAS: C, N.PGRAD_NOISE: 1, N.PGRAD_RGB_W: 3 * C, N.PGRAD_RGB_B: 3}[kind] for kind, _, _, C, _ in entries]
+    dev = entries[0][1].device
+    flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)      # (zeroed: the ToRGB bias entries accumulate with atomics)
+    arr = (N.ParamGrad * len(entries))()
+    outs, off, keep = [], 0, []
+    for i, (kind, inp, aux, C, HW) in enumerate(entries):
+        N.require_device(inp, aux)
+        if not inp.is_contiguous() or (aux is not None and not aux.is_contiguous()):
+            raise RuntimeError('param_grads: inputs must be contiguous')
+        c = arr[i]
+        c.inp, c.aux, c.kind, c.C, c.HW = inp.data_ptr(), (aux.data_ptr() if aux is not None else None), int(kind), int(C), int(HW)
+        c.scale = 1.0 / math.sqrt(C)
+        o = flat[off:off + sizes[i]]
+        c.out = o.data_ptr()
+        off += sizes[i]
+        outs.append(o.view(3, C) if kind == N.PGRAD_RGB_W else o)
+        keep += [inp, aux]
+    N.call('sgdfr_param_grads_f32', arr, len(entries), B, N.stream())
+    return outs
 
 
 def demod_grad(gd, d, qt, s, gs):

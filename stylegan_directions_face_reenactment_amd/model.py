@@ -484,8 +484,8 @@ class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
     # (ReenactmentSession, functional.StreamPipeline loops, bench.py) pass verify_range=False; `G.verify_range_default = False`
     # or SGDFR_VERIFY_RANGE=0 changes the default for a generator / the process.
     verify_range_default = os.environ.get('SGDFR_VERIFY_RANGE', '1') != '0'
-    # frozen generator under autograd: the whole-synthesis Function (False / SGDFR_FUSED_BACKWARD=0: one Function per layer)
-    fused_frozen_backward = os.environ.get('SGDFR_FUSED_BACKWARD', '1') != '0'
+    # under autograd: the whole-synthesis Function (False / SGDFR_FUSED_BACKWARD=0: one Function per layer)
+    fused_backward = os.environ.get('SGDFR_FUSED_BACKWARD', '1') != '0'
 
     def forward(self, styles, return_latents=False, return_features=False, inject_index=None, truncation=1,
                 truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=False, image_out=None,
@@ -574,10 +574,10 @@ class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
             if grad:
                 frozen = not any(p.requires_grad for p in self._params())
                 hooked = any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in layers + to_rgbs)
-                if frozen and self.fused_frozen_backward and not hooked and not return_features and image_out is None:
-                    # frozen generator (the direction trainer): ONE Function for the whole synthesis network -- its backward walks
-                    # every saved activation once (autograd.SynthesisFrozenFn)
-                    image = AG.SynthesisFrozenFn.apply(latent, self, order, layers, to_rgbs, noise)
+                if self.fused_backward and not hooked and not return_features and image_out is None:
+                    # ONE Function for the whole synthesis network -- its backward walks every saved activation once and batches
+                    # the per-layer glue (autograd.SynthesisFn): the direction trainer (frozen generator) and PTI (trained one)
+                    image = AG.SynthesisFn.apply(latent, self, order, layers, to_rgbs, noise, *AG.synthesis_params(self, layers, to_rgbs))
                     return (image, latent) if return_latents else (image, None)
                 if frozen:
                     # ... per-layer Functions (hooked modules): the two batched style launches, differentiable w.r.t. the latent only

@@ -127,8 +127,8 @@ def test_generator_gradient_to_latent_small():
     assert _rel(wh.grad, wr.grad) <= 2e-4
 
 
-def test_fused_frozen_backward_matches_the_per_layer_functions():
-    """autograd.SynthesisFrozenFn (one Function for the frozen synthesis network: functional.grad_join walks every saved
+def test_fused_backward_matches_the_per_layer_functions():
+    """autograd.SynthesisFn (one Function for the frozen synthesis network: functional.grad_join walks every saved
     activation once, functional.styles_batched_bwd does the 20 modulations' backward in two launches) against the per-layer
     Functions it replaces, on the same generator and latents: same image bits, dL/dW+ within the reduction-order noise of the
     atomics both paths use -- and against autograd of the fp64 oracle like the per-layer path."""
@@ -141,10 +141,10 @@ def test_fused_frozen_backward_matches_the_per_layer_functions():
         gimg = S.counter_tensor(31, 'fz.g', (B, 3, size, size)).cuda()
         grads, imgs = [], []
         for fused in (True, False):
-            G.fused_frozen_backward = fused
+            G.fused_backward = fused
             wh = w.cuda().requires_grad_(True)
             img, lat = G([wh], input_is_latent=True, truncation=0.7, truncation_latent=tr, return_latents=True)
-            assert (type(img.grad_fn).__name__ == 'SynthesisFrozenFnBackward') == fused
+            assert (type(img.grad_fn).__name__ == 'SynthesisFnBackward') == fused
             assert lat.shape == (B, G.n_latent, 512)
             (img * gimg).sum().backward()
             grads.append(wh.grad.clone())
@@ -161,6 +161,51 @@ def test_fused_frozen_backward_matches_the_per_layer_functions():
             from stylegan_directions_face_reenactment_amd import functional as F_
             assert _rel(grads[0], wr.grad) <= (2e-4 if F_.PRECISION == 'fp16x3' else 5e-3)
         assert G.saturated_pairs() == 0
+
+
+def test_fused_backward_parameter_gradients_match_the_per_layer_functions():
+    """The same Function with every generator parameter trainable (PTI, libs/optimization.py:47-68): dL/dW of all convs, the
+    modulation weights / biases, noise strengths, activation biases, ToRGB weights / biases and the constant input -- against the
+    per-layer Functions on the same generator, and (conv weights) against autograd of the fp64 oracle."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    size, B = 64, 2
+    G = hip_generator(size, 1).train()
+    w = S.synthetic_latents(37, B, n_latent=G.n_latent, key='fzp.w').cuda()
+    tr = S.counter_tensor(37, 'fzp.t', (1, 512)).cuda()
+    target = torch.tanh(S.counter_tensor(37, 'fzp.g', (B, 3, size, size))).cuda()
+    got = []
+    for fused in (True, False):
+        G.fused_backward = fused
+        G.zero_grad()
+        img, _ = G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr)
+        assert (type(img.grad_fn).__name__ == 'SynthesisFnBackward') == fused
+        ((img - target) ** 2).mean().backward()
+        got.append({k: p.grad.clone() for k, p in G.named_parameters() if p.grad is not None})
+    fused_g, layer_g = got
+    assert set(fused_g) == set(layer_g) and len(fused_g) >= 5 * 9 + 4 * 5 + 1
+    # (a noise strength's gradient is ONE scalar, sum_{b,c,p} g_pre * noise: a sum of random signs accumulated by atomics in both
+    #  paths -- its "relative" difference is the cancellation noise of the sum itself, 1e-3 here; it is checked against the oracle below)
+    worst = max((_rel(fused_g[k], layer_g[k]), k) for k in fused_g if float(layer_g[k].abs().max()) > 0 and not k.endswith('noise.weight'))
+    worst_nz = max((_rel(fused_g[k], layer_g[k]), k) for k in fused_g if k.endswith('noise.weight'))
+    print('fused vs per-layer parameter gradients: worst rel %.2e (%s), noise strengths %.2e (%s), %d tensors'
+          % (worst[0], worst[1], worst_nz[0], worst_nz[1], len(fused_g)))
+    # (the two paths' forwards differ by 3e-6 in the image -- per-layer style kernels against the batched ones -- and a weight
+    #  gradient cancels: measured 2.5e-4 between the paths where the fused one is 7.6e-5 and the per-layer one 2.5e-4 from the oracle)
+    assert worst[0] <= 1e-3, worst
+    assert worst_nz[0] <= 1e-2, worst_nz
+    P = {k: v.double() for k, v in synthetic_state(size, 1).items()}
+    for k in P:
+        P[k].requires_grad_(k in fused_g)
+    ref, _ = O.generator_forward(P, [w.cpu().double()], input_is_latent=True, truncation=0.7, truncation_latent=tr.cpu().double())
+    ((ref - target.cpu().double()) ** 2).mean().backward()
+    tol = 2e-4 if F_.PRECISION == 'fp16x3' else 5e-3
+    for k in ('convs.5.conv.weight', 'convs.4.conv.weight', 'conv1.conv.weight', 'to_rgbs.2.conv.weight', 'convs.3.activate.bias',
+              'convs.2.conv.modulation.weight', 'to_rgbs.1.conv.modulation.bias', 'input.input'):
+        assert _rel(fused_g[k], P[k].grad) <= tol, (k, _rel(fused_g[k], P[k].grad))
+    nz_scale = max(float(P[k].grad.abs().max()) for k in P if k.endswith('noise.weight'))          # (scalars: against the largest of them)
+    for k in fused_g:
+        if k.endswith('noise.weight'):
+            assert abs(float(fused_g[k]) - float(P[k].grad)) <= 10 * tol * nz_scale, k
 
 
 def test_grad_join_equals_the_three_passes_it_replaces():
