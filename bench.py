@@ -563,7 +563,8 @@ def _leg_triple(leg):
     roof = leg.get('conv_roofline') or leg.get('roofline') or {}
     t = _pick(leg, 'value', 'unit', 'ms_per_step')
     t.update({k: roof[k] for k in ('frac', 'peak') if k in roof})
-    for k in ('max_abs_vs_oracle', 'max_abs_between_the_two_paths', 'launches_per_step', 'tflops', 'hbm_gbs', 'hbm_frac', 'precision'):
+    for k in ('max_abs_vs_oracle', 'max_abs_between_the_two_paths', 'launches_per_step', 'tflops', 'hbm_gbs', 'hbm_frac', 'precision',
+              'batches', 'rerendered_batches', 'plan_widenings', 'max_abs_vs_fp32_kernels'):
         if isinstance(leg.get(k), (int, float, str)):
             t[k] = leg[k]
     for k in ('generator_only_ms_per_step', 'e4e_source_ms'):
@@ -900,6 +901,14 @@ def other_config_legs(args, rank, world, dev):
         finally:
             F_.set_default(F_.config().replace(cross_terms=base_cfg.cross_terms))
         torch.cuda.empty_cache()
+    if args.config == 'synthesis' and args.precision == 'fp16x3':
+        t0 = time.perf_counter()
+        try:
+            legs['range_plan_stress'] = range_plan_stress(args, dev)
+            legs['range_plan_stress']['leg_wall_s'] = round(time.perf_counter() - t0, 1)
+        except Exception as e:
+            legs['range_plan_stress'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+        torch.cuda.empty_cache()
     for name, fn in (('inference', run_inference), ('trainer', run_trainer), ('pti', run_pti)):
         sub = argparse.Namespace(**vars(args))
         sub.config, sub.batch = name, DEFAULT_BATCH[name]
@@ -928,6 +937,38 @@ def other_config_legs(args, rank, world, dev):
             legs[name] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
         torch.cuda.empty_cache()
     return legs
+
+
+def range_plan_stress(args, dev, n_batches=200, B=8):
+    """VERDICT r5 item 7 as a counter of the default run: the fp16x3 range plan on trained-LIKE weights (heavy-tailed conv weights,
+    log-normal modulation biases: synthetic.trained_like_state_dict) with W+ codes from the e4e stand-in on `n_batches` batches of random
+    images (every tenth batch 4x louder); each batch goes through the reference-shaped VERIFIED call.  Reports how many batches had to
+    be rendered twice and the largest difference of the first / last five batches against the fp32-MFMA kernels of the same generator.
+    (tests/test_gpu_generator.py::test_range_plan_on_trained_like_weights holds every frame to the bar and checks rows against the oracle.)"""
+    from stylegan_directions_face_reenactment_amd.encoder import Encoder4Editing
+    G, template = generator_state_template(args.size, args.cm)
+    G.load_state_dict(S.trained_like_state_dict(template, seed=SEED))
+    G = G.eval().to(dev)
+    enc = Encoder4Editing(50, 'ir_se', args.size).eval()
+    enc.load_state_dict(S.synthetic_encoder_state(enc.state_dict(), seed=SEED + 1))
+    enc = enc.to(dev)
+    tr = S.counter_tensor(SEED, 'rp.t', (1, 512)).to(dev)
+    worst = scale = 0.0
+    with torch.no_grad():
+        for i in range(n_batches):
+            x = S.counter_tensor(SEED, 'rp.x.%d' % (i % 16), (B, 3, args.size, args.size), 0.0, 0.5).clamp_(-1, 1).to(dev)
+            w = enc(x) * ((4.0 if i % 10 == 9 else 1.0) * (1.0 + 0.01 * (i // 16)))
+            img, _ = G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr)
+            if i < 5 or i >= n_batches - 5:
+                with F_.precision('fp32'):
+                    ref, _ = G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr)
+                worst, scale = max(worst, float((img - ref).abs().max())), max(scale, float(ref.abs().max()))
+    st = G.range_stats()
+    return {'value': round(st['rerendered'] / n_batches, 4), 'unit': 'fraction of verified batches rendered twice', 'batches': n_batches,
+            'per_gpu_batch': B, 'rerendered_batches': st['rerendered'], 'plan_widenings': st['widenings'], 'mode_after': st['mode'],
+            'fp16_saturated_pairs': G.saturated_pairs(), 'max_abs_vs_fp32_kernels': worst, 'max_abs_image': round(scale, 2),
+            'workload': 'Generator(%d,cm=%d) with trained-like weights (1 %% of the input channels x30, log-normal modulation biases), W+ from '
+                        'the synthetic e4e encoder on random images, every tenth batch x4, psi=0.7, verified G([w]) calls' % (args.size, args.cm)}
 
 
 def _direction_ranges():

@@ -611,6 +611,7 @@ class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
             # generator to bf16x3 and -- while the budget of automatic widenings lasts -- asked for a recalibration: the second
             # pass below measures THIS batch, widens the plan and renders in fp16x3 again (verified like the first); without
             # budget it renders in bf16 terms (fp32 exponent range, nothing to verify).
+            self.__dict__['_rerendered'] = self.__dict__.get('_rerendered', 0) + 1
             # (rendered again from the caller's styles with THIS pass's resolved inject_index and noise tensors -- the same image,
             #  not a new random draw; a token that is merely suspect / stale asked for no recalibration: straight to bf16 terms)
             if depth <= self.AUTO_RECALIBRATIONS and (getattr(self, '_range_state', None) or {}).get('recal'):

@@ -162,6 +162,14 @@ class RangePlanMixin:
             return st['mode']
         return cfg.precision
 
+    def range_stats(self):
+        """Counters of this generator's fp16x3 range plan since its weights last changed: verified forwards that were rendered a
+        second time (`rerendered`: each one costs that batch a second forward), plan widenings (`widenings`), the arithmetic the
+        next forward runs in (`mode`), and what the plan allows per layer (`x_log2`)."""
+        st = getattr(self, '_range_state', None) or {}
+        return {'rerendered': self.__dict__.get('_rerendered', 0), 'widenings': st.get('version', 0), 'mode': self.range_mode(),
+                'x_log2': list(st.get('x_log2', []))}
+
     def take_range_token(self):
         """The RangeToken of the latest no-grad forward (None when that forward did not run in fp16x3)."""
         tok = self.__dict__.get('_last_token')

@@ -102,6 +102,29 @@ def synthetic_state_dict(template, seed=0, lr_mlp=0.01):
     return out
 
 
+def trained_like_state_dict(template, seed=0, outlier_fraction=0.01, outlier_gain=30.0, bias_sigma=0.5):
+    """synthetic_state_dict reshaped towards what a TRAINED g_ema looks like: heavy-tailed weights instead of
+    N(0,1) everywhere --
+      * every 3x3 conv weight: `outlier_fraction` of its INPUT channels (at least one) multiplied by `outlier_gain` (outlier
+        channels that dominate the contraction; a gain on output channels would be undone by the demodulation);
+      * every modulation bias of a 3x3 conv (constructor value 1, model.py:216): log-normal, exp(N(0, bias_sigma^2)) -- per-channel
+        style magnitudes spread over several binades;
+      * ToRGB weights (no demodulation) keep their scale.
+    The fp16x3 range plan is calibrated on the first batch; this is the weight set its re-render rate is quoted on
+    (tests/test_gpu_generator.py::test_range_plan_on_trained_like_weights, bench.py `range_plan_stress`)."""
+    import torch
+    out = synthetic_state_dict(template, seed)
+    for key, t in out.items():
+        if key.endswith('conv.weight') and t.dim() == 5 and t.shape[-1] == 3:
+            cin = t.shape[2]
+            n = max(1, int(round(outlier_fraction * cin)))
+            pick = torch.from_numpy(counter_normal(seed, key + '.outliers', cin)).argsort()[:n]
+            t[:, :, pick] *= outlier_gain
+        elif key.endswith('conv.modulation.bias') and ('to_rgb' not in key):
+            t.copy_(torch.exp(counter_tensor(seed, key + '.lognormal', tuple(t.shape), 0.0, bias_sigma)))
+    return out
+
+
 def synthetic_latents(seed, batch, n_latent=14, style_dim=512, key='wplus', std=1.0):
     """Random W+ codes [B, n_latent, 512] (bench config 2: 'random w+')."""
     return counter_tensor(seed, key, (batch, n_latent, style_dim), 0.0, std)

@@ -288,6 +288,58 @@ def test_cm2_generator_without_plane_padding_takes_the_direct_kernel_at_256():
     assert maxabs(a, b) <= IMG_TOL
 
 
+@pytest.mark.timeout(1200)
+def test_range_plan_on_trained_like_weights():
+    """the fp16x3 range plan (calibrated on the first batch of a weight version) on what a trained g_ema looks
+    like -- heavy-tailed conv weights (1 % of the input channels x 30), log-normal modulation biases (synthetic.trained_like_state_dict)
+    -- with W+ codes from the e4e stand-in on 200 batches of random images: how many verified forwards had to be rendered twice, and
+    every returned frame against the fp32-MFMA kernels of the same generator (no range plan, no fp16), three of them against the
+    fp64 oracle.  Bar: re-render rate < 1 % after the first widening, every frame within 1e-3 (images scaled to |img| <= ~10)."""
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    from stylegan_directions_face_reenactment_amd.encoder import Encoder4Editing
+    from stylegan_directions_face_reenactment_amd.model import Generator
+    if F_.PRECISION == 'fp32':
+        pytest.skip('the range plan belongs to the fp16x3 arithmetic')
+    state = S.trained_like_state_dict(O.template_state(256, 512, 8, 1), seed=SEED)
+    G = Generator(256, 512, 8, channel_multiplier=1)
+    G.load_state_dict(state, strict=True)
+    G = G.eval().cuda()
+    enc = Encoder4Editing(50, 'ir_se', 256).eval()
+    enc.load_state_dict(S.synthetic_encoder_state(enc.state_dict(), seed=SEED), strict=True)
+    enc = enc.cuda()
+    tr = S.counter_tensor(SEED, 'rp.t', (1, 512)).cuda()
+    n_batches, B = 200, 8
+    worst, scale, keep = 0.0, 0.0, []
+    first_widening_at = None
+    with torch.no_grad():
+        for i in range(n_batches):
+            # (every tenth batch: 4x louder codes -- an outlier source; the e4e stand-in's codes are N(0, ~1) per row)
+            x = S.counter_tensor(SEED, 'rp.x.%d' % i, (B, 3, 256, 256), 0.0, 0.5).clamp_(-1, 1).cuda()
+            w = enc(x) * (4.0 if i % 10 == 9 else 1.0)
+            img, _ = G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr)       # the reference-shaped call: verified
+            with F_.precision('fp32'):
+                ref, _ = G([w], input_is_latent=True, truncation=0.7, truncation_latent=tr)
+            worst = max(worst, maxabs(img, ref))
+            scale = max(scale, float(ref.abs().max()))
+            st = G.range_stats()
+            if first_widening_at is None and st['widenings']:
+                first_widening_at = i
+            if i in (0, 9, 199):
+                keep.append((w[:1].cpu(), img[:1].cpu()))
+    st = G.range_stats()
+    after = st['rerendered'] - (1 if first_widening_at is not None else 0)
+    print('trained-like weights, %d batches of %d e4e codes: %d re-rendered (first widening at batch %s, %d widenings), mode %s; every frame '
+          'within %.2e of the fp32 kernels (max |img| %.1f)' % (n_batches, B, st['rerendered'], first_widening_at, st['widenings'], st['mode'],
+                                                              worst, scale))
+    assert after / n_batches < 0.01, st
+    bar = 1e-3 * max(1.0, scale / 10.0)          # (BASELINE's 1e-3 is quoted on |img| <= ~10)
+    assert worst <= bar
+    P64 = O.cast_state(state, torch.float64)
+    for w1, img1 in keep:
+        ref64, _ = O.generator_forward(P64, [w1.double()], input_is_latent=True, truncation=0.7, truncation_latent=tr.cpu().double())
+        assert maxabs(img1, ref64) <= bar
+
+
 def test_winograd_chain_layers_stay_within_the_per_image_bound():
     """The wide plain layers of the chain run in 1-D Winograd form (F(4,3) by default, F(2,3) with functional.WSPLIT_F = 2;
     csrc/wsplit.hip, fed by the blur's transformed hand-over): a different summation order, so not bit-identical to the direct
