@@ -586,7 +586,7 @@ def compact_line(full, args):
     out['config'] = _pick(cfg, 'workload', 'per_gpu_batch', 'global_batch', 'resolution', 'channel_multiplier', 'parallelism',
                           'weight_broadcast_bytes', 'weight_broadcast_ms', 'per_rank_frames_per_s_min_max', 'per_rank_samples_per_s_min_max',
                           'generator_only_ms_per_step', 'e4e_source_ms', 'ranks')
-    out['config']['workload'] = str(out['config'].get('workload', ''))[:400]
+    out['config']['workload'] = str(out['config'].get('workload', ''))[:240]
     out['config']['parallelism'] = str(out['config'].get('parallelism', ''))[:120]
     mo = full.get('max_abs_vs_oracle')
     if isinstance(mo, dict):
@@ -613,7 +613,7 @@ def compact_line(full, args):
     cb = full['cpu_baseline']
     out['cpu_baseline'] = {k: cb.get(k) for k in ('value', 'unit', 'cores', 'kind')}
     out['cpu_baseline'].update(_pick(cb, 'host_cores', 'all_cores_value', 'all_cores_note', 'bound_to_cores', 'reason'))
-    out['cpu_baseline']['sample'] = None if cb.get('sample') is None else str(cb['sample'])[:160]
+    out['cpu_baseline']['sample'] = None if cb.get('sample') is None else str(cb['sample'])[:90]
     for k in ('verified', 'rerendered_batches', 'fp16_saturated_pairs', 'fp16_range_mode'):
         if k in full:
             out[k] = full[k]
@@ -626,11 +626,12 @@ def compact_line(full, args):
     for k in ('alt_arithmetic', 'fallback_arithmetic'):
         if isinstance(full.get(k), dict):
             legs[k] = _leg_triple(full[k])
+            legs[k].pop('unit', None)
     for k, v in (full.get('other_configs') or {}).items():
         legs[k] = _leg_triple(v)
     if legs:
         out['legs'] = legs
-    out['detail'] = DETAIL_FILE + ' (+ the stderr line that starts BENCH_DETAIL): per-layer / per-launch tables of every leg'
+    out['detail'] = DETAIL_FILE + ' / stderr line BENCH_DETAIL: every table of every leg'
     return out
 
 

@@ -16,7 +16,8 @@ class GraphReplayMixin:
     # Captured signatures kept per generator.  Each capture keeps EVERY intermediate of its forward alive in a private memory pool
     # (about 70 MB per image at 256^2, cm=1: 4.5 GB for a B=64 capture; the eager path frees layer by layer), and each HIP stream
     # that replays gets its own capture (the stream id is part of the key).  Host-bound forwards (the default policy) are small;
-    # big ones are only captured when the caller asks for it (graph=True / verify_range=True), at most MAX_BIG_GRAPHS at a time.
+    # big ones are captured when the caller asks for it (graph=True / verify_range=True) or, for calls verified by default, when
+    # the capture is a small share of the device's memory (_capture_fits) -- at most MAX_BIG_GRAPHS at a time.
     MAX_GRAPHS = 4
     MAX_BIG_GRAPHS = 2
 
@@ -42,7 +43,11 @@ class GraphReplayMixin:
         if not isinstance(w, torch.Tensor) or not w.is_cuda or w.dtype != torch.float32 or w.requires_grad:
             return None
         if graph is None and not (verify_range and verify_explicit) and self._graph_work(w) > self.GRAPH_MAX_WORK:
-            return None
+            # not host-bound, and nobody asked for a replay.  A forward that is verified by default (the reference-shaped `G([w])`)
+            # still exposes its ~1 ms of enqueue time to the wait: it is replayed when the capture's pinned intermediates are a small
+            # share of THIS device's memory (round 6: 4.5 GB for B=64 on a 288 GB part), otherwise it keeps running eagerly
+            if not (verify_range and self._capture_fits(w)):
+                return None
         if image_out is not None and image_out.frames is not None:
             return None
         if truncation < 1 and truncation_latent is None:
@@ -64,6 +69,19 @@ class GraphReplayMixin:
 
     def _graph_work(self, w):
         return w.shape[0] * (self.size / 256.0) ** 2
+
+    CAPTURE_BYTES_PER_WORK = 72e6       # intermediates a capture pins per unit of _graph_work (256^2 image, cm=1; cm=2: twice)
+    CAPTURE_MAX_SHARE = 0.03            # of the device's total memory, per capture (and at most a quarter of what is free now)
+
+    def _capture_fits(self, w):
+        """May a big forward be captured WITHOUT the caller asking?  Only when its pinned intermediates are a small share of the
+        device: <= CAPTURE_MAX_SHARE of total memory and <= 25 % of the memory free right now."""
+        est = self.CAPTURE_BYTES_PER_WORK * self._graph_work(w) * (2 if getattr(self, 'channel_multiplier', 1) >= 2 else 1)
+        try:
+            free, total = torch.cuda.mem_get_info(w.device)
+        except Exception:       # noqa: BLE001
+            return False
+        return est <= self.CAPTURE_MAX_SHARE * total and est <= 0.25 * free
 
     def _replay_or_run(self, key, styles, return_latents, return_features, inject_index, truncation, truncation_latent, input_is_latent,
                        image_out, verify_range):

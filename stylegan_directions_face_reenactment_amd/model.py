@@ -362,6 +362,7 @@ class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
         super().__init__()
         self.size = size
         self.style_dim = style_dim
+        self.channel_multiplier = channel_multiplier
         self.style = nn.Sequential(
             PixelNorm(), *[EqualLinear(style_dim, style_dim, lr_mul=lr_mlp, activation='fused_lrelu')
                            for _ in range(n_mlp)])
@@ -502,8 +503,9 @@ class Generator(RangePlanMixin, GraphReplayMixin, PlannerMixin, nn.Module):
         (B=8: 1.34 -> 1.43 ms), so it pays where the HOST is the bound -- small batches (B=1: 917 -> 1462 frames/s, B=4 +3 %),
         i.e. batch * (size/256)^2 <= GRAPH_MAX_WORK -- and for verified forwards, whose wait exposes the enqueue time at every
         batch size (generate_image at B=32: 7.8 k -> 8.3 k frames/s) -- verify_range=True passed explicitly; a raw `G([w])`, verified
-        only by default, is replayed when it is host-bound and runs eagerly otherwise (a B=64 capture pins ~4.5 GB of
-        intermediates, graph_runner.MAX_BIG_GRAPHS).  Weight changes (tracked like the weight packs; after
+        only by default, is replayed when it is host-bound or when the capture's pinned intermediates (~4.5 GB at B=64) are a
+        small share of the device's memory (graph_runner._capture_fits: <= 3 % of total, <= 25 % of what is free), and runs
+        eagerly otherwise (graph_runner.MAX_BIG_GRAPHS).  Weight changes (tracked like the weight packs; after
         `.data` edits call invalidate_packs()), a change of arithmetic / range plan, hooks, style mixing, caller-supplied
         noise and randomize_noise run eagerly.  Switch off: `G.use_graphs = False` or SGDFR_GRAPHS=0."""
         cfg = getattr(self, 'config', None)
