@@ -1,4 +1,4 @@
-"""profiles/<out>_trainer_*: the generator legs of the direction-learning step (scripts/train_step_bench.py, B=16: 2 no-grad forwards
+"""profiles/<out>_trainer_*: the generator legs of the direction-learning step (scripts/train_step_bench.py, B=16: one no-grad forward of 2B rows
 + grad forward + backward to A) from rocprofv3 --kernel-trace --stats (gpurun_out/prof_<tag>_train) and one SQ PMC pass
 (gpurun_out/pmc_<tag>_train_sq), aggregated per kernel:  python scripts/summarize_trainer.py r4d r04_d"""
 import collections, csv, shutil, sys
@@ -14,7 +14,7 @@ for r in rows:
         r['Counter_Name']] = float(r['Counter_Value'])
 agg = collections.OrderedDict()
 for (disp, name, grid), c in d.items():
-    if not any(t in name for t in ('split_mfma', 'wsplit_kernel', 'modconv_mfma', 'wino', 'wgrad', 'act_grad', 'scale_reduce', 'blur', 'torgb')):
+    if not any(t in name for t in ('split_mfma', 'wsplit_kernel', 'wswide', 'modconv_mfma', 'wino', 'wgrad', 'act_grad', 'grad_join', 'scale_reduce', 'blur', 'torgb', 'styles_batched', 'absmax', 'split_range', 'splitk_reduce', 'linear_skinny')):
         continue
     a = agg.setdefault((name, grid), [0, 0.0, 0.0, 0.0, 0.0, 0.0])
     dur = kt.get(disp, 0)
@@ -27,7 +27,7 @@ for (disp, name, grid), c in d.items():
     a[5] += c.get('SQ_WAVE_CYCLES', 0)
 tot = sum(a[1] for a in agg.values())
 L = ['# Direction-learning step, generator legs (%s)\n' % out,
-     '`python scripts/train_step_bench.py 16` (B=16, 256x256, cm=1, G frozen: 2 no-grad forwards + grad forward + backward to A) under',
+     '`python scripts/train_step_bench.py 16` (B=16, 256x256, cm=1, G frozen: source + target rows in one no-grad forward of 32 + grad forward + backward to A through autograd.SynthesisFn) under',
      '`rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY',
      'SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE`; kernel stats of the un-instrumented run: `profiles/%s_trainer_step_kernel_stats.csv`.' % out,
      'Launches aggregated per (kernel, grid) over the whole run (13 steps), sorted by total time; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES /',
