@@ -407,7 +407,7 @@ def cpu_worker(size, cm, threads, B, seconds, max_reps, bind=0):
           flush=True)
 
 
-def cpu_baseline(size, cm, budget_s=40.0):
+def cpu_baseline(size, cm, budget_s=30.0):
     """Times the oracle (checker side) on the host CPU, every leg in a fresh subprocess (cpu_worker) while this process -- the
     one that owns the GPU context -- sleeps in subprocess.run.  A short sweep (1.5 s per leg, B=2) over thread counts, each
     unbound and bound to as many cores of one socket, PICKS the configuration; two sustained legs then run at it (B=2, and B=8)
