@@ -946,7 +946,7 @@ def other_config_legs(args, rank, world, dev):
                 legs[name]['fp16_saturated_pairs'] = line['fp16_saturated_pairs']
             if 'one_batch_at_a_time' in line:
                 legs[name]['one_batch_at_a_time'] = line['one_batch_at_a_time']
-            for k in ('launches_per_step', 'tflops', 'hbm_gbs', 'hbm_frac', 'eager', 'loss_first_last'):
+            for k in ('launches_per_step', 'tflops', 'hbm_gbs', 'hbm_frac', 'eager', 'loss_first_last', 'needed_gradients_only'):
                 if k in line:
                     legs[name][k] = line[k]
         except Exception as e:          # a neighbour leg must never take the headline line down with it
@@ -1249,6 +1249,18 @@ def run_pti(args, rank, world, dev):
     conv_fl = sum(fl for _, _, fl, _ in t.conv)
     runner = FT.GraphedStep(make_step(torch.optim.Adam(params, lr=3e-3, capturable=True)), warmup=3)
     elapsed, mine, loss = timed_region(runner, args, dev)
+    # the same step computing only the gradients the optimizer reads (finetune.optimize_g(freeze_unused=True)): the weights it
+    # produces are the same, the never-read .grad of the other 5 layers / mapping network is not formed
+    ids = {id(p) for p in params}
+    flags = [(p, p.requires_grad) for p in G.parameters()]
+    for p in G.parameters():
+        p.requires_grad_(id(p) in ids)
+    try:
+        runner2 = FT.GraphedStep(make_step(torch.optim.Adam(params, lr=3e-3, capturable=True)), warmup=3)
+        needed_el, _, _ = timed_region(runner2, args, dev)
+    finally:
+        for p, rg in flags:
+            p.requires_grad_(rg)
     if rank != 0:
         return None
     # algorithmic work of a step: forward convs + dL/dx convs + dL/dW convs = 3 x the forward's conv FLOPs; bytes:
@@ -1270,6 +1282,8 @@ def run_pti(args, rank, world, dev):
     out['eager'] = {'ms_per_step': round(e_el / args.steps * 1e3, 3), 'device_launches_per_step': launches,
                     'conv_launches_per_step': len(t.conv), 'conv_ms_per_step': round(conv_s * 1e3, 3),
                     'conv_tflops': round(conv_fl / conv_s / 1e12, 2) if conv_s else None}
+    out['needed_gradients_only'] = {'ms_per_step': round(needed_el / args.steps * 1e3, 3),
+                                    'what': 'optimize_g(freeze_unused=True): only the gradients Adam reads (convs[4..11]); same updated weights'}
     out['launches_per_step'] = launches
     out['tflops'] = round(step_gflop / ms, 2)          # GFLOP / ms = TFLOP/s
     out['hbm_gbs'] = round(step_bytes / (ms * 1e-3) / 1e9, 1)
