@@ -7,6 +7,8 @@
 //   * ToRGB backward (dx and the 3 x Cin reductions that give d(style) and d(w_rgb))
 //   * transposed weight pack
 // Reductions use one wave per (b, c) plane chunk + fp32 atomics into zero-initialised buffers.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace sgdfr {
@@ -185,6 +187,113 @@ __global__ __launch_bounds__(256) void grad_join_kernel(const float* __restrict_
             atomicAdd(&rb[2 * C + c], q2);
         }
         if (g_absmax && gm != 0u) atomicMax(g_absmax + pl, gm);
+    }
+}
+
+// The same pass for activations that a ToRGB reads (float4 path): a wave owns GJ_CPW consecutive channels of one (image, chunk)
+// and keeps that chunk of the three RGB-gradient planes in registers (96 VGPRs) -- one wave per channel re-read them for every
+// channel (20 B of L2 traffic per element on the last layer: 3.2 TB/s effective against 4.7 on the layers without the RGB term).
+// Per element the expressions and their order are grad_join_kernel's: same g_pre bits.
+constexpr int GJ_CPW = 4;
+__global__ __launch_bounds__(256) void grad_join_rgb_kernel(const float* __restrict__ out, const float* __restrict__ gu,
+                                                           const float* __restrict__ s_next, const float* __restrict__ g_rgb,
+                                                           const float* __restrict__ w_rgb, const float* __restrict__ s_rgb,
+                                                           float rgb_scale, const float* __restrict__ noise, int64_t noise_bstride,
+                                                           const float* __restrict__ noise_w, const float* __restrict__ bias,
+                                                           float* __restrict__ g_pre, float* __restrict__ sums,
+                                                           unsigned* __restrict__ g_absmax, float* __restrict__ r_next,
+                                                           float* __restrict__ r_rgb, int B, int C, int HW, int chunks, float slope,
+                                                           float gain, int want_y) {
+    constexpr int IT = kChunk / 256;          // float4 iterations of a chunk
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cgroups = (C + GJ_CPW - 1) / GJ_CPW;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    if (wid >= (int64_t)B * cgroups * chunks) return;
+    const int ch = (int)(wid % chunks);
+    const int64_t t = wid / chunks;
+    const int cg = (int)(t % cgroups), b = (int)(t / cgroups);
+    const int lo = ch * kChunk, hi = min(HW, lo + kChunk);
+    const float* gb = g_rgb + (int64_t)b * 3 * HW;
+    const float* nzb = noise ? noise + (int64_t)b * noise_bstride : nullptr;
+    const float nwv = (noise && noise_w) ? noise_w[0] : 0.f;
+    const float inv_pos = 1.f / gain, inv_neg = 1.f / (gain * slope);
+    float4 r0[IT], r1[IT], r2[IT], nz4[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int p = lo + (it * 64 + lane) * 4;
+        const bool in = p < hi;
+        r0[it] = in ? *reinterpret_cast<const float4*>(gb + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        r1[it] = in ? *reinterpret_cast<const float4*>(gb + HW + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        r2[it] = in ? *reinterpret_cast<const float4*>(gb + 2 * (int64_t)HW + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        nz4[it] = (in && nzb) ? *reinterpret_cast<const float4*>(nzb + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int cc = 0; cc < GJ_CPW; ++cc) {
+        const int c = cg * GJ_CPW + cc;
+        if (c >= C) break;
+        const int64_t pl = (int64_t)b * C + c;
+        const float bv = bias ? bias[c] : 0.f;
+        const float sn = gu ? s_next[pl] : 0.f;
+        const float c0 = w_rgb[c] * rgb_scale, c1 = w_rgb[C + c] * rgb_scale, c2 = w_rgb[2 * C + c] * rgb_scale;
+        const float sr = s_rgb[pl];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, rn = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
+        unsigned gm = 0u;
+        const int64_t base = pl * HW;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int p = lo + (it * 64 + lane) * 4;
+            if (p >= hi) continue;
+            float o[4], g[4], gp[4];
+            *reinterpret_cast<float4*>(o) = *reinterpret_cast<const float4*>(out + base + p);
+            const float g0[4] = {r0[it].x, r0[it].y, r0[it].z, r0[it].w}, g1[4] = {r1[it].x, r1[it].y, r1[it].z, r1[it].w},
+                        g2[4] = {r2[it].x, r2[it].y, r2[it].z, r2[it].w}, nz[4] = {nz4[it].x, nz4[it].y, nz4[it].z, nz4[it].w};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) g[v] = 0.f;
+            if (gu) {
+                float u[4];
+                *reinterpret_cast<float4*>(u) = *reinterpret_cast<const float4*>(gu + base + p);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    rn = fmaf(o[v], u[v], rn);
+                    g[v] = u[v] * sn;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float tt = sr * (c0 * g0[v] + c1 * g1[v] + c2 * g2[v]);
+                g[v] = gu ? g[v] + tt : tt;
+                q0 = fmaf(o[v], g0[v], q0);
+                q1 = fmaf(o[v], g1[v], q1);
+                q2 = fmaf(o[v], g2[v], q2);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                gp[v] = g[v] * (o[v] > 0.f ? 1.f : slope) * gain;
+                gm = max(gm, __float_as_uint(fabsf(gp[v])));
+                const float nzv = nzb ? nz[v] : 0.f;
+                s0 += gp[v];
+                s1 = fmaf(gp[v], nzv, s1);
+                if (want_y) {
+                    const float pre = o[v] * (o[v] > 0.f ? inv_pos : inv_neg);
+                    s2 = fmaf(gp[v], pre - nwv * nzv - bv, s2);
+                }
+            }
+            *reinterpret_cast<float4*>(g_pre + base + p) = *reinterpret_cast<const float4*>(gp);
+        }
+        s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+        rn = wave_sum(rn); q0 = wave_sum(q0); q1 = wave_sum(q1); q2 = wave_sum(q2);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gm = max(gm, (unsigned)__shfl_xor((int)gm, o, 64));
+        if (lane == 0) {
+            atomicAdd(&sums[pl * 3 + 0], s0);
+            atomicAdd(&sums[pl * 3 + 1], s1);
+            if (want_y) atomicAdd(&sums[pl * 3 + 2], s2);
+            if (gu) atomicAdd(&r_next[pl], rn);
+            float* rb = r_rgb + (int64_t)b * 3 * C;
+            atomicAdd(&rb[c], q0);
+            atomicAdd(&rb[C + c], q1);
+            atomicAdd(&rb[2 * C + c], q2);
+            if (g_absmax && gm != 0u) atomicMax(g_absmax + pl, gm);
+        }
     }
 }
 
@@ -399,6 +508,13 @@ extern "C" int sgdfr_grad_join_f32(const float* out, const float* gu, const floa
     auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool vec = HW % 4 == 0 && noise_bstride % 4 == 0 && aligned(out) && aligned(gu) && aligned(g_rgb) && aligned(g_add) &&
                      aligned(noise) && aligned(g_pre);
+    static const int rgb_reuse = getenv("SGDFR_GRAD_JOIN_RGB") ? atoi(getenv("SGDFR_GRAD_JOIN_RGB")) : 1;     // (0: A/B against one wave per channel)
+    if (vec && g_rgb && !g_add && rgb_reuse && HW >= 1024) {
+        const int64_t w4 = (int64_t)B * ((C + GJ_CPW - 1) / GJ_CPW) * chunks;
+        hipLaunchKernelGGL(grad_join_rgb_kernel, dim3(wave_grid(w4)), dim3(256), 0, st, out, gu, s_next, g_rgb, w_rgb, s_rgb, rgb_scale,
+                           noise, noise_bstride, noise_w, bias, g_pre, sums, g_absmax, r_next, r_rgb, B, C, HW, chunks, slope, gain, want_y);
+        return check_launch("grad_join(rgb)");
+    }
     if (vec)
         hipLaunchKernelGGL(grad_join_kernel<4>, dim3(wave_grid(waves)), dim3(256), 0, st, out, gu, s_next, g_rgb, w_rgb, s_rgb, rgb_scale,
                            g_add, noise, noise_bstride, noise_w, bias, g_pre, sums, g_absmax, r_next, r_rgb, B, C, HW, chunks, slope,

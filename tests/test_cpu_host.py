@@ -272,3 +272,29 @@ def test_config_object_is_frozen_scoped_and_seeded_from_the_environment():
     assert G.range_mode() == 'fp32'
     import copy
     assert copy.deepcopy(G).config == G.config
+
+
+def test_bench_compact_line_is_small_and_complete():
+    """the line the driver parses is the compact record (<= bench.LINE_LIMIT bytes whatever the legs carry), with
+    every contract key, the roofline fields and one scalar triple per secondary leg; built here from a committed full record."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r06_c_bench_detail.json')))
+    args = bench.parse_args([])
+    line = bench._sig(bench.compact_line(full, args))
+    text = json.dumps(line)
+    assert len(text) <= bench.LINE_LIMIT and len(text) < 0.25 * len(json.dumps(full))
+    assert set(bench.CONTRACT_KEYS) <= set(line)
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'dominant_kernel', 'end_to_end')) <= set(line['roofline'])
+    assert line['roofline']['dominant_kernel']['name'] == 'split mode1/deep' and 0.2 < line['roofline']['dominant_kernel']['frac'] < 1
+    assert set(('value', 'unit', 'cores', 'kind', 'sample', 'host_cores')) <= set(line['cpu_baseline'])
+    for leg in ('single_stream', 'default_call', 'alt_arithmetic', 'synthesis_cm2', 'synthesis_fp8_cross_terms', 'inference', 'trainer', 'pti',
+                'range_plan_stress'):
+        assert 'value' in line['legs'][leg] or 'frames_per_s' in line['legs'][leg], leg
+    # the fp8 leg is priced against its own peak (one fp16 + one fp8 MFMA per product), never against the three-product one
+    assert line['legs']['synthesis_fp8_cross_terms']['peak'] > 1500 and line['legs']['synthesis_fp8_cross_terms']['frac'] < 0.5
+    # nothing table-shaped survives in the compact line
+    def depth_lists(o):
+        return any(isinstance(v, list) and len(v) > 3 for v in (o.values() if isinstance(o, dict) else [])) or \
+            any(depth_lists(v) for v in (o.values() if isinstance(o, dict) else []) if isinstance(v, dict))
+    assert not depth_lists(line)

@@ -212,7 +212,7 @@ def test_grad_join_equals_the_three_passes_it_replaces():
     """functional.grad_join on one activation: g = gu*s_next + ToRGB term, then act_grad_reduce -- against scale_reduce + torgb_bwd +
     a tensor add + act_grad_reduce (g_pre bit-identical: same expressions, a two-term sum; reductions within summation order)."""
     from stylegan_directions_face_reenactment_amd import functional as F_
-    for B, C, H in ((3, 16, 4), (2, 64, 32), (2, 8, 64), (1, 24, 6)):
+    for B, C, H in ((3, 16, 4), (2, 64, 32), (2, 8, 64), (1, 24, 6), (2, 8, 5), (3, 4, 47)):      # (H = 5, 47: the scalar path, ragged chunks)
         mk = lambda key, shape, scale=1.0: S.counter_tensor(33, key, shape, 0.0, scale).cuda()
         out, gu, g_rgb = mk('o', (B, C, H, H)), mk('gu', (B, C, H, H)), mk('gr', (B, 3, H, H))
         s_next, s_rgb, w_rgb = mk('sn', (B, C)), mk('sr', (B, C)), mk('wr', (3, C))
@@ -237,6 +237,59 @@ def test_grad_join_equals_the_three_passes_it_replaces():
                 assert j_r is None
             if use_rgb:
                 assert _rel(j_r2, r2) <= 1e-5
+
+
+def test_batched_style_backward_and_small_parameter_gradients_match_torch():
+    """functional.styles_batched_bwd (ds of demodulated / plain / ToRGB layers, latent gradient summed per latent row, modulation weight
+    and bias gradients), functional.demod_dq and functional.param_grads against the tensor expressions of the per-layer Functions
+    (autograd.StyleFn / StyledConvFn / ToRGBFn backward) in fp64."""
+    from stylegan_directions_face_reenactment_amd import functional as F_, _native as N
+    torch.manual_seed(0)
+    B, L, D = 5, 4, 512
+    dev = 'cuda'
+    rnd = lambda *shape: torch.randn(*shape, device=dev)
+    latent = rnd(B, L, D)
+    layers = []          # (kind, latent row, cin, cout)
+    for kind, li, cin, cout in (('demod', 0, 64, 48), ('rgb', 1, 48, 3), ('demod', 1, 48, 130), ('plain', 2, 130, 16), ('rgb', 3, 16, 3), ('demod', 3, 512, 512)):
+        e = {'latent_index': li, 'mod_w': rnd(cin, D), 'want_w': True, 'want_b': True}
+        if kind == 'rgb':
+            e['rgb_r'], e['rgb_w'] = rnd(B, 3, cin), rnd(3, cin)
+        else:
+            e['gs'] = rnd(B, cin)
+            if kind == 'demod':
+                sums = rnd(B, cout, 3)
+                e['a'], e['d'], e['s'], e['qt'] = sums[:, :, 2], rnd(B, cout).abs() + 0.5, rnd(B, cin), rnd(cin, cout).abs()
+        layers.append((kind, e))
+    glat = F_.styles_batched_bwd([e for _, e in layers], B, L, D, latent=latent)
+    want = torch.zeros(B, L, D, dtype=torch.float64, device=dev)
+    for kind, e in layers:
+        cin = e['mod_w'].shape[0]
+        if kind == 'rgb':
+            ds = (e['rgb_r'].double() * e['rgb_w'].double().unsqueeze(0)).sum(1) / cin ** 0.5
+        elif kind == 'plain':
+            ds = e['gs'].double()
+        else:
+            a, d = e['a'].double(), e['d'].double()
+            ds = e['gs'].double() + e['s'].double() * ((-(a / d) * d ** 3) @ e['qt'].double().t())
+        want[:, e['latent_index']] += ds @ e['mod_w'].double() / D ** 0.5
+        assert _rel(e['gmod_w'], ds.t() @ latent[:, e['latent_index']].double() / D ** 0.5) <= 2e-5
+        assert _rel(e['gmod_b'], ds.sum(0)) <= 2e-5
+    assert _rel(glat, want) <= 2e-5
+    # dL/dQ of the demodulation
+    cout, cin = 48, 64
+    sums, d, s_ = rnd(B, cout, 3), rnd(B, cout).abs() + 0.5, rnd(B, cin)
+    a = sums[:, :, 2]
+    dq = F_.demod_dq(a, d, s_)
+    coeff = (a.double() / d.double()) * d.double() ** 3 * -0.5
+    assert _rel(dq, coeff.t() @ (s_.double() ** 2)) <= 2e-5
+    # bias / noise strength / ToRGB weight / ToRGB bias gradients in one launch
+    C, HW = 40, 33 * 33
+    sums2, r_rgb, s_rgb, g_rgb = rnd(B, C, 3), rnd(B, 3, C), rnd(B, C), rnd(B, 3, 33, 33)
+    gb, gn, gw, gbr = F_.param_grads([(N.PGRAD_BIAS, sums2, None, C, 0), (N.PGRAD_NOISE, sums2, None, C, 0),
+                                      (N.PGRAD_RGB_W, r_rgb, s_rgb, C, 0), (N.PGRAD_RGB_B, g_rgb, None, 3, HW)], B)
+    assert _rel(gb, sums2[:, :, 0].double().sum(0)) <= 1e-5 and _rel(gn, sums2[:, :, 1].double().sum().view(1)) <= 1e-5
+    assert _rel(gw, (r_rgb.double() * s_rgb.double().unsqueeze(1)).sum(0) / C ** 0.5) <= 1e-5
+    assert _rel(gbr, g_rgb.double().sum((0, 2, 3))) <= 1e-5
 
 
 def test_direction_matrix_gradient_golden():
