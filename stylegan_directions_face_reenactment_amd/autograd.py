@@ -388,18 +388,30 @@ class SynthesisFn(Function):
                                             noise_weight=layer.noise.weight, bias=layer.activate.bias, activate=True,
                                             batch=B if li == 0 else None, return_planes=True, split=mod.packed_split)
             else:
-                out = F_.modconv3x3(x, mod.packed()[0], s, d, mod.out_channel, noise=nz, noise_weight=layer.noise.weight,
-                                    bias=layer.activate.bias, activate=True, batch=B if li == 0 else None, wino=mod.packed_wino,
-                                    split=mod.packed_split)
                 k = li // 2
                 rgb = to_rgbs[k]
-                fir = None
-                if skip is not None:
-                    up = getattr(rgb, 'upsample', None)
-                    if up is None or tuple(up.kernel.shape) != (4, 4) or up.pad != (2, 1):
-                        raise NotImplementedError('ToRGB skip path is built for the 4-tap 2x Upsample')
-                    fir = up.kernel
-                skip = F_.torgb(out, rgb.conv.weight.view(3, mod.out_channel), sd[sd_of_rgb[k]][0], bias=rgb.bias.view(3), skip=skip, fir=fir)
+                H = x.shape[2]
+                # the ToRGB that reads this layer is accumulated in the conv's own epilogue where the split kernel runs the layer in
+                # one pass (as on the no-grad path: per-cout-tile partial sums + one small finish launch instead of a pass that
+                # re-reads the activation)
+                fuse = F_.config().precision != 'fp32' and F_.rgb_fusable(B, mod.in_channel, mod.out_channel, H, H)
+                res = F_.modconv3x3(x, mod.packed()[0], s, d, mod.out_channel, noise=nz, noise_weight=layer.noise.weight,
+                                    bias=layer.activate.bias, activate=True, batch=B if li == 0 else None, wino=mod.packed_wino,
+                                    split=mod.packed_split,
+                                    rgb=(rgb.conv.weight.view(3, mod.out_channel), sd[sd_of_rgb[k]][0]) if fuse else None)
+                if fuse:
+                    out, part = res
+                    skip = rgb.finish(part, skip)
+                else:
+                    out = res
+                    fir = None
+                    if skip is not None:
+                        up = getattr(rgb, 'upsample', None)
+                        if up is None or tuple(up.kernel.shape) != (4, 4) or up.pad != (2, 1):
+                            raise NotImplementedError('ToRGB skip path is built for the 4-tap 2x Upsample')
+                        fir = up.kernel
+                    skip = F_.torgb(out, rgb.conv.weight.view(3, mod.out_channel), sd[sd_of_rgb[k]][0], bias=rgb.bias.view(3), skip=skip,
+                                    fir=fir)
             saved.append((out, planes))
             noises.append(nz)
             x = out

@@ -149,8 +149,9 @@ def test_fused_backward_matches_the_per_layer_functions():
             (img * gimg).sum().backward()
             grads.append(wh.grad.clone())
             imgs.append(img.detach())
-        assert torch.equal(imgs[0], imgs[1])
-        assert _rel(grads[0], grads[1]) <= 2e-6
+        # (same conv kernels; the fused path accumulates ToRGB in the conv epilogues as the no-grad path does: per-tile partial sums)
+        assert maxabs(imgs[0], imgs[1]) <= 2e-6 * max(1.0, float(imgs[1].abs().max()))
+        assert _rel(grads[0], grads[1]) <= 1e-5
         if size == 64:
             P = {k: v.double() for k, v in synthetic_state(64, 1).items()}
             wr = w.double().requires_grad_(True)
