@@ -70,7 +70,7 @@ def test_bench_two_ranks_sharing_this_gpu_over_gloo():
     full = line['_detail']
     far = full['max_abs_vs_oracle']['last_rank_shard']
     assert far['within_bar'] and far['fp16x3'] <= 1e-3 and full['max_abs_vs_oracle']['within_bar']
-    assert far['fp16x3'] == line['max_abs_vs_oracle_last_rank']
+    assert abs(far['fp16x3'] - line['max_abs_vs_oracle_last_rank']) <= 1e-4 * far['fp16x3']     # (the compact line keeps 5 significant digits)
     assert line['config']['weight_broadcast_bytes'] > 4 * 20e6
     lo, hi = line['config']['per_rank_frames_per_s_min_max']
     assert 0 < lo <= hi
