@@ -442,7 +442,7 @@ extern "C" int sgdfr_modconv_prepack_split_f32(const float* weight, unsigned sho
 }
 
 template <int MODE, int ET, int WM, int WN, int MI, int NI, int NSS = 3, bool XIN = false>
-static int launch_split(const SplitParams& p, hipStream_t st) {
+static int launch_split(const SplitParams& p, hipStream_t st, int lid0 = 0, int count = -1) {
     constexpr int NTHR = WM * WN * 64;
     const int nex = (2 * p.xs + NTHR - 1) / NTHR;
     constexpr int NEX_MAX = (MODE == SGDFR_MODE_DOWN3) ? 3 : 4;    // staged positions <= 4 x 256 (UP3: PT + P + 2, 4 slots from P = 513 on)
@@ -461,7 +461,8 @@ static int launch_split(const SplitParams& p, hipStream_t st) {
         return 2;
     }
     SplitParams q = p;
-    q.total_blocks = p.n_pix_tiles * p.n_cout_tiles * p.ksplit;
+    q.total_blocks = count >= 0 ? count : p.n_pix_tiles * p.n_cout_tiles * p.ksplit;      // (lid0 / count: a sub-range of the tiles)
+    q.lid0 = lid0;
     // Persistent blocks (one per CU, each walking its share of the tiles and staging the next tile's first channel block
     // and first two weight slabs while the current one finishes; see RING3 in the kernel).  Round 1 (two weight slots: the
     // next tile's first wait drained the tile's own stores) only gained on the layers of >= 12 short tiles per CU; with the
@@ -479,6 +480,41 @@ static int launch_split(const SplitParams& p, hipStream_t st) {
     return check_launch("modconv2d_split");
 }
 
+// The deep-plan transposed conv with its TAIL ROUND on half tiles.  One block holds a CU, so a launch of T tiles costs
+// ceil(T / 256) tile times: 1092 / 2114 / 4161 tiles (the 32^2 / 64^2 / 128^2 levels at B=64) pay for 5 / 9 / 17 rounds, the last
+// one 27 % / 26 % / 25 % full -- 15 % / 8 % / 4 % of the launch; at B=32 and B=16 (configs[2], configs[4]) twice and four times
+// that.  When the last round has <= 128 tiles, the whole rounds run as before (tiles [0, n_full)) and a second launch covers
+// the same remaining (cout tile, position) range with 64 x 128 tiles (NI = 1: 2 x as many blocks of half the work, still one
+// round): 4.5 / 8.5 / 16.5 rounds.  Per output element nothing changes -- same channel-block, tap and product order -- so the
+// planes are bit-identical (tests/test_gpu_split.py).  SGDFR_SPLIT_UP_TAIL=0 switches it off, n > 1 = allow it up to n tiles of whole
+// rounds (read per call: same-process A/B).
+template <int ET, bool XIN>
+static int launch_up_deep_tail(const SplitParams& p, hipStream_t st) {
+    const char* env = getenv("SGDFR_SPLIT_UP_TAIL");
+    const int total = p.n_pix_tiles * p.n_cout_tiles;
+    const int n_full = total / 256 * 256, tail = total - n_full;
+    // Measured (scripts/up_tail_ab.py, profiles/r06_up_tail_ab.txt): it pays while the launch is SHORT -- up to two whole rounds
+    // (512@16^2 at B=64: 258 -> 239 us; B=32: 164 -> 141 and 255 -> 234 us) -- and loses 1-7 % from four rounds on: blocks of a long
+    // launch finish at different times, so its last round is already ragged, and the second launch adds a drain + launch gap.
+    const int max_full = (env && atoi(env) > 1) ? atoi(env) : 512;
+    if ((env && atoi(env) == 0) || p.ksplit != 1 || n_full == 0 || n_full > max_full || tail == 0 || tail > 128)
+        return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 1, XIN>(p, st);
+    if (int rc = launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 1, XIN>(p, st, 0, n_full)) return rc;
+    SplitParams t = p;           // the same positions in 128-wide tiles
+    constexpr int PT2 = 128;
+    t.xlen = PT2 + p.P + 2;
+    t.xs = (t.xlen + 63) & ~63;                  // (8 waves: staged positions padded to whole 64-lane pieces, as split_geometry does)
+    t.simgs = (t.xlen - 1) / p.rps + 2;
+    t.n_pix_tiles = (int)((p.total_pix + PT2 - 1) / PT2);
+    t.desync = 0;
+    fill_fastdivs(t);
+    const int c0 = n_full / p.n_pix_tiles, p0 = n_full - c0 * p.n_pix_tiles;      // cout-major tile order: (c0, p0) is the first tile left
+    const int lid0 = c0 * t.n_pix_tiles + 2 * p0;
+    const int count = t.n_cout_tiles * t.n_pix_tiles - lid0;
+    if (count <= 0) return 0;
+    return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 1, 1, XIN>(t, st, lid0, count);
+}
+
 template <int ET>
 static int launch_plan(int cfg, const SplitParams& p, hipStream_t st, bool xin) {
     if (xin) {
@@ -486,7 +522,7 @@ static int launch_plan(int cfg, const SplitParams& p, hipStream_t st, bool xin) 
             case 0: return launch_split<SGDFR_MODE_PLAIN3, ET, 2, 4, 2, 2, 3, true>(p, st);
             case 1: return launch_split<SGDFR_MODE_PLAIN3, ET, 1, 8, 2, 2, 3, true>(p, st);
             case 3: return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 3, true>(p, st);
-            case 4: return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 1, true>(p, st);
+            case 4: return launch_up_deep_tail<ET, true>(p, st);
             case 5: return launch_split<SGDFR_MODE_DOWN3, ET, 2, 4, 2, 2, 1, true>(p, st);
             case 6: return launch_split<SGDFR_MODE_PLAIN3, ET, 2, 4, 2, 4, 3, true>(p, st);
             case 8: return launch_split<SGDFR_MODE_PLAIN3, ET, 1, 4, 2, 2, 3, true>(p, st);
@@ -502,7 +538,7 @@ static int launch_plan(int cfg, const SplitParams& p, hipStream_t st, bool xin) 
         case 1: return launch_split<SGDFR_MODE_PLAIN3, ET, 1, 8, 2, 2, 3>(p, st);
         case 2: return launch_split<SGDFR_MODE_UP3, ET, 4, 2, 1, 2, 3>(p, st);
         case 3: return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 3>(p, st);
-        default: return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 1>(p, st);
+        default: return launch_up_deep_tail<ET, false>(p, st);      // (the autograd forward's fp32-input form of the same plan)
     }
 }
 

@@ -94,6 +94,8 @@ struct SplitParams {
     const float* f8_max;         // SGDFR_SPLIT_FP16F8: the pack's trailer (max |w * scale|, source of the weights' fp8 exponent)
     // divisors of the per-tile index arithmetic (fill_fastdivs() on the host, after the geometry is final)
     FastDiv fd_xs, fd_seglen, fd_P, fd_R, fd_RP, fd_rps, fd_HW, fd_W, fd_TC, fd_tiles_x, fd_per_img, fd_npt, fd_tps, fd_Cin;
+    // (new fields go HERE, at the end: a field in the middle moves the kernel's scalar argument loads and has cost 12 % before)
+    int lid0;                    // first tile id of this launch (total_blocks counts from it): the tail launch of launch_up_deep_tail()
 };
 
 static void fill_fastdivs(SplitParams& p) {
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void split_mfma
         const int nblk = PERSIST ? min((int)gridDim.x, p.total_blocks - base) : (int)gridDim.x, q8 = nblk >> 3, r8 = nblk & 7;
         if ((int)blockIdx.x >= nblk) return -1;
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        return base + (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        return p.lid0 + base + (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     };
     struct TileOrg { int ks, ct, pt, q0, img0, row0, col0; };
     auto tile_org = [&](int lid) -> TileOrg {

@@ -433,6 +433,45 @@ def test_padded_parity_planes_equal_dense_planes(cin, cout, H, B):
         assert torch.equal(a, b), wino
 
 
+@pytest.mark.parametrize('cin,cout,H,B,arith', [(64, 64, 64, 16, 'fp16x3'), (32, 128, 32, 60, 'fp16x3'), (64, 64, 16, 230, 'bf16x3'),
+                                                (16, 64, 128, 4, 'fp16x3'), (32, 192, 32, 40, 'fp16x3')])
+def test_tail_round_on_half_tiles_writes_the_same_planes(cin, cout, H, B, arith):
+    """Round 6: the deep-plan transposed conv runs its whole rounds of 256 tiles as before and the LAST, partly filled round on
+    64 x 128 tiles in a second launch (split.hip launch_up_deep_tail).  Same planes bit for bit as one launch of full tiles
+    (SGDFR_SPLIT_UP_TAIL=0), dense and padded + interleaved, for tails that start inside a cout tile and at its boundary."""
+    import os
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    N = F_.N
+    if not F_.xin_ok(B, cin, cout, H, H, N.MODE_UP3) or not F_._shape_query('sgdfr_modconv2d_split_f8_ok', B, cin, cout, H, H, N.MODE_UP3):
+        pytest.skip('not the deep plan with a pre-split input')
+    x = S.counter_tensor(17, 'tl.x', (B, cin, H, H)).cuda()
+    w = S.counter_tensor(17, 'tl.w', (1, cout, cin, 3, 3)).cuda()
+    s = S.counter_tensor(17, 'tl.s', (B, cin), 1.0, 0.3).cuda()
+    d = S.counter_tensor(17, 'tl.d', (B, cout), 1.0, 0.2).cuda()
+    wsp = F_.prepack_split(w, arith)
+    xs = F_.to_split(x, s, arith)
+    rp = (H + 1) * (H + 1)
+    ps = (rp + 31) // 32 * 32
+    tiles = [-(-B * n // 256) * (cout // 64) for n in (rp, ps)]
+    assert any(t > 256 and 0 < t % 256 <= 128 for t in tiles), tiles          # (the case exercises a tail launch in at least one layout)
+    old = os.environ.get('SGDFR_SPLIT_UP_TAIL')
+    try:
+        out = {}
+        for flag in ('0', '100000'):      # (off / on for any number of whole rounds)
+            os.environ['SGDFR_SPLIT_UP_TAIL'] = flag
+            out[flag] = (F_.modconv_split(xs, wsp, None, d, cout, arith=arith, mode=N.MODE_UP3, x_split=tuple(x.shape), batch=B),
+                         F_.modconv_split(xs, wsp, None, d, cout, arith=arith, mode=N.MODE_UP3, x_split=tuple(x.shape), batch=B, plane_stride=ps),
+                         F_.modconv_split(x, wsp, s, d, cout, arith=arith, mode=N.MODE_UP3))      # (the fp32-input form of the plan: autograd forward)
+    finally:
+        if old is None:
+            os.environ.pop('SGDFR_SPLIT_UP_TAIL', None)
+        else:
+            os.environ['SGDFR_SPLIT_UP_TAIL'] = old
+    valid = lambda il: il.view(B, cout, ps, 4)[:, :, :rp]          # (the stride padding of a padded plane is never written)
+    assert torch.equal(out['0'][0], out['100000'][0]) and torch.equal(valid(out['0'][1]), valid(out['100000'][1]))
+    assert torch.equal(out['0'][2], out['100000'][2]) and torch.equal(out['0'][2], out['0'][0])
+
+
 def test_fp16_split_saturates_instead_of_overflowing():
     """|x*s| beyond the fp16-split range (1.04e6) clamps; nothing becomes inf/nan."""
     from stylegan_directions_face_reenactment_amd import functional as F_
