@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 19
+#define SGDFR_ABI_VERSION 20
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -199,10 +199,13 @@ int sgdfr_modconv2d_wino_f32(const float* x, int64_t x_bstride, const float* u, 
                              float gain, void* stream);
 
 /* t [B*C, 4, H+1, W+1] (phase planes from MODE_UP3) -> y [B, C, 2H, 2W]:
- *   y = act( upfirdn2d(T, fir[4,4], pad=(1,1)) + noise_w[0]*noise[oy,ox] + bias[c] )   (model.py:257,287, fused_act.py:81) */
+ *   y = act( upfirdn2d(T, fir[4,4], pad=(1,1)) + noise_w[0]*noise[oy,ox] + bias[c] )   (model.py:257,287, fused_act.py:81)
+ * y_absmax (optional, [B*C] words ZEROED by the caller): fp32 bit pattern of max |y| per (image, channel) plane from the same pass --
+ * the range plan of the fp16-split conv that reads y (sgdfr_split_range_f32 with x_absmax_bstride = C), instead of a separate
+ * sgdfr_absmax_f32 pass over y (autograd forward). */
 int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const float* noise, int64_t noise_bstride,
                             const float* noise_w, const float* bias, float* y, int B, int C, int H, int W, int act,
-                            float slope, float gain, void* stream);
+                            float slope, float gain, unsigned int* y_absmax, void* stream);
 
 /* sgdfr_blur_bias_act_f32 with the result multiplied by the NEXT layer's modulation s_next [B,C] and written in that layer's
  * split input form xs [B][C/8][2][2H*2W][8] (see sgdfr_to_split_f32) instead of fp32 NCHW.  plane_stride: 0 = t is the dense

@@ -41,3 +41,28 @@ for B in (64, 32, 16):
                 t.setdefault(flag, []).append(bench(run))
         print('B=%2d %3d->%3d @%3d^2: %5d tiles = %5.2f rounds | one launch %6.1f us | tail on half tiles %6.1f us (%+.1f %%)'
               % (B, cin, cout, H, tiles, tiles / 256, min(t['0']), min(t['100000']), 100 * (min(t['100000']) / min(t['0']) - 1)))
+
+
+# the adjoint (dL/d(x*s) of the transposed conv, mode DOWN3: 128 x 256 tiles, tail on 128 x 128) at the trainer's per-rank batch
+print('--- DOWN3 (backward of the transposed conv)')
+for B in (16, 32, 64):
+    for cin, cout, H in ((512, 256, 32), (256, 128, 64), (128, 64, 128)):       # forward shapes: the adjoint maps cout planes -> cin
+        if not F_.split_ok(B, cout, cin, H, H, N.MODE_DOWN3):
+            continue
+        w = S.counter_tensor(3, 'wd', (1, cout, cin, 3, 3)).cuda()
+        gT = S.counter_tensor(3, 'gT', (B, cout, 4, H + 1, H + 1)).cuda()
+        d = S.counter_tensor(3, 'dd', (B, cout), 1.0, 0.2).cuda()
+        gxs = F_.planes_to_split(gT, d, 'fp16x3')
+        wsp = F_.prepack_split(w, 'fp16x3', adjoint='down')
+        tiles = -(-B * (H + 1) * (H + 1) // 256) * (cin // 128)
+        run = lambda: F_.modconv_split(gxs, wsp, None, None, cin, mode=N.MODE_DOWN3, arith='fp16x3', x_split=(B, cout, H, H), batch=B)
+        t, outs = {}, {}
+        for rep in range(2):
+            for flag in ('0', '100000'):
+                os.environ['SGDFR_SPLIT_UP_TAIL'] = flag
+                t.setdefault(flag, []).append(bench(run))
+                outs[flag] = run()
+        same = torch.equal(outs['0'], outs['100000'])
+        print('B=%2d %3d->%3d @%3d^2: %5d tiles = %5.2f rounds | one launch %6.1f us | tail on half tiles %6.1f us (%+.1f %%) %s'
+              % (B, cout, cin, H, tiles, tiles / 256, min(t['0']), min(t['100000']), 100 * (min(t['100000']) / min(t['0']) - 1),
+                 'same bits' if same else 'DIFFERENT BITS'))

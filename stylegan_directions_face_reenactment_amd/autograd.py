@@ -375,6 +375,12 @@ class SynthesisFn(Function):
         sd_of_rgb = [1] + [4 + 3 * k for k in range(len(to_rgbs) - 1)]
         x, skip = gen.input.input, None
         saved, noises = [], []
+        # max |x| per (image, channel) plane of every plain layer's input comes out of the blur that produced it (one zeroed buffer
+        # for all of them) instead of a separate pass over the largest activations of the forward
+        want_max = F_.config().precision == 'fp16x3' and bool(F_.config().range_plan)
+        ups = [l.conv for l in layers if l.conv.upsample]
+        words = torch.zeros(B * sum(m.out_channel for m in ups), device=latent.device, dtype=torch.int32) if (want_max and ups) else None
+        woff, x_max = 0, None
         for li, layer in enumerate(layers):
             mod = layer.conv
             s, d = sd[sd_of_layer[li]]
@@ -384,9 +390,14 @@ class SynthesisFn(Function):
                 nz = torch.empty(B, 1, r, r, device=latent.device, dtype=torch.float32).normal_()
             planes = None
             if mod.upsample:
+                out_max = None
+                if words is not None:
+                    out_max = words[woff:woff + B * mod.out_channel].view(B, mod.out_channel)
+                    woff += B * mod.out_channel
                 out, planes = F_.modconv3x3(x, mod.packed()[0], s, d, mod.out_channel, upsample=True, fir=mod.blur.kernel, noise=nz,
                                             noise_weight=layer.noise.weight, bias=layer.activate.bias, activate=True,
-                                            batch=B if li == 0 else None, return_planes=True, split=mod.packed_split)
+                                            batch=B if li == 0 else None, return_planes=True, split=mod.packed_split, absmax_out=out_max)
+                x_max = out_max
             else:
                 k = li // 2
                 rgb = to_rgbs[k]
@@ -398,7 +409,8 @@ class SynthesisFn(Function):
                 res = F_.modconv3x3(x, mod.packed()[0], s, d, mod.out_channel, noise=nz, noise_weight=layer.noise.weight,
                                     bias=layer.activate.bias, activate=True, batch=B if li == 0 else None, wino=mod.packed_wino,
                                     split=mod.packed_split,
-                                    rgb=(rgb.conv.weight.view(3, mod.out_channel), sd[sd_of_rgb[k]][0]) if fuse else None)
+                                    rgb=(rgb.conv.weight.view(3, mod.out_channel), sd[sd_of_rgb[k]][0]) if fuse else None, x_absmax=x_max)
+                x_max = None
                 if fuse:
                     out, part = res
                     skip = rgb.finish(part, skip)

@@ -488,18 +488,20 @@ static int launch_split(const SplitParams& p, hipStream_t st, int lid0 = 0, int 
 // round): 4.5 / 8.5 / 16.5 rounds.  Per output element nothing changes -- same channel-block, tap and product order -- so the
 // planes are bit-identical (tests/test_gpu_split.py).  SGDFR_SPLIT_UP_TAIL=0 switches it off, n > 1 = allow it up to n tiles of whole
 // rounds (read per call: same-process A/B).
-template <int ET, bool XIN>
-static int launch_up_deep_tail(const SplitParams& p, hipStream_t st) {
+template <int MODE, int ET, int MI, bool XIN>
+static int launch_deep_tail(const SplitParams& p, hipStream_t st) {
     const char* env = getenv("SGDFR_SPLIT_UP_TAIL");
     const int total = p.n_pix_tiles * p.n_cout_tiles;
     const int n_full = total / 256 * 256, tail = total - n_full;
     // Measured (scripts/up_tail_ab.py, profiles/r06_up_tail_ab.txt): it pays while the launch is SHORT -- up to two whole rounds
     // (512@16^2 at B=64: 258 -> 239 us; B=32: 164 -> 141 and 255 -> 234 us) -- and loses 1-7 % from four rounds on: blocks of a long
     // launch finish at different times, so its last round is already ragged, and the second launch adds a drain + launch gap.
-    const int max_full = (env && atoi(env) > 1) ? atoi(env) : 512;
+    // (the adjoint -- 128 x 256 tiles, no plane stores -- still gains at four whole rounds: 179 -> 175, 301 -> 286, 616 -> 544 us; from
+    //  eight on it is +- 2 %)
+    const int max_full = (env && atoi(env) > 1) ? atoi(env) : (MODE == SGDFR_MODE_DOWN3 ? 1024 : 512);
     if ((env && atoi(env) == 0) || p.ksplit != 1 || n_full == 0 || n_full > max_full || tail == 0 || tail > 128)
-        return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 1, XIN>(p, st);
-    if (int rc = launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 1, XIN>(p, st, 0, n_full)) return rc;
+        return launch_split<MODE, ET, 2, 4, MI, 2, 1, XIN>(p, st);
+    if (int rc = launch_split<MODE, ET, 2, 4, MI, 2, 1, XIN>(p, st, 0, n_full)) return rc;
     SplitParams t = p;           // the same positions in 128-wide tiles
     constexpr int PT2 = 128;
     t.xlen = PT2 + p.P + 2;
@@ -512,7 +514,7 @@ static int launch_up_deep_tail(const SplitParams& p, hipStream_t st) {
     const int lid0 = c0 * t.n_pix_tiles + 2 * p0;
     const int count = t.n_cout_tiles * t.n_pix_tiles - lid0;
     if (count <= 0) return 0;
-    return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 1, 1, XIN>(t, st, lid0, count);
+    return launch_split<MODE, ET, 2, 4, MI, 1, 1, XIN>(t, st, lid0, count);
 }
 
 template <int ET>
@@ -522,8 +524,8 @@ static int launch_plan(int cfg, const SplitParams& p, hipStream_t st, bool xin) 
             case 0: return launch_split<SGDFR_MODE_PLAIN3, ET, 2, 4, 2, 2, 3, true>(p, st);
             case 1: return launch_split<SGDFR_MODE_PLAIN3, ET, 1, 8, 2, 2, 3, true>(p, st);
             case 3: return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 3, true>(p, st);
-            case 4: return launch_up_deep_tail<ET, true>(p, st);
-            case 5: return launch_split<SGDFR_MODE_DOWN3, ET, 2, 4, 2, 2, 1, true>(p, st);
+            case 4: return launch_deep_tail<SGDFR_MODE_UP3, ET, 1, true>(p, st);
+            case 5: return launch_deep_tail<SGDFR_MODE_DOWN3, ET, 2, true>(p, st);      // (the adjoint: 128 x 256 tiles, tail on 128 x 128)
             case 6: return launch_split<SGDFR_MODE_PLAIN3, ET, 2, 4, 2, 4, 3, true>(p, st);
             case 8: return launch_split<SGDFR_MODE_PLAIN3, ET, 1, 4, 2, 2, 3, true>(p, st);
             default: set_error("modconv_split: pre-split input is not built for tiling plan %d", cfg); return 1;
@@ -538,7 +540,7 @@ static int launch_plan(int cfg, const SplitParams& p, hipStream_t st, bool xin) 
         case 1: return launch_split<SGDFR_MODE_PLAIN3, ET, 1, 8, 2, 2, 3>(p, st);
         case 2: return launch_split<SGDFR_MODE_UP3, ET, 4, 2, 1, 2, 3>(p, st);
         case 3: return launch_split<SGDFR_MODE_UP3, ET, 2, 4, 1, 2, 3>(p, st);
-        default: return launch_up_deep_tail<ET, false>(p, st);      // (the autograd forward's fp32-input form of the same plan)
+        default: return launch_deep_tail<SGDFR_MODE_UP3, ET, 1, false>(p, st);      // (the autograd forward's fp32-input form of the same plan)
     }
 }
 

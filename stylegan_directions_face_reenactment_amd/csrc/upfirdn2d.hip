@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void blur_bias_act_kernel(const float* __restr
                                                            const float* __restrict__ noise, int64_t noise_bstride,
                                                            const float* __restrict__ noise_w,
                                                            const float* __restrict__ bias, float* __restrict__ y, int B,
-                                                           int C, int H, int W, int act, float slope, float gain) {
+                                                           int C, int H, int W, int act, float slope, float gain,
+                                                           unsigned* __restrict__ y_absmax, int wave_planes) {
     float kf[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) kf[i] = fir[15 - i];  // flipped: kf[ky*4+kx] = K[3-ky][3-kx] (uniform -> SGPRs)
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(256) void blur_bias_act_kernel(const float* __restr
             cok[v] = tc >= 0;
             coff[v] = (tc & 1) * GH * GW + (tc >> 1);
         }
+        unsigned gm = 0u;       // bit pattern of max |y| over this strip (y_absmax: the range plan of the conv that reads y)
         float win[5][5];
         auto load_row = [&](int tr, float (&dst)[5]) {  // T row tr in [-1, 2H+1]; rows 2H+1 are stored zeros
             const bool rok = tr >= 0;
@@ -178,11 +180,24 @@ __global__ __launch_bounds__(256) void blur_bias_act_kernel(const float* __restr
                     v1 = lrelu_gain(v1, slope, gain);
                 }
                 *reinterpret_cast<float2*>(y + (pl * 2 * H + oy) * OW + 2 * n) = make_float2(v0, v1);
+                gm = max(gm, max(__float_as_uint(fabsf(v0)), __float_as_uint(fabsf(v1))));
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u)
 #pragma unroll
                 for (int v = 0; v < 5; ++v) win[u][v] = win[u + 2][v];
+        }
+        if (y_absmax) {
+            // one word per (image, channel) plane, as sgdfr_act_grad_reduce_f32 keeps them.  wave_planes: a wave's 64 strips lie
+            // inside one plane and all 64 lanes are here (strips per plane and the grid stride are multiples of 64): one atomic
+            // per wave; otherwise (tiny planes) one per strip.
+            if (wave_planes) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) gm = max(gm, (unsigned)__shfl_xor((int)gm, o, 64));      // (integer max: NaN / Inf patterns survive)
+                if ((threadIdx.x & 63) == 0 && gm != 0u) atomicMax(y_absmax + pl, gm);
+            } else if (gm != 0u) {
+                atomicMax(y_absmax + pl, gm);
+            }
         }
     }
 }
@@ -755,7 +770,7 @@ extern "C" int sgdfr_upfirdn2d(const void* x, const void* k, void* y, int major,
 
 extern "C" int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const float* noise, int64_t noise_bstride,
                                        const float* noise_w, const float* bias, float* y, int B, int C, int H, int W,
-                                       int act, float slope, float gain, void* stream) {
+                                       int act, float slope, float gain, unsigned int* y_absmax, void* stream) {
     SGDFR_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0, "blur_bias_act: bad shape %d %d %d %d", B, C, H, W);
     if (B == 0) return 0;
     SGDFR_REQUIRE(t && fir && y, "blur_bias_act: null pointer");
@@ -763,8 +778,11 @@ extern "C" int sgdfr_blur_bias_act_f32(const float* t, const float* fir, const f
     const int64_t strips = (int64_t)B * C * ((H + BLUR_QV - 1) / BLUR_QV) * W;
     int64_t g = (strips + 255) / 256;
     if (g > 256 * 32) g = 256 * 32;
+    // (strips of one plane: HS * W; a wave stays inside a plane and is complete when that is a multiple of 64 -- the grid stride,
+    //  a multiple of 256, then keeps it so)
+    const int wave_planes = ((int64_t)((H + BLUR_QV - 1) / BLUR_QV) * W) % 64 == 0 ? 1 : 0;
     hipLaunchKernelGGL(blur_bias_act_kernel, dim3((int)g), dim3(256), 0, as_stream(stream), t, fir, noise,
-                       noise_bstride, noise_w, bias, y, B, C, H, W, act, slope, gain);
+                       noise_bstride, noise_w, bias, y, B, C, H, W, act, slope, gain, y_absmax, wave_planes);
     return check_launch("blur_bias_act");
 }
 

@@ -269,10 +269,11 @@ def ones_like_rows(B, C, device):
     return t
 
 
-def _exact_range(x, s, d, batch):
-    """Range plan from the true max |x| of each image (two small launches): what a stand-alone layer call uses."""
+def _exact_range(x, s, d, batch, x_absmax=None):
+    """Range plan from the true max |x| of each image (two small launches): what a stand-alone layer call uses.  x_absmax: the
+    per-plane words a producer already measured (one launch)."""
     B = s.shape[0] if batch is None else batch
-    return split_range(s, d, absmax(x, per_image=True, batch=B))
+    return split_range(s, d, x_absmax if x_absmax is not None else absmax(x, per_image=True, batch=B))
 
 
 def _noise_args(noise, B, H, W):
@@ -727,19 +728,24 @@ def modconv_raw(x, wp, s, d, cout, mode, H, W, noise=None, noise_weight=None, bi
     return y
 
 
-def blur_bias_act(planes, fir, H, W, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2, out=None):
-    """planes [B,C,4,H+1,W+1] -> [B,C,2H,2W]: 4x4 FIR (pad 1,1) + noise + bias + leaky-ReLU."""
+def blur_bias_act(planes, fir, H, W, noise=None, noise_weight=None, bias=None, activate=False, slope=0.2, gain=SQRT2, out=None,
+                  absmax_out=None):
+    """planes [B,C,4,H+1,W+1] -> [B,C,2H,2W]: 4x4 FIR (pad 1,1) + noise + bias + leaky-ReLU.  absmax_out: a ZEROED int32 [B,C]
+    tensor that receives the bit pattern of max |y| per (image, channel) plane (for the range plan of the conv that reads y)."""
     N.require_device(planes, fir, bias, noise_weight)
     B, C = planes.shape[0], planes.shape[1]
     nz, nzb = _noise_args(noise, B, 2 * H, 2 * W)
     y = out if out is not None else torch.empty(B, C, 2 * H, 2 * W, device=planes.device, dtype=torch.float32)
     if tuple(y.shape) != (B, C, 2 * H, 2 * W) or not y.is_contiguous():
         raise RuntimeError('blur_bias_act: out must be a contiguous [B,C,2H,2W] tensor')
+    if absmax_out is not None and (absmax_out.dtype != torch.int32 or not absmax_out.is_cuda or absmax_out.numel() != B * C or
+                                   not absmax_out.is_contiguous()):
+        raise RuntimeError('blur_bias_act: absmax_out must be a contiguous int32 device tensor with B*C words')
     # algorithmic bytes: every parity plane read once (4 (H+1)(W+1) floats per channel), every output element written once
     _timed_hbm('blur %d ch %dx%d -> %dx%d fp32' % (C, H, W, 2 * H, 2 * W), B * C * (16 * (H + 1) * (W + 1) + 16 * H * W), lambda: N.call(
         'sgdfr_blur_bias_act_f32', N.ptr(planes), N.ptr(N.f32c(fir)), N.ptr(nz), nzb,
         N.ptr(noise_weight) if nz is not None else None, N.ptr(bias), N.ptr(y), B, C, H, W, int(activate),
-        float(slope), float(gain), N.stream()))
+        float(slope), float(gain), N.ptr(absmax_out), N.stream()))
     return y
 
 
@@ -770,9 +776,11 @@ def blur_bias_act_split(planes, fir, H, W, s_next, noise=None, noise_weight=None
 
 def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_weight=None, bias=None,
                activate=False, slope=0.2, gain=SQRT2, batch=None, return_planes=False, wino=None, split=None, rgb=None,
-               want_y=True, ranged=False):
+               want_y=True, ranged=False, x_absmax=None, absmax_out=None):
     """Shared-weight modulated 3x3 conv (model.py:232-273) with the StyledConv tail fused in
     (noise model.py:287, bias + leaky-ReLU op/fused_act.py:81-86).
+    x_absmax: int32 [B,Cin] words of max |x| per plane when the producer of x already measured them (blur_bias_act(absmax_out=)):
+    the exact range plan then needs no pass over x; absmax_out (upsample=True): zeroed int32 [B,Cout] for the same words of the result.
 
     x [B,Cin,H,W], or a [1,Cin,H,W] constant broadcast over `batch` images (ConstantInput,
     model.py:296-300, without materialising the repeat).  upsample=True runs the stride-2 transposed
@@ -782,7 +790,7 @@ def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_we
         B = s.shape[0] if batch is None else batch
         if split is not None and split_ok(B, cin, cout, H, W):
             if config().range_plan and not ranged and config().precision == 'fp16x3' and d is not None:
-                s, d = _exact_range(x, s, d, batch)       # (ranged: the caller's s, d already carry a plan)
+                s, d = _exact_range(x, s, d, batch, x_absmax)       # (ranged: the caller's s, d already carry a plan)
             return modconv_split(x, split() if callable(split) else split, s, d, cout, noise, noise_weight, bias,
                                  activate, slope, gain, batch, rgb=rgb, want_y=want_y)
         if rgb is not None:
@@ -798,11 +806,11 @@ def modconv3x3(x, wp, s, d, cout, upsample=False, fir=None, noise=None, noise_we
     use_split = split is not None and split_ok(Bu, cin, cout, H, W, N.MODE_UP3)
     if use_split:
         if config().range_plan and not ranged and config().precision == 'fp16x3' and d is not None:
-            s, d = _exact_range(x, s, d, batch)
+            s, d = _exact_range(x, s, d, batch, x_absmax)
         planes = modconv_split(x, split() if callable(split) else split, s, d, cout, batch=batch, mode=N.MODE_UP3)
     else:
         planes = modconv_raw(x, wp, s, d, cout, N.MODE_UP3, H, W, batch=batch, desc='up3 %d->%d @%dx%d' % (cin, cout, H, W))
-    y = blur_bias_act(planes, fir, H, W, noise, noise_weight, bias, activate, slope, gain)
+    y = blur_bias_act(planes, fir, H, W, noise, noise_weight, bias, activate, slope, gain, absmax_out=absmax_out)
     return (y, planes) if return_planes else y
 
 

@@ -472,6 +472,36 @@ def test_tail_round_on_half_tiles_writes_the_same_planes(cin, cout, H, B, arith)
     assert torch.equal(out['0'][2], out['100000'][2]) and torch.equal(out['0'][2], out['0'][0])
 
 
+@pytest.mark.parametrize('C,cin,H,B', [(64, 256, 32, 32), (128, 128, 16, 240), (64, 128, 64, 17)])
+def test_tail_round_of_the_adjoint_writes_the_same_gradient(C, cin, H, B):
+    """The same two-launch arrangement for mode DOWN3 (dL/d(x*s) of the transposed conv: 128 x 256 tiles, tail on 128 x 128):
+    bit-identical to one launch of full tiles."""
+    import os
+    from stylegan_directions_face_reenactment_amd import functional as F_
+    N = F_.N
+    if not F_.split_ok(B, C, cin, H, H, N.MODE_DOWN3):
+        pytest.skip('shape not on the split adjoint')
+    tiles = -(-B * (H + 1) * (H + 1) // 256) * (cin // 128)
+    assert tiles > 256 and 0 < tiles % 256 <= 128, tiles
+    w = S.counter_tensor(19, 'td.w', (1, C, cin, 3, 3)).cuda()
+    gT = S.counter_tensor(19, 'td.g', (B, C, 4, H + 1, H + 1)).cuda()
+    d = S.counter_tensor(19, 'td.d', (B, C), 1.0, 0.2).cuda()
+    gxs = F_.planes_to_split(gT, d, 'fp16x3')
+    wsp = F_.prepack_split(w, 'fp16x3', adjoint='down')
+    old = os.environ.get('SGDFR_SPLIT_UP_TAIL')
+    try:
+        out = {}
+        for flag in ('0', '100000'):
+            os.environ['SGDFR_SPLIT_UP_TAIL'] = flag
+            out[flag] = F_.modconv_split(gxs, wsp, None, None, cin, mode=N.MODE_DOWN3, arith='fp16x3', x_split=(B, C, H, H), batch=B)
+    finally:
+        if old is None:
+            os.environ.pop('SGDFR_SPLIT_UP_TAIL', None)
+        else:
+            os.environ['SGDFR_SPLIT_UP_TAIL'] = old
+    assert torch.equal(out['0'], out['100000'])
+
+
 def test_fp16_split_saturates_instead_of_overflowing():
     """|x*s| beyond the fp16-split range (1.04e6) clamps; nothing becomes inf/nan."""
     from stylegan_directions_face_reenactment_amd import functional as F_
