@@ -263,18 +263,37 @@ def conv_roofline(step, steps, peak, kernel_desc, units_per_step):
             'conv_ms_per_step': round(conv_s / steps * 1e3, 3),
             'alg_gflop_per_unit': round(conv_flops / (units_per_step * steps) / 1e9, 3),
             'per_layer': [_layer_entry(desc, sec, fl, n, base_peak) for desc, (sec, fl, n) in per_layer.items()],
-            'kernel_families': kernel_families(per_layer, steps, base_peak, conv_s),
+            'kernel_families': kernel_families(per_layer, steps, base_peak, conv_s, units_per_step),
             'hbm_bound': hbm_rows(hbm_rec, steps)}
 
 
-def kernel_families(per_layer, steps, peak, conv_s):
+def _family(desc, batch):
+    """Kernel family of a conv row: the first two words of its description (three for 'bwd ...' rows); the F(4,3) rows are told
+    apart by the kernel that really runs them -- wswide_kernel (128 x 128 tiles) where the library's own query says so, else the
+    64-tile wsplit_kernel."""
+    import re
+    words = desc.split()
+    n = next((i for i, w in enumerate(words) if '->' in w), 2)          # everything in front of the 'Cin->Cout' word
+    key = ' '.join(words[:n])
+    m = re.search(r'F\(4,3\) (\d+)->(\d+) @(\d+)x(\d+)', desc)
+    if m and batch:
+        cin, cout, h, w = (int(x) for x in m.groups())
+        try:
+            if F_._shape_query('sgdfr_modconv2d_wsplit_wide', int(batch), cin, cout, h, w):
+                key += '/wide'
+        except Exception:       # noqa: BLE001
+            pass
+    return key + (' [f8 cross]' if desc.endswith('[f8 cross]') else '')
+
+
+def kernel_families(per_layer, steps, peak, conv_s, batch=None):
     """The conv launches of a step grouped by kernel family (the first two words of a row's description: 'split mode1' = the transposed
     conv of split_kernel.h, 'wsplit F(4,3)' = the Winograd form, 'split mode0' = the direct plain conv, 'bwd ...' = the adjoints), largest
     share of conv time first: launches and us per step, algorithmic TFLOP/s, fraction of the row peak, share of the conv time.  The
     first entry is the DOMINANT kernel of the line (roofline.dominant_kernel)."""
     fam = {}
     for desc, (sec, fl, n) in per_layer.items():
-        key = ' '.join(desc.split()[:3 if desc.startswith('bwd') else 2]) + (' [f8 cross]' if desc.endswith('[f8 cross]') else '')
+        key = _family(desc, batch)
         a = fam.setdefault(key, [0.0, 0.0, 0, 0.0])
         a[0] += sec
         a[1] += fl
