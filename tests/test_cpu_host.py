@@ -298,3 +298,18 @@ def test_bench_compact_line_is_small_and_complete():
         return any(isinstance(v, list) and len(v) > 3 for v in (o.values() if isinstance(o, dict) else [])) or \
             any(depth_lists(v) for v in (o.values() if isinstance(o, dict) else []) if isinstance(v, dict))
     assert not depth_lists(line)
+
+
+def test_bench_kernel_families_name_the_kernel_that_runs_a_row():
+    """bench._family: conv rows group by kernel -- the deep-plan transposed conv apart from the K-sliced small layers, the F(4,3)
+    rows by the tiling the library's own query picks (wswide_kernel vs the 64-tile wsplit_kernel), adjoint rows by their kind."""
+    import bench
+    assert bench._family('split mode1/deep 512->256 @32x32', 64) == 'split mode1/deep'
+    assert bench._family('split mode1 512->512 @4x4 K/4', 64) == 'split mode1'
+    assert bench._family('wsplit F(4,3) 512->512 @32x32', 64) == 'wsplit F(4,3)/wide'
+    assert bench._family('wsplit F(4,3) 512->512 @16x16', 64) == 'wsplit F(4,3)'          # a quarter of a wide tile per image: 64-tile kernel
+    assert bench._family('wsplit F(4,3) 512->512 @32x32 [f8 cross]', 64) == 'wsplit F(4,3)/wide [f8 cross]'
+    assert bench._family('bwd split down3 256->512 @32x32', 16) == 'bwd split down3'
+    assert bench._family('bwd split3 256->256 @64x64', 16) == 'bwd split3'
+    assert bench.row_peak('wsplit F(4,3) 512->512 @32x32 [f8 cross]', bench.SPLIT_PEAK_TFLOPS) == bench.F8_CROSS_PEAK_TFLOPS
+    assert abs(bench.F8_CROSS_PEAK_TFLOPS - 1666.7) < 0.1
