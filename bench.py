@@ -1251,13 +1251,11 @@ def run_pti(args, rank, world, dev):
         def step():
             img, _ = G([latent], input_is_latent=True, return_latents=False, truncation=0.7, truncation_latent=trunc)
             loss = FT.l2_loss_fn(img, target, lam)
-            opt.zero_grad(set_to_none=False)
+            opt.zero_grad(set_to_none=True)
             loss.backward()
             opt.step()
             return loss.detach()
         return step
-    for p in params:
-        p.grad = torch.zeros_like(p)
     eager = make_step(torch.optim.Adam(params, lr=3e-3))
     e_el, _, l0 = timed_region(eager, args, dev)
     launches = count_device_launches(eager)
@@ -1266,7 +1264,7 @@ def run_pti(args, rank, world, dev):
     torch.cuda.synchronize()
     conv_s = sum(e0.elapsed_time(e1) for e0, e1, _, _ in t.conv) * 1e-3
     conv_fl = sum(fl for _, _, fl, _ in t.conv)
-    runner = FT.GraphedStep(make_step(torch.optim.Adam(params, lr=3e-3, capturable=True)), warmup=3)
+    runner = FT.GraphedStep(make_step(torch.optim.Adam(params, lr=3e-3, capturable=True)), warmup=3, clear_grads_of=list(G.parameters()))
     elapsed, mine, loss = timed_region(runner, args, dev)
     # the same step computing only the gradients the optimizer reads (finetune.optimize_g(freeze_unused=True)): the weights it
     # produces are the same, the never-read .grad of the other 5 layers / mapping network is not formed
@@ -1275,7 +1273,7 @@ def run_pti(args, rank, world, dev):
     for p in G.parameters():
         p.requires_grad_(id(p) in ids)
     try:
-        runner2 = FT.GraphedStep(make_step(torch.optim.Adam(params, lr=3e-3, capturable=True)), warmup=3)
+        runner2 = FT.GraphedStep(make_step(torch.optim.Adam(params, lr=3e-3, capturable=True)), warmup=3, clear_grads_of=list(G.parameters()))
         needed_el, _, _ = timed_region(runner2, args, dev)
     finally:
         for p, rg in flags:

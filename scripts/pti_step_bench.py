@@ -27,7 +27,7 @@ def main():
     def step():
         img, _ = G([latent], input_is_latent=True, return_latents=False, truncation=0.7, truncation_latent=trunc)
         loss = ((img - target) ** 2).mean()
-        opt.zero_grad(set_to_none=False) if 'graph' in sys.argv[2:] else opt.zero_grad()
+        opt.zero_grad()
         loss.backward()
         opt.step()
         return loss
@@ -41,7 +41,8 @@ def main():
                 step()
         torch.cuda.current_stream().wait_stream(side)
         cg = torch.cuda.CUDAGraph()
-        opt.zero_grad(set_to_none=True)
+        for p in G.parameters():
+            p.grad = None
         with torch.cuda.graph(cg):
             static_loss = step()
         eager_step = step

@@ -1,8 +1,8 @@
 """Generator fine-tuning on one source (PTI), the counterpart of libs/optimization.py:25-72 (`optimize_g`): same parameter
 selection, optimiser and truncation; the perceptual loss is the caller's (LPIPS and the losses around it are neighbours of
-the hot path).  The step -- forward, backward with the HIP autograd kernels, Adam -- can be captured once and
-replayed as a hipGraph: at one source per step the eager step is bound by its ~560 host launches (7-8 ms), the replay takes
-~6 ms (scripts/pti_step_bench.py)."""
+the hot path).  The step -- forward, backward through autograd.SynthesisFn, Adam -- can be captured once and
+replayed as a hipGraph: at one source per step the eager step is bound by its host launches (~5 ms), the replay takes
+3.4-3.8 ms (bench.py --config pti, scripts/pti_step_bench.py)."""
 import torch
 
 from . import functional as F_
@@ -25,13 +25,18 @@ class GraphedStep:
     with capturable=True) after `warmup` eager calls on a side stream, then replays it.  Call it like step_fn; the returned
     tensor is the static output of the captured step."""
 
-    def __init__(self, step_fn, warmup=3):
+    def __init__(self, step_fn, warmup=3, clear_grads_of=()):
+        """clear_grads_of: parameters whose .grad is set to None right before the capture, so that the captured backward WRITES their
+        gradients (into buffers of the graph's pool) instead of adding to tensors left by the warm-up steps -- one in-place add per
+        parameter tensor and step otherwise (the whole-network capture recipe of torch.cuda.graphs)."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 step_fn()
         torch.cuda.current_stream().wait_stream(side)
+        for p in clear_grads_of:
+            p.grad = None
         self.graph = torch.cuda.CUDAGraph()
         with F_.capture_graph(self.graph):
             self.out = step_fn()          # recorded, not executed: the first replay is step warmup + 1
@@ -65,7 +70,7 @@ def optimize_g(generator, latent, real_imgs, trunc, opt_steps=200, lr=3e-3, opti
         imgs_gen, _ = generator([latent], input_is_latent=True, return_latents=False, truncation=truncation,
                                 truncation_latent=trunc)
         loss = loss_fn(imgs_gen, real_imgs, pt_l2_lambda)
-        optimizer.zero_grad(set_to_none=False)
+        optimizer.zero_grad(set_to_none=True)         # (optimization.py:66: the backward then writes fresh gradients, no zero + add pair)
         loss.backward()
         optimizer.step()
         return loss.detach()
@@ -73,10 +78,7 @@ def optimize_g(generator, latent, real_imgs, trunc, opt_steps=200, lr=3e-3, opti
     loss = None
     try:
         if graph and opt_steps > 4:
-            for p in params:                      # grads must exist (and keep their storage) before the capture
-                if p.grad is None:
-                    p.grad = torch.zeros_like(p)
-            runner = GraphedStep(step, warmup=3)
+            runner = GraphedStep(step, warmup=3, clear_grads_of=list(generator.parameters()))
             for _ in range(opt_steps - runner.steps_done):
                 loss = runner()
         else:
