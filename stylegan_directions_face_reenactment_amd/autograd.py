@@ -339,6 +339,20 @@ class ToRGBFn(Function):
 
 # ------------------------------------------------------------------ the whole synthesis network as one Function
 
+_flip_cache = {}
+
+
+def _flipped(fir):
+    """torch.flip(fir, [0, 1]) of a FIR buffer, cached per (storage, version): six flips per backward otherwise."""
+    key = (fir.data_ptr(), fir._version, fir.device)
+    t = _flip_cache.get(key)
+    if t is None:
+        if len(_flip_cache) > 32:
+            _flip_cache.clear()
+        t = _flip_cache[key] = torch.flip(fir, [0, 1]).contiguous()
+    return t
+
+
 def synthesis_params(gen, layers, to_rgbs):
     """The parameter tensors SynthesisFn takes (and returns gradients for), in its order."""
     ps = [gen.input.input]
@@ -462,8 +476,7 @@ class SynthesisFn(Function):
         for k in range(nr - 1, 0, -1):
             g = g_rgb[k]
             H, W = g.shape[2], g.shape[3]
-            fir = to_rgbs[k].upsample.kernel
-            g_rgb[k - 1] = upfirdn2d_native_op(g.reshape(B * 3, H, W, 1), torch.flip(fir, [0, 1]), 1, 1, 2, 2, 1, 1, 1, 1).view(B, 3, H // 2, W // 2)
+            g_rgb[k - 1] = upfirdn2d_native_op(g.reshape(B * 3, H, W, 1), _flipped(to_rgbs[k].upsample.kernel), 1, 1, 2, 2, 1, 1, 1, 1).view(B, 3, H // 2, W // 2)
         # one zeroed workspace for every reduction of this backward (sums, max |g|, r, r_rgb: 8 words per (image, channel) plane)
         work = torch.zeros(8 * B * sum(l.conv.out_channel for l in layers), device=dev, dtype=torch.float32)
         woff = 0
