@@ -464,6 +464,9 @@ def cpu_baseline(size, cm, budget_s=26.0):
     # (bounded: on the 256-thread GPU hosts an unbound all-cores team did not finish ONE batch-2 forward in 120 s -- r06_a -- so the leg
     #  runs batch 1 under a 15 s limit and reports the bound it proves when it times out)
     allc = leg(host, 1, 2.0, 2, 0, timeout=15) if host != best_thr or best_bind else main
+    # one thread per PHYSICAL core (SMT siblings are numbered + host/2 on the GPU hosts): the largest team that still finishes -- measured
+    # outside the bench on such a host (round 6): 64 threads 3.5, 128 threads 2.0 frames/s, 256 threads 58.7 s per batch-1 forward = 0.017
+    phys = leg(max(1, host // 2), 1, 2.0, 4, 0, timeout=20) if host >= 16 else None
     if allc.get('error') and 'timed out' in allc['error']:
         allc['upper_bound_frames_per_s'] = round(1 / 15.0, 3)
     return {'value': round(top['frames_per_s'], 3), 'unit': 'frames/s', 'cores': best_thr, 'host_cores': host, 'kind': 'port',
@@ -472,6 +475,8 @@ def cpu_baseline(size, cm, budget_s=26.0):
             'all_cores_note': ('%d threads, unbound: no forward finished in 15 s (< %.3f frames/s)' % (host, 1 / 15.0)) if not allc['reps']
             else '%d threads, unbound, batch %d' % (host, allc['batch']),
             'all_cores_leg': {k: (round(v, 3) if isinstance(v, float) else v) for k, v in allc.items()},
+            'physical_cores_value': round(phys['frames_per_s'], 3) if (phys and phys['reps']) else None,
+            'physical_cores': max(1, host // 2) if phys else None,
             'sustained_legs': [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in (main, b8)],
             'thread_sweep_batch2_short': {'%d threads, %s' % (t, 'bound' if b else 'unbound'): v for (t, b), v in sweep.items()},
             'sample': '%d forwards of batch %d in %.1f s (`value` = the better of two sustained legs: batch 2 and batch 8, first rows of '
@@ -631,7 +636,8 @@ def compact_line(full, args):
     out['roofline'] = r
     cb = full['cpu_baseline']
     out['cpu_baseline'] = {k: cb.get(k) for k in ('value', 'unit', 'cores', 'kind')}
-    out['cpu_baseline'].update(_pick(cb, 'host_cores', 'all_cores_value', 'all_cores_note', 'bound_to_cores', 'reason'))
+    out['cpu_baseline'].update(_pick(cb, 'host_cores', 'all_cores_value', 'all_cores_note', 'physical_cores', 'physical_cores_value',
+                                     'bound_to_cores', 'reason'))
     out['cpu_baseline']['sample'] = None if cb.get('sample') is None else str(cb['sample'])[:90]
     for k in ('verified', 'rerendered_batches', 'fp16_saturated_pairs', 'fp16_range_mode'):
         if k in full:
