@@ -220,19 +220,29 @@ def timed_region(step, args, dev, finish=None):
     """W warm-up steps, then EXACTLY K steps between (barrier + synchronize) pairs; returns (max over ranks, this rank).
     finish: called after the K-th step inside the timed region (a pipelined step checks the PREVIOUS step's result: the last
     step's own check belongs to the K steps too)."""
+    import gc
     for _ in range(max(args.warmup, 1)):
         out = step()
-    D.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if finish is not None:
-        finish()
-    torch.cuda.synchronize()
-    mine = time.perf_counter() - t0
-    D.barrier()
-    elapsed = time.perf_counter() - t0
+    # (the K-step region is a fraction of a second -- 0.11 s at the driver's K=20: one cyclic-GC pause of the interpreter inside it
+    #  costs several per cent, so the collector runs BEFORE the region and is held off inside it)
+    gc.collect()
+    gc_was = gc.isenabled()
+    gc.disable()
+    try:
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if finish is not None:
+            finish()
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
+        D.barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        if gc_was:
+            gc.enable()
     return D.max_over_ranks(elapsed, dev), mine, out
 
 
