@@ -52,7 +52,9 @@ def main():
             if F_._shape_query('sgdfr_modconv2d_split_ksplit_hint', B, cin, cout, H, H, N.MODE_UP3) == 1:
                 rp = (H + 1) * (H + 1); ps = (rp + 31) // 32 * 32
                 c = F_.modconv_split(x, wsp, s, d, cout, arith='fp16x3', mode=N.MODE_UP3, plane_stride=ps)
-                assert torch.equal(c[..., :rp], a.view(B, cout, 4, rp)), ('up padded', B, cin, cout, H)
+                # (padded planes are INTERLEAVED since round 4: [B, cout, ps, px, py] -> [B, cout, phase 2*py+px, position])
+                planar = c.view(B, cout, ps, 2, 2).permute(0, 1, 4, 3, 2).reshape(B, cout, 4, ps)[..., :rp]
+                assert torch.equal(planar, a.view(B, cout, 4, rp)), ('up padded', B, cin, cout, H)
         else:
             C, co = cin, cout          # planes have C channels, dL/dx has co
             if co % 128 or not F_.split_ok(B, C, co, H, H, N.MODE_DOWN3):
