@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 20
+#define SGDFR_ABI_VERSION 21
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -543,6 +543,14 @@ int sgdfr_modconv_wgrad_parts_f32(const float* g, const float* d, const float* x
                                   int B, int Cin, int Cout, int H, int W, int mode, void* stream);
 int sgdfr_modconv_wgrad_finish_parts_f32(const float* part, int ksplit, const float* wp, const float* dq, float* dweight,
                                          int Cout, int Cin, void* stream);
+/* sgdfr_modconv_wgrad_finish_parts_f32 with the demodulation term taken from the ORIGINAL weight tensor weight [Cout][Cin][3][3]
+ * (= wp / scale transposed) instead of the packed copy: every stream of the launch is then contiguous (the packed form forces 4-byte
+ * gathers at a stride of 9*Cout floats); slices are summed four-way interleaved, in fixed order (deterministic, not the bits of the
+ * sequential sum).  Instead of dq the call may take what sgdfr_demod_dq_f32 takes -- a (= d * dL/dd, element stride a_stride), d [B,Cout],
+ * s [B,Cin] -- and forms dq itself (same expression and order): one launch less per layer. */
+int sgdfr_modconv_wgrad_finish_parts_oik_f32(const float* part, int ksplit, const float* weight, const float* dq, const float* a,
+                                             int64_t a_stride, const float* d, const float* s, int B, float* dweight, int Cout, int Cin,
+                                             void* stream);
 
 /* Measurement aid (csrc/probe.hip; no reference counterpart): the rate v_mfma_f32_32x32x16_{f16,bf16} sustains on THIS device,
  * in 16-bit TFLOP/s -- arith SGDFR_SPLIT_FP16/BF16; lds_fragments 1: operands re-read from LDS at the split conv's ratio

@@ -23,7 +23,7 @@ if os.environ.get('SGDFR_LIB'):
     else:
         import warnings as _warnings
         _warnings.warn('SGDFR_LIB is set but ignored (set SGDFR_ALLOW_LIB_OVERRIDE=1 to load a probe build)', RuntimeWarning)
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -48,6 +48,8 @@ SIGNATURES = {
     'sgdfr_modconv_wgrad_finish_f32': [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _i, _i, ctypes.c_void_p],
     'sgdfr_modconv_wgrad_parts_f32': [_c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _i, _i, _i, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_modconv_wgrad_finish_parts_f32': [_c_f32p, _i, _c_f32p, _c_f32p, _c_f32p, _i, _i, ctypes.c_void_p],
+    'sgdfr_modconv_wgrad_finish_parts_oik_f32': [_c_f32p, _i, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _i, _c_f32p, _i, _i,
+                                                 ctypes.c_void_p],
     'sgdfr_modconv_prepack_wino_f32': [_c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p],
     'sgdfr_modconv2d_wino_supported': [_i, _i, _i, _i, _i],
     'sgdfr_modconv2d_wino_f32': [_c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _i64, _c_f32p, _c_f32p, _c_f32p,

@@ -297,7 +297,7 @@ class StyledConvFn(Function):
             if d is not None:      # dL/dQ[o,i] = sum_b dL/dd * (-d^3/2) * s^2   (d = rsqrt(sum_i s^2 Q + eps))
                 coeff = (A / d) * d.pow(3) * -0.5
                 dq = F_.linear(_t(coeff), _t(s * s))
-            gweight = F_.wgrad(gT if up else g_pre, d, x, s, cout, up, wp=mod.packed()[0], dq=dq)
+            gweight = F_.wgrad(gT if up else g_pre, d, x, s, cout, up, wp=mod.packed()[0], dq=dq, weight=mod.weight)
         gnw = sums[:, :, 1].sum().view(1) if (noise_w is not None and ctx.needs_input_grad[4]) else None
         gb = sums[:, :, 0].sum(0) if (bias is not None and ctx.needs_input_grad[5]) else None
         return gx, gs, gd, gweight, gnw, gb, None, None, None, None
@@ -511,8 +511,8 @@ class SynthesisFn(Function):
             A[li] = A_up if mod.upsample else (sums[:, :, 2] if d is not None else None)
             if want_w:
                 x = ctx.saved[li - 1][0] if li > 0 else gen.input.input
-                dq = F_.demod_dq(A[li], d, s) if d is not None else None
-                grads[lay_p(li, 0)] = F_.wgrad(gT if mod.upsample else g_pre, d, x, s, C, mod.upsample, wp=mod.packed()[0], dq=dq)
+                grads[lay_p(li, 0)] = F_.wgrad(gT if mod.upsample else g_pre, d, x, s, C, mod.upsample, wp=mod.packed()[0],
+                                               a=A[li] if d is not None else None, weight=mod.weight)
             if need[lay_p(li, 3)]:
                 small.append((lay_p(li, 3), (1,), (N.PGRAD_NOISE, sums, None, C, 0)))
             if need[lay_p(li, 4)]:

@@ -224,6 +224,63 @@ __global__ __launch_bounds__(256) void wgrad_finish_parts_kernel(const float* __
     }
 }
 
+// The same finish with every stream coalesced.  wgrad_finish_parts_kernel walks the OUTPUT order of the slices (i fastest), so its
+// reads of wp[i][k][o] are 4-byte gathers at a stride of 9*Cout floats and its writes of dW[o][i][k] 4-byte scatters at a stride of 9
+// (512 x 512: 151 MB of cache lines for 9.4 MB of weights; 28 us per launch, a tenth of a PTI step for 13 layers).  Here a block owns
+// one cout and 64 input channels: thread (ii, kg) sums the slices ks = kg (mod 4) of its channel for all nine taps (64-float rows of
+// `part`), the four partial sums meet in LDS in fixed order, and the 576 outputs leave as ONE contiguous run of dW[o][i0..i0+63][0..8]
+// -- the demodulation term read from the ORIGINAL weight tensor w[o][i][k] (wp = w * scale, the same product prepack_kernel formed) at
+// the same addresses.
+constexpr int WF_IT = 64;
+// dq may also be formed here: with a (= d * dL/dd, element stride a_stride), d [B,Cout] and s [B,Cin] given instead of dq,
+// dq[o,i] = sum_b (-0.5 * (a/d) * d^3)[b,o] * s[b,i]^2 (sgdfr_demod_dq_f32's expression and order) -- one launch less per layer.
+__global__ __launch_bounds__(256) void wgrad_finish_parts_oik_kernel(const float* __restrict__ part, int ksplit,
+                                                                    const float* __restrict__ w, const float* __restrict__ dq,
+                                                                    const float* __restrict__ a, int64_t a_stride,
+                                                                    const float* __restrict__ d, const float* __restrict__ sty, int B,
+                                                                    float* __restrict__ dw, int Cout, int Cin, float scale) {
+    __shared__ float red[4][9][WF_IT];
+    __shared__ float dql[WF_IT];
+    const int o = blockIdx.y, i0 = blockIdx.x * WF_IT;
+    const int ii = threadIdx.x & (WF_IT - 1), kg = threadIdx.x >> 6;
+    const int64_t total = (int64_t)Cout * Cin * 9;
+    const bool in = i0 + ii < Cin;
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    if (in) {
+        for (int ks = kg; ks < ksplit; ks += 4) {
+            const float* src = part + (int64_t)ks * total + (int64_t)o * Cin + i0 + ii;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k] += src[(int64_t)k * Cout * Cin];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[kg][k][ii] = acc[k];
+    if (a && kg == 0) {
+        float t = 0.f;
+        if (in) {
+            for (int b = 0; b < B; ++b) {
+                const float dv = d[(int64_t)b * Cout + o];
+                const float coeff = (a[((int64_t)b * Cout + o) * a_stride] / dv) * (dv * dv * dv) * -0.5f;
+                const float sv = sty[(int64_t)b * Cin + i0 + ii];
+                t = fmaf(coeff, sv * sv, t);
+            }
+        }
+        dql[ii] = t;
+    }
+    __syncthreads();
+    const int n_i = min(WF_IT, Cin - i0);
+    const int64_t obase = ((int64_t)o * Cin + i0) * 9;
+    for (int j = threadIdx.x; j < n_i * 9; j += 256) {
+        const int i = j / 9, k = j - i * 9;
+        float v = ((red[0][k][i] + red[1][k][i]) + red[2][k][i]) + red[3][k][i];
+        if (dq) v = fmaf(2.f * (w[obase + j] * scale), dq[(int64_t)o * Cin + i0 + i], v);
+        else if (a) v = fmaf(2.f * (w[obase + j] * scale), dql[i], v);
+        dw[obase + j] = v * scale;
+    }
+}
+
 // K slices of a shape: ~1024 blocks, at least 4 pixel chunks per block
 static int wgrad_ksplit(const WgradParams& p, int* chunks_per_block) {
     const int ntile = ((p.Cout + 63) / 64) * ((p.Cin + 63) / 64);
@@ -304,6 +361,18 @@ extern "C" int sgdfr_modconv_wgrad_finish_parts_f32(const float* part, int kspli
     hipLaunchKernelGGL(wgrad_finish_parts_kernel, dim3((int)gsz), dim3(256), 0, as_stream(stream), part, ksplit, wp, dq, dweight,
                        Cout, Cin, 1.0f / sqrtf((float)Cin * 9));
     return check_launch("modconv_wgrad_finish_parts");
+}
+
+extern "C" int sgdfr_modconv_wgrad_finish_parts_oik_f32(const float* part, int ksplit, const float* weight, const float* dq,
+                                                        const float* a, int64_t a_stride, const float* d, const float* s, int B,
+                                                        float* dweight, int Cout, int Cin, void* stream) {
+    SGDFR_REQUIRE(Cout > 0 && Cin > 0 && ksplit > 0, "wgrad_finish_parts_oik: bad shape %d %d x%d", Cout, Cin, ksplit);
+    SGDFR_REQUIRE(part && dweight && (weight || (!dq && !a)), "wgrad_finish_parts_oik: null pointer");
+    SGDFR_REQUIRE(!(dq && a), "wgrad_finish_parts_oik: give dq OR (a, d, s), not both");
+    SGDFR_REQUIRE(!a || (d && s && B > 0 && a_stride >= 1), "wgrad_finish_parts_oik: a needs d, s, B and a_stride >= 1");
+    hipLaunchKernelGGL(wgrad_finish_parts_oik_kernel, dim3((Cin + WF_IT - 1) / WF_IT, Cout), dim3(256), 0, as_stream(stream), part, ksplit,
+                       weight, dq, a, a_stride, d, s, B, dweight, Cout, Cin, 1.0f / sqrtf((float)Cin * 9));
+    return check_launch("modconv_wgrad_finish_parts_oik");
 }
 
 extern "C" int sgdfr_modconv_wgrad_f32(const float* g, const float* d, const float* x, int64_t x_bstride, const float* s,

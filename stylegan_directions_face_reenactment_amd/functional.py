@@ -1065,10 +1065,19 @@ def demod_grad(gd, d, qt, s, gs):
     return ds
 
 
-def wgrad(g, d, x, s, cout, upsample, wp=None, dq=None):
+def config_wgrad_oik():
+    """SGDFR_WGRAD_OIK=0 keeps the gather-form finish launch (read per call: same-process A/B)."""
+    import os
+    return os.environ.get('SGDFR_WGRAD_OIK', '1') != '0'
+
+
+def wgrad(g, d, x, s, cout, upsample, wp=None, dq=None, weight=None, a=None):
     """dL/dW [1,Cout,Cin,3,3] of a modulated 3x3 conv.  g: activation gradient [B,Cout,H,W] (plain) or the
-    parity planes of dL/dT [B,Cout,4,H+1,W+1] (upsample); x [B or 1,Cin,H,W]; dq [Cout,Cin] = dL/dQ or None."""
-    N.require_device(g, d, x, s, wp, dq)
+    parity planes of dL/dT [B,Cout,4,H+1,W+1] (upsample); x [B or 1,Cin,H,W]; dq [Cout,Cin] = dL/dQ or None.  weight: the layer's
+    own [1,Cout,Cin,3,3] parameter -- with it the finish launch reads the demodulation term from there (contiguous) instead of
+    gathering it from the packed copy `wp`; a ([B,Cout] view of d*dL/dd, instead of dq): that launch then forms dL/dQ itself
+    (demod_dq's expression) where the shape takes the sliced form."""
+    N.require_device(g, d, x, s, wp, dq, weight)
     x, g = N.f32c(x), N.f32c(g)
     B = s.shape[0]
     _, cin, H, W = x.shape
@@ -1080,8 +1089,17 @@ def wgrad(g, d, x, s, cout, upsample, wp=None, dq=None):
         part = torch.empty(ks, 9, cout, cin, device=x.device, dtype=torch.float32)
         N.call('sgdfr_modconv_wgrad_parts_f32', N.ptr(g), N.ptr(d), N.ptr(x), xb, N.ptr(s), N.ptr(part), B, cin, cout, H, W, mode,
                N.stream())
-        N.call('sgdfr_modconv_wgrad_finish_parts_f32', N.ptr(part), ks, N.ptr(wp), N.ptr(dq), N.ptr(dw), cout, cin, N.stream())
+        if weight is not None and config_wgrad_oik():
+            a_ptr, a_stride = (N.ptr(a), a.stride(1)) if (a is not None and dq is None) else (None, 1)
+            N.call('sgdfr_modconv_wgrad_finish_parts_oik_f32', N.ptr(part), ks, N.ptr(N.f32c(weight.detach())), N.ptr(dq), a_ptr, a_stride,
+                   N.ptr(d) if a_ptr is not None else None, N.ptr(s) if a_ptr is not None else None, B, N.ptr(dw), cout, cin, N.stream())
+        else:
+            if dq is None and a is not None:
+                dq = demod_dq(a, d, s)
+            N.call('sgdfr_modconv_wgrad_finish_parts_f32', N.ptr(part), ks, N.ptr(wp), N.ptr(dq), N.ptr(dw), cout, cin, N.stream())
         return dw
+    if dq is None and a is not None:
+        dq = demod_dq(a, d, s)
     dwp = torch.empty(cin, 9, cout, device=x.device, dtype=torch.float32)
     N.call('sgdfr_modconv_wgrad_f32', N.ptr(g), N.ptr(d), N.ptr(x), xb, N.ptr(s), N.ptr(dwp), B, cin, cout, H, W, mode, N.stream())
     N.call('sgdfr_modconv_wgrad_finish_f32', N.ptr(dwp), N.ptr(wp), N.ptr(dq), N.ptr(dw), cout, cin, N.stream())
