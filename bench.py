@@ -1275,7 +1275,7 @@ def run_pti(args, rank, world, dev):
             opt.step()
             return loss.detach()
         return step
-    eager = make_step(torch.optim.Adam(params, lr=3e-3))
+    eager = make_step(FT.FusedAdam(params, lr=3e-3))
     e_el, _, l0 = timed_region(eager, args, dev)
     launches = count_device_launches(eager)
     with timing.collect() as t:                  # the conv launches of one eager step (forward rows + `bwd ...` rows)
@@ -1283,7 +1283,7 @@ def run_pti(args, rank, world, dev):
     torch.cuda.synchronize()
     conv_s = sum(e0.elapsed_time(e1) for e0, e1, _, _ in t.conv) * 1e-3
     conv_fl = sum(fl for _, _, fl, _ in t.conv)
-    runner = FT.GraphedStep(make_step(torch.optim.Adam(params, lr=3e-3, capturable=True)), warmup=3, clear_grads_of=list(G.parameters()))
+    runner = FT.GraphedStep(make_step(FT.FusedAdam(params, lr=3e-3)), warmup=3, clear_grads_of=list(G.parameters()))
     elapsed, mine, loss = timed_region(runner, args, dev)
     # the same step computing only the gradients the optimizer reads (finetune.optimize_g(freeze_unused=True)): the weights it
     # produces are the same, the never-read .grad of the other 5 layers / mapping network is not formed
@@ -1292,7 +1292,7 @@ def run_pti(args, rank, world, dev):
     for p in G.parameters():
         p.requires_grad_(id(p) in ids)
     try:
-        runner2 = FT.GraphedStep(make_step(torch.optim.Adam(params, lr=3e-3, capturable=True)), warmup=3, clear_grads_of=list(G.parameters()))
+        runner2 = FT.GraphedStep(make_step(FT.FusedAdam(params, lr=3e-3)), warmup=3, clear_grads_of=list(G.parameters()))
         needed_el, _, _ = timed_region(runner2, args, dev)
     finally:
         for p, rg in flags:

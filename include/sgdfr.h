@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SGDFR_ABI_VERSION 21
+#define SGDFR_ABI_VERSION 22
 
 /* modes of sgdfr_modconv2d_fwd_f32 */
 #define SGDFR_MODE_PLAIN3 0 /* 3x3, pad 1, same resolution                      (model.py:267-271) */
@@ -518,6 +518,20 @@ typedef struct sgdfr_param_grad {
     float scale;
 } sgdfr_param_grad;
 int sgdfr_param_grads_f32(const sgdfr_param_grad* entries, int n, int B, void* stream);
+
+/* One Adam step (torch.optim.Adam as libs/optimization.py:41,66-68 uses it: no weight decay, no amsgrad) over a list of parameter
+ * tensors in ONE launch: p, g (gradient), m (exp_avg), v (exp_avg_sq), n elements each; step[0] = the step count t >= 1 as a float on
+ * the device (the caller increments it before the call, so a captured step needs no host value):
+ *   m += (g - m)(1 - beta1) ; v = v beta2 + (1 - beta2) g^2 ; p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps) */
+#define SGDFR_MAX_ADAM_TENSORS 96
+typedef struct sgdfr_adam_tensor {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t n;
+} sgdfr_adam_tensor;
+int sgdfr_adam_f32(const sgdfr_adam_tensor* tensors, int n, const float* step, float lr, float beta1, float beta2, float eps, void* stream);
 
 /* ds[b,i] = gs[b,i] + s[b,i] * sum_o (-gd[b,o] * d[b,o]^3) * qt[i,o]   (chain rule through d = rsqrt(sum s^2 q + eps)) */
 int sgdfr_demod_grad_f32(const float* gd, const float* d, const float* qt, const float* s, const float* gs, float* ds,

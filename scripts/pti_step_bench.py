@@ -33,7 +33,8 @@ def main():
         return loss
     graph = 'graph' in sys.argv[2:]
     if graph:        # the whole step (forward, backward, Adam) as one hipGraph replay: nothing left of the ~560 host launches
-        opt = torch.optim.Adam(params, lr=3e-3, capturable=True)
+        from stylegan_directions_face_reenactment_amd.finetune import FusedAdam
+        opt = FusedAdam(params, lr=3e-3) if 'fused' in sys.argv[2:] else torch.optim.Adam(params, lr=3e-3, capturable=True)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -23,7 +23,7 @@ if os.environ.get('SGDFR_LIB'):
     else:
         import warnings as _warnings
         _warnings.warn('SGDFR_LIB is set but ignored (set SGDFR_ALLOW_LIB_OVERRIDE=1 to load a probe build)', RuntimeWarning)
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _c_f32p = ctypes.c_void_p
 _i, _i64, _f = ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -131,6 +131,13 @@ class ParamGrad(ctypes.Structure):
                 ('HW', ctypes.c_int), ('scale', ctypes.c_float)]
 
 
+class AdamTensor(ctypes.Structure):
+    """struct sgdfr_adam_tensor (include/sgdfr.h)."""
+    _fields_ = [('p', ctypes.c_void_p), ('g', ctypes.c_void_p), ('m', ctypes.c_void_p), ('v', ctypes.c_void_p), ('n', ctypes.c_int64)]
+
+
+MAX_ADAM_TENSORS = 96
+SIGNATURES['sgdfr_adam_f32'] = [ctypes.POINTER(AdamTensor), _i, _c_f32p, _f, _f, _f, _f, ctypes.c_void_p]
 PGRAD_BIAS, PGRAD_NOISE, PGRAD_RGB_W, PGRAD_RGB_B = 0, 1, 2, 3
 MAX_PARAM_GRADS = 64
 SIGNATURES['sgdfr_styles_batched_bwd_f32'] = [ctypes.POINTER(StyleGradLayer), _i, _c_f32p, _c_f32p, _i, _i, _i, ctypes.c_void_p]

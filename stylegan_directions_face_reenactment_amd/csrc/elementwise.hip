@@ -295,6 +295,57 @@ extern "C" int sgdfr_latent_prepare_f32(const float* w, int w_is_plus, const flo
     return check_launch("latent_prepare");
 }
 
+// ---------------------------------------------------------------- Adam over a list of parameter tensors, one launch
+// The PTI step (libs/optimization.py:41,66-68: torch.optim.Adam, default betas / eps, no weight decay) updates 24 parameter tensors;
+// torch's capturable multi-tensor Adam takes ~100 launches for them under a hipGraph (its per-parameter step-size tensors).  Here
+// blockIdx -> (tensor, 1024-element chunk); the step count lives on the device (the captured step increments it before this launch).
+//   m = m + (g - m) (1 - b1) ; v = v b2 + (1 - b2) g^2 ; p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// (torch/optim/adam.py _single_tensor_adam, the non-capturable order of operations)
+struct AdamBatch {
+    sgdfr_adam_tensor t[SGDFR_MAX_ADAM_TENSORS];
+    int chunk_start[SGDFR_MAX_ADAM_TENSORS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamBatch ab, const float* __restrict__ step, float lr, float b1, float b2, float eps) {
+    int ti = 0;
+    while (ti + 1 < ab.n && (int)blockIdx.x >= ab.chunk_start[ti + 1]) ++ti;
+    const sgdfr_adam_tensor& e = ab.t[ti];
+    const float t = step[0];
+    const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+    const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+    const int64_t i0 = (int64_t)(blockIdx.x - ab.chunk_start[ti]) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = i0 + u * 256 + threadIdx.x;
+        if (i >= e.n) break;
+        const float g = e.g[i];
+        float m = e.m[i], v = e.v[i];
+        m = m + (g - m) * (1.f - b1);
+        v = fmaf(g * g, 1.f - b2, v * b2);
+        e.m[i] = m;
+        e.v[i] = v;
+        e.p[i] = e.p[i] - step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+    }
+}
+
+extern "C" int sgdfr_adam_f32(const sgdfr_adam_tensor* tensors, int n, const float* step, float lr, float beta1, float beta2, float eps,
+                              void* stream) {
+    SGDFR_REQUIRE(n > 0 && n <= SGDFR_MAX_ADAM_TENSORS && tensors && step, "adam: 1..%d tensors and a device step count", SGDFR_MAX_ADAM_TENSORS);
+    AdamBatch ab;
+    ab.n = n;
+    int chunks = 0;
+    for (int i = 0; i < n; ++i) {
+        SGDFR_REQUIRE(tensors[i].p && tensors[i].g && tensors[i].m && tensors[i].v && tensors[i].n > 0, "adam: tensor %d: null pointer / empty", i);
+        ab.t[i] = tensors[i];
+        ab.chunk_start[i] = chunks;
+        chunks += (int)((tensors[i].n + 1023) / 1024);
+    }
+    ab.chunk_start[n] = chunks;
+    hipLaunchKernelGGL(adam_kernel, dim3(chunks), dim3(256), 0, as_stream(stream), ab, step, lr, beta1, beta2, eps);
+    return check_launch("adam");
+}
+
 extern "C" int sgdfr_image_to_u8_f32(const float* x, unsigned char* y, int B, int H, int W, void* stream) {
     SGDFR_REQUIRE(B >= 0 && H > 0 && W > 0, "image_to_u8: bad shape %d %d %d", B, H, W);
     if (B == 0) return 0;

@@ -302,6 +302,31 @@ def test_blur_leaves_the_per_plane_maximum_of_what_it_writes(B, C, H):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
+def test_fused_adam_equals_torch_adam():
+    """finetune.FusedAdam (sgdfr_adam_f32: every parameter tensor of the step in one launch, step count on the device) against
+    torch.optim.Adam with the reference's settings (libs/optimization.py:41: default betas / eps, no weight decay) over several steps;
+    the parameters' version counters move (the weight packs of ModulatedConv2d are keyed on them)."""
+    from stylegan_directions_face_reenactment_amd.finetune import FusedAdam
+    torch.manual_seed(3)
+    shapes = [(1, 64, 32, 3, 3), (512,), (1,), (130, 512), (3, 7)]
+    a = [torch.randn(*sh, device='cuda').requires_grad_(True) for sh in shapes]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    oa, ob = FusedAdam(a, lr=3e-3), torch.optim.Adam(b, lr=3e-3)
+    for step in range(6):
+        grads = [torch.randn_like(t) * (10.0 ** (step - 3)) for t in a]
+        for t, u, g in zip(a, b, grads):
+            t.grad, u.grad = g.clone(), g.clone()
+        v0 = [t._version for t in a]
+        oa.step()
+        ob.step()
+        assert all(t._version > v for t, v in zip(a, v0))
+        for t, u in zip(a, b):
+            assert torch.allclose(t, u, rtol=2e-6, atol=1e-7), (step, tuple(t.shape), maxabs(t, u))
+    assert float(oa.step_count) == 6.0
+    oa.zero_grad()
+    assert all(t.grad is None for t in a)
+
+
 def test_batched_style_backward_and_small_parameter_gradients_match_torch():
     """functional.styles_batched_bwd (ds of demodulated / plain / ToRGB layers, latent gradient summed per latent row, modulation weight
     and bias gradients), functional.demod_dq and functional.param_grads against the tensor expressions of the per-layer Functions
