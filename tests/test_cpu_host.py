@@ -279,7 +279,7 @@ def test_bench_compact_line_is_small_and_complete():
     every contract key, the roofline fields and one scalar triple per secondary leg; built here from a committed full record."""
     import json
     import bench
-    full = json.load(open(os.path.join(ROOT, 'profiles', 'r06_h_bench_detail.json')))
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r06_i_bench_detail.json')))
     args = bench.parse_args([])
     line = bench._sig(bench.compact_line(full, args))
     text = json.dumps(line)
